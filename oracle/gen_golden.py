@@ -1,0 +1,259 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE'S OWN PYTHON in the authoring container.
+
+TEST INFRASTRUCTURE ONLY -- needs /root/reference, never runs on the GPU box.
+
+Recipe: the eight third-party packages the reference imports
+but this image lacks are replaced by MagicMock modules; the Drake-dependent constructors are
+bypassed with ``Cls.__new__``; the three pieces of arithmetic that live in those packages
+(drake_pytorch closures for M, F and geometry kinematics; sappy's QP solve) are supplied by
+``oracle/dpll_oracle.py``.  Everything else executed here -- contactnets_loss,
+forward_dynamics, Integrator.simulate, MultibodyTerms / LagrangianTerms / ContactTerms
+.forward, GeometryCollider, Box, DeepSupportConvex / HomogeneousICNN,
+InertialParameterConverter, state_space, quaternion, TrajectorySliceDataset and
+DrakeMultibodyLearnableExperiment.contactnets_loss -- is the reference's unmodified code,
+and its outputs are what the fixtures record.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = '/root/reference'
+ASSETS = os.path.join(REFERENCE, 'assets')
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+DT = 0.0068  # reference examples/contactnets_simple.py:52
+
+for _name in ['fcl', 'pywavefront', 'sappy', 'drake_pytorch', 'optuna', 'optuna.trial', 'optuna.logging', 'wandb',
+              'pydrake', 'pydrake.geometry', 'pydrake.multibody', 'pydrake.multibody.plant',
+              'pydrake.multibody.tree', 'pydrake.multibody.parsing', 'pydrake.symbolic', 'pydrake.systems',
+              'pydrake.systems.framework', 'pydrake.systems.analysis', 'pydrake.autodiffutils', 'pydrake.math',
+              'pydrake.visualization', 'pydrake.all', 'pydrake.common', 'pydrake.systems.primitives',
+              'pydrake.geometry.render', 'pydrake.systems.sensors']:
+    sys.modules.setdefault(_name, MagicMock())
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, REPO)
+
+from torch import nn  # noqa: E402
+from torch.nn import ModuleList, Parameter  # noqa: E402
+
+from dair_pll import state_space  # noqa: E402
+from dair_pll.data_config import TrajectorySliceConfig  # noqa: E402
+from dair_pll.dataset_management import TrajectorySliceDataset  # noqa: E402
+from dair_pll.drake_experiment import DrakeMultibodyLearnableExperiment  # noqa: E402
+from dair_pll.geometry import Box, DeepSupportConvex, Plane  # noqa: E402
+from dair_pll.inertia import InertialParameterConverter  # noqa: E402
+from dair_pll.integrator import VelocityIntegrator  # noqa: E402
+from dair_pll.multibody_learnable_system import MultibodyLearnableSystem  # noqa: E402
+from dair_pll.multibody_terms import ContactTerms, LagrangianTerms, MultibodyTerms  # noqa: E402
+from dair_pll.system import System  # noqa: E402
+
+from oracle import dpll_oracle as O  # noqa: E402
+
+assert torch.get_default_dtype() == torch.float64  # reference inertia.py:96
+
+
+class RecordingSolver:
+    """Stands in for sappy.SAPSolver(); records exactly what the reference passes."""
+
+    def __init__(self):
+        self.calls = []
+
+    def apply(self, J, q, eps):
+        f = O.sap_solve(J, q, eps)
+        self.calls.append((J.detach().clone(), q.detach().clone(), eps, f.detach().clone()))
+        return f
+
+
+def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0):
+    """The reference's MultibodyLearnableSystem with Drake-dependent construction bypassed."""
+    spec = O.parse_urdf(urdf)
+    geoms = O.geometry_table(spec)
+    n_joints = spec['n_joints']
+
+    lt = LagrangianTerms.__new__(LagrangianTerms)
+    nn.Module.__init__(lt)
+    lt.mass_matrix = lambda q, inertia: O.mass_matrix(spec, q, inertia, inertia_mode)
+    lt.lagrangian_forces = lambda q, v, u, inertia: O.lagrangian_forces(spec, q, v, inertia, inertia_mode)
+    pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
+                          for b in spec['bodies']])
+    lt.inertial_parameters = Parameter(InertialParameterConverter.pi_cm_to_theta(pi_cm), requires_grad=True)
+
+    ct = ContactTerms.__new__(ContactTerms)
+    nn.Module.__init__(ct)
+    ct.geometry_rotations = lambda q: O.geometry_kinematics(spec, q)[0]
+    ct.geometry_translations = lambda q: O.geometry_kinematics(spec, q)[1]
+    ct.geometry_spatial_jacobians = lambda q: O.geometry_kinematics(spec, q)[2]
+    modules = []
+    for geom in geoms:
+        if geom['kind'] == 'plane':
+            modules.append(Plane())
+        elif geom['kind'] == 'box':
+            modules.append(Box(torch.tensor(geom['half']), 4))
+        else:
+            torch.manual_seed(mesh_seed)
+            modules.append(DeepSupportConvex(torch.tensor(geom['vertices'])))
+    ct.geometries = ModuleList(modules)
+    ct.friction_params = Parameter(torch.tensor([g['mu'] for g in geoms]), requires_grad=True)
+    n_g = len(geoms)
+    ct.collision_candidates = torch.tensor([[0] * (n_g - 1), list(range(1, n_g))]).long()
+
+    mt = MultibodyTerms.__new__(MultibodyTerms)
+    nn.Module.__init__(mt)
+    mt.lagrangian_terms = lt
+    mt.contact_terms = ct
+
+    system = MultibodyLearnableSystem.__new__(MultibodyLearnableSystem)
+    space = state_space.ProductSpace([state_space.FixedBaseSpace(0), state_space.FloatingBaseSpace(n_joints)])
+    System.__init__(system, space, VelocityIntegrator(space, system.sim_step, DT))
+    system.multibody_terms = mt
+    system.solver = RecordingSolver()
+    system.dt = DT
+    system.set_carry_sampler(lambda: torch.tensor([False]))
+    system.max_batch_dim = 1
+    return system, spec
+
+
+def named_grads(system) -> dict:
+    return {name: param.grad.detach().clone().numpy() for name, param in system.named_parameters()}
+
+
+def named_values(system) -> dict:
+    out = {name: param.detach().clone().numpy() for name, param in system.named_parameters()}
+    for index, geometry in enumerate(system.multibody_terms.contact_terms.geometries):
+        if isinstance(geometry, DeepSupportConvex):
+            out[f'multibody_terms.contact_terms.geometries.{index}.perturbations'] = \
+                geometry.perturbations.detach().clone().numpy()
+    return out
+
+
+def record_case(name: str, urdf: str, x: torch.Tensor, x_plus: torch.Tensor, inertia_mode: str,
+                sim_steps: int = 4, sim_rows=None) -> None:
+    system, _ = build_reference_system(urdf, inertia_mode)
+    out = {'urdf': os.path.basename(urdf), 'dt': DT, 'inertia_mode': inertia_mode,
+           'x': x.numpy(), 'x_plus': x_plus.numpy()}
+    for key, value in named_values(system).items():
+        out['param/' + key] = value
+
+    # --- terms at the next state (what the loss evaluates, Q6) -------------------------
+    q_plus, v_plus = system.space.q_v(x_plus)
+    u = torch.zeros(x.shape[:-1] + (0,))
+    with torch.no_grad():
+        D, M, J, phi, a = system.multibody_terms(q_plus, v_plus, u)
+    out.update({'terms/D': D.numpy(), 'terms/M': M.numpy(), 'terms/J': J.numpy(), 'terms/phi': phi.numpy(),
+                'terms/a': a.numpy()})
+
+    # --- loss through the caller's wrapper (A17) and gradients --------------------------
+    system.solver.calls.clear()
+    loss_batch = system.contactnets_loss(x, u, x_plus)
+    J_M, q_s, eps, f_s = system.solver.calls[-1]
+    out.update({'loss': loss_batch.detach().numpy(), 'solver_loss/J': J_M.numpy(), 'solver_loss/q': q_s.numpy(),
+                'solver_loss/eps': eps, 'solver_loss/f': f_s.numpy()})
+    kkt = O.kkt_residuals(J_M, q_s, eps, f_s)
+    out['solver_loss/kkt'] = np.array([kkt[k].max().item() for k in ('primal', 'dual', 'complementarity')])
+    system.zero_grad()
+    mean_loss = DrakeMultibodyLearnableExperiment.contactnets_loss(None, x.unsqueeze(-2), x_plus.unsqueeze(-2),
+                                                                 system)
+    mean_loss.backward()
+    out['loss_mean'] = mean_loss.detach().numpy()
+    for key, value in named_grads(system).items():
+        out['grad/' + key] = value
+
+    # --- forward dynamics / step / simulate --------------------------------------------
+    system.solver.calls.clear()
+    q, v = system.space.q_v(x)
+    with torch.no_grad():
+        v_next = system.forward_dynamics(q, v, u)
+        J_M, q_s, eps, f_s = system.solver.calls[-1]
+        x_next, _ = system.integrator.step(x, torch.zeros(x.shape[:-1] + (1,)))
+        rows = list(range(min(8, x.shape[0]))) if sim_rows is None else sim_rows
+        x_0 = x[rows].unsqueeze(-2)
+        traj, _ = system.simulate(x_0, torch.zeros((len(rows), 1)), sim_steps)
+    kkt = O.kkt_residuals(J_M, q_s, eps, f_s)
+    out.update({'dynamics/v_next': v_next.numpy(), 'dynamics/x_next': x_next.numpy(),
+                'solver_dynamics/J': J_M.numpy(), 'solver_dynamics/q': q_s.numpy(), 'solver_dynamics/eps': eps,
+                'solver_dynamics/f': f_s.numpy(),
+                'solver_dynamics/kkt': np.array([kkt[k].max().item()
+                                                 for k in ('primal', 'dual', 'complementarity')]),
+                'simulate/rows': np.array(rows), 'simulate/steps': sim_steps, 'simulate/traj': traj.numpy()})
+    os.makedirs(GOLDEN, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print(f'{name}: B={x.shape[0]} loss mean {float(mean_loss):.6e} kkt(loss) {out["solver_loss/kkt"]} '
+          f'kkt(dyn) {out["solver_dynamics/kkt"]}')
+
+
+def cube_pairs(files, stride: int = 1):
+    """(x, x_plus) pairs exactly as TrajectorySliceDataset builds them
+    (reference dataset_management.py:43-59 with the default TrajectorySliceConfig)."""
+    dataset = TrajectorySliceDataset(TrajectorySliceConfig())
+    for index in files:
+        dataset.add_slices_from_trajectory(torch.load(os.path.join(ASSETS, 'contactnets_cube', f'{index}.pt')))
+    past = torch.stack(dataset.previous_states_slices)[::stride]
+    future = torch.stack(dataset.future_states_slices)[::stride]
+    return past[..., -1, :].clone(), future[..., 0, :].clone()
+
+
+def elbow_pairs(n_traj: int = 6, steps: int = 120, keep_every: int = 5, seed: int = 0):
+    """Synthetic elbow tosses: initial states drawn like UniformSampler(space, ELBOW_SAMPLER_RANGE,
+    ELBOW_X_0) (reference state_space.py:900-948, examples/contactnets_simple.py:60-67) and
+    rolled out with the reference's own simulate on the stub-built system."""
+    system, _ = build_reference_system(os.path.join(ASSETS, 'contactnets_elbow.urdf'), 'reference_literal')
+    x_0 = torch.tensor([1., 0., 0., 0., 0., 0., 0.21 + .015, np.pi, 0., 0., 0., 0., 0., -.075, 0.])
+    ranges = torch.tensor([2 * np.pi, 2 * np.pi, 2 * np.pi, .03, .03, .015, np.pi, 6., 6., 6., .5, .5, .075, 6.])
+    gen = torch.Generator().manual_seed(seed)
+    space = system.space
+    xs, xps = [], []
+    with torch.no_grad():
+        for _ in range(n_traj):
+            delta = (2 * torch.rand(ranges.shape, generator=gen) - 1) * ranges
+            start = space.shift_state(x_0.unsqueeze(0), delta.unsqueeze(0))
+            traj, _ = system.simulate(start.unsqueeze(-2), torch.zeros((1, 1)), steps)
+            traj = traj[0]
+            xs.append(traj[:-1][::keep_every])
+            xps.append(traj[1:][::keep_every])
+    return torch.cat(xs).clone(), torch.cat(xps).clone()
+
+
+def record_bench_batch(name: str, n_pairs: int = 4096, seed: int = 0) -> None:
+    """BASELINE configs[1] inputs: ``n_pairs`` of the 57,812 real cube (x, x+) pairs,
+    torch.Generator().manual_seed(seed) randperm; expected loss / gradients from the reference run."""
+    cube = os.path.join(ASSETS, 'contactnets_cube.urdf')
+    x_all, xp_all = cube_pairs(range(550))
+    pick = torch.randperm(x_all.shape[0], generator=torch.Generator().manual_seed(seed))[:n_pairs]
+    x, x_plus = x_all[pick].clone(), xp_all[pick].clone()
+    system, _ = build_reference_system(cube, 'reference_literal')
+    u = torch.zeros(x.shape[:-1] + (0,))
+    loss = system.contactnets_loss(x, u, x_plus)
+    system.zero_grad()
+    loss.mean().backward()
+    out = {'urdf': os.path.basename(cube), 'dt': DT, 'inertia_mode': 'reference_literal', 'n_total_pairs': x_all.shape[0],
+           'x': x.numpy(), 'x_plus': x_plus.numpy(), 'loss': loss.detach().numpy(),
+           'loss_mean': loss.mean().detach().numpy()}
+    for key, value in named_values(system).items():
+        out['param/' + key] = value
+    for key, value in named_grads(system).items():
+        out['grad/' + key] = value
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print(f'{name}: {n_pairs} of {x_all.shape[0]} pairs, loss mean {loss.mean().item():.6e}')
+
+
+def main() -> None:
+    cube = os.path.join(ASSETS, 'contactnets_cube.urdf')
+    record_bench_batch('cube_box_4096')
+    x, xp = cube_pairs([0, 1, 2])
+    record_case('cube_box_literal', cube, x, xp, 'reference_literal')
+    record_case('cube_box_physical', cube, x[::4], xp[::4], 'physical')
+    record_case('cube_box_config1', cube, x[:1], xp[:1], 'reference_literal')  # BASELINE configs[0]
+    ex, exp_ = elbow_pairs()
+    record_case('elbow_box_literal', os.path.join(ASSETS, 'contactnets_elbow.urdf'), ex, exp_, 'reference_literal')
+    mx, mxp = cube_pairs([3], stride=2)
+    record_case('cube_mesh_literal', os.path.join(ASSETS, 'contactnets_cube_mesh.urdf'), mx, mxp,
+                'reference_literal')
+
+
+if __name__ == '__main__':
+    main()
