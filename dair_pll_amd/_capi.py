@@ -1,0 +1,106 @@
+"""ctypes binding of ``libdpll_hip.so`` (``include/dpll.h``).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+from typing import Optional
+
+from .urdf import ModelSpec, check_supported
+
+MAX_JOINTS = 2
+MAX_BODIES = 3
+F32, F64 = 0, 1
+INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libdpll_hip.so')
+
+
+class ModelDesc(ctypes.Structure):
+    """``dpll_model_desc_t``"""
+    _fields_ = [('n_joints', c_int32), ('inertia_mode', c_int32), ('dt', c_double), ('gravity_z', c_double),
+                ('joint_origin', (c_double * 3) * MAX_JOINTS), ('joint_axis', (c_double * 3) * MAX_JOINTS),
+                ('geom_origin', (c_double * 3) * MAX_BODIES)]
+
+
+class SolverOpts(ctypes.Structure):
+    """``dpll_solver_opts_t``"""
+    _fields_ = [('max_iter', c_int32), ('max_ls', c_int32), ('tol', c_double), ('stall_tol', c_double),
+                ('ls_tol', c_double)]
+
+
+class Params(ctypes.Structure):
+    """``dpll_params_t``"""
+    _fields_ = [('theta', c_void_p), ('friction', c_void_p), ('lengths', c_void_p)]
+
+
+def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal') -> ModelDesc:
+    check_supported(spec)
+    desc = ModelDesc()
+    desc.n_joints = spec.n_joints
+    desc.inertia_mode = INERTIA_MODES[inertia_mode]
+    desc.dt = dt
+    desc.gravity_z = spec.gravity_z
+    for index, body in enumerate(spec.bodies):
+        for axis in range(3):
+            desc.geom_origin[index][axis] = body.geoms[0].origin[axis]
+            if index > 0:
+                desc.joint_origin[index - 1][axis] = body.joint_origin[axis]
+                desc.joint_axis[index - 1][axis] = body.joint_axis[axis]
+    return desc
+
+
+class DpllError(RuntimeError):
+    pass
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def library() -> ctypes.CDLL:
+    """Loads the HIP library or raises -- callers never get a silent fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpllError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        f'or `make -C {os.path.join(_HERE, "csrc")}`; there is no CPU fallback')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.dpll_last_error.restype = c_char_p
+    lib.dpll_abi_version.restype = c_int
+    lib.dpll_model_create.argtypes = [POINTER(ModelDesc), POINTER(c_void_p)]
+    lib.dpll_model_destroy.argtypes = [c_void_p]
+    lib.dpll_model_destroy.restype = None
+    lib.dpll_model_set_solver.argtypes = [c_void_p, c_int, POINTER(SolverOpts)]
+    lib.dpll_model_get_solver.argtypes = [c_void_p, c_int, POINTER(SolverOpts)]
+    for name in ('dpll_n_x', 'dpll_n_contacts', 'dpll_param_count'):
+        getattr(lib, name).argtypes = [c_void_p]
+    lib.dpll_workspace_bytes.argtypes = [c_void_p, c_int64]
+    lib.dpll_workspace_bytes.restype = c_int64
+    lib.dpll_contactnets_loss.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64,
+                                          c_int64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_void_p]
+    lib.dpll_step.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                              c_void_p, c_void_p]
+    lib.dpll_simulate.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                  c_void_p]
+    lib.dpll_terms.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        message = library().dpll_last_error()
+        raise DpllError(f'dpll call failed ({status}): {message.decode() if message else "?"}')
+
+
+EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_model_destroy',
+                    'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
+                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_step', 'dpll_simulate',
+                    'dpll_terms']

@@ -1,0 +1,1043 @@
+// dpll_core.hpp -- per-trajectory-item math of the contact-dynamics hot path.
+//
+// Everything here is straight-line, fully unrolled, register-resident arithmetic for ONE batch item,
+// written so that a group of G lanes (one lane per contact on the GPU, G = 1 in the host-side
+// sanitizer build under tests/hostsim) cooperates on the item: per-contact quantities live in the
+// lane that owns the contact, the small dense blocks (M, Hessian, Cholesky factors; n_v = 6..8) are
+// replicated across the group, and sums over contacts go through `Lanes::group_sum`.
+//
+// What is computed follows dair_pll (file:line under /root/reference/dair_pll):
+//   * MultibodyTerms.forward                multibody_terms.py:584-609
+//   * LagrangianTerms.forward               multibody_terms.py:214-237 (M, M^-1 F; definitions :123-157)
+//   * ContactTerms.forward                  multibody_terms.py:428-521 (phi, J; plane-vs-box geometry.py:554-582)
+//   * InertialParameterConverter            inertia.py:206-234, 305-331, 377-382
+//   * contactnets_loss                      multibody_learnable_system.py:104-197
+//   * forward_dynamics                      multibody_learnable_system.py:199-304
+//   * VelocityIntegrator.step / exponential integrator.py:153-162, state_space.py:466-486, quaternion.py:89-147,276-309
+// The cone QP that dair_pll delegates to sappy.SAPSolver is solved here by a semi-smooth Newton
+// method on its unconstrained primal, in generalized-velocity coordinates (see sap_newton).
+//
+// The design does NOT mirror the reference's tensor graph: there is no D = J M^-1 J^T, no M^-1, no
+// J matrix in memory; the backward pass is a hand-derived adjoint that emits gradients with respect
+// to the per-body inertial 10-vectors, the pair friction coefficients and the box half lengths, which
+// are reduced over the batch on chip and chained to the learnable parameters once per launch.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DPLL_HD __host__ __device__ __forceinline__
+#else
+#define DPLL_HD inline __attribute__((always_inline))
+#endif
+
+#define DPLL_UNROLL _Pragma("unroll")
+
+namespace dpll {
+
+constexpr int kMaxJoints = 2;   // revolute joints in a serial chain hanging off the floating base
+constexpr int kMaxBodies = kMaxJoints + 1;
+constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
+constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
+
+// Plain-old-data model description, passed to kernels by value.
+struct ModelDesc {
+  int32_t n_joints;
+  int32_t inertia_mode;  // 0: reference_literal (rotational inertia taken as I_cm / m), 1: physical
+  double dt;
+  double gravity_z;
+  double joint_origin[kMaxJoints][3];  // joint j+1 frame origin in the parent body frame
+  double joint_axis[kMaxJoints][3];    // unit axis, same in parent and child frames
+  double geom_origin[kMaxBodies][3];   // one convex geometry per body: its origin in the body frame
+};
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T> DPLL_HD T tsqrt(T x) { return sqrt(x); }
+template <> DPLL_HD float tsqrt<float>(float x) { return sqrtf(x); }
+template <typename T> DPLL_HD T tabs(T x) { return x < T(0) ? -x : x; }
+template <typename T> DPLL_HD T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> DPLL_HD T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> DPLL_HD T texp(T x) { return exp(x); }
+template <> DPLL_HD float texp<float>(float x) { return expf(x); }
+template <typename T> DPLL_HD void tsincos(T x, T& s, T& c) { s = sin(x); c = cos(x); }
+template <> DPLL_HD void tsincos<float>(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
+
+DPLL_HD bool bad_number(float x) {
+  uint32_t u; __builtin_memcpy(&u, &x, 4);
+  return (u & 0x7f800000u) == 0x7f800000u;  // inf or nan
+}
+DPLL_HD bool bad_number(double x) {
+  uint64_t u; __builtin_memcpy(&u, &x, 8);
+  return (u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+}
+
+template <typename T> DPLL_HD void cross(const T (&a)[3], const T (&b)[3], T (&c)[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T> DPLL_HD T dot3(const T (&a)[3], const T (&b)[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// y = A x, y = A^T x for 3x3
+template <typename T> DPLL_HD void mat3_vec(const T (&A)[3][3], const T (&x)[3], T (&y)[3]) {
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) y[i] = A[i][0] * x[0] + A[i][1] * x[1] + A[i][2] * x[2];
+}
+template <typename T> DPLL_HD void mat3t_vec(const T (&A)[3][3], const T (&x)[3], T (&y)[3]) {
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) y[i] = A[0][i] * x[0] + A[1][i] * x[1] + A[2][i] * x[2];
+}
+template <typename T> DPLL_HD void mat3_mul(const T (&A)[3][3], const T (&B)[3][3], T (&C)[3][3]) {
+  DPLL_UNROLL for (int i = 0; i < 3; ++i)
+    DPLL_UNROLL for (int j = 0; j < 3; ++j) C[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+}
+// symmetric 3x3 stored as (xx,yy,zz,xy,xz,yz) times vector
+template <typename T> DPLL_HD void sym3_vec(const T* s, const T (&x)[3], T (&y)[3]) {
+  y[0] = s[0] * x[0] + s[3] * x[1] + s[4] * x[2];
+  y[1] = s[3] * x[0] + s[1] * x[1] + s[5] * x[2];
+  y[2] = s[4] * x[0] + s[5] * x[1] + s[2] * x[2];
+}
+
+// quaternion.rotate as a matrix: homogeneous quadratic in the quaternion, NOT normalised
+// (quaternion.py:150-164; quirk Q2 in DESIGN.md).
+template <typename T> DPLL_HD void quat_to_rot(const T* q, T (&R)[3][3]) {
+  const T w = q[0], x = q[1], y = q[2], z = q[3];
+  const T ww = w * w, xx = x * x, yy = y * y, zz = z * z;
+  R[0][0] = ww + xx - yy - zz; R[0][1] = T(2) * (x * y - w * z); R[0][2] = T(2) * (x * z + w * y);
+  R[1][0] = T(2) * (x * y + w * z); R[1][1] = ww - xx + yy - zz; R[1][2] = T(2) * (y * z - w * x);
+  R[2][0] = T(2) * (x * z - w * y); R[2][1] = T(2) * (y * z + w * x); R[2][2] = ww - xx - yy + zz;
+}
+
+// Rodrigues rotation about a unit axis.
+template <typename T> DPLL_HD void axis_rot(const T (&k)[3], T angle, T (&R)[3][3]) {
+  T s, c; tsincos(angle, s, c);
+  const T v = T(1) - c;
+  R[0][0] = c + k[0] * k[0] * v;        R[0][1] = k[0] * k[1] * v - k[2] * s; R[0][2] = k[0] * k[2] * v + k[1] * s;
+  R[1][0] = k[1] * k[0] * v + k[2] * s; R[1][1] = c + k[1] * k[1] * v;        R[1][2] = k[1] * k[2] * v - k[0] * s;
+  R[2][0] = k[2] * k[0] * v - k[1] * s; R[2][1] = k[2] * k[1] * v + k[0] * s; R[2][2] = c + k[2] * k[2] * v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inertial parameterisation: theta (log-Cholesky, 10) -> iota = [m, h = m c, I_o_eff] about the
+// body origin.  Generic in the scalar type so that the finalize kernel can push dual numbers
+// through it.  inertia.py:206-234 (theta_to_pi_o), :305-331 (pi_o_to_pi_cm), :377-382 (I_cm / m).
+// ---------------------------------------------------------------------------------------------
+template <typename S> DPLL_HD S s_exp(const S& x);
+template <> DPLL_HD float s_exp<float>(const float& x) { return expf(x); }
+template <> DPLL_HD double s_exp<double>(const double& x) { return exp(x); }
+
+template <typename S> DPLL_HD void theta_to_iota(const S (&th)[10], int inertia_mode, S (&iota)[kIota]) {
+  const S &alpha = th[0], &d1 = th[1], &d2 = th[2], &d3 = th[3], &s12 = th[4], &s23 = th[5], &s13 = th[6],
+          &t1 = th[7], &t2 = th[8], &t3 = th[9];
+  const S e1 = s_exp(d1), e2 = s_exp(d2), e3 = s_exp(d3);
+  const S sc = s_exp(alpha + alpha);
+  // pi_o = [m, m c, I_o(xx,yy,zz,xy,xz,yz)]
+  const S m = sc * (t1 * t1 + t2 * t2 + t3 * t3 + S(1));
+  const S h0 = sc * (t1 * e1), h1 = sc * (t1 * s12 + t2 * e2), h2 = sc * (t1 * s13 + t2 * s23 + t3 * e3);
+  const S oxx = sc * (s12 * s12 + s23 * s23 + s13 * s13 + e2 * e2 + e3 * e3);
+  const S oyy = sc * (s13 * s13 + s23 * s23 + e1 * e1 + e3 * e3);
+  const S ozz = sc * (s12 * s12 + e1 * e1 + e2 * e2);
+  const S oxy = sc * (S(0) - s12 * e1), oxz = sc * (S(0) - s13 * e1), oyz = sc * (S(0) - s12 * s13 - s23 * e2);
+  iota[0] = m; iota[1] = h0; iota[2] = h1; iota[3] = h2;
+  if (inertia_mode == 1) {  // physical: rotational inertia about the origin is pi_o's own
+    iota[4] = oxx; iota[5] = oyy; iota[6] = ozz; iota[7] = oxy; iota[8] = oxz; iota[9] = oyz;
+    return;
+  }
+  // reference_literal: central inertia I_cm = I_o + m S(c)^2 is divided by m, then shifted back to
+  // the origin with the true mass: I_eff = I_cm / m - m S(c)^2 = I_o / m + (1 - m) S(c)^2 ... written
+  // out with S(c)^2 = c c^T - |c|^2 1.
+  const S c0 = h0 / m, c1 = h1 / m, c2 = h2 / m;
+  const S cc = c0 * c0 + c1 * c1 + c2 * c2;
+  const S k = S(1) - m;  // coefficient of S(c)^2
+  const S im = S(1) / m;
+  iota[4] = oxx * im + k * (c0 * c0 - cc);
+  iota[5] = oyy * im + k * (c1 * c1 - cc);
+  iota[6] = ozz * im + k * (c2 * c2 - cc);
+  iota[7] = oxy * im + k * (c0 * c1);
+  iota[8] = oxz * im + k * (c0 * c2);
+  iota[9] = oyz * im + k * (c1 * c2);
+}
+
+// spatial inertia applied to a motion vector (w, u):  n = I_o w + h x u,  f = m u - h x w
+template <typename T>
+DPLL_HD void inertia_apply(const T (&io)[kIota], const T (&w)[3], const T (&u)[3], T (&n)[3], T (&f)[3]) {
+  const T h[3] = {io[1], io[2], io[3]};
+  T hw[3], hu[3];
+  cross(h, w, hw);
+  cross(h, u, hu);
+  sym3_vec(&io[4], w, n);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { n[i] += hu[i]; f[i] = io[0] * u[i] - hw[i]; }
+}
+
+// gradient of coef * Y^T I6 Z with respect to iota, accumulated into g
+template <typename T>
+DPLL_HD void inertia_bilinear_grad(T coef, const T (&yw)[3], const T (&yu)[3], const T (&zw)[3], const T (&zu)[3],
+                                   T (&g)[kIota]) {
+  T a[3], b[3];
+  cross(zu, yw, a);
+  cross(yu, zw, b);
+  g[0] += coef * dot3(yu, zu);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) g[1 + i] += coef * (a[i] + b[i]);
+  g[4] += coef * (yw[0] * zw[0]);
+  g[5] += coef * (yw[1] * zw[1]);
+  g[6] += coef * (yw[2] * zw[2]);
+  g[7] += coef * (yw[0] * zw[1] + yw[1] * zw[0]);
+  g[8] += coef * (yw[0] * zw[2] + yw[2] * zw[0]);
+  g[9] += coef * (yw[1] * zw[2] + yw[2] * zw[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// chain kinematics
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NJ> struct Kin {
+  static constexpr int NB = NJ + 1;
+  T R[NB][3][3];    // world <- body
+  T o[NB][3];       // body origin in the world
+  T Rpc[NB][3][3];  // parent <- child (index >= 1)
+  T pj[NB][3];      // joint origin in the parent frame (index >= 1)
+  T ax[NB][3];      // joint axis in body coordinates (index >= 1)
+  T axw[NB][3];     // joint axis in the world (index >= 1)
+};
+
+template <typename T, int NJ> DPLL_HD void kinematics(const ModelDesc& md, const T* q, Kin<T, NJ>& k) {
+  quat_to_rot(q, k.R[0]);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) k.o[0][i] = q[4 + i];
+  DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { k.pj[j][i] = T(md.joint_origin[j - 1][i]); k.ax[j][i] = T(md.joint_axis[j - 1][i]); }
+    axis_rot(k.ax[j], q[7 + j - 1], k.Rpc[j]);
+    mat3_mul(k.R[j - 1], k.Rpc[j], k.R[j]);
+    T t[3];
+    mat3_vec(k.R[j - 1], k.pj[j], t);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) k.o[j][i] = k.o[j - 1][i] + t[i];
+    mat3_vec(k.R[j], k.ax[j], k.axw[j]);
+  }
+}
+
+// Body-frame spatial velocities Y_b = S_b y (angular; linear at the body origin) for a generalized
+// velocity y = [omega_body(3), v_world(3), joint rates]  (state_space.py:412-424).
+template <typename T, int NJ>
+DPLL_HD void body_twists(const Kin<T, NJ>& k, const T* y, T (&Yw)[NJ + 1][3], T (&Yu)[NJ + 1][3]) {
+  const T vl[3] = {y[3], y[4], y[5]};
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) Yw[0][i] = y[i];
+  mat3t_vec(k.R[0], vl, Yu[0]);
+  DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+    T wxp[3], t[3];
+    cross(Yw[j - 1], k.pj[j], wxp);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = Yu[j - 1][i] + wxp[i];
+    mat3t_vec(k.Rpc[j], t, Yu[j]);
+    mat3t_vec(k.Rpc[j], Yw[j - 1], t);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) Yw[j][i] = t[i] + k.ax[j][i] * y[6 + j - 1];
+  }
+}
+
+// Mass matrix by the composite-rigid-body recursion on the 10-vector representation
+// (equals gamma^T M_drake gamma of multibody_terms.py:131).  Full symmetric NV x NV.
+template <typename T, int NJ>
+DPLL_HD void mass_matrix(const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], T (&M)[6 + NJ][6 + NJ]) {
+  constexpr int NB = NJ + 1;
+  T comp[NB][kIota];
+  DPLL_UNROLL for (int b = 0; b < NB; ++b)
+    DPLL_UNROLL for (int i = 0; i < kIota; ++i) comp[b][i] = iota[b][i];
+  DPLL_UNROLL for (int j = NJ; j >= 1; --j) {
+    // joint column: F = I^c_j s_j with s_j = (axis, 0)
+    T n[3], f[3];
+    const T zero[3] = {T(0), T(0), T(0)};
+    inertia_apply(comp[j], k.ax[j], zero, n, f);
+    M[6 + j - 1][6 + j - 1] = dot3(k.ax[j], n);
+    DPLL_UNROLL for (int a = j; a >= 1; --a) {
+      // transform the wrench from body a to its parent a-1
+      T rn[3], rf[3], pxf[3];
+      mat3_vec(k.Rpc[a], n, rn);
+      mat3_vec(k.Rpc[a], f, rf);
+      cross(k.pj[a], rf, pxf);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) { n[i] = rn[i] + pxf[i]; f[i] = rf[i]; }
+      if (a - 1 >= 1) {
+        const T val = dot3(k.ax[a - 1], n);
+        M[6 + a - 2][6 + j - 1] = val;
+        M[6 + j - 1][6 + a - 2] = val;
+      }
+    }
+    T wf[3];
+    mat3_vec(k.R[0], f, wf);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+      M[i][6 + j - 1] = n[i]; M[6 + j - 1][i] = n[i];
+      M[3 + i][6 + j - 1] = wf[i]; M[6 + j - 1][3 + i] = wf[i];
+    }
+    // fold body j's composite inertia into its parent: rotate, then shift the origin by pj
+    const T hc_child[3] = {comp[j][1], comp[j][2], comp[j][3]};
+    T hc[3];
+    mat3_vec(k.Rpc[j], hc_child, hc);
+    const T I[3][3] = {{comp[j][4], comp[j][7], comp[j][8]}, {comp[j][7], comp[j][5], comp[j][9]}, {comp[j][8], comp[j][9], comp[j][6]}};
+    T RI[3][3], RIRt[3][3];
+    mat3_mul(k.Rpc[j], I, RI);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r)
+      DPLL_UNROLL for (int c = 0; c < 3; ++c)
+        RIRt[r][c] = RI[r][0] * k.Rpc[j][c][0] + RI[r][1] * k.Rpc[j][c][1] + RI[r][2] * k.Rpc[j][c][2];
+    const T m = comp[j][0];
+    const T(&d)[3] = k.pj[j];
+    // I' = I - m S(d)^2 - S(d) S(hc) - S(hc) S(d);  S(a) S(b) = b a^T - (a.b) 1
+    const T dd = dot3(d, d), dh = dot3(d, hc);
+    T Ip[3][3];
+    DPLL_UNROLL for (int r = 0; r < 3; ++r)
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+        const T delta = (r == c) ? T(1) : T(0);
+        Ip[r][c] = RIRt[r][c] - m * (d[r] * d[c] - dd * delta) - (hc[r] * d[c] + d[r] * hc[c] - T(2) * dh * delta);
+      }
+    comp[j - 1][0] += m;
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) comp[j - 1][1 + i] += hc[i] + m * d[i];
+    comp[j - 1][4] += Ip[0][0]; comp[j - 1][5] += Ip[1][1]; comp[j - 1][6] += Ip[2][2];
+    comp[j - 1][7] += Ip[0][1]; comp[j - 1][8] += Ip[0][2]; comp[j - 1][9] += Ip[1][2];
+  }
+  // base block [[I_o, S(h) R^T],[R S(h)^T, m 1]]
+  const T(&c0)[kIota] = comp[0];
+  M[0][0] = c0[4]; M[1][1] = c0[5]; M[2][2] = c0[6];
+  M[0][1] = M[1][0] = c0[7]; M[0][2] = M[2][0] = c0[8]; M[1][2] = M[2][1] = c0[9];
+  const T Sh[3][3] = {{T(0), -c0[3], c0[2]}, {c0[3], T(0), -c0[1]}, {-c0[2], c0[1], T(0)}};
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+      // (S(h) R^T)[r][c] = sum_k Sh[r][k] R[c][k]
+      const T val = Sh[r][0] * k.R[0][c][0] + Sh[r][1] * k.R[0][c][1] + Sh[r][2] * k.R[0][c][2];
+      M[r][3 + c] = val; M[3 + c][r] = val;
+      M[3 + r][3 + c] = (r == c) ? c0[0] : T(0);
+    }
+}
+
+// Non-contact generalized force F(q, v) = gamma^T(-C + tau_g) (multibody_terms.py:142-146, n_u = 0)
+// by recursive Newton-Euler at zero generalized acceleration.  Also returns the body twists V and
+// the bias-minus-gravity spatial accelerations AG = A_b - G_b needed by the backward pass.
+template <typename T, int NJ>
+DPLL_HD void bias_forces(const ModelDesc& md, const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], const T* v,
+                         T (&F)[6 + NJ], T (&Vw)[NJ + 1][3], T (&Vu)[NJ + 1][3], T (&AGw)[NJ + 1][3],
+                         T (&AGu)[NJ + 1][3]) {
+  constexpr int NB = NJ + 1;
+  body_twists<T, NJ>(k, v, Vw, Vu);
+  T Aw[NB][3], Au[NB][3];
+  {
+    T wxu[3];
+    cross(Vw[0], Vu[0], wxu);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { Aw[0][i] = T(0); Au[0][i] = -wxu[i]; }
+  }
+  DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+    T wxp[3], t[3], r1[3], r2[3];
+    cross(Aw[j - 1], k.pj[j], wxp);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = Au[j - 1][i] + wxp[i];
+    mat3t_vec(k.Rpc[j], t, r2);
+    mat3t_vec(k.Rpc[j], Aw[j - 1], r1);
+    const T rate = v[6 + j - 1];
+    T sr[3], c1[3], c2[3];
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) sr[i] = k.ax[j][i] * rate;
+    cross(Vw[j], sr, c1);
+    cross(Vu[j], sr, c2);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { Aw[j][i] = r1[i] + c1[i]; Au[j][i] = r2[i] + c2[i]; }
+  }
+  const T gw[3] = {T(0), T(0), T(md.gravity_z)};
+  T Wn[NB][3], Wf[NB][3];
+  DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+    T gb[3];
+    mat3t_vec(k.R[b], gw, gb);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { AGw[b][i] = Aw[b][i]; AGu[b][i] = Au[b][i] - gb[i]; }
+    T n1[3], f1[3], hn[3], hf[3];
+    inertia_apply(iota[b], AGw[b], AGu[b], n1, f1);
+    inertia_apply(iota[b], Vw[b], Vu[b], hn, hf);
+    // V x* (n, f) = (w x n + u x f, w x f)
+    T a1[3], a2[3], a3[3];
+    cross(Vw[b], hn, a1);
+    cross(Vu[b], hf, a2);
+    cross(Vw[b], hf, a3);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { Wn[b][i] = n1[i] + a1[i] + a2[i]; Wf[b][i] = f1[i] + a3[i]; }
+  }
+  DPLL_UNROLL for (int j = NJ; j >= 1; --j) {
+    F[6 + j - 1] = -dot3(k.ax[j], Wn[j]);
+    T rn[3], rf[3], pxf[3];
+    mat3_vec(k.Rpc[j], Wn[j], rn);
+    mat3_vec(k.Rpc[j], Wf[j], rf);
+    cross(k.pj[j], rf, pxf);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { Wn[j - 1][i] += rn[i] + pxf[i]; Wf[j - 1][i] += rf[i]; }
+  }
+  T wf[3];
+  mat3_vec(k.R[0], Wf[0], wf);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { F[i] = -Wn[0][i]; F[3 + i] = -wf[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense symmetric positive definite N x N: Cholesky (lower), solves
+// ---------------------------------------------------------------------------------------------
+template <typename T, int N> DPLL_HD void cholesky(const T (&A)[N][N], T (&L)[N][N], T (&invd)[N]) {
+  DPLL_UNROLL for (int j = 0; j < N; ++j) {
+    T s = A[j][j];
+    DPLL_UNROLL for (int p = 0; p < j; ++p) s -= L[j][p] * L[j][p];
+    const T d = tsqrt(s);
+    const T id = T(1) / d;
+    L[j][j] = d;
+    invd[j] = id;
+    DPLL_UNROLL for (int i = j + 1; i < N; ++i) {
+      T t = A[i][j];
+      DPLL_UNROLL for (int p = 0; p < j; ++p) t -= L[i][p] * L[j][p];
+      L[i][j] = t * id;
+    }
+  }
+}
+template <typename T, int N>
+DPLL_HD void chol_solve(const T (&L)[N][N], const T (&invd)[N], const T (&b)[N], T (&x)[N]) {
+  T y[N];
+  DPLL_UNROLL for (int i = 0; i < N; ++i) {
+    T s = b[i];
+    DPLL_UNROLL for (int p = 0; p < i; ++p) s -= L[i][p] * y[p];
+    y[i] = s * invd[i];
+  }
+  DPLL_UNROLL for (int i = N - 1; i >= 0; --i) {
+    T s = y[i];
+    DPLL_UNROLL for (int p = i + 1; p < N; ++p) s -= L[p][i] * x[p];
+    x[i] = s * invd[i];
+  }
+}
+template <typename T, int N> DPLL_HD void symv(const T (&A)[N][N], const T (&x)[N], T (&y)[N]) {
+  DPLL_UNROLL for (int i = 0; i < N; ++i) {
+    T s = T(0);
+    DPLL_UNROLL for (int j = 0; j < N; ++j) s += A[i][j] * x[j];
+    y[i] = s;
+  }
+}
+template <typename T, int N> DPLL_HD T dotn(const T (&a)[N], const T (&b)[N]) {
+  T s = T(0);
+  DPLL_UNROLL for (int i = 0; i < N; ++i) s += a[i] * b[i];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// contacts: box vs ground half-space (geometry.py:554-582, :162-202, :393-403)
+// ---------------------------------------------------------------------------------------------
+// The `slot`-th (0..3) of the four box corners with the largest support value in body direction d
+// (the reference's torch.topk(sorted=False) leaves the order of the four unspecified, quirk Q3).
+// With a_i = |d_i| h_i sorted a1 >= a2 >= a3 the four best corners are: all signs aligned with d;
+// smallest flipped; middle flipped; and either largest flipped (a1 < a2 + a3) or both smaller ones.
+template <typename T> DPLL_HD void box_corner_signs(const T (&d)[3], const T (&habs)[3], int slot, T (&sgn)[3]) {
+  const T a[3] = {tabs(d[0]) * habs[0], tabs(d[1]) * habs[1], tabs(d[2]) * habs[2]};
+  // rank[i] = number of entries strictly larger (ties broken by index) -> 0 largest .. 2 smallest
+  int rank[3];
+  rank[0] = (a[1] > a[0]) + (a[2] > a[0]);
+  rank[1] = (a[0] >= a[1]) + (a[2] > a[1]);
+  rank[2] = (a[0] >= a[2]) + (a[1] >= a[2]);
+  T amax = T(0), arest = T(0);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { amax = (rank[i] == 0) ? a[i] : amax; arest += (rank[i] == 0) ? T(0) : a[i]; }
+  const bool flip_largest = amax < arest;
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+    bool flip = false;
+    flip = flip || (slot == 1 && rank[i] == 2);
+    flip = flip || (slot == 2 && rank[i] == 1);
+    flip = flip || (slot == 3 && (flip_largest ? rank[i] == 0 : rank[i] != 0));
+    const T s = (d[i] < T(0)) ? T(-1) : T(1);
+    sgn[i] = flip ? -s : s;
+  }
+}
+
+// Rows of the contact-point Jacobian (world = contact frame, ground kinematics are identically
+// zero) for a point `pt` rigidly attached to body `b`:  Jp = [ -S(pt - o_0) R_0, 1, a_i x (pt - o_i) ... ]
+// (multibody_terms.py:385-399 with tensor_utils.py:257-302, restated in closed form).
+template <typename T, int NJ>
+DPLL_HD void contact_jacobian(const Kin<T, NJ>& k, int b, const T (&pt)[3], T (&Jp)[3][6 + NJ]) {
+  T d0[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) d0[i] = pt[i] - k.o[0][i];
+  DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+    const T col[3] = {k.R[0][0][c], k.R[0][1][c], k.R[0][2][c]};
+    T x[3];
+    cross(col, d0, x);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) { Jp[r][c] = x[r]; Jp[r][3 + c] = (r == c) ? T(1) : T(0); }
+  }
+  DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+    T dj[3], x[3];
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dj[i] = pt[i] - k.o[j][i];
+    cross(k.axw[j], dj, x);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) Jp[r][6 + j - 1] = (j <= b) ? x[r] : T(0);
+  }
+}
+
+// world angular velocity of body b under generalized velocity y
+template <typename T, int NJ> DPLL_HD void world_omega(const Kin<T, NJ>& k, int b, const T* y, T (&w)[3]) {
+  const T yb[3] = {y[0], y[1], y[2]};
+  mat3_vec(k.R[0], yb, w);
+  DPLL_UNROLL for (int j = 1; j <= NJ; ++j)
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) w[i] += (j <= b) ? k.axw[j][i] * y[6 + j - 1] : T(0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lorentz-cone projection, z = [t_x, t_y, n] (tensor_utils.py:460-497 ordering), unit cone
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Proj {
+  T g[3];       // projection
+  T that[2];    // unit tangential direction (mid region)
+  T ratio;      // s / r in the mid region
+  int region;   // 0 inside (identity), 1 polar (zero), 2 mid
+};
+template <typename T> DPLL_HD void lorentz_project(const T (&z)[3], Proj<T>& p) {
+  const T r = tsqrt(z[0] * z[0] + z[1] * z[1]);
+  const T n = z[2];
+  const bool inside = r <= n;
+  const bool polar = (r <= -n) && !inside;
+  const T safe = r > T(0) ? r : T(1);
+  const T ir = T(1) / safe;
+  const T s = T(0.5) * (n + r);
+  p.that[0] = z[0] * ir;
+  p.that[1] = z[1] * ir;
+  p.ratio = s * ir;
+  p.region = inside ? 0 : (polar ? 1 : 2);
+  p.g[0] = inside ? z[0] : (polar ? T(0) : p.that[0] * s);
+  p.g[1] = inside ? z[1] : (polar ? T(0) : p.that[1] * s);
+  p.g[2] = inside ? z[2] : (polar ? T(0) : s);
+}
+// w^T dP w for the generalised Jacobian dP of the projection
+template <typename T> DPLL_HD T proj_quadratic(const Proj<T>& p, const T (&w)[3]) {
+  const T full = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const T a = -p.that[1] * w[0] + p.that[0] * w[1];
+  const T b = p.that[0] * w[0] + p.that[1] * w[1] + w[2];
+  const T mid = p.ratio * a * a + T(0.5) * b * b;
+  return p.region == 0 ? full : (p.region == 1 ? T(0) : mid);
+}
+// dP as a symmetric 3x3 (xx, yy, zz, xy, xz, yz)
+template <typename T> DPLL_HD void proj_jacobian(const Proj<T>& p, T (&d)[6]) {
+  const T tx = p.that[0], ty = p.that[1], ra = p.ratio;
+  const T m[6] = {ra * ty * ty + T(0.5) * tx * tx, ra * tx * tx + T(0.5) * ty * ty, T(0.5),
+                  (T(0.5) - ra) * tx * ty, T(0.5) * tx, T(0.5) * ty};
+  DPLL_UNROLL for (int i = 0; i < 6; ++i) {
+    const T ident = (i < 3) ? T(1) : T(0);
+    d[i] = p.region == 0 ? ident : (p.region == 1 ? T(0) : m[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The cone QP:  argmin_{f in K^k} 1/2 f^T (J M^-1 J^T + eps 1) f + q^T f
+// (what dair_pll asks of sappy.SAPSolver.apply(J_M, P^T q, eps), multibody_learnable_system.py:181-184,
+// 295-298, with J_M J_M^T = J M^-1 J^T).  Solved on the equivalent unconstrained primal in the
+// generalized velocity y:
+//      l(y) = 1/2 y^T M y + eps/2 sum_c |P_K(-(J_c y + q_c)/eps)|^2,    f_c = P_K(-(J_c y* + q_c)/eps),
+// whose minimiser satisfies M y* = J^T f, i.e. y* = M^-1 J^T f is exactly the velocity change the
+// loss and the dynamics need.  Semi-smooth Newton with an exact (derivative-based, safeguarded)
+// line search; Newton is affine invariant so the iterates coincide with those of the whitened
+// problem the reference hands to its solver.  TA is the accumulation type of the cone residual
+// J y + q (its O(1) terms cancel to O(eps |f|), so float kernels carry y and that residual in double).
+// ---------------------------------------------------------------------------------------------
+struct SolverOpts {
+  int max_iter;
+  int max_ls;
+  double tol;        // on the Newton decrement relative to 1 + |y|_M
+  double stall_tol;  // a decrement that stopped halving ends the solve only below this (rounding floor)
+  double ls_tol;     // on |l'(alpha)| relative to |l'(0)|
+};
+
+template <typename T, typename TA, int NV, int KPL, class Lanes>
+DPLL_HD int sap_newton(const T (&M)[NV][NV], const T (&Jc)[KPL][3][NV], const T (&qc)[KPL][3], T eps,
+                       const SolverOpts& opt, TA (&y)[NV], T (&f)[KPL][3]) {
+  const T ieps = T(1) / eps;
+  const T tol2 = T(opt.tol * opt.tol);
+  bool active = true;
+  int iters = 0;
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = TA(0);
+  T best = T(3.0e38);
+  int stall = 0;
+  for (int it = 0; it < opt.max_iter; ++it) {
+    // cone residuals and projections
+    T z[KPL][3];
+    Proj<T> pr[KPL];
+    T yT[NV];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) yT[i] = T(y[i]);
+    T jtg[NV];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) jtg[i] = T(0);
+    DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+      DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+        TA s = TA(qc[c][r]);
+        DPLL_UNROLL for (int i = 0; i < NV; ++i) s += TA(Jc[c][r][i]) * y[i];
+        z[c][r] = -T(s) * ieps;
+      }
+      lorentz_project(z[c], pr[c]);
+      DPLL_UNROLL for (int i = 0; i < NV; ++i)
+        jtg[i] += Jc[c][0][i] * pr[c].g[0] + Jc[c][1][i] * pr[c].g[1] + Jc[c][2][i] * pr[c].g[2];
+    }
+    T My[NV], grad[NV];
+    symv<T, NV>(M, yT, My);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) grad[i] = My[i] - Lanes::group_sum(jtg[i]);
+    // Hessian H = M + (1/eps) sum_c J_c^T dP_c J_c
+    T H[NV][NV];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i)
+      DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] = T(0);
+    DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+      T dP[6];
+      proj_jacobian(pr[c], dP);
+      T Tm[3][NV];
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) {
+        Tm[0][i] = dP[0] * Jc[c][0][i] + dP[3] * Jc[c][1][i] + dP[4] * Jc[c][2][i];
+        Tm[1][i] = dP[3] * Jc[c][0][i] + dP[1] * Jc[c][1][i] + dP[5] * Jc[c][2][i];
+        Tm[2][i] = dP[4] * Jc[c][0][i] + dP[5] * Jc[c][1][i] + dP[2] * Jc[c][2][i];
+      }
+      DPLL_UNROLL for (int i = 0; i < NV; ++i)
+        DPLL_UNROLL for (int j = 0; j <= i; ++j)
+          H[i][j] += Jc[c][0][i] * Tm[0][j] + Jc[c][1][i] * Tm[1][j] + Jc[c][2][i] * Tm[2][j];
+    }
+    DPLL_UNROLL for (int i = 0; i < NV; ++i)
+      DPLL_UNROLL for (int j = 0; j <= i; ++j) {
+        H[i][j] = M[i][j] + ieps * Lanes::group_sum(H[i][j]);
+        H[j][i] = H[i][j];
+      }
+    T L[NV][NV], invd[NV], d[NV];
+    cholesky<T, NV>(H, L, invd);
+    chol_solve<T, NV>(L, invd, grad, d);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) d[i] = -d[i];
+    // Newton decrement and stopping rule (the step below is still taken: it only improves y)
+    const T dec2 = -dotn<T, NV>(grad, d);
+    const T ynorm2 = dotn<T, NV>(yT, My);
+    const T scale = T(1) + tsqrt(tmax(ynorm2, T(0)));
+    const bool converged = !(dec2 > tol2 * scale * scale);
+    // stall detection at rounding level: decrement no longer halving
+    const bool improved = dec2 < T(0.25) * best;
+    stall = improved ? 0 : stall + 1;
+    best = tmin(best, dec2);
+    const T stol2 = T(opt.stall_tol * opt.stall_tol);
+    const bool stalled = stall >= 3 && !(dec2 > stol2 * scale * scale);
+    // exact line search on l'(alpha) = 0
+    T Md[NV];
+    symv<T, NV>(M, d, Md);
+    const T yMd = dotn<T, NV>(yT, Md);
+    const T dMd = dotn<T, NV>(d, Md);
+    T jd[KPL][3];
+    DPLL_UNROLL for (int c = 0; c < KPL; ++c)
+      DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+        T s = T(0);
+        DPLL_UNROLL for (int i = 0; i < NV; ++i) s += Jc[c][r][i] * d[i];
+        jd[c][r] = s;
+      }
+    const T slope0 = -dec2;  // l'(0) = grad . d
+    T alpha = T(1), lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
+    bool searching = active && (dec2 > T(0));
+    for (int ls = 0; ls < opt.max_ls; ++ls) {
+      if (!Lanes::wave_any(searching)) break;
+      T part1 = T(0), part2 = T(0);
+      DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+        T za[3];
+        DPLL_UNROLL for (int r = 0; r < 3; ++r) za[r] = z[c][r] - alpha * ieps * jd[c][r];
+        Proj<T> pa;
+        lorentz_project(za, pa);
+        part1 += pa.g[0] * jd[c][0] + pa.g[1] * jd[c][1] + pa.g[2] * jd[c][2];
+        part2 += proj_quadratic(pa, jd[c]);
+      }
+      const T first = yMd + alpha * dMd - Lanes::group_sum(part1);
+      const T second = dMd + ieps * Lanes::group_sum(part2);
+      bool ok = tabs(first) <= T(opt.ls_tol) * tabs(slope0);
+      const T lo_n = first < T(0) ? alpha : lo;
+      const T hi_n = first >= T(0) ? alpha : hi;
+      const T newton = alpha - first / second;
+      const T mid = hi_n < T(0) ? T(2) * alpha : T(0.5) * (lo_n + hi_n);
+      const bool bad = !((newton > lo_n) && (hi_n < T(0) || newton < hi_n));
+      const T nxt = bad ? mid : newton;
+      ok = ok || (hi_n >= T(0) && (hi_n - lo_n) <= T(4) * (sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16)) * hi_n);
+      if (searching) {
+        lo = lo_n;
+        hi = hi_n;
+        alpha = ok ? alpha : nxt;
+        searching = !ok;
+      }
+    }
+#if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
+    if (active) printf("  it %d dec2 %.3e scale %.3e alpha %.4f conv %d stall %d\n", it, double(dec2), double(scale), double(alpha), int(converged), stall);
+#endif
+    if (active) {
+      if (dec2 > T(0)) {
+        DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += TA(alpha) * TA(d[i]);
+      }
+      iters = it + 1;
+      active = !(converged || stalled);
+    }
+    if (!Lanes::wave_any(active)) break;
+  }
+  // forces at the final iterate
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    T z[3];
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      TA s = TA(qc[c][r]);
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) s += TA(Jc[c][r][i]) * y[i];
+      z[r] = -T(s) * ieps;
+    }
+    Proj<T> p;
+    lorentz_project(z, p);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) f[c][r] = p.g[r];
+  }
+  return iters;
+}
+
+// ---------------------------------------------------------------------------------------------
+// learnable parameters as the item code sees them
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NJ> struct Derived {
+  static constexpr int NB = NJ + 1;
+  T iota[NB][kIota];
+  T mu[NB];       // pair coefficient ground-vs-geometry b: 2 mu_0 mu_b / (mu_0 + mu_b), mu = |friction_params| (multibody_terms.py:321-324, :471)
+  T habs[NB][3];  // |length_params| (geometry.py:393-403)
+};
+
+template <typename T, int NJ>
+DPLL_HD void derive_params(const ModelDesc& md, const T* theta, const T* friction, const T* lengths, Derived<T, NJ>& dp) {
+  const T mu0 = tabs(friction[0]);
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
+    T th[10];
+    DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = theta[10 * b + i];
+    theta_to_iota<T>(th, md.inertia_mode, dp.iota[b]);
+    const T mub = tabs(friction[1 + b]);
+    dp.mu[b] = T(2) * mu0 * mub / (mu0 + mub);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = tabs(lengths[3 * b + i]);
+  }
+}
+
+// per-item terms shared by the loss and the dynamics
+template <typename T, int NJ> struct Terms {
+  static constexpr int NB = NJ + 1, NV = 6 + NJ;
+  Kin<T, NJ> kin;
+  T M[NV][NV];
+  T LM[NV][NV], invdM[NV];
+  T a[NV];  // M^-1 F
+  T Vw[NB][3], Vu[NB][3], AGw[NB][3], AGu[NB][3];
+};
+
+template <typename T, int NJ>
+DPLL_HD void compute_terms(const ModelDesc& md, const Derived<T, NJ>& dp, const T* q, const T* v, Terms<T, NJ>& t) {
+  constexpr int NV = 6 + NJ;
+  kinematics<T, NJ>(md, q, t.kin);
+  mass_matrix<T, NJ>(t.kin, dp.iota, t.M);
+  T F[NV];
+  bias_forces<T, NJ>(md, t.kin, dp.iota, v, F, t.Vw, t.Vu, t.AGw, t.AGu);
+  cholesky<T, NV>(t.M, t.LM, t.invdM);
+  chol_solve<T, NV>(t.LM, t.invdM, F, t.a);
+}
+
+// One contact of this lane: geometry index g (= body index), slot 0..3.
+template <typename T, int NJ> struct ContactGeom {
+  static constexpr int NV = 6 + NJ;
+  int body;
+  T sgn[3];      // corner sign pattern
+  T phi;
+  T Jp[3][NV];   // world-frame point Jacobian rows x, y, z
+  T mu;
+};
+
+template <typename T, int NJ>
+DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, const Kin<T, NJ>& kin, int contact,
+                             ContactGeom<T, NJ>& cg) {
+  constexpr int NB = NJ + 1;
+  const int b = contact / kQuery;
+  const int slot = contact % kQuery;
+  cg.body = b;
+  // select this contact's body data (b is lane dependent on the GPU)
+  T R[3][3], o[3], habs[3], gorg[3];
+  T mu = dp.mu[0];
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) R[r][c] = kin.R[0][r][c];
+    o[r] = kin.o[0][r];
+    habs[r] = dp.habs[0][r];
+    gorg[r] = T(md.geom_origin[0][r]);
+  }
+  DPLL_UNROLL for (int j = 1; j < NB; ++j) {
+    const bool pick = (b == j);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) R[r][c] = pick ? kin.R[j][r][c] : R[r][c];
+      o[r] = pick ? kin.o[j][r] : o[r];
+      habs[r] = pick ? dp.habs[j][r] : habs[r];
+      gorg[r] = pick ? T(md.geom_origin[j][r]) : gorg[r];
+    }
+    mu = pick ? dp.mu[j] : mu;
+  }
+  cg.mu = mu;
+  // support direction in the body frame: -(row 2 of R_AB) (geometry.py:560-564)
+  const T d[3] = {-R[2][0], -R[2][1], -R[2][2]};
+  box_corner_signs(d, habs, slot, cg.sgn);
+  T r_b[3], rho[3], pt[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) r_b[i] = gorg[i] + cg.sgn[i] * habs[i];
+  mat3_vec(R, r_b, rho);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) pt[i] = o[i] + rho[i];
+  cg.phi = pt[2];
+  contact_jacobian<T, NJ>(kin, b, pt, cg.Jp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ContactNets loss for one item, forward + adjoint (multibody_learnable_system.py:104-197).
+// Gradient accumulators (all scaled by `weight`, the upstream d(total)/d(loss_item)):
+//   g_iota[b][10]  d/d iota_b          -- identical in every lane of the group
+//   g_mu[b]        d/d (pair friction) -- this lane's contacts only (sum over lanes = item total)
+//   g_len[b][3]    d/d |length_params| -- this lane's contacts only
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NJ> struct LossGrad {
+  static constexpr int NB = NJ + 1;
+  T g_iota[NB][kIota];
+  T g_mu[NB];
+  T g_len[NB][3];
+};
+
+template <typename T, int NJ> DPLL_HD void zero_grad(LossGrad<T, NJ>& g) {
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
+    DPLL_UNROLL for (int i = 0; i < kIota; ++i) g.g_iota[b][i] = T(0);
+    g.g_mu[b] = T(0);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) g.g_len[b][i] = T(0);
+  }
+}
+
+constexpr double kLossEps = 1e-3;       // multibody_learnable_system.py:130
+constexpr double kDynamicsEps = 1e-4;   // multibody_learnable_system.py:283, 298
+constexpr double kInvalidForce = 1e3;   // multibody_learnable_system.py:187
+
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x, const T* xp,
+                    int first_contact, T weight, bool want_grad, LossGrad<T, NJ>& grad, T (&force)[KPL][3],
+                    int& iters) {
+  constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
+  const T dt = T(md.dt), eps = T(kLossEps);
+  const T* v = x + NQ;
+  const T* qp = xp;
+  const T* vp = xp + NQ;
+  Terms<T, NJ> t;
+  compute_terms<T, NJ>(md, dp, qp, vp, t);  // terms at the NEXT state (quirk Q6)
+  T dv[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) dv[i] = vp[i] - (v[i] + t.a[i] * dt);
+  // contacts of this lane
+  ContactGeom<T, NJ> cg[KPL];
+  T Jc[KPL][3][NV], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
+  T pen = T(0);
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    compute_contact<T, NJ>(md, dp, t.kin, first_contact + c, cg[c]);
+    T jdv[3];
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      T s1 = T(0), s2 = T(0);
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) { s1 += cg[c].Jp[r][i] * dv[i]; s2 += cg[c].Jp[r][i] * vp[i]; }
+      jdv[r] = s1;
+      jpv[c][r] = s2;
+    }
+    const T mu = cg[c].mu;
+    slide[c][0] = mu * jpv[c][0];
+    slide[c][1] = mu * jpv[c][1];
+    speed[c] = tsqrt(slide[c][0] * slide[c][0] + slide[c][1] * slide[c][1]);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) {
+      Jc[c][0][i] = mu * cg[c].Jp[0][i];
+      Jc[c][1][i] = mu * cg[c].Jp[1][i];
+      Jc[c][2][i] = cg[c].Jp[2][i];
+    }
+    qc[c][0] = -mu * jdv[0] + dt * slide[c][0];
+    qc[c][1] = -mu * jdv[1] + dt * slide[c][1];
+    qc[c][2] = -jdv[2] + tabs(cg[c].phi) + dt * speed[c];
+    const T neg = tmax(-cg[c].phi, T(0));
+    pen += neg * neg;
+  }
+  pen = Lanes::group_sum(pen);
+  TA y[NV];
+  iters = sap_newton<T, TA, NV, KPL, Lanes>(t.M, Jc, qc, eps, opt, y, force);
+  // invalid-solve mask (multibody_learnable_system.py:186-192)
+  bool bad = false;
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c)
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) bad = bad || bad_number(force[c][r]) || tabs(force[c][r]) > T(kInvalidForce);
+  bad = Lanes::group_any(bad);
+  if (bad) {
+    DPLL_UNROLL for (int c = 0; c < KPL; ++c)
+      DPLL_UNROLL for (int r = 0; r < 3; ++r) force[c][r] = T(0);
+  }
+  // g = J^T f, w = M^-1 g
+  T g[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) g[i] = T(0);
+  T fq = T(0), ff = T(0);
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    DPLL_UNROLL for (int i = 0; i < NV; ++i)
+      g[i] += Jc[c][0][i] * force[c][0] + Jc[c][1][i] * force[c][1] + Jc[c][2][i] * force[c][2];
+    fq += force[c][0] * qc[c][0] + force[c][1] * qc[c][1] + force[c][2] * qc[c][2];
+    ff += force[c][0] * force[c][0] + force[c][1] * force[c][1] + force[c][2] * force[c][2];
+  }
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) g[i] = Lanes::group_sum(g[i]);
+  fq = Lanes::group_sum(fq);
+  ff = Lanes::group_sum(ff);
+  T w[NV], Mdv[NV];
+  chol_solve<T, NV>(t.LM, t.invdM, g, w);
+  symv<T, NV>(t.M, dv, Mdv);
+  const T constant = bad ? T(0) : (T(0.5) * dotn<T, NV>(dv, Mdv) + pen);
+  const T loss = T(0.5) * (dotn<T, NV>(g, w) + eps * ff) + fq + constant;
+  if (!want_grad) return loss;
+
+  // ---- adjoint ------------------------------------------------------------------------------
+  // The value above uses w = M^-1 J^T f (variationally consistent: the loss is stationary in f, so its
+  // error is second order in the solver error).  The adjoint instead takes w = y*, the primal optimum,
+  // which equals M^-1 J^T f at convergence but carries far less rounding error than re-solving with the
+  // projected force (that route amplifies it by |J|^2 / (eps M)).
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) w[i] = T(y[i]);
+  const T wt = bad ? T(0) : weight;
+  T u[NV], abar[NV], bvec[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) { u[i] = w[i] - dv[i]; abar[i] = -dt * (Mdv[i] - g[i]); }
+  chol_solve<T, NV>(t.LM, t.invdM, abar, bvec);
+  // inertial part: sum of bilinear forms in the body twists
+  T Ww[NB][3], Wu[NB][3], Dw[NB][3], Du[NB][3], Bw[NB][3], Bu[NB][3], Aw[NB][3], Au[NB][3];
+  body_twists<T, NJ>(t.kin, w, Ww, Wu);
+  body_twists<T, NJ>(t.kin, dv, Dw, Du);
+  body_twists<T, NJ>(t.kin, bvec, Bw, Bu);
+  body_twists<T, NJ>(t.kin, t.a, Aw, Au);
+  DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+    inertia_bilinear_grad<T>(T(-0.5) * wt, Ww[b], Wu[b], Ww[b], Wu[b], grad.g_iota[b]);
+    inertia_bilinear_grad<T>(T(0.5) * wt, Dw[b], Du[b], Dw[b], Du[b], grad.g_iota[b]);
+    T accw[3], accu[3];
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { accw[i] = Aw[b][i] + t.AGw[b][i]; accu[i] = Au[b][i] + t.AGu[b][i]; }
+    inertia_bilinear_grad<T>(-wt, Bw[b], Bu[b], accw, accu, grad.g_iota[b]);
+    // (V x_m B): (Vw x Bw, Vw x Bu + Vu x Bw)
+    T cw[3], c1[3], c2[3], cu[3];
+    cross(t.Vw[b], Bw[b], cw);
+    cross(t.Vw[b], Bu[b], c1);
+    cross(t.Vu[b], Bw[b], c2);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) cu[i] = c1[i] + c2[i];
+    inertia_bilinear_grad<T>(wt, cw, cu, t.Vw[b], t.Vu[b], grad.g_iota[b]);
+  }
+  // contact part
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    const T mu = cg[c].mu;
+    const T ftx = force[c][0], fty = force[c][1], fn = force[c][2];
+    const T isp = speed[c] > T(0) ? T(1) / speed[c] : T(0);
+    const T shx = slide[c][0] * isp, shy = slide[c][1] * isp;
+    T jpu[3];
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      T s = T(0);
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) s += cg[c].Jp[r][i] * u[i];
+      jpu[r] = s;
+    }
+    const T bx = dt * (fn * shx + ftx), by = dt * (fn * shy + fty);
+    const T gmu = ftx * jpu[0] + fty * jpu[1] + bx * jpv[c][0] + by * jpv[c][1];
+    const T phibar = fn * (cg[c].phi > T(0) ? T(1) : (cg[c].phi < T(0) ? T(-1) : T(0))) - T(2) * tmax(-cg[c].phi, T(0));
+    const T alpha[3] = {mu * ftx, mu * fty, fn};
+    const T beta[3] = {mu * bx, mu * by, T(0)};
+    T ou[3], ov[3], c1[3], c2[3], rhobar[3], rbar[3];
+    world_omega<T, NJ>(t.kin, cg[c].body, u, ou);
+    world_omega<T, NJ>(t.kin, cg[c].body, vp, ov);
+    cross(alpha, ou, c1);
+    cross(beta, ov, c2);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) rhobar[i] = c1[i] + c2[i];
+    rhobar[2] += phibar;
+    // r_bar = R_b^T rho_bar with this contact's body rotation
+    T R[3][3];
+    DPLL_UNROLL for (int r = 0; r < 3; ++r)
+      DPLL_UNROLL for (int cc = 0; cc < 3; ++cc) {
+        T val = t.kin.R[0][r][cc];
+        DPLL_UNROLL for (int j = 1; j < NB; ++j) val = (cg[c].body == j) ? t.kin.R[j][r][cc] : val;
+        R[r][cc] = val;
+      }
+    mat3t_vec(R, rhobar, rbar);
+    DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+      const bool mine = (cg[c].body == b);
+      grad.g_mu[b] += mine ? wt * gmu : T(0);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[b][i] += mine ? wt * cg[c].sgn[i] * rbar[i] : T(0);
+    }
+  }
+  return loss;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One simulation step: forward_dynamics (multibody_learnable_system.py:199-304) + the Lie-group
+// Euler update of VelocityIntegrator.step (integrator.py:153-162, state_space.py:466-486).
+// ---------------------------------------------------------------------------------------------
+template <typename T> DPLL_HD void quat_exp_mul(const T* q, const T (&r)[3], T* out) {
+  // out = q (x) exp(r), quaternion.py:276-309 (exp via sinc), :89-105 (multiply); no re-normalisation
+  const T angle = tsqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const T half = angle * T(0.5);
+  T s, c;
+  tsincos(half, s, c);
+  const T sinc = tabs(half) > T(0) ? s / half : T(1);
+  const T e[4] = {c, r[0] * sinc * T(0.5), r[1] * sinc * T(0.5), r[2] * sinc * T(0.5)};
+  out[0] = q[0] * e[0] - q[1] * e[1] - q[2] * e[2] - q[3] * e[3];
+  out[1] = q[0] * e[1] + e[0] * q[1] + (q[2] * e[3] - q[3] * e[2]);
+  out[2] = q[0] * e[2] + e[0] * q[2] + (q[3] * e[1] - q[1] * e[3]);
+  out[3] = q[0] * e[3] + e[0] * q[3] + (q[1] * e[2] - q[2] * e[1]);
+}
+
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
+                       int first_contact, T* x_next, T (&impulse)[KPL][3], int& iters) {
+  constexpr int NV = 6 + NJ, NQ = 7 + NJ;
+  const T dt = T(md.dt), eps = T(kDynamicsEps);
+  const T* q = x;
+  const T* v = x + NQ;
+  Terms<T, NJ> t;
+  compute_terms<T, NJ>(md, dp, q, v, t);
+  T vm[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];
+  T Jc[KPL][3][NV], qc[KPL][3];
+  const T idt = T(1) / dt;
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    ContactGeom<T, NJ> cg;
+    compute_contact<T, NJ>(md, dp, t.kin, first_contact + c, cg);
+    T jv[3];
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      T s = T(0);
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) s += cg.Jp[r][i] * vm[i];
+      jv[r] = s;
+    }
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) {
+      Jc[c][0][i] = cg.mu * cg.Jp[0][i];
+      Jc[c][1][i] = cg.mu * cg.Jp[1][i];
+      Jc[c][2][i] = cg.Jp[2][i];
+    }
+    qc[c][0] = cg.mu * jv[0];
+    qc[c][1] = cg.mu * jv[1];
+    qc[c][2] = jv[2] + cg.phi * idt;
+  }
+  TA y[NV];
+  iters = sap_newton<T, TA, NV, KPL, Lanes>(t.M, Jc, qc, eps, opt, y, impulse);
+  // v+ = v- + M^-1 J^T impulse = v- + y*: the primal optimum IS that velocity change (M y* = J^T f), and
+  // taking it from y instead of re-solving with the projected impulse avoids amplifying the impulse's
+  // rounding error by |J|^2 / (eps M).
+  T vn[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) vn[i] = T(TA(vm[i]) + y[i]);
+  const T r[3] = {vn[0] * dt, vn[1] * dt, vn[2] * dt};
+  quat_exp_mul<T>(q, r, x_next);
+  DPLL_UNROLL for (int i = 0; i < 3 + NJ; ++i) x_next[4 + i] = q[4 + i] + vn[3 + i] * dt;
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) x_next[NQ + i] = vn[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// chain from the batch-reduced gradients (d/d iota, d/d mu_pair, d/d |length|) to the learnable
+// parameters (theta, friction_params, length_params); double precision, a handful of flops.
+// ---------------------------------------------------------------------------------------------
+struct Dual {
+  double v, d;
+  DPLL_HD Dual() : v(0), d(0) {}
+  DPLL_HD Dual(double a) : v(a), d(0) {}
+  DPLL_HD Dual(double a, double b) : v(a), d(b) {}
+};
+DPLL_HD Dual operator+(const Dual& a, const Dual& b) { return Dual(a.v + b.v, a.d + b.d); }
+DPLL_HD Dual operator-(const Dual& a, const Dual& b) { return Dual(a.v - b.v, a.d - b.d); }
+DPLL_HD Dual operator*(const Dual& a, const Dual& b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+DPLL_HD Dual operator/(const Dual& a, const Dual& b) {
+  const double q = a.v / b.v;
+  return Dual(q, (a.d - q * b.d) / b.v);
+}
+template <> DPLL_HD Dual s_exp<Dual>(const Dual& x) { const double e = exp(x.v); return Dual(e, e * x.d); }
+
+// d(sum_i g_iota[i] iota_i(theta)) / d theta_k for one body
+DPLL_HD double theta_grad_component(int inertia_mode, const double* theta, const double* g_iota, int k) {
+  Dual th[10], io[kIota];
+  DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = Dual(theta[i], i == k ? 1.0 : 0.0);
+  theta_to_iota<Dual>(th, inertia_mode, io);
+  double s = 0.0;
+  DPLL_UNROLL for (int i = 0; i < kIota; ++i) s += g_iota[i] * io[i].d;
+  return s;
+}
+// friction_params gradient: entry 0 is the ground, entry 1 + b the geometry of body b
+DPLL_HD double friction_grad_component(int n_bodies, const double* friction, const double* g_mu, int k) {
+  const double m0 = fabs(friction[0]);
+  double s = 0.0;
+  for (int b = 0; b < n_bodies; ++b) {
+    const double mb = fabs(friction[1 + b]);
+    const double den = (m0 + mb) * (m0 + mb);
+    if (k == 0) s += g_mu[b] * 2.0 * mb * mb / den;
+    if (k == 1 + b) s += g_mu[b] * 2.0 * m0 * m0 / den;
+  }
+  const double p = friction[k];
+  return s * (p > 0.0 ? 1.0 : (p < 0.0 ? -1.0 : 0.0));
+}
+DPLL_HD double length_grad_component(const double* lengths, const double* g_len, int k) {
+  const double p = lengths[k];
+  return g_len[k] * (p > 0.0 ? 1.0 : (p < 0.0 ? -1.0 : 0.0));
+}
+
+// host/one-lane implementation of the lane-group primitives
+struct OneLane {
+  template <typename T> static DPLL_HD T group_sum(T x) { return x; }
+  static DPLL_HD bool group_any(bool x) { return x; }
+  static DPLL_HD bool wave_any(bool x) { return x; }
+};
+
+}  // namespace dpll

@@ -1,0 +1,174 @@
+"""URDF -> :class:`ModelSpec` for the contact-dynamics kernels (host logic, no Drake).
+
+The reference obtains the same facts from Drake's parser and symbolic plant
+(``dair_pll/drake_utils.py:248-335``, ``dair_pll/multibody_terms.py:161-207, 355-376``): per body
+mass / centre of mass / central inertia, the joint tree, collision geometry with
+``drake:mu_static``, and a ground half-space with friction 1.0 added to every plant
+(``drake_utils.py:280-288``).  The kernels support one floating-base serial chain of revolute
+joints with one box collision geometry per body, all of it touching only the ground (the elbow's
+links are collision filtered, ``assets/contactnets_elbow.urdf``), which covers the cube and elbow
+systems of the reference's ContactNets example.
+"""
+from __future__ import annotations
+
+import math
+import os
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+GROUND_MU = 1.0  # dair_pll/drake_utils.py:280-288
+GRAVITY_Z = -9.81  # Drake's default UniformGravityField
+MAX_JOINTS = 2  # dpll_core.hpp kMaxJoints
+
+
+@dataclass
+class GeomSpec:
+    kind: str  # 'box' | 'mesh'
+    origin: List[float]
+    mu: float
+    half_lengths: Optional[List[float]] = None
+    mesh_file: Optional[str] = None
+    vertices: Optional[List[List[float]]] = None
+
+
+@dataclass
+class BodySpec:
+    name: str
+    mass: float
+    com: List[float]
+    inertia_cm: List[float]  # ixx iyy izz ixy ixz iyz about the centre of mass
+    parent: int = -1
+    joint_origin: Optional[List[float]] = None
+    joint_axis: Optional[List[float]] = None
+    geoms: List[GeomSpec] = field(default_factory=list)
+
+
+@dataclass
+class ModelSpec:
+    name: str
+    bodies: List[BodySpec]
+    ground_mu: float = GROUND_MU
+    gravity_z: float = GRAVITY_Z
+
+    @property
+    def n_joints(self) -> int:
+        return len(self.bodies) - 1
+
+    @property
+    def n_q(self) -> int:
+        return 7 + self.n_joints
+
+    @property
+    def n_v(self) -> int:
+        return 6 + self.n_joints
+
+    @property
+    def n_contacts(self) -> int:
+        return 4 * sum(len(b.geoms) for b in self.bodies)
+
+    def friction_init(self) -> List[float]:
+        """``friction_params`` initial value: ground first, then every geometry in body order
+        (``dair_pll/multibody_terms.py:314-317``)."""
+        return [self.ground_mu] + [g.mu for b in self.bodies for g in b.geoms]
+
+
+def _vec(text: Optional[str], n: int = 3) -> List[float]:
+    if text is None:
+        return [0.0] * n
+    vals = [float(tok) for tok in text.split()]
+    if len(vals) != n:
+        raise ValueError(f'expected {n} numbers, got {text!r}')
+    return vals
+
+
+def _no_rotation(element, what: str) -> None:
+    if element is not None and any(abs(r) > 0 for r in _vec(element.get('rpy'))):
+        raise NotImplementedError(f'{what}: rpy != 0 is not supported')
+
+
+def _obj_vertices(path: str) -> List[List[float]]:
+    out = []
+    with open(path, 'r', encoding='utf8') as handle:
+        for line in handle:
+            tok = line.split()
+            if len(tok) >= 4 and tok[0] == 'v':
+                out.append([float(tok[1]), float(tok[2]), float(tok[3])])
+    return out
+
+
+def parse_urdf(path: str) -> ModelSpec:
+    root = ET.parse(path).getroot()
+    by_name = {}
+    order = []
+    for link in root.findall('link'):
+        inertial = link.find('inertial')
+        if inertial is None:
+            raise ValueError(f'link {link.get("name")} has no <inertial>')
+        origin = inertial.find('origin')
+        _no_rotation(origin, 'inertial origin')
+        inertia = inertial.find('inertia')
+        body = BodySpec(name=link.get('name'),
+                        mass=float(inertial.find('mass').get('value')),
+                        com=_vec(origin.get('xyz') if origin is not None else None),
+                        inertia_cm=[float(inertia.get(k)) for k in ('ixx', 'iyy', 'izz', 'ixy', 'ixz', 'iyz')])
+        for col in link.findall('collision'):
+            c_origin = col.find('origin')
+            _no_rotation(c_origin, 'collision origin')
+            mu = None
+            for element in col.iter():
+                if element.tag.endswith('mu_static'):
+                    mu = float(element.get('value'))
+            if mu is None:
+                raise ValueError('collision geometry without drake:mu_static')
+            geometry = col.find('geometry')
+            xyz = _vec(c_origin.get('xyz') if c_origin is not None else None)
+            if geometry.find('box') is not None:
+                size = _vec(geometry.find('box').get('size'))
+                body.geoms.append(GeomSpec('box', xyz, mu, half_lengths=[0.5 * s for s in size]))
+            elif geometry.find('mesh') is not None:
+                filename = geometry.find('mesh').get('filename')
+                mesh_path = os.path.join(os.path.dirname(os.path.abspath(path)), filename)
+                body.geoms.append(GeomSpec('mesh', xyz, mu, mesh_file=filename, vertices=_obj_vertices(mesh_path)))
+            else:
+                raise NotImplementedError('only <box> and <mesh> collision geometry is supported')
+        by_name[body.name] = body
+        order.append(body.name)
+    joints = []
+    children = set()
+    for joint in root.findall('joint'):
+        if joint.get('type') not in ('continuous', 'revolute'):
+            raise NotImplementedError(f'joint type {joint.get("type")!r} is not supported')
+        j_origin = joint.find('origin')
+        _no_rotation(j_origin, 'joint origin')
+        axis = _vec(joint.find('axis').get('xyz')) if joint.find('axis') is not None else [1.0, 0.0, 0.0]
+        norm = math.sqrt(sum(a * a for a in axis))
+        joints.append((joint.find('parent').get('link'), joint.find('child').get('link'),
+                       _vec(j_origin.get('xyz') if j_origin is not None else None), [a / norm for a in axis]))
+        children.add(joints[-1][1])
+    roots = [name for name in order if name not in children]
+    if len(roots) != 1:
+        raise ValueError('expected exactly one root link per URDF (dair_pll/drake_utils.py:309-335)')
+    chain = [roots[0]]
+    for name in chain:
+        for parent, child, origin, axis in joints:
+            if parent == name:
+                body = by_name[child]
+                body.parent = chain.index(parent)
+                body.joint_origin = origin
+                body.joint_axis = axis
+                chain.append(child)
+    if len(chain) != len(order):
+        raise ValueError('disconnected links')
+    return ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain])
+
+
+def check_supported(spec: ModelSpec) -> None:
+    """What the HIP kernels are written for; anything else fails loudly at construction."""
+    if spec.n_joints > MAX_JOINTS:
+        raise NotImplementedError(f'at most {MAX_JOINTS} joints')
+    for index, body in enumerate(spec.bodies):
+        if index > 0 and body.parent != index - 1:
+            raise NotImplementedError('only serial chains (each link hangs off the previous one)')
+        if len(body.geoms) != 1:
+            raise NotImplementedError('exactly one collision geometry per body')

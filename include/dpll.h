@@ -1,0 +1,121 @@
+/* dpll.h -- C ABI of libdpll_hip.so: the MI355X (gfx950) contact-dynamics hot path of dair_pll.
+ *
+ * Drop-in boundary.  dair_pll is pure Python and has no FFI of its own; the functions below are what a
+ * binding for the hot path would call, one per method of the reference's System / Integrator surface
+ * (file:line under /root/reference/dair_pll):
+ *
+ *   dpll_contactnets_loss   <- MultibodyLearnableSystem.contactnets_loss   multibody_learnable_system.py:104-197
+ *                              + the backward pass torch autograd would run (experiment.py:359)
+ *   dpll_step               <- VelocityIntegrator.step(sim_step/forward_dynamics)  integrator.py:153-162,
+ *                              multibody_learnable_system.py:199-313
+ *   dpll_simulate           <- Integrator.simulate                          integrator.py:75-99
+ *   dpll_terms              <- MultibodyTerms.forward                       multibody_terms.py:584-609
+ *   dpll_model_create       <- MultibodyLearnableSystem.__init__ (the facts Drake extracts from the URDF,
+ *                              multibody_learnable_system.py:51-80, drake_utils.py:248-335)
+ *
+ * Conventions: plain pointers and sizes only.  Every data pointer is a DEVICE pointer owned by the caller;
+ * nothing is allocated, freed or synchronised inside a call, so calls may be captured into a hipGraph.
+ * `stream` is a hipStream_t passed as void*.  Batched arrays are row-major (B, n) with an explicit row
+ * stride in elements.  dtype selects float32 or float64 for every array of the call.  Return value: 0 on
+ * success, negative on error with a message available from dpll_last_error() (no exceptions cross the ABI).
+ *
+ * State layout (dair_pll/state_space.py:412-424):  x = [quat wxyz, p_world(3), joint angles |
+ * omega_body(3), v_world(3), joint rates], n_x = 13 + 2 n_joints.
+ * Parameter layout: theta (n_bodies, 10) log-Cholesky inertial parameters (inertia.py:206-234);
+ * friction (1 + n_bodies,) with the ground first (multibody_terms.py:314-317, drake_utils.py:280-288);
+ * lengths (n_bodies, 3) box half lengths (geometry.py:367-403).
+ */
+#ifndef DPLL_H_
+#define DPLL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPLL_MAX_JOINTS 2
+#define DPLL_MAX_BODIES 3
+
+enum dpll_dtype { DPLL_F32 = 0, DPLL_F64 = 1 };
+enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1 };
+
+/* One floating-base serial chain of revolute joints, one box geometry per body, ground half-space at z = 0. */
+typedef struct dpll_model_desc {
+  int32_t n_joints;
+  int32_t inertia_mode;
+  double dt;
+  double gravity_z;
+  double joint_origin[DPLL_MAX_JOINTS][3]; /* joint j+1: origin in the parent body frame */
+  double joint_axis[DPLL_MAX_JOINTS][3];   /* unit axis */
+  double geom_origin[DPLL_MAX_BODIES][3];  /* collision geometry origin in its body frame */
+} dpll_model_desc_t;
+
+typedef struct dpll_solver_opts {
+  int32_t max_iter;  /* Newton iterations */
+  int32_t max_ls;    /* line-search evaluations per iteration */
+  double tol;        /* Newton decrement / (1 + |y|_M) */
+  double stall_tol;  /* a decrement that stopped halving ends the solve only below this */
+  double ls_tol;     /* |l'(alpha)| / |l'(0)| */
+} dpll_solver_opts_t;
+
+typedef struct dpll_model dpll_model_t;
+
+/* Learnable parameters of one call: device pointers, caller owned, never written. */
+typedef struct dpll_params {
+  const void* theta;    /* (n_bodies, 10) */
+  const void* friction; /* (1 + n_bodies,) */
+  const void* lengths;  /* (n_bodies, 3) */
+} dpll_params_t;
+
+const char* dpll_last_error(void);
+int dpll_abi_version(void);
+
+int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out);
+void dpll_model_destroy(dpll_model_t* model);
+/* default solver settings are chosen per dtype at creation; this overrides them */
+int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts_t* opts);
+int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts_t* opts);
+
+int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
+int dpll_n_contacts(const dpll_model_t* model);   /* 4 n_bodies */
+int dpll_param_count(const dpll_model_t* model);  /* 10 n_b + (1 + n_b) + 3 n_b: layout [theta | friction | lengths] */
+
+/* bytes of scratch dpll_contactnets_loss needs for a batch of `batch` items (gradient partial sums) */
+int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch);
+
+/* ContactNets loss of `batch` transitions (x -> x_plus), forward and backward in one pass.
+ *   x, x_plus   (batch, n_x), row strides ld_x / ld_xp elements
+ *   weights     optional (batch,) upstream gradient d(total)/d(loss_i); the effective weight of item i is
+ *               scale * weights[i] (scale alone when weights is NULL), e.g. scale = 1/batch for .mean()
+ *   loss        optional (batch,) per-item loss, as the reference returns it
+ *   grad        optional (dpll_param_count,) <- sum_i weight_i * d loss_i / d params; NULL = forward only
+ *   loss_total  optional (1,) <- sum_i weight_i * loss_i   (requires grad != NULL)
+ *   force       optional (batch, 3 n_contacts) contact impulses in the reference's order
+ *               [normals | (t_x, t_y) per contact] (multibody_terms.py:415-426); contacts of one geometry
+ *               appear in this library's corner order (the reference's topk order is unspecified)
+ *   iters       optional (batch,) int32 Newton iterations used
+ *   workspace   >= dpll_workspace_bytes(model, batch) bytes, 16-byte aligned (may be NULL when grad is NULL)
+ */
+int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                          int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                          double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* One VelocityIntegrator step: x (batch, n_x) -> x_next (batch, n_x). */
+int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
+              int64_t batch, void* x_next, int64_t ld_next, int32_t* iters, void* stream);
+
+/* Integrator.simulate: x0 (batch, n_x) -> traj (batch, steps + 1, n_x) contiguous, traj[:, 0] = x0. */
+int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x0, int64_t ld_x,
+                  int64_t batch, int64_t steps, void* traj, void* stream);
+
+/* MultibodyTerms.forward at (q, v) taken from x: delassus (batch, 3k, 3k), M (batch, n_v, n_v),
+ * J (batch, 3k, n_v), phi (batch, k), a (batch, n_v); any output may be NULL. */
+int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
+               int64_t batch, void* delassus, void* M, void* J, void* phi, void* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPLL_H_ */

@@ -1,0 +1,92 @@
+"""Host build of the kernels' per-item math (one lane per item) -- TEST INFRASTRUCTURE ONLY.
+
+``dair_pll_amd`` never imports this; it exists so the arithmetic in ``csrc/dpll_core.hpp`` can be
+checked against the oracle (and run under sanitizers) in the CPU-only container.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_double, c_int, c_int64, c_void_p
+
+import numpy as np
+
+from dair_pll_amd._capi import ModelDesc, SolverOpts
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(os.path.dirname(_HERE))
+_SRC = os.path.join(_HERE, 'hostsim.cpp')
+_CORE = os.path.join(_REPO, 'dair_pll_amd', 'csrc', 'dpll_core.hpp')
+_LIB = os.path.join(_HERE, 'libhostsim.so')
+_lib = None
+
+
+def build(force: bool = False, sanitize: bool = False) -> str:
+    out = _LIB if not sanitize else os.path.join(_HERE, 'libhostsim_asan.so')
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_CORE))
+    if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
+        flags = ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer'] if sanitize else ['-O2']
+        subprocess.check_call(['g++', '-std=c++17', '-shared', '-fPIC', '-Wall', '-Wno-unknown-pragmas', *flags, '-o',
+                               out, _SRC])
+    return out
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        assert _lib.hostsim_sizeof_model_desc() == ctypes.sizeof(ModelDesc)
+    return _lib
+
+
+def default_opts(dtype) -> SolverOpts:
+    if np.dtype(dtype) == np.float64:
+        return SolverOpts(max_iter=100, max_ls=100, tol=1e-13, stall_tol=1e-10, ls_tol=1e-9)
+    return SolverOpts(max_iter=40, max_ls=30, tol=1e-6, stall_tol=1e-3, ls_tol=1e-4)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(c_void_p) if a is not None else None
+
+
+def loss(desc: ModelDesc, theta, friction, lengths, x, x_plus, dtype=np.float64, scale=None, weights=None, opts=None,
+         mixed=True, want_grad=True):
+    """returns dict(loss, grad (float64, [theta|friction|lengths]), force, iters)"""
+    dtype = np.dtype(dtype)
+    n_b = desc.n_joints + 1
+    k = 4 * n_b
+    arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=dtype))
+    theta, friction, lengths, x, x_plus = map(arr, (theta, friction, lengths, x, x_plus))
+    batch = x.shape[0]
+    scale = 1.0 / batch if scale is None else scale
+    out_loss = np.zeros(batch, dtype=dtype)
+    grad = np.zeros(14 * n_b + 1, dtype=np.float64) if want_grad else None
+    force = np.zeros((batch, 3 * k), dtype=dtype)
+    iters = np.zeros(batch, dtype=np.int32)
+    weights = arr(weights) if weights is not None else None
+    opts = opts or default_opts(dtype)
+    args = [ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction), _ptr(lengths), _ptr(x), _ptr(x_plus),
+            c_int64(batch), _ptr(weights), c_double(scale), _ptr(out_loss), _ptr(grad), _ptr(force), _ptr(iters)]
+    if dtype == np.float64:
+        status = lib().hostsim_loss_f64(*args)
+    else:
+        status = lib().hostsim_loss_f32(*args, c_int(1 if mixed else 0))
+    assert status == 0
+    return {'loss': out_loss, 'grad': grad, 'force': force, 'iters': iters}
+
+
+def step(desc: ModelDesc, theta, friction, lengths, x, dtype=np.float64, opts=None, mixed=True):
+    dtype = np.dtype(dtype)
+    arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=dtype))
+    theta, friction, lengths, x = map(arr, (theta, friction, lengths, x))
+    batch = x.shape[0]
+    x_next = np.zeros_like(x)
+    iters = np.zeros(batch, dtype=np.int32)
+    opts = opts or default_opts(dtype)
+    args = [ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction), _ptr(lengths), _ptr(x),
+            c_int64(batch), _ptr(x_next), _ptr(iters)]
+    if dtype == np.float64:
+        status = lib().hostsim_step_f64(*args)
+    else:
+        status = lib().hostsim_step_f32(*args, c_int(1 if mixed else 0))
+    assert status == 0
+    return x_next, iters
