@@ -1,0 +1,188 @@
+"""Headline benchmark: trajectory-steps/s of the ContactNets loss, forward + backward, on the
+4096-pair cube-toss batch (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f64] [--batch B] [--no-graph]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+One "step" = one pass of the hot path over one batch: every (x, x+) pair goes through MultibodyTerms,
+the cone solve, the loss and the analytic backward to parameter gradients (dpll_contactnets_loss =
+loss kernel + finalize kernel), plus -- for N > 1 -- the single RCCL all-reduce of [loss, gradients].
+Inputs are resident in HBM before the timed region.  Batches shard over ranks (weak scaling: 4096 pairs
+per GPU); `value` is pairs processed by all ranks per second.
+
+The printed JSON line also carries `roofline` (algorithmic bytes of the loss kernel over its HIP-event
+duration, against the 8 TB/s HBM peak) and, on rank 0 at N = 1, `cpu_baseline` (the oracle -- a PyTorch
+CPU float64 restatement of the reference path -- timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+BYTES_PER_STEP = {'f32': 2 * 13 * 4 + 4, 'f64': 2 * 13 * 8 + 8}  # read x, x+; write loss
+
+
+def load_pairs(batch: int, seed: int):
+    """The 4096 real cube pairs of the reference's data set committed as a fixture (inputs only are
+    used here); other batch sizes / ranks resample them with replacement."""
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_4096.npz'))
+    x, xp = g['x'], g['x_plus']
+    if batch != x.shape[0] or seed != 0:
+        pick = np.random.default_rng(seed).integers(0, x.shape[0], size=batch)
+        x, xp = x[pick], xp[pick]
+    return x, xp, float(g['dt'])
+
+
+def cpu_baseline(x, xp, dt, budget_s: float = 20.0):
+    """Oracle timing (checker code; measured, never shipped): float64 PyTorch CPU fwd+bwd."""
+    from oracle import dpll_oracle as O
+    threads = torch.get_num_threads()
+    sample = min(1024, x.shape[0])
+    system = O.OracleSystem(os.path.join(REPO, 'assets', 'cube.urdf'), dt).requires_grad_()
+    xs, xps = torch.tensor(x[:sample]), torch.tensor(xp[:sample])
+
+    def one():
+        system.zero_grad()
+        system.contactnets_loss(xs, xps).mean().backward()
+
+    one()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < budget_s and reps < 50):
+        one()
+        reps += 1
+    elapsed = time.perf_counter() - t0
+    return {'value': sample * reps / elapsed, 'unit': 'trajectory-steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{reps} fwd+bwd passes over the first {sample} pairs of the workload, float64, '
+                      f'oracle/dpll_oracle.py (PyTorch CPU, {threads} threads)'}
+
+
+def main() -> None:
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=2000)
+    parser.add_argument('--warmup', type=int, default=200)
+    parser.add_argument('--dtype', choices=['f32', 'f64'], default='f32')
+    parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
+    parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    args = parser.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.distributed import GradientAllReduce
+
+    dtype = torch.float32 if args.dtype == 'f32' else torch.float64
+    x_np, xp_np, dt = load_pairs(args.batch, seed=rank)
+    system = MultibodyLearnableSystem({'cube': os.path.join(REPO, 'assets', 'cube.urdf')}, dt, dtype=dtype,
+                                      device=str(device))
+    x = torch.tensor(x_np, dtype=dtype, device=device)
+    xp = torch.tensor(xp_np, dtype=dtype, device=device)
+    reducer = GradientAllReduce(system) if distributed else None
+
+    def step():
+        system.contactnets_loss_and_grad(x, xp)
+        if reducer is not None:
+            reducer.all_reduce_mean()
+
+    # eager warm-up (allocates workspace / gradient buffers, builds RCCL communicators)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as error:  # noqa: BLE001 -- fall back to eager launches, say so in the output
+            print(f'[bench] hipGraph capture failed ({error!r}); running eagerly', file=sys.stderr)
+            graph = None
+            use_graph = False
+    run = graph.replay if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
+    total_loss = system.contactnets_loss_and_grad(x, xp).item()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        alg_bytes = BYTES_PER_STEP[args.dtype] * args.batch
+        achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
+        line = {
+            'metric': 'trajectory-steps/sec (fwd+bwd), batched cube-toss contact sim',
+            'value': args.batch * world * args.steps / elapsed,
+            'unit': 'trajectory-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype + (' (cone residual accumulated in f64)' if args.dtype == 'f32' else ''),
+            'data': 'fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set '
+                    '(tests/golden/cube_box_4096.npz, seed 0); ranks > 0 resample with replacement; URDF-initial parameters',
+            'config': {'workload': f'contactnets_cube.urdf, 4 friction contacts, batch={args.batch} per GPU, '
+                                   f'fwd+bwd contactnets_loss', 'per_gpu_batch': args.batch,
+                       'global_batch': args.batch * world, 'launch': 'hipGraph replay' if use_graph else 'eager',
+                       'collective': 'one RCCL all-reduce of [loss, 15 gradients] per step' if distributed else 'none',
+                       'mean_loss': total_loss},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -84,6 +84,9 @@ def library() -> ctypes.CDLL:
     lib.dpll_contactnets_loss.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64,
                                           c_int64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_void_p]
+    lib.dpll_profile_contactnets_loss.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64,
+                                                  c_int64, c_double, c_void_p, c_void_p, c_int64, c_void_p, c_int32,
+                                                  POINTER(ctypes.c_float), POINTER(ctypes.c_float)]
     lib.dpll_step.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_void_p, c_void_p]
     lib.dpll_simulate.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_int64, c_void_p,
@@ -102,5 +105,5 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_model_destroy',
                     'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
-                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_step', 'dpll_simulate',
+                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_simulate',
                     'dpll_terms']

@@ -74,6 +74,16 @@ DPLL_HD bool bad_number(double x) {
   return (u & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
 }
 
+// Reciprocal / reciprocal square root.  float on the GPU: the 1-ulp hardware approximations
+// (v_rcp_f32 / v_rsq_f32), enough for a self-correcting Newton iteration whose answer is judged to 1e-4;
+// double and the host build: exact division / sqrt.
+template <typename T> DPLL_HD T fast_rcp(T x) { return T(1) / x; }
+template <typename T> DPLL_HD T fast_rsqrt(T x) { return T(1) / tsqrt(x); }
+#if defined(__HIP_DEVICE_COMPILE__)
+template <> DPLL_HD float fast_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
+template <> DPLL_HD float fast_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+#endif
+
 template <typename T> DPLL_HD void cross(const T (&a)[3], const T (&b)[3], T (&c)[3]) {
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];
@@ -122,9 +132,23 @@ template <typename T> DPLL_HD void axis_rot(const T (&k)[3], T angle, T (&R)[3][
 // body origin.  Generic in the scalar type so that the finalize kernel can push dual numbers
 // through it.  inertia.py:206-234 (theta_to_pi_o), :305-331 (pi_o_to_pi_cm), :377-382 (I_cm / m).
 // ---------------------------------------------------------------------------------------------
-template <typename S> DPLL_HD S s_exp(const S& x);
-template <> DPLL_HD float s_exp<float>(const float& x) { return expf(x); }
-template <> DPLL_HD double s_exp<double>(const double& x) { return exp(x); }
+// forward-mode dual number: value + one directional derivative
+template <typename T> struct DualT {
+  T v, d;
+  DPLL_HD DualT() : v(0), d(0) {}
+  DPLL_HD DualT(T a) : v(a), d(0) {}
+  DPLL_HD DualT(T a, T b) : v(a), d(b) {}
+};
+template <typename T> DPLL_HD DualT<T> operator+(const DualT<T>& a, const DualT<T>& b) { return DualT<T>(a.v + b.v, a.d + b.d); }
+template <typename T> DPLL_HD DualT<T> operator-(const DualT<T>& a, const DualT<T>& b) { return DualT<T>(a.v - b.v, a.d - b.d); }
+template <typename T> DPLL_HD DualT<T> operator*(const DualT<T>& a, const DualT<T>& b) { return DualT<T>(a.v * b.v, a.d * b.v + a.v * b.d); }
+template <typename T> DPLL_HD DualT<T> operator/(const DualT<T>& a, const DualT<T>& b) {
+  const T q = a.v / b.v;
+  return DualT<T>(q, (a.d - q * b.d) / b.v);
+}
+DPLL_HD float s_exp(const float& x) { return expf(x); }
+DPLL_HD double s_exp(const double& x) { return exp(x); }
+template <typename T> DPLL_HD DualT<T> s_exp(const DualT<T>& x) { const T e = s_exp(x.v); return DualT<T>(e, e * x.d); }
 
 template <typename S> DPLL_HD void theta_to_iota(const S (&th)[10], int inertia_mode, S (&iota)[kIota]) {
   const S &alpha = th[0], &d1 = th[1], &d2 = th[2], &d3 = th[3], &s12 = th[4], &s23 = th[5], &s13 = th[6],
@@ -431,25 +455,48 @@ template <typename T> DPLL_HD void box_corner_signs(const T (&d)[3], const T (&h
   }
 }
 
-// Rows of the contact-point Jacobian (world = contact frame, ground kinematics are identically
-// zero) for a point `pt` rigidly attached to body `b`:  Jp = [ -S(pt - o_0) R_0, 1, a_i x (pt - o_i) ... ]
-// (multibody_terms.py:385-399 with tensor_utils.py:257-302, restated in closed form).
+// Contact-point Jacobian of a point `pt` rigidly attached to body `b` (world = contact frame, the ground's
+// kinematics are identically zero):  Jp = [ A | 1 | j_1 .. j_NJ ]  with  A = -S(pt - o_0) R_0  and
+// j_i = a_i x (pt - o_i) for the joints between the base and body b (0 otherwise)
+// (multibody_terms.py:385-399 with tensor_utils.py:257-302, restated in closed form).  Only A and the joint
+// columns are stored: the identity block costs nothing.
+template <typename T, int NJ> struct CJac {
+  T A[3][3];
+  T j[NJ > 0 ? NJ : 1][3];
+};
+
 template <typename T, int NJ>
-DPLL_HD void contact_jacobian(const Kin<T, NJ>& k, int b, const T (&pt)[3], T (&Jp)[3][6 + NJ]) {
+DPLL_HD void contact_jacobian(const Kin<T, NJ>& k, int b, const T (&pt)[3], CJac<T, NJ>& J) {
   T d0[3];
   DPLL_UNROLL for (int i = 0; i < 3; ++i) d0[i] = pt[i] - k.o[0][i];
   DPLL_UNROLL for (int c = 0; c < 3; ++c) {
     const T col[3] = {k.R[0][0][c], k.R[0][1][c], k.R[0][2][c]};
     T x[3];
     cross(col, d0, x);
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) { Jp[r][c] = x[r]; Jp[r][3 + c] = (r == c) ? T(1) : T(0); }
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) J.A[r][c] = x[r];
   }
-  DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+  DPLL_UNROLL for (int jj = 1; jj <= NJ; ++jj) {
     T dj[3], x[3];
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dj[i] = pt[i] - k.o[j][i];
-    cross(k.axw[j], dj, x);
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) Jp[r][6 + j - 1] = (j <= b) ? x[r] : T(0);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dj[i] = pt[i] - k.o[jj][i];
+    cross(k.axw[jj], dj, x);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) J.j[jj - 1][r] = (jj <= b) ? x[r] : T(0);
   }
+}
+// Jp y and Jp^T a
+template <typename T, typename TY, int NJ> DPLL_HD void cjac_apply(const CJac<T, NJ>& J, const TY* y, TY (&out)[3]) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    TY s = y[3 + r];
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) s += TY(J.A[r][c]) * y[c];
+    DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) s += TY(J.j[jj][r]) * y[6 + jj];
+    out[r] = s;
+  }
+}
+template <typename T, int NJ> DPLL_HD void cjac_apply_t_add(const CJac<T, NJ>& J, const T (&a)[3], T* out) {
+  DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+    out[c] += J.A[0][c] * a[0] + J.A[1][c] * a[1] + J.A[2][c] * a[2];
+    out[3 + c] += a[c];
+  }
+  DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) out[6 + jj] += J.j[jj][0] * a[0] + J.j[jj][1] * a[1] + J.j[jj][2] * a[2];
 }
 
 // world angular velocity of body b under generalized velocity y
@@ -467,31 +514,32 @@ template <typename T> struct Proj {
   T g[3];       // projection
   T that[2];    // unit tangential direction (mid region)
   T ratio;      // s / r in the mid region
-  int region;   // 0 inside (identity), 1 polar (zero), 2 mid
+  bool inside;  // identity region
+  bool polar;   // zero region (neither: the "mid" region, projection onto the cone surface)
 };
 template <typename T> DPLL_HD void lorentz_project(const T (&z)[3], Proj<T>& p) {
-  const T r = tsqrt(z[0] * z[0] + z[1] * z[1]);
+  const T r2 = z[0] * z[0] + z[1] * z[1];
+  const T ir = r2 > T(0) ? fast_rsqrt(r2) : T(0);
+  const T r = r2 * ir;
   const T n = z[2];
-  const bool inside = r <= n;
-  const bool polar = (r <= -n) && !inside;
-  const T safe = r > T(0) ? r : T(1);
-  const T ir = T(1) / safe;
+  p.inside = r <= n;
+  p.polar = (r <= -n) && !p.inside;
   const T s = T(0.5) * (n + r);
   p.that[0] = z[0] * ir;
   p.that[1] = z[1] * ir;
   p.ratio = s * ir;
-  p.region = inside ? 0 : (polar ? 1 : 2);
-  p.g[0] = inside ? z[0] : (polar ? T(0) : p.that[0] * s);
-  p.g[1] = inside ? z[1] : (polar ? T(0) : p.that[1] * s);
-  p.g[2] = inside ? z[2] : (polar ? T(0) : s);
+  p.g[0] = p.inside ? z[0] : (p.polar ? T(0) : p.that[0] * s);
+  p.g[1] = p.inside ? z[1] : (p.polar ? T(0) : p.that[1] * s);
+  p.g[2] = p.inside ? z[2] : (p.polar ? T(0) : s);
 }
-// w^T dP w for the generalised Jacobian dP of the projection
+// w^T dP w for the generalised Jacobian dP of the projection; in the mid region
+// dP = ratio p p^T + 1/2 n n^T with p = (-t_y, t_x, 0), n = (t_x, t_y, 1)
 template <typename T> DPLL_HD T proj_quadratic(const Proj<T>& p, const T (&w)[3]) {
   const T full = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const T a = -p.that[1] * w[0] + p.that[0] * w[1];
+  const T a = p.that[0] * w[1] - p.that[1] * w[0];
   const T b = p.that[0] * w[0] + p.that[1] * w[1] + w[2];
   const T mid = p.ratio * a * a + T(0.5) * b * b;
-  return p.region == 0 ? full : (p.region == 1 ? T(0) : mid);
+  return p.inside ? full : (p.polar ? T(0) : mid);
 }
 // dP as a symmetric 3x3 (xx, yy, zz, xy, xz, yz)
 template <typename T> DPLL_HD void proj_jacobian(const Proj<T>& p, T (&d)[6]) {
@@ -500,7 +548,7 @@ template <typename T> DPLL_HD void proj_jacobian(const Proj<T>& p, T (&d)[6]) {
                   (T(0.5) - ra) * tx * ty, T(0.5) * tx, T(0.5) * ty};
   DPLL_UNROLL for (int i = 0; i < 6; ++i) {
     const T ident = (i < 3) ? T(1) : T(0);
-    d[i] = p.region == 0 ? ident : (p.region == 1 ? T(0) : m[i]);
+    d[i] = p.inside ? ident : (p.polar ? T(0) : m[i]);
   }
 }
 
@@ -511,10 +559,11 @@ template <typename T> DPLL_HD void proj_jacobian(const Proj<T>& p, T (&d)[6]) {
 // generalized velocity y:
 //      l(y) = 1/2 y^T M y + eps/2 sum_c |P_K(-(J_c y + q_c)/eps)|^2,    f_c = P_K(-(J_c y* + q_c)/eps),
 // whose minimiser satisfies M y* = J^T f, i.e. y* = M^-1 J^T f is exactly the velocity change the
-// loss and the dynamics need.  Semi-smooth Newton with an exact (derivative-based, safeguarded)
-// line search; Newton is affine invariant so the iterates coincide with those of the whitened
-// problem the reference hands to its solver.  TA is the accumulation type of the cone residual
-// J y + q (its O(1) terms cancel to O(eps |f|), so float kernels carry y and that residual in double).
+// loss and the dynamics need.  Semi-smooth Newton with a derivative-based, safeguarded line search;
+// Newton is affine invariant so the iterates coincide with those of the whitened problem the reference
+// hands to its solver.  Contact rows are J_c = D_mu [A | 1 | j] (D_mu = diag(mu, mu, 1)): every product
+// with J exploits the identity block.  TA is the accumulation type of the cone residual J y + q (its O(1)
+// terms cancel to O(eps |f|), so float kernels carry y and that residual in double).
 // ---------------------------------------------------------------------------------------------
 struct SolverOpts {
   int max_iter;
@@ -524,95 +573,121 @@ struct SolverOpts {
   double ls_tol;     // on |l'(alpha)| relative to |l'(0)|
 };
 
-template <typename T, typename TA, int NV, int KPL, class Lanes>
-DPLL_HD int sap_newton(const T (&M)[NV][NV], const T (&Jc)[KPL][3][NV], const T (&qc)[KPL][3], T eps,
-                       const SolverOpts& opt, TA (&y)[NV], T (&f)[KPL][3]) {
-  const T ieps = T(1) / eps;
-  const T tol2 = T(opt.tol * opt.tol);
+// in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
+template <typename T, int N> DPLL_HD void cholesky_fast(const T (&A)[N][N], T (&L)[N][N], T (&invd)[N]) {
+  DPLL_UNROLL for (int j = 0; j < N; ++j) {
+    T s = A[j][j];
+    DPLL_UNROLL for (int p = 0; p < j; ++p) s -= L[j][p] * L[j][p];
+    const T id = fast_rsqrt(s);
+    invd[j] = id;
+    DPLL_UNROLL for (int i = j + 1; i < N; ++i) {
+      T t = A[i][j];
+      DPLL_UNROLL for (int p = 0; p < j; ++p) t -= L[i][p] * L[j][p];
+      L[i][j] = t * id;
+    }
+  }
+}
+
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL], const T (&mu)[KPL],
+                       const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3]) {
+  constexpr int NV = 6 + NJ;
+  const T ieps = fast_rcp(eps);
+  const T tol2 = T(opt.tol * opt.tol), stol2 = T(opt.stall_tol * opt.stall_tol), ls_tol = T(opt.ls_tol);
   bool active = true;
   int iters = 0;
   DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = TA(0);
   T best = T(3.0e38);
   int stall = 0;
   for (int it = 0; it < opt.max_iter; ++it) {
-    // cone residuals and projections
+    // cone residuals z = -(J y + q) / eps, projections, J^T gamma
     T z[KPL][3];
     Proj<T> pr[KPL];
-    T yT[NV];
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) yT[i] = T(y[i]);
-    T jtg[NV];
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) jtg[i] = T(0);
+    T yT[NV], jtg[NV];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) { yT[i] = T(y[i]); jtg[i] = T(0); }
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-      DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-        TA s = TA(qc[c][r]);
-        DPLL_UNROLL for (int i = 0; i < NV; ++i) s += TA(Jc[c][r][i]) * y[i];
-        z[c][r] = -T(s) * ieps;
-      }
+      TA jy[3];
+      cjac_apply<T, TA, NJ>(Jc[c], y, jy);
+      z[c][0] = -T(TA(mu[c]) * jy[0] + TA(qc[c][0])) * ieps;
+      z[c][1] = -T(TA(mu[c]) * jy[1] + TA(qc[c][1])) * ieps;
+      z[c][2] = -T(jy[2] + TA(qc[c][2])) * ieps;
       lorentz_project(z[c], pr[c]);
-      DPLL_UNROLL for (int i = 0; i < NV; ++i)
-        jtg[i] += Jc[c][0][i] * pr[c].g[0] + Jc[c][1][i] * pr[c].g[1] + Jc[c][2][i] * pr[c].g[2];
+      const T a[3] = {mu[c] * pr[c].g[0], mu[c] * pr[c].g[1], pr[c].g[2]};
+      cjac_apply_t_add<T, NJ>(Jc[c], a, jtg);
     }
     T My[NV], grad[NV];
     symv<T, NV>(M, yT, My);
     DPLL_UNROLL for (int i = 0; i < NV; ++i) grad[i] = My[i] - Lanes::group_sum(jtg[i]);
-    // Hessian H = M + (1/eps) sum_c J_c^T dP_c J_c
+    // Hessian H = M + sum_c [A 1 j]^T C [A 1 j],  C = D_mu dP D_mu / eps
     T H[NV][NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
       DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] = T(0);
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
       T dP[6];
       proj_jacobian(pr[c], dP);
-      T Tm[3][NV];
-      DPLL_UNROLL for (int i = 0; i < NV; ++i) {
-        Tm[0][i] = dP[0] * Jc[c][0][i] + dP[3] * Jc[c][1][i] + dP[4] * Jc[c][2][i];
-        Tm[1][i] = dP[3] * Jc[c][0][i] + dP[1] * Jc[c][1][i] + dP[5] * Jc[c][2][i];
-        Tm[2][i] = dP[4] * Jc[c][0][i] + dP[5] * Jc[c][1][i] + dP[2] * Jc[c][2][i];
+      const T m1 = mu[c] * ieps, m2 = mu[c] * m1;
+      const T C[3][3] = {{dP[0] * m2, dP[3] * m2, dP[4] * m1}, {dP[3] * m2, dP[1] * m2, dP[5] * m1}, {dP[4] * m1, dP[5] * m1, dP[2] * ieps}};
+      T CA[3][3];
+      mat3_mul(C, Jc[c].A, CA);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+        DPLL_UNROLL for (int j = 0; j <= i; ++j) {
+          H[i][j] += Jc[c].A[0][i] * CA[0][j] + Jc[c].A[1][i] * CA[1][j] + Jc[c].A[2][i] * CA[2][j];
+          H[3 + i][3 + j] += C[i][j];
+        }
+        DPLL_UNROLL for (int j = 0; j < 3; ++j) H[3 + i][j] += CA[i][j];
       }
-      DPLL_UNROLL for (int i = 0; i < NV; ++i)
-        DPLL_UNROLL for (int j = 0; j <= i; ++j)
-          H[i][j] += Jc[c][0][i] * Tm[0][j] + Jc[c][1][i] * Tm[1][j] + Jc[c][2][i] * Tm[2][j];
+      DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) {
+        T u[3];
+        mat3_vec(C, Jc[c].j[jj], u);
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+          H[6 + jj][i] += Jc[c].A[0][i] * u[0] + Jc[c].A[1][i] * u[1] + Jc[c].A[2][i] * u[2];
+          H[6 + jj][3 + i] += u[i];
+        }
+        DPLL_UNROLL for (int kk = 0; kk <= jj; ++kk) H[6 + jj][6 + kk] += dot3(Jc[c].j[kk], u);
+      }
     }
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
       DPLL_UNROLL for (int j = 0; j <= i; ++j) {
-        H[i][j] = M[i][j] + ieps * Lanes::group_sum(H[i][j]);
+        H[i][j] = M[i][j] + Lanes::group_sum(H[i][j]);
         H[j][i] = H[i][j];
       }
     T L[NV][NV], invd[NV], d[NV];
-    cholesky<T, NV>(H, L, invd);
+    cholesky_fast<T, NV>(H, L, invd);
     chol_solve<T, NV>(L, invd, grad, d);
     DPLL_UNROLL for (int i = 0; i < NV; ++i) d[i] = -d[i];
     // Newton decrement and stopping rule (the step below is still taken: it only improves y)
     const T dec2 = -dotn<T, NV>(grad, d);
     const T ynorm2 = dotn<T, NV>(yT, My);
     const T scale = T(1) + tsqrt(tmax(ynorm2, T(0)));
-    const bool converged = !(dec2 > tol2 * scale * scale);
-    // stall detection at rounding level: decrement no longer halving
-    const bool improved = dec2 < T(0.25) * best;
+    const T scale2 = scale * scale;
+    const bool converged = !(dec2 > tol2 * scale2);
+    const bool improved = dec2 < T(0.25) * best;  // decrement still halving?
     stall = improved ? 0 : stall + 1;
     best = tmin(best, dec2);
-    const T stol2 = T(opt.stall_tol * opt.stall_tol);
-    const bool stalled = stall >= 3 && !(dec2 > stol2 * scale * scale);
-    // exact line search on l'(alpha) = 0
-    T Md[NV];
-    symv<T, NV>(M, d, Md);
-    const T yMd = dotn<T, NV>(yT, Md);
-    const T dMd = dotn<T, NV>(d, Md);
+    const bool stalled = stall >= 3 && !(dec2 > stol2 * scale2);
+    // line search on l'(alpha) = y.Md + alpha d.Md - sum_c gamma_c(alpha) . (J_c d); from H d = -grad:
+    //   d.Md = dec2 - (1/eps) sum_c (J_c d)^T dP_c (J_c d)
     T jd[KPL][3];
-    DPLL_UNROLL for (int c = 0; c < KPL; ++c)
-      DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-        T s = T(0);
-        DPLL_UNROLL for (int i = 0; i < NV; ++i) s += Jc[c][r][i] * d[i];
-        jd[c][r] = s;
-      }
-    const T slope0 = -dec2;  // l'(0) = grad . d
+    T curv = T(0);
+    DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+      T t[3];
+      cjac_apply<T, T, NJ>(Jc[c], d, t);
+      jd[c][0] = mu[c] * t[0];
+      jd[c][1] = mu[c] * t[1];
+      jd[c][2] = t[2];
+      curv += proj_quadratic(pr[c], jd[c]);
+    }
+    const T dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
+    const T yMd = dotn<T, NV>(My, d);
+    const T slope_tol = ls_tol * dec2;  // |l'(0)| = dec2
     T alpha = T(1), lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
     bool searching = active && (dec2 > T(0));
     for (int ls = 0; ls < opt.max_ls; ++ls) {
       if (!Lanes::wave_any(searching)) break;
       T part1 = T(0), part2 = T(0);
+      const T step = alpha * ieps;
       DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-        T za[3];
-        DPLL_UNROLL for (int r = 0; r < 3; ++r) za[r] = z[c][r] - alpha * ieps * jd[c][r];
+        const T za[3] = {z[c][0] - step * jd[c][0], z[c][1] - step * jd[c][1], z[c][2] - step * jd[c][2]};
         Proj<T> pa;
         lorentz_project(za, pa);
         part1 += pa.g[0] * jd[c][0] + pa.g[1] * jd[c][1] + pa.g[2] * jd[c][2];
@@ -620,41 +695,34 @@ DPLL_HD int sap_newton(const T (&M)[NV][NV], const T (&Jc)[KPL][3][NV], const T 
       }
       const T first = yMd + alpha * dMd - Lanes::group_sum(part1);
       const T second = dMd + ieps * Lanes::group_sum(part2);
-      bool ok = tabs(first) <= T(opt.ls_tol) * tabs(slope0);
+      bool ok = tabs(first) <= slope_tol;
       const T lo_n = first < T(0) ? alpha : lo;
       const T hi_n = first >= T(0) ? alpha : hi;
-      const T newton = alpha - first / second;
+      const T newton = alpha - first * fast_rcp(second);
       const T mid = hi_n < T(0) ? T(2) * alpha : T(0.5) * (lo_n + hi_n);
       const bool bad = !((newton > lo_n) && (hi_n < T(0) || newton < hi_n));
       const T nxt = bad ? mid : newton;
       ok = ok || (hi_n >= T(0) && (hi_n - lo_n) <= T(4) * (sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16)) * hi_n);
-      if (searching) {
-        lo = lo_n;
-        hi = hi_n;
-        alpha = ok ? alpha : nxt;
-        searching = !ok;
-      }
+      lo = searching ? lo_n : lo;
+      hi = searching ? hi_n : hi;
+      alpha = (searching && !ok) ? nxt : alpha;
+      searching = searching && !ok;
     }
 #if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
     if (active) printf("  it %d dec2 %.3e scale %.3e alpha %.4f conv %d stall %d\n", it, double(dec2), double(scale), double(alpha), int(converged), stall);
 #endif
-    if (active) {
-      if (dec2 > T(0)) {
-        DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += TA(alpha) * TA(d[i]);
-      }
-      iters = it + 1;
-      active = !(converged || stalled);
-    }
+    const bool move = active && (dec2 > T(0));
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += move ? TA(alpha) * TA(d[i]) : TA(0);
+    iters = active ? it + 1 : iters;
+    active = active && !(converged || stalled);
     if (!Lanes::wave_any(active)) break;
   }
   // forces at the final iterate
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    T z[3];
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-      TA s = TA(qc[c][r]);
-      DPLL_UNROLL for (int i = 0; i < NV; ++i) s += TA(Jc[c][r][i]) * y[i];
-      z[r] = -T(s) * ieps;
-    }
+    TA jy[3];
+    cjac_apply<T, TA, NJ>(Jc[c], y, jy);
+    const T z[3] = {-T(TA(mu[c]) * jy[0] + TA(qc[c][0])) * ieps, -T(TA(mu[c]) * jy[1] + TA(qc[c][1])) * ieps,
+                    -T(jy[2] + TA(qc[c][2])) * ieps};
     Proj<T> p;
     lorentz_project(z, p);
     DPLL_UNROLL for (int r = 0; r < 3; ++r) f[c][r] = p.g[r];
@@ -685,6 +753,24 @@ DPLL_HD void derive_params(const ModelDesc& md, const T* theta, const T* frictio
   }
 }
 
+// Same, plus the derivative of every iota_b along ONE theta component `seed` (index into the flattened
+// (n_bodies, 10) theta, negative = none): the loss kernel gives each lane a different seed so that a wave
+// holds the whole Jacobian d iota / d theta and can chain its batch-reduced d/d iota to d/d theta itself.
+template <typename T, int NJ>
+DPLL_HD void derive_params_seeded(const ModelDesc& md, const T* theta, const T* friction, const T* lengths, int seed,
+                                  Derived<T, NJ>& dp, T (&diota)[NJ + 1][kIota]) {
+  const T mu0 = tabs(friction[0]);
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
+    DualT<T> th[10], io[kIota];
+    DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = DualT<T>(theta[10 * b + i], (seed == 10 * b + i) ? T(1) : T(0));
+    theta_to_iota<DualT<T>>(th, md.inertia_mode, io);
+    DPLL_UNROLL for (int i = 0; i < kIota; ++i) { dp.iota[b][i] = io[i].v; diota[b][i] = io[i].d; }
+    const T mub = tabs(friction[1 + b]);
+    dp.mu[b] = T(2) * mu0 * mub / (mu0 + mub);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = tabs(lengths[3 * b + i]);
+  }
+}
+
 // per-item terms shared by the loss and the dynamics
 template <typename T, int NJ> struct Terms {
   static constexpr int NB = NJ + 1, NV = 6 + NJ;
@@ -695,10 +781,25 @@ template <typename T, int NJ> struct Terms {
   T Vw[NB][3], Vu[NB][3], AGw[NB][3], AGu[NB][3];
 };
 
-template <typename T, int NJ>
-DPLL_HD void compute_terms(const ModelDesc& md, const Derived<T, NJ>& dp, const T* q, const T* v, Terms<T, NJ>& t) {
+template <typename T, typename TA, int NJ> DPLL_HD void convert_kin(const Kin<TA, NJ>& a, Kin<T, NJ>& k) {
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b)
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) { k.R[b][r][c] = T(a.R[b][r][c]); k.Rpc[b][r][c] = T(a.Rpc[b][r][c]); }
+      k.o[b][r] = T(a.o[b][r]); k.pj[b][r] = T(a.pj[b][r]); k.ax[b][r] = T(a.ax[b][r]); k.axw[b][r] = T(a.axw[b][r]);
+    }
+}
+
+// Kinematics run in the accumulation type TA (double in the float kernels): the signed distance
+// phi = o_z + (R r)_z is a cancellation of O(0.1) terms down to O(1e-4) that the dynamics then divides by dt,
+// and evaluating it in float perturbs the next velocity by up to 2e-4 in weakly constrained directions.
+template <typename T, typename TA, int NJ>
+DPLL_HD void compute_terms(const ModelDesc& md, const Derived<T, NJ>& dp, const T* q, const T* v, Terms<T, NJ>& t,
+                           Kin<TA, NJ>& kinA) {
   constexpr int NV = 6 + NJ;
-  kinematics<T, NJ>(md, q, t.kin);
+  TA qA[7 + NJ];
+  DPLL_UNROLL for (int i = 0; i < 7 + NJ; ++i) qA[i] = TA(q[i]);
+  kinematics<TA, NJ>(md, qA, kinA);
+  convert_kin<T, TA, NJ>(kinA, t.kin);
   mass_matrix<T, NJ>(t.kin, dp.iota, t.M);
   T F[NV];
   bias_forces<T, NJ>(md, t.kin, dp.iota, v, F, t.Vw, t.Vu, t.AGw, t.AGu);
@@ -708,50 +809,56 @@ DPLL_HD void compute_terms(const ModelDesc& md, const Derived<T, NJ>& dp, const 
 
 // One contact of this lane: geometry index g (= body index), slot 0..3.
 template <typename T, int NJ> struct ContactGeom {
-  static constexpr int NV = 6 + NJ;
   int body;
   T sgn[3];      // corner sign pattern
   T phi;
-  T Jp[3][NV];   // world-frame point Jacobian rows x, y, z
   T mu;
+  T R[3][3];     // rotation of the contact's body
+  CJac<T, NJ> J; // world-frame point Jacobian
 };
 
-template <typename T, int NJ>
-DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, const Kin<T, NJ>& kin, int contact,
-                             ContactGeom<T, NJ>& cg) {
+template <typename T, typename TA, int NJ>
+DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, const Kin<T, NJ>& kin,
+                             const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ>& cg) {
   constexpr int NB = NJ + 1;
   const int b = contact / kQuery;
   const int slot = contact % kQuery;
   cg.body = b;
   // select this contact's body data (b is lane dependent on the GPU)
-  T R[3][3], o[3], habs[3], gorg[3];
+  T o[3], habs[3], gorg[3];
+  TA Rz[3], oz = kinA.o[0][2];  // third row of the body rotation and origin height, in TA, for phi
   T mu = dp.mu[0];
   DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-    DPLL_UNROLL for (int c = 0; c < 3; ++c) R[r][c] = kin.R[0][r][c];
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) cg.R[r][c] = kin.R[0][r][c];
     o[r] = kin.o[0][r];
     habs[r] = dp.habs[0][r];
     gorg[r] = T(md.geom_origin[0][r]);
+    Rz[r] = kinA.R[0][2][r];
   }
   DPLL_UNROLL for (int j = 1; j < NB; ++j) {
     const bool pick = (b == j);
     DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-      DPLL_UNROLL for (int c = 0; c < 3; ++c) R[r][c] = pick ? kin.R[j][r][c] : R[r][c];
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) cg.R[r][c] = pick ? kin.R[j][r][c] : cg.R[r][c];
       o[r] = pick ? kin.o[j][r] : o[r];
       habs[r] = pick ? dp.habs[j][r] : habs[r];
       gorg[r] = pick ? T(md.geom_origin[j][r]) : gorg[r];
+      Rz[r] = pick ? kinA.R[j][2][r] : Rz[r];
     }
+    oz = pick ? kinA.o[j][2] : oz;
     mu = pick ? dp.mu[j] : mu;
   }
   cg.mu = mu;
   // support direction in the body frame: -(row 2 of R_AB) (geometry.py:560-564)
-  const T d[3] = {-R[2][0], -R[2][1], -R[2][2]};
+  const T d[3] = {-cg.R[2][0], -cg.R[2][1], -cg.R[2][2]};
   box_corner_signs(d, habs, slot, cg.sgn);
   T r_b[3], rho[3], pt[3];
   DPLL_UNROLL for (int i = 0; i < 3; ++i) r_b[i] = gorg[i] + cg.sgn[i] * habs[i];
-  mat3_vec(R, r_b, rho);
+  mat3_vec(cg.R, r_b, rho);
   DPLL_UNROLL for (int i = 0; i < 3; ++i) pt[i] = o[i] + rho[i];
-  cg.phi = pt[2];
-  contact_jacobian<T, NJ>(kin, b, pt, cg.Jp);
+  TA phiA = oz;
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) phiA += Rz[i] * (TA(gorg[i]) + TA(cg.sgn[i]) * TA(habs[i]));
+  cg.phi = T(phiA);
+  contact_jacobian<T, NJ>(kin, b, pt, cg.J);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,56 +897,48 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
   const T* qp = xp;
   const T* vp = xp + NQ;
   Terms<T, NJ> t;
-  compute_terms<T, NJ>(md, dp, qp, vp, t);  // terms at the NEXT state (quirk Q6)
+  Kin<TA, NJ> kinA;
+  compute_terms<T, TA, NJ>(md, dp, qp, vp, t, kinA);  // terms at the NEXT state (quirk Q6)
   T dv[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) dv[i] = vp[i] - (v[i] + t.a[i] * dt);
   // contacts of this lane
   ContactGeom<T, NJ> cg[KPL];
-  T Jc[KPL][3][NV], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
+  CJac<T, NJ> Jc[KPL];
+  T mu[KPL], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
   T pen = T(0);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    compute_contact<T, NJ>(md, dp, t.kin, first_contact + c, cg[c]);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c]);
+    Jc[c] = cg[c].J;
+    mu[c] = cg[c].mu;
     T jdv[3];
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-      T s1 = T(0), s2 = T(0);
-      DPLL_UNROLL for (int i = 0; i < NV; ++i) { s1 += cg[c].Jp[r][i] * dv[i]; s2 += cg[c].Jp[r][i] * vp[i]; }
-      jdv[r] = s1;
-      jpv[c][r] = s2;
-    }
-    const T mu = cg[c].mu;
-    slide[c][0] = mu * jpv[c][0];
-    slide[c][1] = mu * jpv[c][1];
+    cjac_apply<T, T, NJ>(Jc[c], dv, jdv);
+    cjac_apply<T, T, NJ>(Jc[c], vp, jpv[c]);
+    slide[c][0] = mu[c] * jpv[c][0];
+    slide[c][1] = mu[c] * jpv[c][1];
     speed[c] = tsqrt(slide[c][0] * slide[c][0] + slide[c][1] * slide[c][1]);
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) {
-      Jc[c][0][i] = mu * cg[c].Jp[0][i];
-      Jc[c][1][i] = mu * cg[c].Jp[1][i];
-      Jc[c][2][i] = cg[c].Jp[2][i];
-    }
-    qc[c][0] = -mu * jdv[0] + dt * slide[c][0];
-    qc[c][1] = -mu * jdv[1] + dt * slide[c][1];
+    qc[c][0] = -mu[c] * jdv[0] + dt * slide[c][0];
+    qc[c][1] = -mu[c] * jdv[1] + dt * slide[c][1];
     qc[c][2] = -jdv[2] + tabs(cg[c].phi) + dt * speed[c];
     const T neg = tmax(-cg[c].phi, T(0));
     pen += neg * neg;
   }
   pen = Lanes::group_sum(pen);
   TA y[NV];
-  iters = sap_newton<T, TA, NV, KPL, Lanes>(t.M, Jc, qc, eps, opt, y, force);
+  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, force);
   // invalid-solve mask (multibody_learnable_system.py:186-192)
   bool bad = false;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c)
     DPLL_UNROLL for (int r = 0; r < 3; ++r) bad = bad || bad_number(force[c][r]) || tabs(force[c][r]) > T(kInvalidForce);
   bad = Lanes::group_any(bad);
-  if (bad) {
-    DPLL_UNROLL for (int c = 0; c < KPL; ++c)
-      DPLL_UNROLL for (int r = 0; r < 3; ++r) force[c][r] = T(0);
-  }
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c)
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) force[c][r] = bad ? T(0) : force[c][r];
   // g = J^T f, w = M^-1 g
   T g[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) g[i] = T(0);
   T fq = T(0), ff = T(0);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    DPLL_UNROLL for (int i = 0; i < NV; ++i)
-      g[i] += Jc[c][0][i] * force[c][0] + Jc[c][1][i] * force[c][1] + Jc[c][2][i] * force[c][2];
+    const T a[3] = {mu[c] * force[c][0], mu[c] * force[c][1], force[c][2]};
+    cjac_apply_t_add<T, NJ>(Jc[c], a, g);
     fq += force[c][0] * qc[c][0] + force[c][1] * qc[c][1] + force[c][2] * qc[c][2];
     ff += force[c][0] * force[c][0] + force[c][1] * force[c][1] + force[c][2] * force[c][2];
   }
@@ -858,7 +957,7 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
   // error is second order in the solver error).  The adjoint instead takes w = y*, the primal optimum,
   // which equals M^-1 J^T f at convergence but carries far less rounding error than re-solving with the
   // projected force (that route amplifies it by |J|^2 / (eps M)).
-  DPLL_UNROLL for (int i = 0; i < NV; ++i) w[i] = T(y[i]);
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) w[i] = bad ? T(0) : T(y[i]);
   const T wt = bad ? T(0) : weight;
   T u[NV], abar[NV], bvec[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) { u[i] = w[i] - dv[i]; abar[i] = -dt * (Mdv[i] - g[i]); }
@@ -885,21 +984,16 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
   }
   // contact part
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    const T mu = cg[c].mu;
     const T ftx = force[c][0], fty = force[c][1], fn = force[c][2];
     const T isp = speed[c] > T(0) ? T(1) / speed[c] : T(0);
     const T shx = slide[c][0] * isp, shy = slide[c][1] * isp;
     T jpu[3];
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-      T s = T(0);
-      DPLL_UNROLL for (int i = 0; i < NV; ++i) s += cg[c].Jp[r][i] * u[i];
-      jpu[r] = s;
-    }
+    cjac_apply<T, T, NJ>(Jc[c], u, jpu);
     const T bx = dt * (fn * shx + ftx), by = dt * (fn * shy + fty);
     const T gmu = ftx * jpu[0] + fty * jpu[1] + bx * jpv[c][0] + by * jpv[c][1];
     const T phibar = fn * (cg[c].phi > T(0) ? T(1) : (cg[c].phi < T(0) ? T(-1) : T(0))) - T(2) * tmax(-cg[c].phi, T(0));
-    const T alpha[3] = {mu * ftx, mu * fty, fn};
-    const T beta[3] = {mu * bx, mu * by, T(0)};
+    const T alpha[3] = {mu[c] * ftx, mu[c] * fty, fn};
+    const T beta[3] = {mu[c] * bx, mu[c] * by, T(0)};
     T ou[3], ov[3], c1[3], c2[3], rhobar[3], rbar[3];
     world_omega<T, NJ>(t.kin, cg[c].body, u, ou);
     world_omega<T, NJ>(t.kin, cg[c].body, vp, ov);
@@ -907,15 +1001,7 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
     cross(beta, ov, c2);
     DPLL_UNROLL for (int i = 0; i < 3; ++i) rhobar[i] = c1[i] + c2[i];
     rhobar[2] += phibar;
-    // r_bar = R_b^T rho_bar with this contact's body rotation
-    T R[3][3];
-    DPLL_UNROLL for (int r = 0; r < 3; ++r)
-      DPLL_UNROLL for (int cc = 0; cc < 3; ++cc) {
-        T val = t.kin.R[0][r][cc];
-        DPLL_UNROLL for (int j = 1; j < NB; ++j) val = (cg[c].body == j) ? t.kin.R[j][r][cc] : val;
-        R[r][cc] = val;
-      }
-    mat3t_vec(R, rhobar, rbar);
+    mat3t_vec(cg[c].R, rhobar, rbar);  // r_bar = R_b^T rho_bar
     DPLL_UNROLL for (int b = 0; b < NB; ++b) {
       const bool mine = (cg[c].body == b);
       grad.g_mu[b] += mine ? wt * gmu : T(0);
@@ -951,31 +1037,26 @@ DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const Solv
   const T* q = x;
   const T* v = x + NQ;
   Terms<T, NJ> t;
-  compute_terms<T, NJ>(md, dp, q, v, t);
+  Kin<TA, NJ> kinA;
+  compute_terms<T, TA, NJ>(md, dp, q, v, t, kinA);
   T vm[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];
-  T Jc[KPL][3][NV], qc[KPL][3];
+  CJac<T, NJ> Jc[KPL];
+  T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     ContactGeom<T, NJ> cg;
-    compute_contact<T, NJ>(md, dp, t.kin, first_contact + c, cg);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg);
+    Jc[c] = cg.J;
+    mu[c] = cg.mu;
     T jv[3];
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-      T s = T(0);
-      DPLL_UNROLL for (int i = 0; i < NV; ++i) s += cg.Jp[r][i] * vm[i];
-      jv[r] = s;
-    }
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) {
-      Jc[c][0][i] = cg.mu * cg.Jp[0][i];
-      Jc[c][1][i] = cg.mu * cg.Jp[1][i];
-      Jc[c][2][i] = cg.Jp[2][i];
-    }
+    cjac_apply<T, T, NJ>(Jc[c], vm, jv);
     qc[c][0] = cg.mu * jv[0];
     qc[c][1] = cg.mu * jv[1];
     qc[c][2] = jv[2] + cg.phi * idt;
   }
   TA y[NV];
-  iters = sap_newton<T, TA, NV, KPL, Lanes>(t.M, Jc, qc, eps, opt, y, impulse);
+  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, impulse);
   // v+ = v- + M^-1 J^T impulse = v- + y*: the primal optimum IS that velocity change (M y* = J^T f), and
   // taking it from y instead of re-solving with the projected impulse avoids amplifying the impulse's
   // rounding error by |J|^2 / (eps M).
@@ -991,20 +1072,7 @@ DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const Solv
 // chain from the batch-reduced gradients (d/d iota, d/d mu_pair, d/d |length|) to the learnable
 // parameters (theta, friction_params, length_params); double precision, a handful of flops.
 // ---------------------------------------------------------------------------------------------
-struct Dual {
-  double v, d;
-  DPLL_HD Dual() : v(0), d(0) {}
-  DPLL_HD Dual(double a) : v(a), d(0) {}
-  DPLL_HD Dual(double a, double b) : v(a), d(b) {}
-};
-DPLL_HD Dual operator+(const Dual& a, const Dual& b) { return Dual(a.v + b.v, a.d + b.d); }
-DPLL_HD Dual operator-(const Dual& a, const Dual& b) { return Dual(a.v - b.v, a.d - b.d); }
-DPLL_HD Dual operator*(const Dual& a, const Dual& b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
-DPLL_HD Dual operator/(const Dual& a, const Dual& b) {
-  const double q = a.v / b.v;
-  return Dual(q, (a.d - q * b.d) / b.v);
-}
-template <> DPLL_HD Dual s_exp<Dual>(const Dual& x) { const double e = exp(x.v); return Dual(e, e * x.d); }
+using Dual = DualT<double>;
 
 // d(sum_i g_iota[i] iota_i(theta)) / d theta_k for one body
 DPLL_HD double theta_grad_component(int inertia_mode, const double* theta, const double* g_iota, int k) {

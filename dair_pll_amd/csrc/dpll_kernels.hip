@@ -1,0 +1,594 @@
+// dpll_kernels.hip -- gfx950 kernels and the C ABI (include/dpll.h) of the contact-dynamics hot path.
+//
+// Mapping: ONE LANE PER CONTACT.  A batch item (one (x, x+) transition or one trajectory) is owned by a
+// group of G = 4 n_bodies adjacent lanes of a wavefront (cube: 4 lanes, 16 items per wave; elbow: 8 lanes,
+// 8 items per wave).  Each lane keeps its contact's witness point, 3 x n_v Jacobian rows and cone state in
+// registers; the n_v x n_v blocks (M, Newton Hessian, Cholesky factors) are replicated over the group and
+// sums over contacts are DPP butterflies (quad_perm / row_half_mirror), so the inner solver loop touches
+// neither LDS nor memory.  One wave per workgroup: at the benchmark batch (4096 items = 256 waves) every
+// wave gets a CU of its own, which is what a latency-bound Newton iteration wants; bigger batches loop
+// items inside the wave (grid capped) and fill the chip with more waves per SIMD.
+//
+// Gradients never leave the chip per item: each wave reduces its items' d/d(iota, mu, |length|) with
+// cross-lane adds, writes one row of double partial sums, and a one-block finalize kernel sums the rows in
+// a fixed order (bitwise reproducible, no float atomics) and chains them to (theta, friction, lengths).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/dpll.h"
+#include "dpll_core.hpp"
+
+namespace {
+
+using namespace dpll;
+
+static_assert(sizeof(ModelDesc) == sizeof(dpll_model_desc_t), "ModelDesc must mirror dpll_model_desc_t");
+static_assert(sizeof(SolverOpts) == sizeof(dpll_solver_opts_t), "SolverOpts must mirror dpll_solver_opts_t");
+static_assert(kMaxJoints == DPLL_MAX_JOINTS && kMaxBodies == DPLL_MAX_BODIES, "limits");
+
+constexpr int kWave = 64;
+constexpr int kMaxLossBlocks = 2048;  // partial-sum rows; 8 one-wave workgroups per CU
+
+// ---- cross-lane primitives --------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+  // old = 0 + bound_ctrl lets the backend fold the move into the consuming add (v_add_f32_dpp); every
+  // source lane of the controls used here is inside the wave, so the value of `old` never shows
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int lo = (int)(unsigned)(u & 0xffffffffull), hi = (int)(unsigned)(u >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+  return __builtin_bit_cast(double, r);
+}
+constexpr int kQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int kRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
+constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
+
+template <int G> struct GpuLanes {
+  static_assert(G == 4 || G == 8, "one lane per contact: 4 (one body) or 8 (two bodies)");
+  template <typename T> static __device__ __forceinline__ T group_sum(T x) {
+    x += dpp_mov<kQuadXor1>(x);
+    x += dpp_mov<kQuadXor2>(x);
+    if (G == 8) x += dpp_mov<kRowHalfMirror>(x);  // both quads hold their own sum -> mirror pairs them
+    return x;
+  }
+  static __device__ __forceinline__ bool group_any(bool x) {
+    const unsigned long long b = __ballot(x);
+    const int base = (threadIdx.x & (kWave - 1)) & ~(G - 1);
+    return ((b >> base) & ((1ull << G) - 1ull)) != 0ull;
+  }
+  static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
+};
+
+// sum over the whole wave of a value that is already uniform inside each group of G lanes, counting every
+// group once; the result is valid in every lane
+template <int G> __device__ __forceinline__ double wave_sum_of_groups(double x) {
+  if (G == 4) x += dpp_mov<kRowHalfMirror>(x);
+  x += dpp_mov<kRowMirror>(x);
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+template <typename T, int NJ> struct Dims {
+  static constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NB, G = K;
+  static constexpr int IPW = kWave / G;                       // items per wave
+  static constexpr int P = NB * 10 + (NB + 1) + NB * 3;       // learnable parameters [theta | friction | lengths]
+  static constexpr int PI = 1 + P;                            // partial-sum row: [loss | d/d params]
+};
+
+template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
+
+// ---- ContactNets loss, forward + backward -----------------------------------------------------
+template <typename T, int NJ>
+__global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+                                                     const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                     const T* __restrict__ x, long long ld_x,
+                                                     const T* __restrict__ xp, long long ld_xp, long long batch,
+                                                     const T* __restrict__ weights, double scale, T* __restrict__ loss,
+                                                     T* __restrict__ force, int* __restrict__ iters,
+                                                     double* __restrict__ partials, int want_grad) {
+  using D = Dims<T, NJ>;
+  using Lanes = GpuLanes<D::G>;
+  const int lane = threadIdx.x;
+  const int cidx = lane % D::G;
+  const int slot = lane / D::G;
+  // lane l >= 1 owns learnable parameter l - 1 of the output row and carries d iota / d theta_(l-1)
+  Derived<T, NJ> dp;
+  T diota[D::NB][kIota];
+  derive_params_seeded<T, NJ>(md, theta, friction, lengths, lane - 1, dp, diota);
+  LossGrad<T, NJ> acc;
+  zero_grad(acc);
+  double loss_acc = 0.0;
+  const long long stride = (long long)gridDim.x * D::IPW;
+  for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
+    const long long item = base + slot;
+    const bool valid = item < batch;
+    const long long it = valid ? item : batch - 1;  // idle groups shadow the last item: keeps every lane live for DPP
+    T xr[D::NX], xpr[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
+    const T w = valid ? T(scale) * (weights ? weights[it] : T(1)) : T(0);
+    T f[1][3];
+    int n_it = 0;
+    const T L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it);
+    if (valid) {
+      if (cidx == 0) {
+        if (loss) loss[it] = L;
+        if (iters) iters[it] = n_it;
+      }
+      if (force) {
+        T* row = force + it * (3 * D::K);
+        row[cidx] = f[0][2];
+        row[D::K + 2 * cidx] = f[0][0];
+        row[D::K + 2 * cidx + 1] = f[0][1];
+      }
+    }
+    loss_acc += (cidx == 0) ? double(w) * double(L) : 0.0;
+  }
+  if (!want_grad) return;
+  // wave reduction of d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
+  // parameter per lane: the row this wave writes is already in parameter space
+  const double loss_sum = wave_sum_of_groups<D::G>(Lanes::group_sum(loss_acc));
+  double s_mu[D::NB], s_len[D::NB * 3];
+  double theta_bar = 0.0;
+#pragma unroll
+  for (int b = 0; b < D::NB; ++b) {
+#pragma unroll
+    for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
+      theta_bar += wave_sum_of_groups<D::G>(double(acc.g_iota[b][i])) * double(diota[b][i]);
+    s_mu[b] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_mu[b])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_len[b][i])));
+  }
+  const int k = lane - 1;
+  double fr[D::NB + 1], ln[D::NB * 3];
+#pragma unroll
+  for (int i = 0; i < D::NB + 1; ++i) fr[i] = double(friction[i]);
+#pragma unroll
+  for (int i = 0; i < D::NB * 3; ++i) ln[i] = double(lengths[i]);
+  double val = loss_sum;
+  if (k >= 0 && k < D::NB * 10) val = theta_bar;
+  // friction and length components: evaluate all (a handful of flops) and select, no runtime indexing
+#pragma unroll
+  for (int i = 0; i < D::NB + 1; ++i) {
+    const double c = friction_grad_component(D::NB, fr, s_mu, i);
+    val = (k == D::NB * 10 + i) ? c : val;
+  }
+#pragma unroll
+  for (int i = 0; i < D::NB * 3; ++i) {
+    const double c = length_grad_component(ln, s_len, i);
+    val = (k == D::NB * 10 + D::NB + 1 + i) ? c : val;
+  }
+  if (lane < D::PI) partials[(long long)blockIdx.x * D::PI + lane] = val;
+}
+
+// sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ partials, int n_rows,
+                                                       T* __restrict__ grad, T* __restrict__ loss_total) {
+  using D = Dims<T, NJ>;
+  static_assert(D::PI <= 32, "partial row must fit 32 columns");
+  __shared__ double red[8][32];
+  const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
+  double s = 0.0;
+  if (col < D::PI)
+    for (int r = rowg; r < n_rows; r += 8) s += partials[(long long)r * D::PI + col];
+  red[rowg][col] = s;
+  __syncthreads();
+  if (threadIdx.x < D::PI) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += red[r][col];
+    if (threadIdx.x == 0) {
+      if (loss_total) *loss_total = T(t);
+    } else {
+      grad[threadIdx.x - 1] = T(t);
+    }
+  }
+}
+
+// ---- simulation: `steps` VelocityIntegrator steps per item, trajectory written as it goes ---------
+template <typename T, int NJ>
+__global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+                                                         const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                         const T* __restrict__ x0, long long ld_x, long long batch,
+                                                         long long steps, T* __restrict__ out, long long ld_item,
+                                                         long long ld_step, int write_x0, int* __restrict__ iters) {
+  using D = Dims<T, NJ>;
+  using Lanes = GpuLanes<D::G>;
+  const int lane = threadIdx.x;
+  const int cidx = lane % D::G;
+  const int slot = lane / D::G;
+  Derived<T, NJ> dp;
+  derive_params<T, NJ>(md, theta, friction, lengths, dp);
+  const long long stride = (long long)gridDim.x * D::IPW;
+  for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
+    const long long item = base + slot;
+    const bool valid = item < batch;
+    const long long it = valid ? item : batch - 1;
+    T xr[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) xr[i] = x0[it * ld_x + i];
+    T* dst = out + it * ld_item;
+    if (write_x0) {
+      if (valid && cidx == 0) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) dst[i] = xr[i];
+      }
+      dst += ld_step;
+    }
+    int total = 0;
+    for (long long s = 0; s < steps; ++s) {
+      T xn[D::NX], imp[1][3];
+      int n_it = 0;
+      step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it);
+      total += n_it;
+#pragma unroll
+      for (int i = 0; i < D::NX; ++i) xr[i] = xn[i];
+      if (valid && cidx == 0) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) dst[i] = xr[i];
+      }
+      dst += ld_step;
+    }
+    if (iters && valid && cidx == 0) iters[it] = total;
+  }
+}
+
+// ---- MultibodyTerms.forward for API parity (off the hot path: the loss / step kernels never form D) ----
+template <typename T, int NJ>
+__global__ __launch_bounds__(kWave) void terms_kernel(ModelDesc md, const T* __restrict__ theta,
+                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                      const T* __restrict__ x, long long ld_x, long long batch,
+                                                      T* __restrict__ Dout, T* __restrict__ Mout, T* __restrict__ Jout,
+                                                      T* __restrict__ phiout, T* __restrict__ aout) {
+  using D = Dims<T, NJ>;
+  constexpr int NV = D::NV, K = D::K;
+  __shared__ T Jrows[D::IPW][3 * K][NV];
+  const int lane = threadIdx.x;
+  const int cidx = lane % D::G;
+  const int slot = lane / D::G;
+  Derived<T, NJ> dp;
+  derive_params<T, NJ>(md, theta, friction, lengths, dp);
+  const long long stride = (long long)gridDim.x * D::IPW;
+  for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
+    const long long item = base + slot;
+    const bool valid = item < batch;
+    const long long it = valid ? item : batch - 1;
+    T xr[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) xr[i] = x[it * ld_x + i];
+    Terms<T, NJ> t;
+    Kin<typename Acc<T>::type, NJ> kinA;
+    compute_terms<T, typename Acc<T>::type, NJ>(md, dp, xr, xr + D::NQ, t, kinA);
+    ContactGeom<T, NJ> cg;
+    compute_contact<T, typename Acc<T>::type, NJ>(md, dp, t.kin, kinA, cidx, cg);
+    // rows of J in the reference order [normals | mu (t_x, t_y) per contact] (multibody_terms.py:415-426)
+    T mine[3][NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      T col[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) col[r] = i < 3 ? cg.J.A[r][i] : (i < 6 ? (r == i - 3 ? T(1) : T(0)) : cg.J.j[i >= 6 ? i - 6 : 0][r]);
+      mine[0][i] = col[2]; mine[1][i] = cg.mu * col[0]; mine[2][i] = cg.mu * col[1];
+    }
+    const int rows[3] = {cidx, K + 2 * cidx, K + 2 * cidx + 1};
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) Jrows[slot][rows[r]][i] = mine[r][i];
+    __syncthreads();
+    if (valid) {
+      if (phiout) phiout[it * K + cidx] = cg.phi;
+      if (Jout) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int i = 0; i < NV; ++i) Jout[(it * 3 * K + rows[r]) * NV + i] = mine[r][i];
+      }
+      if (cidx == 0) {
+        if (Mout) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) Mout[(it * NV + i) * NV + j] = t.M[i][j];
+        }
+        if (aout) {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) aout[it * NV + i] = t.a[i];
+        }
+      }
+      if (Dout) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          T w[NV];
+          chol_solve<T, NV>(t.LM, t.invdM, mine[r], w);
+          for (int c = 0; c < 3 * K; ++c) {
+            T s = T(0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += w[i] * Jrows[slot][c][i];
+            Dout[(it * 3 * K + rows[r]) * (3 * K) + c] = s;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "") {
+  std::snprintf(g_error, sizeof(g_error), fmt, detail);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t err = hipGetLastError();
+  if (err != hipSuccess) {
+    std::snprintf(g_error, sizeof(g_error), "%s: %s", what, hipGetErrorString(err));
+    return -5;
+  }
+  return 0;
+}
+
+SolverOpts default_opts(int dtype) {
+  SolverOpts o;
+  if (dtype == DPLL_F64) {
+    o.max_iter = 100; o.max_ls = 50; o.tol = 1e-13; o.stall_tol = 1e-10; o.ls_tol = 0.1;
+  } else {
+    o.max_iter = 60; o.max_ls = 30; o.tol = 1e-6; o.stall_tol = 1e-5; o.ls_tol = 0.1;
+  }
+  return o;
+}
+
+template <typename T, int NJ> int loss_blocks(long long batch) {
+  using D = Dims<T, NJ>;
+  long long blocks = (batch + D::IPW - 1) / D::IPW;
+  if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+struct dpll_model {
+  ModelDesc desc;
+  SolverOpts opts[2];
+};
+
+namespace {
+
+template <typename T, int NJ>
+int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
+                long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* grad,
+                void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
+                hipStream_t stream) {
+  using D = Dims<T, NJ>;
+  const int blocks = loss_blocks<T, NJ>(batch);
+  const int want_grad = grad != nullptr;
+  if (want_grad) {
+    if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+      return fail(-3, "dpll_contactnets_loss: workspace too small%s");
+  } else if (loss_total) {
+    return fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
+  }
+  hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                     ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                     want_grad);
+  if (int rc = check_launch("loss_kernel")) return rc;
+  if (want_grad) {
+    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)workspace, blocks,
+                       (T*)grad, (T*)loss_total);
+    if (int rc = check_launch("finalize_kernel")) return rc;
+  }
+  return 0;
+}
+
+// measuring utility: `reps` back-to-back loss+finalize launches with HIP events recorded on the launch
+// stream around each kernel; returns the average duration of each kernel in milliseconds
+template <typename T, int NJ>
+int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
+                 long long ld_xp, long long batch, double scale, void* grad, void* workspace, long long workspace_bytes,
+                 hipStream_t stream, int reps, float* ms_loss, float* ms_finalize) {
+  using D = Dims<T, NJ>;
+  const int blocks = loss_blocks<T, NJ>(batch);
+  if (!grad || !workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+    return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
+  hipEvent_t* ev = new (std::nothrow) hipEvent_t[3 * (size_t)reps];
+  if (!ev) return fail(-4, "dpll_profile_contactnets_loss: out of memory%s");
+  for (int i = 0; i < 3 * reps; ++i) (void)hipEventCreate(&ev[i]);
+  for (int r = 0; r < reps; ++r) {
+    (void)hipEventRecord(ev[3 * r], stream);
+    hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x,
+                       (const T*)xp, ld_xp, batch, (const T*)nullptr, scale, (T*)nullptr, (T*)nullptr, (int*)nullptr,
+                       (double*)workspace, 1);
+    (void)hipEventRecord(ev[3 * r + 1], stream);
+    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)workspace, blocks,
+                       (T*)grad, (T*)nullptr);
+    (void)hipEventRecord(ev[3 * r + 2], stream);
+  }
+  int rc = check_launch("profile launches");
+  (void)hipEventSynchronize(ev[3 * reps - 1]);
+  double t_loss = 0.0, t_fin = 0.0;
+  for (int r = 0; r < reps; ++r) {
+    float a = 0.f, b = 0.f;
+    (void)hipEventElapsedTime(&a, ev[3 * r], ev[3 * r + 1]);
+    (void)hipEventElapsedTime(&b, ev[3 * r + 1], ev[3 * r + 2]);
+    t_loss += a;
+    t_fin += b;
+  }
+  for (int i = 0; i < 3 * reps; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  if (ms_loss) *ms_loss = (float)(t_loss / reps);
+  if (ms_finalize) *ms_finalize = (float)(t_fin / reps);
+  return rc;
+}
+
+template <typename T, int NJ>
+int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x,
+                    long long batch, long long steps, void* out, long long ld_item, long long ld_step, int write_x0,
+                    int32_t* iters, hipStream_t stream) {
+  using D = Dims<T, NJ>;
+  long long blocks = (batch + D::IPW - 1) / D::IPW;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((simulate_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
+                     (T*)out, ld_item, ld_step, write_x0, (int*)iters);
+  return check_launch("simulate_kernel");
+}
+
+template <typename T, int NJ>
+int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm,
+                 void* M, void* J, void* phi, void* a, hipStream_t stream) {
+  using D = Dims<T, NJ>;
+  long long blocks = (batch + D::IPW - 1) / D::IPW;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((terms_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, (const T*)p->theta,
+                     (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J,
+                     (T*)phi, (T*)a);
+  return check_launch("terms_kernel");
+}
+
+int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long long batch, const char* who) {
+  if (!m) return fail(-1, "%s: null model", who);
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "%s: dtype must be DPLL_F32 or DPLL_F64", who);
+  if (!p || !p->theta || !p->friction || !p->lengths) return fail(-1, "%s: null parameter pointer", who);
+  if (batch < 0) return fail(-1, "%s: negative batch", who);
+  return 0;
+}
+
+#define DPLL_DISPATCH(FN, ...)                                                               \
+  do {                                                                                       \
+    const int nj = model->desc.n_joints;                                                     \
+    if (dtype == DPLL_F32 && nj == 0) return FN<float, 0>(__VA_ARGS__);                      \
+    if (dtype == DPLL_F32 && nj == 1) return FN<float, 1>(__VA_ARGS__);                      \
+    if (dtype == DPLL_F64 && nj == 0) return FN<double, 0>(__VA_ARGS__);                     \
+    if (dtype == DPLL_F64 && nj == 1) return FN<double, 1>(__VA_ARGS__);                     \
+    return fail(-2, "%s: kernels are built for 0 or 1 joints", #FN);                         \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* dpll_last_error(void) { return g_error; }
+int dpll_abi_version(void) { return 1; }
+
+int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
+  if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
+  if (desc->n_joints < 0 || desc->n_joints > 1)
+    return fail(-2, "dpll_model_create: this build supports 0 or 1 revolute joints%s");
+  if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");
+  if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL)
+    return fail(-1, "dpll_model_create: unknown inertia_mode%s");
+  dpll_model* m = new (std::nothrow) dpll_model;
+  if (!m) return fail(-4, "dpll_model_create: out of memory%s");
+  std::memcpy(&m->desc, desc, sizeof(ModelDesc));
+  m->opts[DPLL_F32] = default_opts(DPLL_F32);
+  m->opts[DPLL_F64] = default_opts(DPLL_F64);
+  *out = m;
+  return 0;
+}
+
+void dpll_model_destroy(dpll_model_t* model) { delete model; }
+
+int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts_t* opts) {
+  if (!model || !opts || (dtype != DPLL_F32 && dtype != DPLL_F64)) return fail(-1, "dpll_model_set_solver: bad argument%s");
+  if (opts->max_iter < 1 || opts->max_ls < 1) return fail(-1, "dpll_model_set_solver: iteration limits must be >= 1%s");
+  std::memcpy(&model->opts[dtype], opts, sizeof(SolverOpts));
+  return 0;
+}
+
+int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts_t* opts) {
+  if (!model || !opts || (dtype != DPLL_F32 && dtype != DPLL_F64)) return fail(-1, "dpll_model_get_solver: bad argument%s");
+  std::memcpy(opts, &model->opts[dtype], sizeof(SolverOpts));
+  return 0;
+}
+
+int dpll_n_x(const dpll_model_t* model) { return model ? 13 + 2 * model->desc.n_joints : -1; }
+int dpll_n_contacts(const dpll_model_t* model) { return model ? kQuery * (model->desc.n_joints + 1) : -1; }
+int dpll_param_count(const dpll_model_t* model) {
+  if (!model) return -1;
+  const int nb = model->desc.n_joints + 1;
+  return 10 * nb + (nb + 1) + 3 * nb;
+}
+
+int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
+  if (!model || batch < 0) return -1;
+  const int nb = model->desc.n_joints + 1;
+  const int64_t ipw = kWave / (kQuery * nb);
+  int64_t blocks = (batch + ipw - 1) / ipw;
+  if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+  if (blocks < 1) blocks = 1;
+  const int64_t pi = 1 + 10 * nb + (nb + 1) + 3 * nb;
+  return blocks * pi * (int64_t)sizeof(double);
+}
+
+int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                          int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                          double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_loss")) return rc;
+  if (batch == 0) return fail(-1, "dpll_contactnets_loss: empty batch%s");
+  if (!x || !x_plus) return fail(-1, "dpll_contactnets_loss: null state pointer%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss: row stride smaller than n_x%s");
+  DPLL_DISPATCH(launch_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total,
+                force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                                  int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, double scale,
+                                  void* grad, void* workspace, int64_t workspace_bytes, void* stream, int32_t reps,
+                                  float* ms_loss_kernel, float* ms_finalize_kernel) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_profile_contactnets_loss")) return rc;
+  if (batch == 0 || !x || !x_plus || reps < 1 || reps > 100000) return fail(-1, "dpll_profile_contactnets_loss: bad argument%s");
+  DPLL_DISPATCH(profile_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, scale, grad, workspace,
+                workspace_bytes, (hipStream_t)stream, reps, ms_loss_kernel, ms_finalize_kernel);
+}
+
+int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
+              int64_t batch, void* x_next, int64_t ld_next, int32_t* iters, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_step")) return rc;
+  if (batch == 0) return 0;
+  if (!x || !x_next) return fail(-1, "dpll_step: null state pointer%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx || ld_next < nx) return fail(-1, "dpll_step: row stride smaller than n_x%s");
+  DPLL_DISPATCH(launch_simulate, model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters,
+                (hipStream_t)stream);
+}
+
+int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x0, int64_t ld_x,
+                  int64_t batch, int64_t steps, void* traj, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_simulate")) return rc;
+  if (steps < 0) return fail(-1, "dpll_simulate: negative steps%s");
+  if (batch == 0) return 0;
+  if (!x0 || !traj) return fail(-1, "dpll_simulate: null state pointer%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx) return fail(-1, "dpll_simulate: row stride smaller than n_x%s");
+  DPLL_DISPATCH(launch_simulate, model, dtype, params, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, 1,
+                nullptr, (hipStream_t)stream);
+}
+
+int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
+               int64_t batch, void* delassus, void* M, void* J, void* phi, void* a, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_terms")) return rc;
+  if (batch == 0) return 0;
+  if (!x) return fail(-1, "dpll_terms: null state pointer%s");
+  if (ld_x < dpll_n_x(model)) return fail(-1, "dpll_terms: row stride smaller than n_x%s");
+  DPLL_DISPATCH(launch_terms, model, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,387 @@
+"""``MultibodyLearnableSystem``: the reference's system surface on top of ``libdpll_hip.so``.
+
+Mirrors ``dair_pll/multibody_learnable_system.py:41-333`` and ``dair_pll/system.py:47-191`` for the
+hot path: same constructor, same method names / argument meaning / shapes, same ``state_dict`` keys
+
+    multibody_terms.lagrangian_terms.inertial_parameters        (n_bodies, 10)
+    multibody_terms.contact_terms.friction_params               (n_geometries,)   ground first
+    multibody_terms.contact_terms.geometries.{i}.length_params  (1, 3)            boxes, i >= 1
+
+The arithmetic runs in hand-written gfx950 kernels; PyTorch only owns device memory, streams and the
+autograd plumbing.  There is no CPU fallback: every compute method raises unless its tensors live
+on a ROCm device and the HIP library is built.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+from torch.nn import Module, ModuleList, Parameter
+
+from . import _capi
+from .inertia import pi_cm_to_theta
+from .integrator import VelocityIntegrator
+from .state_space import FloatingBaseSpace
+from .urdf import ModelSpec, check_supported, parse_urdf
+
+_DTYPES = {torch.float32: _capi.F32, torch.float64: _capi.F64}
+
+
+def _ptr(tensor: Optional[Tensor]) -> Optional[int]:
+    return None if tensor is None else tensor.data_ptr()
+
+
+class Plane(Module):
+    """Ground half-space z <= 0 (``dair_pll/geometry.py:94-129``); no parameters."""
+
+
+class Box(Module):
+    """``dair_pll/geometry.py:367-412``: ``length_params`` are the half lengths, shape ``(1, 3)``."""
+
+    def __init__(self, half_lengths: Tensor) -> None:
+        super().__init__()
+        self.length_params = Parameter(half_lengths.reshape(1, 3).clone(), requires_grad=True)
+
+    def get_half_lengths(self) -> Tensor:
+        return torch.abs(self.length_params)
+
+
+class LagrangianTerms(Module):
+    def __init__(self, theta: Tensor) -> None:
+        super().__init__()
+        self.inertial_parameters = Parameter(theta.clone(), requires_grad=True)
+
+
+class ContactTerms(Module):
+    def __init__(self, friction: Tensor, geometries: List[Module]) -> None:
+        super().__init__()
+        self.friction_params = Parameter(friction.clone(), requires_grad=True)
+        self.geometries = ModuleList(geometries)
+
+    def get_friction_coefficients(self) -> Tensor:
+        return torch.abs(self.friction_params)
+
+
+class MultibodyTerms(Module):
+    """Container with the reference's parameter tree; ``forward`` is ``MultibodyTerms.forward``
+    (``dair_pll/multibody_terms.py:584-609``) evaluated by ``dpll_terms``."""
+
+    def __init__(self, spec: ModelSpec, dtype: torch.dtype, device: torch.device) -> None:
+        super().__init__()
+        pi_cm = np.array([[b.mass] + [b.mass * c for c in b.com] + list(b.inertia_cm) for b in spec.bodies])
+        theta = np.stack([pi_cm_to_theta(row) for row in pi_cm])  # multibody_terms.py:186-188
+        as_t = lambda a: torch.tensor(np.asarray(a), dtype=dtype, device=device)
+        self.lagrangian_terms = LagrangianTerms(as_t(theta))
+        geometries: List[Module] = [Plane()]
+        for body in spec.bodies:
+            geom = body.geoms[0]
+            if geom.kind != 'box':
+                raise NotImplementedError('only box collision geometry is implemented in the HIP kernels so far')
+            geometries.append(Box(as_t(geom.half_lengths)))
+        self.contact_terms = ContactTerms(as_t(spec.friction_init()), geometries)
+        object.__setattr__(self, '_owner', None)  # plain attribute: the owner must not become a submodule
+
+    def forward(self, q: Tensor, v: Tensor, u: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+        assert self._owner is not None
+        return self._owner._terms(q, v)
+
+
+class _LossFunction(torch.autograd.Function):
+    """Per-item loss with the hand-written adjoint as its backward."""
+
+    @staticmethod
+    def forward(ctx, system, x, x_plus, *params):  # pylint: disable=arguments-differ
+        ctx.system = system
+        ctx.save_for_backward(x, x_plus)
+        return system._launch_loss(x, x_plus, weights=None, scale=1.0, want_grad=False)[0]
+
+    @staticmethod
+    def backward(ctx, grad_output):  # pylint: disable=arguments-differ
+        x, x_plus = ctx.saved_tensors
+        system = ctx.system
+        _, flat_grad, _ = system._launch_loss(x, x_plus, weights=grad_output.contiguous(), scale=1.0, want_grad=True)
+        return (None, None, None) + tuple(system._split_flat(flat_grad.clone()))
+
+
+class MultibodyLearnableSystem(Module):
+    """Drop-in for ``dair_pll.multibody_learnable_system.MultibodyLearnableSystem``."""
+
+    def __init__(self, init_urdfs: Dict[str, str], dt: float, output_urdfs_dir: Optional[str] = None,
+                 inertia_mode: str = 'reference_literal', dtype: torch.dtype = torch.float32,
+                 device: Optional[str] = None) -> None:
+        super().__init__()
+        if len(init_urdfs) != 1:
+            raise NotImplementedError('one URDF (one floating-base chain) per system')
+        if dtype not in _DTYPES:
+            raise TypeError('dtype must be torch.float32 or torch.float64')
+        self.urdfs = dict(init_urdfs)
+        self.output_urdfs_dir = output_urdfs_dir
+        self.spec = parse_urdf(next(iter(init_urdfs.values())))
+        check_supported(self.spec)
+        self.dt = dt
+        self.inertia_mode = inertia_mode
+        self.dtype = dtype
+        dev = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
+        self.space = FloatingBaseSpace(self.spec.n_joints)
+        self.multibody_terms = MultibodyTerms(self.spec, dtype, dev)
+        object.__setattr__(self.multibody_terms, '_owner', self)
+        self.integrator = VelocityIntegrator(self.space, self.sim_step, dt)
+        self.integrator.fused_simulate = self._fused_simulate
+        self.max_batch_dim = 1  # multibody_learnable_system.py:80
+        self.carry_callback = lambda: torch.tensor([False])  # :79
+        self._desc = _capi.make_desc(self.spec, dt, inertia_mode)
+        self._handle: Optional[ctypes.c_void_p] = None
+        self._flat: Optional[Tensor] = None
+        self._grad_buf: Optional[Tensor] = None  # [loss_total | flat gradient]: one buffer = one all-reduce
+        self._flat_grad: Optional[Tensor] = None
+        self._workspace: Optional[Tensor] = None
+        self._loss_total: Optional[Tensor] = None
+        self.grad_world = 1      # set by distributed.GradientAllReduce
+        self.global_batch = 0
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def _param_list(self) -> List[Parameter]:
+        terms = self.multibody_terms
+        boxes = [g.length_params for g in terms.contact_terms.geometries if isinstance(g, Box)]
+        return [terms.lagrangian_terms.inertial_parameters, terms.contact_terms.friction_params] + boxes
+
+    def n_params(self) -> int:
+        return sum(p.numel() for p in self._param_list())
+
+    def _packed(self) -> Tensor:
+        """All learnable parameters as views of ONE flat device buffer ``[theta | friction |
+        lengths]`` (the layout ``dpll_param_count`` documents), so a kernel call needs no gather
+        and an optimizer's in-place update is seen by the next call."""
+        params = self._param_list()
+        flat = self._flat
+        ok = flat is not None and flat.dtype == params[0].dtype and flat.device == params[0].device
+        offset = 0
+        if ok:
+            for p in params:
+                if p.data_ptr() != flat.data_ptr() + offset * flat.element_size() or not p.is_contiguous():
+                    ok = False
+                    break
+                offset += p.numel()
+        if not ok:
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+            offset = 0
+            for p in params:
+                p.data = flat[offset:offset + p.numel()].view(p.shape)
+                offset += p.numel()
+            self._flat = flat
+            self._flat_grad = self._grad_buf = self._loss_total = None
+        return flat
+
+    def _alloc_grad_buffer(self, n_params: int, device) -> None:
+        self._grad_buf = torch.zeros(1 + n_params, dtype=self.dtype, device=device)
+        self._loss_total = self._grad_buf[:1]
+        self._flat_grad = self._grad_buf[1:]
+
+    def grad_buffer(self) -> Tensor:
+        """``[mean loss | gradient of every parameter]`` of the last :meth:`contactnets_loss_and_grad`
+        call, one contiguous tensor whose slices ARE the parameters' ``.grad`` -- the object a
+        data-parallel all-reduce acts on."""
+        if self._grad_buf is None:
+            self._alloc_grad_buffer(self._packed().numel(), self._packed().device)
+        return self._grad_buf
+
+    def _split_flat(self, flat: Tensor) -> List[Tensor]:
+        out, offset = [], 0
+        for p in self._param_list():
+            out.append(flat[offset:offset + p.numel()].view(p.shape))
+            offset += p.numel()
+        return out
+
+    # ---- native handle ------------------------------------------------------------------------
+    def _model(self) -> ctypes.c_void_p:
+        if self._handle is None:
+            handle = ctypes.c_void_p()
+            _capi.check(_capi.library().dpll_model_create(ctypes.byref(self._desc), ctypes.byref(handle)))
+            self._handle = handle
+        return self._handle
+
+    def __del__(self):
+        handle = getattr(self, '_handle', None)
+        if handle is not None and _capi._lib is not None:
+            _capi._lib.dpll_model_destroy(handle)
+            self._handle = None
+
+    def set_solver(self, **kwargs) -> None:
+        """Override ``max_iter / max_ls / tol / stall_tol / ls_tol`` for this system's dtype."""
+        lib = _capi.library()
+        opts = _capi.SolverOpts()
+        code = _DTYPES[self.dtype]
+        _capi.check(lib.dpll_model_get_solver(self._model(), code, ctypes.byref(opts)))
+        for key, value in kwargs.items():
+            setattr(opts, key, value)
+        _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
+
+    def _check_input(self, tensor: Tensor, width: int, what: str) -> Tensor:
+        if not tensor.is_cuda:
+            raise _capi.DpllError(f'{what} must live on a ROCm device: the HIP kernels are the only implementation')
+        if tensor.shape[-1] != width:
+            raise AssertionError(f'{what}: last dimension {tensor.shape[-1]} != {width}')
+        tensor = tensor.detach()
+        if tensor.dtype != self.dtype:
+            tensor = tensor.to(self.dtype)
+        tensor = tensor.reshape(-1, width)
+        return tensor if tensor.stride(-1) == 1 and tensor.stride(0) >= width else tensor.contiguous()
+
+    def _params_struct(self, flat: Tensor) -> _capi.Params:
+        n_b = self.spec.n_joints + 1
+        base, size = flat.data_ptr(), flat.element_size()
+        return _capi.Params(base, base + 10 * n_b * size, base + (10 * n_b + n_b + 1) * size)
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- ContactNets loss -----------------------------------------------------------------------
+    def _launch_loss(self, x: Tensor, x_plus: Tensor, weights: Optional[Tensor], scale: float, want_grad: bool,
+                     force: Optional[Tensor] = None, iters: Optional[Tensor] = None,
+                     loss: Optional[Tensor] = None, want_loss: bool = True):
+        lib = _capi.library()
+        flat = self._packed()
+        batch = x.shape[0]
+        if loss is None and want_loss:
+            loss = torch.empty(batch, dtype=self.dtype, device=x.device)
+        grad = total = workspace = None
+        ws_bytes = 0
+        if want_grad:
+            if self._flat_grad is None or self._flat_grad.device != x.device:
+                self._alloc_grad_buffer(flat.numel(), x.device)
+            grad, total = self._flat_grad, self._loss_total
+            ws_bytes = lib.dpll_workspace_bytes(self._model(), batch)
+            if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
+                self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            workspace = self._workspace
+        params = self._params_struct(flat)
+        _capi.check(lib.dpll_contactnets_loss(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x),
+                                              x.stride(0), _ptr(x_plus), x_plus.stride(0), batch, _ptr(weights),
+                                              float(scale), _ptr(loss), _ptr(grad), _ptr(total), _ptr(force),
+                                              _ptr(iters), _ptr(workspace), ws_bytes, self._stream()))
+        return loss, grad, total
+
+    def contactnets_loss(self, x: Tensor, u: Tensor, x_plus: Tensor, loss_pool=None) -> Tensor:
+        """``(*, n_x), (*, ?), (*, n_x) -> (*,)`` ContactNets loss
+        (``multibody_learnable_system.py:104-197``); differentiable with respect to the module's
+        parameters (the backward pass re-runs the fused kernel with ``grad_output`` as weights)."""
+        del u, loss_pool  # n_u = 0 for the supported systems; pools are accepted and ignored
+        batch_shape = x.shape[:-1]
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        self._packed()
+        loss = _LossFunction.apply(self, xf, xpf, *self._param_list())
+        return loss.reshape(batch_shape)
+
+    def contactnets_loss_and_grad(self, x: Tensor, x_plus: Tensor, accumulate: bool = False) -> Tensor:
+        """Fused training step: mean loss over the batch AND its parameter gradients in one pass,
+        i.e. what ``loss = system.contactnets_loss(x, u, x_plus).mean(); loss.backward()`` produces
+        (``drake_experiment.py:202-224`` + ``experiment.py:355-359``).  Returns the mean loss as a
+        one-element device tensor (no host sync) and writes ``.grad`` of every parameter."""
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        denom = self.global_batch if self.global_batch > 0 else xf.shape[0] * self.grad_world
+        _, grad, total = self._launch_loss(xf, xpf, None, 1.0 / denom, True, want_loss=False)
+        for param, piece in zip(self._param_list(), self._split_flat(grad)):
+            if accumulate and param.grad is not None:
+                param.grad = param.grad + piece
+            elif param.grad is None or param.grad.data_ptr() != piece.data_ptr():
+                param.grad = piece
+        return total
+
+    def profile_loss_kernels(self, x: Tensor, x_plus: Tensor, reps: int = 100) -> Tuple[float, float]:
+        """Average duration in ms of (loss kernel, finalize kernel) measured with HIP events on the
+        launch stream (``dpll_profile_contactnets_loss``).  Synchronises."""
+        lib = _capi.library()
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        self._launch_loss(xf, xpf, None, 1.0 / xf.shape[0], True, want_loss=False)  # allocates grad / workspace
+        flat = self._packed()
+        params = self._params_struct(flat)
+        ms_loss, ms_fin = ctypes.c_float(0.0), ctypes.c_float(0.0)
+        _capi.check(lib.dpll_profile_contactnets_loss(
+            self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(xf), xf.stride(0), _ptr(xpf), xpf.stride(0),
+            xf.shape[0], 1.0 / xf.shape[0], _ptr(self._flat_grad), _ptr(self._workspace), self._workspace.numel(),
+            self._stream(), reps, ctypes.byref(ms_loss), ctypes.byref(ms_fin)))
+        return ms_loss.value, ms_fin.value
+
+    def contact_forces(self, x: Tensor, x_plus: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """Loss, the detached contact impulses ``(*, 3k)`` (``[normals | (t_x, t_y) per contact]``)
+        and solver iteration counts; diagnostic twin of :meth:`contactnets_loss`."""
+        batch_shape = x.shape[:-1]
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        force = torch.empty((xf.shape[0], 3 * self.spec.n_contacts), dtype=self.dtype, device=xf.device)
+        iters = torch.empty(xf.shape[0], dtype=torch.int32, device=xf.device)
+        loss, _, _ = self._launch_loss(xf, xpf, None, 1.0, False, force=force, iters=iters)
+        return loss.reshape(batch_shape), force.reshape(batch_shape + (-1,)), iters.reshape(batch_shape)
+
+    # ---- dynamics -------------------------------------------------------------------------------
+    def _step(self, x: Tensor) -> Tensor:
+        lib = _capi.library()
+        flat = self._packed()
+        x_next = torch.empty((x.shape[0], self.space.n_x), dtype=self.dtype, device=x.device)
+        params = self._params_struct(flat)
+        _capi.check(lib.dpll_step(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
+                                  x.shape[0], _ptr(x_next), x_next.stride(0), None, self._stream()))
+        return x_next
+
+    def forward_dynamics(self, q: Tensor, v: Tensor, u: Tensor, dynamics_pool=None) -> Tensor:
+        """``(*, n_q), (*, n_v), (*, ?) -> (*, n_v)`` next velocity by Anitescu's convex contact
+        model (``multibody_learnable_system.py:199-304``).  Not differentiable yet (forward only)."""
+        del u, dynamics_pool
+        batch_shape = q.shape[:-1]
+        x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
+        return self._step(x)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))
+
+    def sim_step(self, x: Tensor, carry: Tensor) -> Tuple[Tensor, Tensor]:
+        """``Integrator.partial_step`` callback (``multibody_learnable_system.py:306-313``)."""
+        q, v = self.space.q_v(x)
+        return self.forward_dynamics(q, v, torch.zeros(q.shape[:-1] + (0,), device=q.device)), carry
+
+    def step(self, x: Tensor) -> Tensor:
+        """One fused ``VelocityIntegrator.step``: ``(*, n_x) -> (*, n_x)``."""
+        batch_shape = x.shape[:-1]
+        return self._step(self._check_input(x, self.space.n_x, 'x')).reshape(batch_shape + (self.space.n_x,))
+
+    def _fused_simulate(self, x_0: Tensor, steps: int) -> Tensor:
+        lib = _capi.library()
+        batch_shape = x_0.shape[:-1]
+        x = self._check_input(x_0, self.space.n_x, 'x_0')
+        flat = self._packed()
+        traj = torch.empty((x.shape[0], steps + 1, self.space.n_x), dtype=self.dtype, device=x.device)
+        params = self._params_struct(flat)
+        _capi.check(lib.dpll_simulate(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
+                                      x.shape[0], steps, _ptr(traj), self._stream()))
+        return traj.reshape(batch_shape + (steps + 1, self.space.n_x))
+
+    def preprocess_initial_condition(self, x_0: Tensor, carry_0: Tensor) -> Tuple[Tensor, Tensor]:
+        """``dair_pll/system.py:147-173``: keep the last state of the initial sequence."""
+        assert len(x_0.shape) >= 2
+        assert x_0.shape[-1] == self.space.n_x
+        return x_0[..., -1, :], carry_0
+
+    def simulate(self, x_0: Tensor, carry_0: Tensor, steps: int = 1) -> Tuple[Tensor, Tensor]:
+        """``(*, T_0, n_x) -> (*, steps + 1, n_x)`` (``dair_pll/system.py:97-129``).  Extra batch
+        dimensions are flattened into the kernel's batch instead of being iterated in Python."""
+        x, carry = self.preprocess_initial_condition(x_0, carry_0)
+        return self.integrator.simulate(x, carry, steps)
+
+    # ---- terms ----------------------------------------------------------------------------------
+    def _terms(self, q: Tensor, v: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+        lib = _capi.library()
+        batch_shape = q.shape[:-1]
+        x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
+        flat = self._packed()
+        n, n_v, k = x.shape[0], self.space.n_v, self.spec.n_contacts
+        new = lambda *shape: torch.empty((n,) + shape, dtype=self.dtype, device=x.device)
+        delassus, mass, jac, phi, acc = new(3 * k, 3 * k), new(n_v, n_v), new(3 * k, n_v), new(k), new(n_v)
+        params = self._params_struct(flat)
+        _capi.check(lib.dpll_terms(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0), n,
+                                   _ptr(delassus), _ptr(mass), _ptr(jac), _ptr(phi), _ptr(acc), self._stream()))
+        shape = lambda t: t.reshape(batch_shape + t.shape[1:])
+        return shape(delassus), shape(mass), shape(jac), shape(phi), shape(acc)
