@@ -170,23 +170,38 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
   if (lane < D::PI) partials[(long long)blockIdx.x * D::PI + lane] = val;
 }
 
-// sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype
+// sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype.
+// 32 row groups x 32 columns = 1024 threads; every thread first issues all of its (independent) loads,
+// so the kernel costs about one memory round trip instead of one per row.
+constexpr int kFinalizeThreads = 1024;
+constexpr int kFinalizeLoads = kMaxLossBlocks / 32;  // rows per thread at the largest grid
+
 template <typename T, int NJ>
-__global__ __launch_bounds__(256) void finalize_kernel(const double* __restrict__ partials, int n_rows,
-                                                       T* __restrict__ grad, T* __restrict__ loss_total) {
+__global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double* __restrict__ partials, int n_rows,
+                                                                    T* __restrict__ grad, T* __restrict__ loss_total) {
   using D = Dims<T, NJ>;
   static_assert(D::PI <= 32, "partial row must fit 32 columns");
-  __shared__ double red[8][32];
+  __shared__ double red[32][33];
   const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
+  double v[kFinalizeLoads];
+#pragma unroll
+  for (int i = 0; i < kFinalizeLoads; ++i) {
+    const int r = rowg + 32 * i;
+    v[i] = (col < D::PI && r < n_rows) ? partials[(long long)r * D::PI + col] : 0.0;
+    if (32 * (i + 1) >= n_rows) break;  // uniform: n_rows is a kernel argument
+  }
   double s = 0.0;
-  if (col < D::PI)
-    for (int r = rowg; r < n_rows; r += 8) s += partials[(long long)r * D::PI + col];
+#pragma unroll
+  for (int i = 0; i < kFinalizeLoads; ++i) {
+    s += v[i];
+    if (32 * (i + 1) >= n_rows) break;
+  }
   red[rowg][col] = s;
   __syncthreads();
   if (threadIdx.x < D::PI) {
     double t = 0.0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) t += red[r][col];
+    for (int r = 0; r < 32; ++r) t += red[r][col];
     if (threadIdx.x == 0) {
       if (loss_total) *loss_total = T(t);
     } else {
@@ -388,7 +403,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                      want_grad);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
-    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)workspace, blocks,
+    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
                        (T*)grad, (T*)loss_total);
     if (int rc = check_launch("finalize_kernel")) return rc;
   }
@@ -415,7 +430,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
                        (const T*)xp, ld_xp, batch, (const T*)nullptr, scale, (T*)nullptr, (T*)nullptr, (int*)nullptr,
                        (double*)workspace, 1);
     (void)hipEventRecord(ev[3 * r + 1], stream);
-    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)workspace, blocks,
+    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
                        (T*)grad, (T*)nullptr);
     (void)hipEventRecord(ev[3 * r + 2], stream);
   }

@@ -220,10 +220,10 @@ class MultibodyLearnableSystem(Module):
         _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
 
     def _check_input(self, tensor: Tensor, width: int, what: str) -> Tensor:
-        if not tensor.is_cuda:
-            raise _capi.DpllError(f'{what} must live on a ROCm device: the HIP kernels are the only implementation')
         if tensor.shape[-1] != width:
             raise AssertionError(f'{what}: last dimension {tensor.shape[-1]} != {width}')
+        if not tensor.is_cuda:
+            raise _capi.DpllError(f'{what} must live on a ROCm device: the HIP kernels are the only implementation')
         tensor = tensor.detach()
         if tensor.dtype != self.dtype:
             tensor = tensor.to(self.dtype)

@@ -1,0 +1,129 @@
+"""Host-side logic that needs no GPU: URDF parsing, parameter tree / state_dict contract, the C ABI
+library's exported symbols, argument validation that happens before any launch, batch sharding."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ASSET_DIR, REPO
+from dair_pll_amd import FloatingBaseSpace, MultibodyLearnableSystem, VelocityIntegrator, parse_urdf
+from dair_pll_amd import _capi
+from dair_pll_amd.distributed import shard_bounds
+from dair_pll_amd.inertia import pi_cm_to_theta, theta_to_pi_cm
+
+
+def test_urdf_cube_and_elbow():
+    cube = parse_urdf(os.path.join(ASSET_DIR, 'cube.urdf'))
+    assert cube.n_joints == 0 and cube.n_contacts == 4
+    assert cube.bodies[0].mass == 0.37 and cube.bodies[0].geoms[0].half_lengths == [0.0524] * 3
+    assert cube.friction_init() == [1.0, 0.15]
+    elbow = parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf'))
+    assert elbow.n_joints == 1 and elbow.n_contacts == 8 and elbow.n_q == 8 and elbow.n_v == 7
+    assert elbow.bodies[1].parent == 0 and elbow.bodies[1].joint_axis == [0.0, 1.0, 0.0]
+    assert elbow.bodies[1].joint_origin == [-0.035, 0.06, 0.0]
+
+
+def test_theta_round_trip():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        mass = rng.uniform(0.1, 2.0)
+        com = rng.uniform(-0.05, 0.05, 3)
+        a = rng.normal(size=(3, 3)) * 0.03
+        inertia = a @ a.T + 1e-4 * np.eye(3)
+        pi_cm = np.concatenate(([mass], mass * com, [inertia[0, 0], inertia[1, 1], inertia[2, 2], inertia[0, 1],
+                                                      inertia[0, 2], inertia[1, 2]]))
+        # a physically valid inertia needs the triangle inequalities; enforce by adding a sphere
+        pi_cm[4:7] += np.trace(inertia)
+        assert np.abs(theta_to_pi_cm(pi_cm_to_theta(pi_cm)) - pi_cm).max() < 1e-12
+
+
+def test_state_dict_contract_matches_reference_names(golden):
+    g = golden('cube_box_literal')
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, 0.0068, device='cpu',
+                                      dtype=torch.float64)
+    names = dict(system.named_parameters())
+    expected = {key[len('param/'):] for key in g.files if key.startswith('param/')}
+    assert set(names) == expected
+    for name, param in names.items():
+        assert tuple(param.shape) == g['param/' + name].shape
+        assert np.abs(param.detach().numpy() - g['param/' + name]).max() < 1e-12  # URDF-initial values
+    # flat packing: parameters alias one buffer in the documented order, survive load_state_dict and .to()
+    flat = system._packed()
+    assert flat.numel() == 15
+    system.load_state_dict({k: v.clone() + 1 for k, v in system.state_dict().items()})
+    assert torch.equal(system._packed(), flat) and flat[0].item() == pytest.approx(g['param/' + list(names)[0]].ravel()[0] + 1)
+    system.float()
+    assert system._packed().dtype == torch.float32
+    assert system.space.n_x == 13 and system.max_batch_dim == 1
+    assert system.carry_callback().tolist() == [False]
+
+
+def test_compute_calls_fail_loudly_without_gpu_tensors():
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, 0.0068, device='cpu')
+    x = torch.zeros(2, 13)
+    with pytest.raises(_capi.DpllError):
+        system.contactnets_loss(x, torch.zeros(2, 0), x)
+    with pytest.raises(_capi.DpllError):
+        system.simulate(x.unsqueeze(-2), torch.zeros(2, 1), 3)
+    with pytest.raises(AssertionError):
+        system._check_input(torch.zeros(2, 12), 13, 'x')
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, 'include', 'dpll.h')).read()
+    declared = set(re.findall(r'\b(dpll_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(_capi.EXPORTED_SYMBOLS)
+    lib = _capi.library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dpll_abi_version() == 1
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9)
+    # host-only entry points work without a GPU and validate their arguments
+    desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
+    handle = ctypes.c_void_p()
+    assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
+    assert lib.dpll_n_x(handle) == 15 and lib.dpll_n_contacts(handle) == 8 and lib.dpll_param_count(handle) == 29
+    assert lib.dpll_workspace_bytes(handle, 4096) == 512 * 30 * 8
+    opts = _capi.SolverOpts()
+    assert lib.dpll_model_get_solver(handle, _capi.F32, ctypes.byref(opts)) == 0 and opts.max_iter == 60
+    opts.max_iter = 0
+    assert lib.dpll_model_set_solver(handle, _capi.F32, ctypes.byref(opts)) != 0
+    assert b'iteration limits' in lib.dpll_last_error()
+    params = _capi.Params(None, None, None)
+    assert lib.dpll_contactnets_loss(handle, _capi.F32, ctypes.byref(params), None, 15, None, 15, 4, None, 1.0, None,
+                                     None, None, None, None, None, 0, None) != 0
+    assert b'null parameter pointer' in lib.dpll_last_error()
+    lib.dpll_model_destroy(handle)
+    desc.n_joints = 2
+    assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) != 0
+
+
+def test_integrator_generic_path_matches_space_euler_step():
+    """VelocityIntegrator with a user callback (no GPU): q+ = q (+) v+ dt, trajectory layout."""
+    space = FloatingBaseSpace(1)
+    torch.manual_seed(0)
+    x0 = torch.randn(5, space.n_x, dtype=torch.float64)
+    x0[:, :4] /= x0[:, :4].norm(dim=-1, keepdim=True)
+    integrator = VelocityIntegrator(space, lambda x, carry: (space.v(x) * 0.5, carry), 0.01)
+    traj, carry = integrator.simulate(x0, torch.zeros(5, 1), 3)
+    assert traj.shape == (5, 4, space.n_x) and carry.shape == (5, 4, 1)
+    assert torch.equal(traj[:, 0], x0)
+    v1 = x0[:, space.n_q:] * 0.5
+    assert torch.allclose(traj[:, 1, space.n_q:], v1)
+    assert torch.allclose(traj[:, 1, 4:space.n_q], x0[:, 4:space.n_q] + 0.01 * v1[:, 3:])
+    # quaternion update against the oracle's implementation
+    from oracle import dpll_oracle as O
+    expect = O.quat_multiply(x0[:, :4], O.quat_exp(v1[:, :3] * 0.01))
+    assert torch.allclose(traj[:, 1, :4], expect, atol=1e-15)
+
+
+def test_shard_bounds_cover_batch():
+    for batch, world in ((4096, 8), (65536, 8), (10, 4), (3, 8)):
+        spans = [shard_bounds(batch, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == batch
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,127 @@
+"""The per-item math of the HIP kernels (csrc/dpll_core.hpp), compiled for the host with one lane
+per item (tests/hostsim), against the fixtures recorded from the reference run.  CPU only.
+
+This is how the arithmetic the GPU runs is checked in the GPU-less container (and under
+sanitizers); the GPU parity tests proper are tests/test_hip_parity.py."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import hostsim
+from conftest import ASSET_DIR
+from dair_pll_amd._capi import make_desc
+from dair_pll_amd.urdf import parse_urdf
+
+URDF = {'contactnets_cube.urdf': 'cube.urdf', 'contactnets_elbow.urdf': 'elbow.urdf'}
+P = 'multibody_terms.'
+CASES = ['cube_box_literal', 'cube_box_physical', 'cube_box_config1', 'elbow_box_literal']
+
+
+def setup(g):
+    spec = parse_urdf(os.path.join(ASSET_DIR, URDF[str(g['urdf'])]))
+    desc = make_desc(spec, float(g['dt']), str(g['inertia_mode']))
+    n_b = spec.n_joints + 1
+    theta = g['param/' + P + 'lagrangian_terms.inertial_parameters']
+    friction = g['param/' + P + 'contact_terms.friction_params']
+    lengths = np.concatenate([g['param/' + P + f'contact_terms.geometries.{i + 1}.length_params'] for i in range(n_b)])
+    names = [P + 'lagrangian_terms.inertial_parameters', P + 'contact_terms.friction_params'] + \
+        [P + f'contact_terms.geometries.{i + 1}.length_params' for i in range(n_b)]
+    grad_ref = np.concatenate([g['grad/' + n].ravel() for n in names]) if 'grad/' + names[0] in g.files else None
+    return desc, theta, friction, lengths, grad_ref
+
+
+@pytest.mark.parametrize('case', CASES + ['cube_box_4096'])
+def test_loss_and_gradient_float64(golden, case):
+    g = golden(case)
+    desc, theta, friction, lengths, grad_ref = setup(g)
+    out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float64)
+    assert np.abs(out['loss'] - g['loss']).max() < 1e-12
+    assert np.abs(out['grad'] - grad_ref).max() <= 1e-9 * max(1.0, np.abs(grad_ref).max())
+
+
+@pytest.mark.parametrize('case', CASES + ['cube_box_4096'])
+@pytest.mark.parametrize('mixed', [True, False])
+def test_loss_float32(golden, case, mixed):
+    """float32 arithmetic; `mixed` = kinematics, cone residual and y carried in double, which is what
+    the float GPU kernels do.  Tolerance 1e-4 from BASELINE.json; the achieved error is ~1e-7."""
+    g = golden(case)
+    desc, theta, friction, lengths, grad_ref = setup(g)
+    out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float32, mixed=mixed)
+    assert np.abs(out['loss'] - g['loss']).max() < (5e-6 if mixed else 1e-4)
+    if case == 'cube_box_4096':  # no resting-contact kinks in the sampled batch: gradients comparable as they are
+        assert np.abs(out['grad'] - grad_ref).max() <= (2e-4 if mixed else 5e-3) * np.abs(grad_ref).max()
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_step_matches_reference_run(golden, case):
+    g = golden(case)
+    desc, theta, friction, lengths, _ = setup(g)
+    x_next, iters = hostsim.step(desc, theta, friction, lengths, g['x'], dtype=np.float64)
+    assert np.abs(x_next - g['dynamics/x_next']).max() < 1e-10
+    assert iters.max() < 100
+    x_next32, _ = hostsim.step(desc, theta, friction, lengths, g['x'], dtype=np.float32)
+    assert np.abs(x_next32 - g['dynamics/x_next']).max() < 1e-4
+
+
+def test_forces_satisfy_kkt(golden):
+    """the recorded (J_M, P^T q, eps) problems of the reference run: the host solver's forces are the
+    unique KKT point (compared with the recorded solution, contact order canonicalised by sorting)."""
+    g = golden('cube_box_literal')
+    desc, theta, friction, lengths, _ = setup(g)
+    out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float64)
+    k = 4
+    f_ref = g['solver_loss/f'].reshape(-1, k, 3)  # per contact [t_x, t_y, n]
+    mine = out['force']
+    fn = mine[:, :k]
+    ft = mine[:, k:].reshape(-1, k, 2)
+    assert np.abs(np.sort(fn, -1) - np.sort(f_ref[..., 2], -1)).max() < 1e-9
+    assert np.abs(np.sort(np.linalg.norm(ft, axis=-1), -1) - np.sort(np.linalg.norm(f_ref[..., :2], axis=-1), -1)).max() < 1e-9
+    assert (np.linalg.norm(ft, axis=-1) <= fn + 1e-12).all()
+
+
+def test_weights_are_linear(golden):
+    g = golden('cube_box_literal')
+    desc, theta, friction, lengths, _ = setup(g)
+    rng = np.random.default_rng(0)
+    w1, w2 = rng.random(g['x'].shape[0]), rng.random(g['x'].shape[0])
+    run = lambda w: hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], weights=w, scale=1.0)['grad']
+    assert np.abs(run(w1) + 2 * run(w2) - run(w1 + 2 * w2)).max() < 1e-12
+
+
+def test_free_flight_has_zero_force_and_tiny_loss(golden):
+    g = golden('cube_box_literal')
+    desc, theta, friction, lengths, _ = setup(g)
+    airborne = g['terms/phi'].min(-1) > 0.02
+    assert airborne.sum() > 20
+    out = hostsim.loss(desc, theta, friction, lengths, g['x'][airborne], g['x_plus'][airborne])
+    assert np.abs(out['force']).max() == 0.0
+    assert out['loss'].max() < 5e-4  # measurement noise of real data: 1/2 dv^T M dv with no contact impulse
+    assert np.abs(out['loss'] - g['loss'][airborne]).max() < 1e-15
+    assert out['iters'].max() <= 1
+
+
+def test_sanitized_build_runs_clean(golden):
+    """ASan/UBSan build of the same math in a child process (GPU sanitizers are unavailable on the pool)."""
+    import subprocess
+    import sys
+    lib = hostsim.build(sanitize=True)
+    code = f'''
+import sys, ctypes, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+import hostsim
+hostsim._lib = ctypes.CDLL({lib!r})
+from test_host_math import setup
+g = np.load({os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'elbow_box_literal.npz')!r})
+desc, theta, friction, lengths, grad_ref = setup(g)
+for dtype in (np.float64, np.float32):
+    out = hostsim.loss(desc, theta, friction, lengths, g['x'][:32], g['x_plus'][:32], dtype=dtype)
+    hostsim.step(desc, theta, friction, lengths, g['x'][:32], dtype=dtype)
+print('sanitized ok')
+'''
+    asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so']).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0', PYTHONPATH=os.path.dirname(__file__))
+    result = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert result.returncode == 0 and 'sanitized ok' in result.stdout, result.stderr[-2000:]
+    assert 'runtime error' not in result.stderr
