@@ -33,6 +33,9 @@
 #endif
 
 #define DPLL_UNROLL _Pragma("unroll")
+#ifndef DPLL_CORE_STAMP
+#define DPLL_CORE_STAMP(slot) do {} while (0)
+#endif
 
 namespace dpll {
 
@@ -924,7 +927,9 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
   }
   pen = Lanes::group_sum(pen);
   TA y[NV];
+  DPLL_CORE_STAMP(4);
   iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, force);
+  DPLL_CORE_STAMP(5);
   // invalid-solve mask (multibody_learnable_system.py:186-192)
   bool bad = false;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c)

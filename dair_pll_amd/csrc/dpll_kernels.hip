@@ -19,6 +19,25 @@
 #include <new>
 
 #include "../../include/dpll.h"
+
+// Diagnostic build only (-DDPLL_STAMPS, never shipped): shader-clock stamps per wave at phase boundaries of
+// the loss kernel, written to a buffer of their own that no kernel reads.
+#ifdef DPLL_STAMPS
+__device__ unsigned long long g_stamps[2048][8];
+#define DPLL_STAMP(slot)                                                                                   \
+  do {                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    unsigned long long t_;                                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    if (threadIdx.x == 0) g_stamps[blockIdx.x][slot] = t_;                                                 \
+  } while (0)
+#else
+#define DPLL_STAMP(slot) do {} while (0)
+#endif
+#ifdef DPLL_STAMPS
+#define DPLL_CORE_STAMP(slot) DPLL_STAMP(slot)
+#endif
 #include "dpll_core.hpp"
 
 namespace {
@@ -80,11 +99,17 @@ template <int G> __device__ __forceinline__ double wave_sum_of_groups(double x) 
 template <typename T, int NJ> struct Dims {
   static constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NB, G = K;
   static constexpr int IPW = kWave / G;                       // items per wave
+#ifdef DPLL_LOSS_IPW
+  static constexpr int IPWL = DPLL_LOSS_IPW < IPW ? DPLL_LOSS_IPW : IPW;  // distinct items per wave in the loss kernel
+#else
+  static constexpr int IPWL = IPW;
+#endif
   static constexpr int P = NB * 10 + (NB + 1) + NB * 3;       // learnable parameters [theta | friction | lengths]
   static constexpr int PI = 1 + P;                            // partial-sum row: [loss | d/d params]
 };
 
 template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
+
 
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
 template <typename T, int NJ>
@@ -100,6 +125,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
   const int slot = lane / D::G;
+  DPLL_STAMP(0);
   // lane l >= 1 owns learnable parameter l - 1 of the output row and carries d iota / d theta_(l-1)
   Derived<T, NJ> dp;
   T diota[D::NB][kIota];
@@ -107,10 +133,10 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
   LossGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
-  const long long stride = (long long)gridDim.x * D::IPW;
-  for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
-    const long long item = base + slot;
-    const bool valid = item < batch;
+  const long long stride = (long long)gridDim.x * D::IPWL;
+  for (long long base = (long long)blockIdx.x * D::IPWL; base < batch; base += stride) {
+    const long long item = base + slot % D::IPWL;  // lane groups beyond IPWL shadow the first ones (same trip counts)
+    const bool valid = item < batch && slot < D::IPWL;
     const long long it = valid ? item : batch - 1;  // idle groups shadow the last item: keeps every lane live for DPP
     T xr[D::NX], xpr[D::NX];
 #pragma unroll
@@ -118,6 +144,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     const T w = valid ? T(scale) * (weights ? weights[it] : T(1)) : T(0);
     T f[1][3];
     int n_it = 0;
+    DPLL_STAMP(1);
     const T L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it);
     if (valid) {
       if (cidx == 0) {
@@ -132,6 +159,16 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
       }
     }
     loss_acc += (cidx == 0) ? double(w) * double(L) : 0.0;
+#ifdef DPLL_STAMPS
+    {
+      const int mx = __builtin_amdgcn_readfirstlane(n_it);  // not the max, just a sample; max below
+      int m = n_it;
+      for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+      if (threadIdx.x == 0) g_stamps[blockIdx.x][6] = (unsigned long long)m;
+      (void)mx;
+    }
+#endif
+    DPLL_STAMP(2);
   }
   if (!want_grad) return;
   // wave reduction of d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
@@ -168,6 +205,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     val = (k == D::NB * 10 + D::NB + 1 + i) ? c : val;
   }
   if (lane < D::PI) partials[(long long)blockIdx.x * D::PI + lane] = val;
+  DPLL_STAMP(3);
 }
 
 // sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype.
@@ -368,7 +406,7 @@ SolverOpts default_opts(int dtype) {
 
 template <typename T, int NJ> int loss_blocks(long long batch) {
   using D = Dims<T, NJ>;
-  long long blocks = (batch + D::IPW - 1) / D::IPW;
+  long long blocks = (batch + D::IPWL - 1) / D::IPWL;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -498,6 +536,12 @@ int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long lo
 
 extern "C" {
 
+#ifdef DPLL_STAMPS
+int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8 * (size_t)n_rows);
+}
+#endif
+
 const char* dpll_last_error(void) { return g_error; }
 int dpll_abi_version(void) { return 1; }
 
@@ -543,7 +587,10 @@ int dpll_param_count(const dpll_model_t* model) {
 int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (!model || batch < 0) return -1;
   const int nb = model->desc.n_joints + 1;
-  const int64_t ipw = kWave / (kQuery * nb);
+  int64_t ipw = kWave / (kQuery * nb);
+#ifdef DPLL_LOSS_IPW
+  if (DPLL_LOSS_IPW < ipw) ipw = DPLL_LOSS_IPW;
+#endif
   int64_t blocks = (batch + ipw - 1) / ipw;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;

@@ -1,0 +1,39 @@
+"""Diagnostic only: per-wave shader-clock stamps of the loss kernel.  Needs the -DDPLL_STAMPS build:
+
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -DDPLL_STAMPS -shared \
+        -o tools/diag/libdpll_hip_stamps.so dair_pll_amd/csrc/dpll_kernels.hip
+
+Prints where the slowest, the median and the fastest wave spend their time."""
+import ctypes, os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from dair_pll_amd import _capi
+_capi.LIB_PATH = os.path.join(REPO, 'tools', 'diag', os.environ.get('DPLL_DIAG_LIB', 'libdpll_hip_stamps.so'))
+from dair_pll_amd import MultibodyLearnableSystem
+dtype = torch.float64 if 'f64' in sys.argv else torch.float32
+g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_4096.npz'))
+s = MultibodyLearnableSystem({'cube': os.path.join(REPO, 'assets', 'cube.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+x = torch.tensor(g['x'], dtype=dtype, device='cuda:0'); xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+for _ in range(5): s.contactnets_loss_and_grad(x, xp)
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+for _ in range(50): s.contactnets_loss_and_grad(x, xp)
+e1.record(); torch.cuda.synchronize(); print('eager us per call', e0.elapsed_time(e1) * 20)
+torch.cuda.synchronize()
+lib = _capi.library()
+NR = int(os.environ.get('DPLL_DIAG_ROWS', '256')); out = np.zeros((NR, 8), dtype=np.uint64)
+lib.dpll_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.dpll_debug_read_stamps(out.ctypes.data_as(ctypes.c_void_p), NR) == 0
+t = out.astype(np.int64)
+names = ['params(0->1)', 'loads+terms+contacts(1->4)', 'newton(4->5)', 'adjoint(5->2)', 'reduce+store(2->3)']
+seg = np.stack([t[:, 1] - t[:, 0], t[:, 4] - t[:, 1], t[:, 5] - t[:, 4], t[:, 2] - t[:, 5], t[:, 3] - t[:, 2]], 1)
+total = t[:, 3] - t[:, 0]
+its = t[:, 6]
+order = np.argsort(total)
+print('stamp units: s_memtime ticks')
+for label, idx in (('slowest', order[-1]), ('median', order[len(order) // 2]), ('fastest', order[0])):
+    print(label, 'wave', idx, 'total', total[idx], 'max newton iters in wave', its[idx], dict(zip(names, seg[idx])))
+print('mean per segment', dict(zip(names, seg.mean(0).round(0))), 'mean total', total.mean())
+print('newton ticks per iteration (slowest wave)', seg[order[-1], 2] / max(1, its[order[-1]]))
+print('launch skew: last start', t[:, 0].max() - t[:, 0].min(), 'last end', t[:, 3].max() - t[:, 0].min())
