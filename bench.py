@@ -28,13 +28,16 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-BYTES_PER_STEP = {'f32': 2 * 13 * 4 + 4, 'f64': 2 * 13 * 8 + 8}  # read x, x+; write loss
+BYTES_PER_STEP = {('cube', 'f32'): 2 * 13 * 4 + 4, ('cube', 'f64'): 2 * 13 * 8 + 8,  # read x, x+; write loss
+                  ('elbow', 'f32'): 2 * 15 * 4 + 4, ('elbow', 'f64'): 2 * 15 * 8 + 8}
 
 
-def load_pairs(batch: int, seed: int):
-    """The 4096 real cube pairs of the reference's data set committed as a fixture (inputs only are
-    used here); other batch sizes / ranks resample them with replacement."""
-    g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_4096.npz'))
+def load_pairs(batch: int, seed: int, workload: str = 'cube'):
+    """cube: the 4096 real cube pairs of the reference's data set committed as a fixture (inputs only
+    are used here); other batch sizes / ranks resample them with replacement.
+    elbow: the 144 synthetic elbow-toss pairs of the elbow fixture, resampled to the batch size."""
+    name = 'cube_box_4096.npz' if workload == 'cube' else 'elbow_box_literal.npz'
+    g = np.load(os.path.join(REPO, 'tests', 'golden', name))
     x, xp = g['x'], g['x_plus']
     if batch != x.shape[0] or seed != 0:
         pick = np.random.default_rng(seed).integers(0, x.shape[0], size=batch)
@@ -42,12 +45,12 @@ def load_pairs(batch: int, seed: int):
     return x, xp, float(g['dt'])
 
 
-def cpu_baseline(x, xp, dt, budget_s: float = 20.0):
+def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
     """Oracle timing (checker code; measured, never shipped): float64 PyTorch CPU fwd+bwd."""
     from oracle import dpll_oracle as O
     threads = torch.get_num_threads()
     sample = min(1024, x.shape[0])
-    system = O.OracleSystem(os.path.join(REPO, 'assets', 'cube.urdf'), dt).requires_grad_()
+    system = O.OracleSystem(os.path.join(REPO, 'assets', workload + '.urdf'), dt).requires_grad_()
     xs, xps = torch.tensor(x[:sample]), torch.tensor(xp[:sample])
 
     def one():
@@ -72,6 +75,8 @@ def main() -> None:
     parser.add_argument('--warmup', type=int, default=200)
     parser.add_argument('--dtype', choices=['f32', 'f64'], default='f32')
     parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
+    parser.add_argument('--workload', choices=['cube', 'elbow'], default='cube',
+                        help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     parser.add_argument('--steps-per-graph', type=int, default=50,
                         help='steps captured per hipGraph (amortises the ~10 us replay floor); the timed region '
@@ -96,8 +101,8 @@ def main() -> None:
     from dair_pll_amd.distributed import GradientAllReduce
 
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
-    x_np, xp_np, dt = load_pairs(args.batch, seed=rank)
-    system = MultibodyLearnableSystem({'cube': os.path.join(REPO, 'assets', 'cube.urdf')}, dt, dtype=dtype,
+    x_np, xp_np, dt = load_pairs(args.batch, seed=rank, workload=args.workload)
+    system = MultibodyLearnableSystem({args.workload: os.path.join(REPO, 'assets', args.workload + '.urdf')}, dt, dtype=dtype,
                                       device=str(device))
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
@@ -159,9 +164,18 @@ def main() -> None:
     ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
     total_loss = system.contactnets_loss_and_grad(x, xp).item()
 
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the configuration they measured
+        with open(os.path.join(REPO, 'profiles', 'r01_hbm_traffic.json')) as handle:
+            pmc = json.load(handle)
+        if (pmc['workload'], pmc['dtype'], pmc['batch']) == (args.workload, args.dtype, args.batch):
+            traffic = pmc['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        alg_bytes = BYTES_PER_STEP[args.dtype] * args.batch
+        alg_bytes = BYTES_PER_STEP[(args.workload, args.dtype)] * args.batch
         achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
         line = {
             'metric': 'trajectory-steps/sec (fwd+bwd), batched cube-toss contact sim',
@@ -171,21 +185,25 @@ def main() -> None:
             'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype + (' (cone residual accumulated in f64)' if args.dtype == 'f32' else ''),
-            'data': 'fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set '
-                    '(tests/golden/cube_box_4096.npz, seed 0); ranks > 0 resample with replacement; URDF-initial parameters',
-            'config': {'workload': f'contactnets_cube.urdf, 4 friction contacts, batch={args.batch} per GPU, '
-                                   f'fwd+bwd contactnets_loss', 'per_gpu_batch': args.batch,
+            'data': ('fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set '
+                     '(tests/golden/cube_box_4096.npz, seed 0); ranks > 0 resample with replacement; URDF-initial parameters')
+            if args.workload == 'cube' else 'synthetic elbow tosses (tests/golden/elbow_box_literal.npz) resampled with replacement',
+            'config': {'workload': (f'contactnets_cube.urdf, 4 friction contacts, batch={args.batch} per GPU, '
+                                    f'fwd+bwd contactnets_loss') if args.workload == 'cube' else
+                                   (f'contactnets_elbow.urdf, 8 friction contacts, batch={args.batch} per GPU, '
+                                    f'fwd+bwd contactnets_loss (synthetic elbow tosses, resampled)'), 'per_gpu_batch': args.batch,
                        'global_batch': args.batch * world, 'launch': f'hipGraph replay, {per_graph} steps per graph' if use_graph else 'eager',
                        'collective': 'one RCCL all-reduce of [loss, 15 gradients] per step' if distributed else 'none',
                        'mean_loss': total_loss},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' if traffic else None,
                          'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt)
+            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
