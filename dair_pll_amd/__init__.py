@@ -6,8 +6,8 @@ surface.  Device side: ``csrc/libdpll_hip.so`` (hand-written gfx950 kernels behi
 """
 from .integrator import Integrator, VelocityIntegrator
 from .state_space import FloatingBaseSpace
-from .system import Box, MultibodyLearnableSystem, MultibodyTerms, Plane
+from .system import Box, DeepSupportConvex, HomogeneousICNN, MultibodyLearnableSystem, MultibodyTerms, Plane
 from .urdf import ModelSpec, parse_urdf
 
 __all__ = ['MultibodyLearnableSystem', 'MultibodyTerms', 'Integrator', 'VelocityIntegrator', 'FloatingBaseSpace',
-           'Box', 'Plane', 'ModelSpec', 'parse_urdf']
+           'Box', 'Plane', 'DeepSupportConvex', 'HomogeneousICNN', 'ModelSpec', 'parse_urdf']

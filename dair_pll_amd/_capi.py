@@ -38,6 +38,12 @@ class Params(ctypes.Structure):
     _fields_ = [('theta', c_void_p), ('friction', c_void_p), ('lengths', c_void_p)]
 
 
+class MeshParams(ctypes.Structure):
+    """``dpll_mesh_params_t``"""
+    _fields_ = [('hidden_weight', c_void_p), ('input_weight0', c_void_p), ('input_weight1', c_void_p),
+                ('output_weight', c_void_p), ('perturbations', c_void_p)]
+
+
 def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal') -> ModelDesc:
     check_supported(spec)
     desc = ModelDesc()
@@ -91,6 +97,16 @@ def library() -> ctypes.CDLL:
                               c_void_p, c_void_p]
     lib.dpll_simulate.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                   c_void_p]
+    lib.dpll_mesh_param_count.argtypes = [c_void_p]
+    lib.dpll_mesh_workspace_bytes.argtypes = [c_void_p, c_int64, c_int]
+    lib.dpll_mesh_workspace_bytes.restype = c_int64
+    lib.dpll_contactnets_loss_mesh.argtypes = [c_void_p, c_int, POINTER(Params), POINTER(MeshParams), c_void_p, c_int64,
+                                               c_void_p, c_int64, c_int64, c_void_p, c_double, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
+    lib.dpll_step_mesh.argtypes = [c_void_p, c_int, POINTER(Params), POINTER(MeshParams), c_void_p, c_int64, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.dpll_mesh_support_points.argtypes = [c_void_p, c_int, POINTER(MeshParams), c_void_p, c_int64, c_int64, c_void_p,
+                                             c_void_p, c_int64, c_void_p]
     lib.dpll_terms.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]
     _lib = lib
@@ -106,4 +122,5 @@ def check(status: int) -> None:
 EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_model_destroy',
                     'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
                     'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_simulate',
-                    'dpll_terms']
+                    'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
+                    'dpll_step_mesh', 'dpll_mesh_support_points']

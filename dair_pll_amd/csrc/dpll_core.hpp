@@ -752,7 +752,7 @@ DPLL_HD void derive_params(const ModelDesc& md, const T* theta, const T* frictio
     theta_to_iota<T>(th, md.inertia_mode, dp.iota[b]);
     const T mub = tabs(friction[1 + b]);
     dp.mu[b] = T(2) * mu0 * mub / (mu0 + mub);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = tabs(lengths[3 * b + i]);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = lengths ? tabs(lengths[3 * b + i]) : T(0);
   }
 }
 
@@ -770,7 +770,7 @@ DPLL_HD void derive_params_seeded(const ModelDesc& md, const T* theta, const T* 
     DPLL_UNROLL for (int i = 0; i < kIota; ++i) { dp.iota[b][i] = io[i].v; diota[b][i] = io[i].d; }
     const T mub = tabs(friction[1 + b]);
     dp.mu[b] = T(2) * mu0 * mub / (mu0 + mub);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = tabs(lengths[3 * b + i]);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = lengths ? tabs(lengths[3 * b + i]) : T(0);
   }
 }
 
@@ -820,9 +820,12 @@ template <typename T, int NJ> struct ContactGeom {
   CJac<T, NJ> J; // world-frame point Jacobian
 };
 
+// `witness` (mesh geometry, DeepSupportConvex): the support point of this contact in the geometry frame, already
+// evaluated by the ICNN kernels (geometry.py:309-325); nullptr = box corner chosen here.
 template <typename T, typename TA, int NJ>
 DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, const Kin<T, NJ>& kin,
-                             const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ>& cg) {
+                             const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ>& cg,
+                             const T* witness = nullptr) {
   constexpr int NB = NJ + 1;
   const int b = contact / kQuery;
   const int slot = contact % kQuery;
@@ -853,13 +856,19 @@ DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, cons
   cg.mu = mu;
   // support direction in the body frame: -(row 2 of R_AB) (geometry.py:560-564)
   const T d[3] = {-cg.R[2][0], -cg.R[2][1], -cg.R[2][2]};
-  box_corner_signs(d, habs, slot, cg.sgn);
+  T wit[3];
+  if (witness) {
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { cg.sgn[i] = T(0); wit[i] = witness[i]; }
+  } else {
+    box_corner_signs(d, habs, slot, cg.sgn);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = cg.sgn[i] * habs[i];
+  }
   T r_b[3], rho[3], pt[3];
-  DPLL_UNROLL for (int i = 0; i < 3; ++i) r_b[i] = gorg[i] + cg.sgn[i] * habs[i];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) r_b[i] = gorg[i] + wit[i];
   mat3_vec(cg.R, r_b, rho);
   DPLL_UNROLL for (int i = 0; i < 3; ++i) pt[i] = o[i] + rho[i];
   TA phiA = oz;
-  DPLL_UNROLL for (int i = 0; i < 3; ++i) phiA += Rz[i] * (TA(gorg[i]) + TA(cg.sgn[i]) * TA(habs[i]));
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) phiA += Rz[i] * (TA(gorg[i]) + TA(wit[i]));
   cg.phi = T(phiA);
   contact_jacobian<T, NJ>(kin, b, pt, cg.J);
 }
@@ -893,7 +902,7 @@ constexpr double kInvalidForce = 1e3;   // multibody_learnable_system.py:187
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x, const T* xp,
                     int first_contact, T weight, bool want_grad, LossGrad<T, NJ>& grad, T (&force)[KPL][3],
-                    int& iters) {
+                    int& iters, const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kLossEps);
   const T* v = x + NQ;
@@ -910,7 +919,7 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
   T mu[KPL], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
   T pen = T(0);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c]);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr);
     Jc[c] = cg[c].J;
     mu[c] = cg[c].mu;
     T jdv[3];
@@ -1007,6 +1016,9 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
     DPLL_UNROLL for (int i = 0; i < 3; ++i) rhobar[i] = c1[i] + c2[i];
     rhobar[2] += phibar;
     mat3t_vec(cg[c].R, rhobar, rbar);  // r_bar = R_b^T rho_bar
+    if (rbar_out) {
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = wt * rbar[i];
+    }
     DPLL_UNROLL for (int b = 0; b < NB; ++b) {
       const bool mine = (cg[c].body == b);
       grad.g_mu[b] += mine ? wt * gmu : T(0);
@@ -1036,7 +1048,8 @@ template <typename T> DPLL_HD void quat_exp_mul(const T* q, const T (&r)[3], T* 
 
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
-                       int first_contact, T* x_next, T (&impulse)[KPL][3], int& iters) {
+                       int first_contact, T* x_next, T (&impulse)[KPL][3], int& iters,
+                       const T (*witness)[3] = nullptr) {
   constexpr int NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kDynamicsEps);
   const T* q = x;
@@ -1051,7 +1064,7 @@ DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const Solv
   const T idt = T(1) / dt;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     ContactGeom<T, NJ> cg;
-    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg, witness ? witness[c] : nullptr);
     Jc[c] = cg.J;
     mu[c] = cg.mu;
     T jv[3];

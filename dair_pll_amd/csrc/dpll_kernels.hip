@@ -39,6 +39,7 @@ __device__ unsigned long long g_stamps[2048][8];
 #define DPLL_CORE_STAMP(slot) DPLL_STAMP(slot)
 #endif
 #include "dpll_core.hpp"
+#include "dpll_mesh_kernels.hpp"
 
 namespace {
 
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
                                                      const T* __restrict__ xp, long long ld_xp, long long batch,
                                                      const T* __restrict__ weights, double scale, T* __restrict__ loss,
                                                      T* __restrict__ force, int* __restrict__ iters,
-                                                     double* __restrict__ partials, int want_grad) {
+                                                     double* __restrict__ partials, int want_grad,
+                                                     const T* __restrict__ witness, T* __restrict__ rbar_out) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<D::G>;
   const int lane = threadIdx.x;
@@ -145,7 +147,18 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     T f[1][3];
     int n_it = 0;
     DPLL_STAMP(1);
-    const T L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it);
+    // mesh geometry: this contact's support point comes from the ICNN kernels; its adjoint goes back to them
+    T wit[1][3] = {{T(0), T(0), T(0)}}, rb[1][3] = {{T(0), T(0), T(0)}};
+    if (witness) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
+    }
+    const T L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it,
+                                                                  witness ? wit : nullptr, rbar_out ? rb : nullptr);
+    if (rbar_out && valid) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
+    }
     if (valid) {
       if (cidx == 0) {
         if (loss) loss[it] = L;
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
 #pragma unroll
   for (int i = 0; i < D::NB + 1; ++i) fr[i] = double(friction[i]);
 #pragma unroll
-  for (int i = 0; i < D::NB * 3; ++i) ln[i] = double(lengths[i]);
+  for (int i = 0; i < D::NB * 3; ++i) ln[i] = lengths ? double(lengths[i]) : 0.0;
   double val = loss_sum;
   if (k >= 0 && k < D::NB * 10) val = theta_bar;
   // friction and length components: evaluate all (a handful of flops) and select, no runtime indexing
@@ -254,7 +267,8 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
                                                          const T* __restrict__ x0, long long ld_x, long long batch,
                                                          long long steps, T* __restrict__ out, long long ld_item,
-                                                         long long ld_step, int write_x0, int* __restrict__ iters) {
+                                                         long long ld_step, int write_x0, int* __restrict__ iters,
+                                                         const T* __restrict__ witness) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<D::G>;
   const int lane = threadIdx.x;
@@ -282,7 +296,12 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
     for (long long s = 0; s < steps; ++s) {
       T xn[D::NX], imp[1][3];
       int n_it = 0;
-      step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it);
+      T wit[1][3] = {{T(0), T(0), T(0)}};
+      if (witness) {  // mesh geometry: support points of the CURRENT state, one step per launch
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
+      }
+      step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it, witness ? wit : nullptr);
       total += n_it;
 #pragma unroll
       for (int i = 0; i < D::NX; ++i) xr[i] = xn[i];
@@ -438,7 +457,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                      ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                     want_grad);
+                     want_grad, (const T*)nullptr, (T*)nullptr);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
     hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
@@ -466,7 +485,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
     hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x,
                        (const T*)xp, ld_xp, batch, (const T*)nullptr, scale, (T*)nullptr, (T*)nullptr, (int*)nullptr,
-                       (double*)workspace, 1);
+                       (double*)workspace, 1, (const T*)nullptr, (T*)nullptr);
     (void)hipEventRecord(ev[3 * r + 1], stream);
     hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
                        (T*)grad, (T*)nullptr);
@@ -492,13 +511,13 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
 template <typename T, int NJ>
 int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x,
                     long long batch, long long steps, void* out, long long ld_item, long long ld_step, int write_x0,
-                    int32_t* iters, hipStream_t stream) {
+                    int32_t* iters, hipStream_t stream, const void* witness = nullptr) {
   using D = Dims<T, NJ>;
   long long blocks = (batch + D::IPW - 1) / D::IPW;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL((simulate_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
-                     (T*)out, ld_item, ld_step, write_x0, (int*)iters);
+                     (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)witness);
   return check_launch("simulate_kernel");
 }
 
@@ -512,6 +531,119 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
                      (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J,
                      (T*)phi, (T*)a);
   return check_launch("terms_kernel");
+}
+
+
+// ---- mesh (DeepSupportConvex) path: one floating body, N = 4 * batch support queries ----------------
+struct MeshPlan {
+  long long N;
+  int loss_blocks, gemm_blocks, b1_blocks, n_slabs;
+  size_t off_A, off_AT, off_a, off_P, off_RB, off_M1, off_U0, off_rows, off_b1, off_slabs, total;
+};
+
+template <typename T> MeshPlan mesh_plan(long long batch) {
+  MeshPlan pl;
+  pl.N = 4 * batch;
+  pl.loss_blocks = loss_blocks<T, 0>(batch);
+  const long long tiles = (pl.N + kTileRows - 1) / kTileRows;
+  pl.gemm_blocks = (int)(tiles < 2048 ? tiles : 2048);
+  pl.b1_blocks = (int)(tiles < 256 ? tiles : 256);
+  long long slabs = pl.N / 1024;
+  pl.n_slabs = (int)(slabs < 1 ? 1 : (slabs > 64 ? 64 : slabs));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+  pl.off_A = take(sizeof(T) * kW * kW);
+  pl.off_AT = take(sizeof(T) * kW * kW);
+  pl.off_a = take(sizeof(T) * kW);
+  pl.off_P = take(sizeof(T) * 3 * pl.N);
+  pl.off_RB = take(sizeof(T) * 3 * pl.N);
+  pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
+  pl.off_U0 = take(sizeof(T) * kW * pl.N);
+  pl.off_rows = take(sizeof(double) * 16 * pl.loss_blocks);
+  pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
+  pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
+  pl.total = off;
+  return pl;
+}
+
+template <typename T> IcnnWeights<T> mesh_weights(const dpll_mesh_params_t* mp) {
+  return IcnnWeights<T>{(const T*)mp->hidden_weight, (const T*)mp->input_weight0, (const T*)mp->input_weight1,
+                        (const T*)mp->output_weight, (const T*)mp->perturbations};
+}
+
+// forward half: prep + the two forward GEMMs -> P (and M1, U0 for the backward half)
+template <typename T>
+int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, hipStream_t stream) {
+  T* A = (T*)(ws + pl.off_A); T* AT = (T*)(ws + pl.off_AT); T* a = (T*)(ws + pl.off_a);
+  hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a);
+  hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
+                     (uint32_t*)(ws + pl.off_M1));
+  hipLaunchKernelGGL((icnn_fwd2_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)AT,
+                     (const T*)a, (const uint32_t*)(ws + pl.off_M1), (T*)(ws + pl.off_U0), (T*)(ws + pl.off_P));
+  return check_launch("icnn forward");
+}
+
+template <typename T>
+int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
+                     long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
+                     void* loss, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
+                     long long workspace_bytes, hipStream_t stream) {
+  const MeshPlan pl = mesh_plan<T>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_contactnets_loss_mesh: workspace too small%s");
+  if (!grad && loss_total) return fail(-3, "dpll_contactnets_loss_mesh: loss_total requires grad%s");
+  char* ws = (char*)workspace;
+  const IcnnWeights<T> w = mesh_weights<T>(mp);
+  if (int rc = mesh_forward<T>(pl, w, ws, (const T*)xp, ld_xp, stream)) return rc;  // terms live at the NEXT state
+  const int want_grad = grad != nullptr;
+  hipLaunchKernelGGL((loss_kernel<T, 0>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                     (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
+                     batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
+                     want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);
+  if (int rc = check_launch("loss_kernel (mesh)")) return rc;
+  if (!want_grad) return 0;
+  hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
+                     (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
+                     (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
+  hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
+                     (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
+                     (T*)(ws + pl.off_slabs));
+  const int n_out = kW * kW + 7 * kW + 16;
+  hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3((n_out + 255) / 256), dim3(256), 0, stream, w,
+                     (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,
+                     (const T*)(ws + pl.off_slabs), pl.n_slabs, (T*)grad, (T*)loss_total);
+  return check_launch("icnn backward");
+}
+
+template <typename T>
+int launch_mesh_step(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
+                     long long ld_x, long long batch, void* x_next, long long ld_next, void* workspace,
+                     long long workspace_bytes, hipStream_t stream) {
+  const MeshPlan pl = mesh_plan<T>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_step_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  if (int rc = mesh_forward<T>(pl, mesh_weights<T>(mp), ws, (const T*)x, ld_x, stream)) return rc;
+  dpll_params_t q = *p;
+  q.lengths = nullptr;
+  return launch_simulate<T, 0>(m, dtype, &q, x, ld_x, batch, 1, x_next, ld_next, 0, 0, nullptr, stream, ws + pl.off_P);
+}
+
+template <typename T>
+int launch_mesh_support(const dpll_mesh_params_t* mp, const void* x, long long ld_x, long long batch, void* points,
+                        void* workspace, long long workspace_bytes, hipStream_t stream) {
+  const MeshPlan pl = mesh_plan<T>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_mesh_support_points: workspace too small%s");
+  char* ws = (char*)workspace;
+  if (int rc = mesh_forward<T>(pl, mesh_weights<T>(mp), ws, (const T*)x, ld_x, stream)) return rc;
+  if (hipMemcpyAsync(points, ws + pl.off_P, sizeof(T) * 3 * pl.N, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+    return fail(-5, "dpll_mesh_support_points: copy failed%s");
+  return 0;
+}
+
+int check_mesh(const dpll_model* m, const dpll_mesh_params_t* mp, const char* who) {
+  if (m->desc.n_joints != 0) return fail(-2, "%s: mesh geometry is implemented for single-body systems", who);
+  if (!mp || !mp->hidden_weight || !mp->input_weight0 || !mp->input_weight1 || !mp->output_weight || !mp->perturbations)
+    return fail(-1, "%s: null mesh parameter pointer", who);
+  return 0;
 }
 
 int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long long batch, const char* who) {
@@ -543,7 +675,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 1; }
+int dpll_abi_version(void) { return 2; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -642,6 +774,56 @@ int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* par
   if (ld_x < nx) return fail(-1, "dpll_simulate: row stride smaller than n_x%s");
   DPLL_DISPATCH(launch_simulate, model, dtype, params, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, 1,
                 nullptr, (hipStream_t)stream);
+}
+
+int dpll_mesh_param_count(const dpll_model_t* model) { return model ? 12 + kW * kW + 7 * kW : -1; }
+
+int64_t dpll_mesh_workspace_bytes(const dpll_model_t* model, int64_t batch, int dtype) {
+  if (!model || batch < 1) return -1;
+  return (int64_t)(dtype == DPLL_F64 ? mesh_plan<double>(batch).total : mesh_plan<float>(batch).total);
+}
+
+int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,
+                               const dpll_mesh_params_t* mesh, const void* x, int64_t ld_x, const void* x_plus,
+                               int64_t ld_xp, int64_t batch, const void* weights, double scale, void* loss, void* grad,
+                               void* loss_total, void* force, int32_t* iters, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  if (!model) return fail(-1, "dpll_contactnets_loss_mesh: null model%s");
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_contactnets_loss_mesh: bad dtype%s");
+  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_contactnets_loss_mesh: null parameter pointer%s");
+  if (int rc = check_mesh(model, mesh, "dpll_contactnets_loss_mesh")) return rc;
+  if (batch < 1 || !x || !x_plus || ld_x < 13 || ld_xp < 13) return fail(-1, "dpll_contactnets_loss_mesh: bad state arguments%s");
+  if (dtype == DPLL_F32)
+    return launch_mesh_loss<float>(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
+                                   loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+  return launch_mesh_loss<double>(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
+                                  loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                   const void* x, int64_t ld_x, int64_t batch, void* x_next, int64_t ld_next, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  if (!model) return fail(-1, "dpll_step_mesh: null model%s");
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_step_mesh: bad dtype%s");
+  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_step_mesh: null parameter pointer%s");
+  if (int rc = check_mesh(model, mesh, "dpll_step_mesh")) return rc;
+  if (batch < 1 || !x || !x_next || ld_x < 13 || ld_next < 13) return fail(-1, "dpll_step_mesh: bad state arguments%s");
+  if (dtype == DPLL_F32)
+    return launch_mesh_step<float>(model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
+                                   (hipStream_t)stream);
+  return launch_mesh_step<double>(model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
+                                  (hipStream_t)stream);
+}
+
+int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_mesh_params_t* mesh, const void* x,
+                             int64_t ld_x, int64_t batch, void* points, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  if (!model) return fail(-1, "dpll_mesh_support_points: null model%s");
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_mesh_support_points: bad dtype%s");
+  if (int rc = check_mesh(model, mesh, "dpll_mesh_support_points")) return rc;
+  if (batch < 1 || !x || !points || ld_x < 4) return fail(-1, "dpll_mesh_support_points: bad arguments%s");
+  if (dtype == DPLL_F32) return launch_mesh_support<float>(mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
+  return launch_mesh_support<double>(mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,

@@ -49,6 +49,49 @@ class Box(Module):
         return torch.abs(self.length_params)
 
 
+ICNN_WIDTH = 256
+ICNN_DEPTH = 2
+ICNN_SLOPE = 0.5
+
+
+class HomogeneousICNN(Module):
+    """Parameter container of ``dair_pll/deep_support_function.py:125-194`` (depth 2, width 256,
+    LeakyReLU(0.5)); initial values follow the reference's distributions (``:147-183``).  Evaluation
+    (support points = input Jacobian, ``:238-266``) runs in the HIP kernels."""
+
+    def __init__(self, scale: float, dtype: torch.dtype, device: torch.device) -> None:
+        super().__init__()
+        width, slope = ICNN_WIDTH, ICNN_SLOPE
+        scale_hidden = 2 * (2.0 / (1 + slope**2))**0.5 / width
+        hidden = [Parameter((2 * (torch.rand((width, width)) - 0.5) * scale_hidden).to(device=device, dtype=dtype))
+                  for _ in range(ICNN_DEPTH - 1)]
+        inputs = []
+        for layer in range(ICNN_DEPTH):
+            weight = torch.empty((3, width))
+            torch.nn.init.kaiming_uniform_(weight)
+            if layer > 0:
+                weight = weight * 2**(-0.5)
+            inputs.append(Parameter(weight.to(device=device, dtype=dtype)))
+        scale_out = scale * 2 * (2.0 / (width * (1 + slope**2)))**0.5
+        self.hidden_weights = torch.nn.ParameterList(hidden)
+        self.input_weights = torch.nn.ParameterList(inputs)
+        self.output_weight = Parameter((2 * (torch.rand(width) - 0.5) * scale_out).to(device=device, dtype=dtype))
+
+
+class DeepSupportConvex(Module):
+    """``dair_pll/geometry.py:255-325``: convex shape given by its support function network.
+    ``perturbations`` (``:306-307``) is a fixed buffer outside the ``state_dict``, as in the reference;
+    ``train(False)`` does NOT build an fcl mesh (quirk Q7: body-body collision is out of scope)."""
+
+    def __init__(self, vertices: Tensor, dtype: torch.dtype, device: torch.device, n_query: int = 4,
+                 perturbation: float = 0.4) -> None:
+        super().__init__()
+        scale = float((vertices.max(dim=0).values - vertices.min(dim=0).values).norm() / 2)
+        self.network = HomogeneousICNN(scale, dtype, device)
+        pert = torch.cat((torch.zeros((1, 3)), perturbation * (torch.rand((n_query - 1, 3)) - 0.5)))
+        self.register_buffer('perturbations', pert.to(device=device, dtype=dtype), persistent=False)
+
+
 class LagrangianTerms(Module):
     def __init__(self, theta: Tensor) -> None:
         super().__init__()
@@ -78,9 +121,10 @@ class MultibodyTerms(Module):
         geometries: List[Module] = [Plane()]
         for body in spec.bodies:
             geom = body.geoms[0]
-            if geom.kind != 'box':
-                raise NotImplementedError('only box collision geometry is implemented in the HIP kernels so far')
-            geometries.append(Box(as_t(geom.half_lengths)))
+            if geom.kind == 'box':
+                geometries.append(Box(as_t(geom.half_lengths)))
+            else:
+                geometries.append(DeepSupportConvex(torch.tensor(geom.vertices), dtype, device))
         self.contact_terms = ContactTerms(as_t(spec.friction_init()), geometries)
         object.__setattr__(self, '_owner', None)  # plain attribute: the owner must not become a submodule
 
@@ -145,8 +189,37 @@ class MultibodyLearnableSystem(Module):
     # ---- parameters ---------------------------------------------------------------------------
     def _param_list(self) -> List[Parameter]:
         terms = self.multibody_terms
-        boxes = [g.length_params for g in terms.contact_terms.geometries if isinstance(g, Box)]
-        return [terms.lagrangian_terms.inertial_parameters, terms.contact_terms.friction_params] + boxes
+        shape: List[Parameter] = []
+        for geometry in terms.contact_terms.geometries:
+            if isinstance(geometry, Box):
+                shape.append(geometry.length_params)
+            elif isinstance(geometry, DeepSupportConvex):
+                net = geometry.network
+                shape += [net.hidden_weights[0], net.input_weights[0], net.input_weights[1], net.output_weight]
+        return [terms.lagrangian_terms.inertial_parameters, terms.contact_terms.friction_params] + shape
+
+    def _mesh(self) -> Optional['DeepSupportConvex']:
+        for geometry in self.multibody_terms.contact_terms.geometries:
+            if isinstance(geometry, DeepSupportConvex):
+                return geometry
+        return None
+
+    def _mesh_struct(self, flat: Tensor) -> _capi.MeshParams:
+        base, size, width = flat.data_ptr(), flat.element_size(), ICNN_WIDTH
+        off = 12
+        mesh = self._mesh()
+        pert = mesh.perturbations
+        if pert.dtype != flat.dtype or pert.device != flat.device:
+            mesh.perturbations = pert = pert.to(device=flat.device, dtype=flat.dtype)
+        return _capi.MeshParams(base + off * size, base + (off + width * width) * size,
+                                base + (off + width * width + 3 * width) * size,
+                                base + (off + width * width + 6 * width) * size, pert.contiguous().data_ptr())
+
+    def _mesh_workspace(self, batch: int, device) -> Tensor:
+        need = _capi.library().dpll_mesh_workspace_bytes(self._model(), batch, _DTYPES[self.dtype])
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._workspace
 
     def n_params(self) -> int:
         return sum(p.numel() for p in self._param_list())
@@ -254,11 +327,19 @@ class MultibodyLearnableSystem(Module):
             if self._flat_grad is None or self._flat_grad.device != x.device:
                 self._alloc_grad_buffer(flat.numel(), x.device)
             grad, total = self._flat_grad, self._loss_total
-            ws_bytes = lib.dpll_workspace_bytes(self._model(), batch)
+            ws_bytes = lib.dpll_workspace_bytes(self._model(), batch) if self._mesh() is None else 0
             if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
                 self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
             workspace = self._workspace
         params = self._params_struct(flat)
+        if self._mesh() is not None:
+            workspace = self._mesh_workspace(batch, x.device)
+            mesh = self._mesh_struct(flat)
+            _capi.check(lib.dpll_contactnets_loss_mesh(
+                self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(x), x.stride(0),
+                _ptr(x_plus), x_plus.stride(0), batch, _ptr(weights), float(scale), _ptr(loss), _ptr(grad), _ptr(total),
+                _ptr(force), _ptr(iters), _ptr(workspace), workspace.numel(), self._stream()))
+            return loss, grad, total
         _capi.check(lib.dpll_contactnets_loss(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x),
                                               x.stride(0), _ptr(x_plus), x_plus.stride(0), batch, _ptr(weights),
                                               float(scale), _ptr(loss), _ptr(grad), _ptr(total), _ptr(force),
@@ -293,6 +374,23 @@ class MultibodyLearnableSystem(Module):
                 param.grad = piece
         return total
 
+    def support_points(self, x: Tensor) -> Tensor:
+        """``DeepSupportConvex.get_vertices`` for the ground-contact direction of every state:
+        ``(*, n_x) -> (*, 4, 3)`` support points in the body frame (mesh systems only)."""
+        if self._mesh() is None:
+            raise TypeError('support_points needs a mesh (DeepSupportConvex) geometry')
+        lib = _capi.library()
+        batch_shape = x.shape[:-1]
+        xf = self._check_input(x, self.space.n_x, 'x')
+        flat = self._packed()
+        workspace = self._mesh_workspace(xf.shape[0], xf.device)
+        mesh = self._mesh_struct(flat)
+        points = torch.empty((xf.shape[0], 4, 3), dtype=self.dtype, device=xf.device)
+        _capi.check(lib.dpll_mesh_support_points(self._model(), _DTYPES[self.dtype], ctypes.byref(mesh), _ptr(xf),
+                                                 xf.stride(0), xf.shape[0], _ptr(points), _ptr(workspace),
+                                                 workspace.numel(), self._stream()))
+        return points.reshape(batch_shape + (4, 3))
+
     def profile_loss_kernels(self, x: Tensor, x_plus: Tensor, reps: int = 100) -> Tuple[float, float]:
         """Average duration in ms of (loss kernel, finalize kernel) measured with HIP events on the
         launch stream (``dpll_profile_contactnets_loss``).  Synchronises."""
@@ -326,6 +424,13 @@ class MultibodyLearnableSystem(Module):
         flat = self._packed()
         x_next = torch.empty((x.shape[0], self.space.n_x), dtype=self.dtype, device=x.device)
         params = self._params_struct(flat)
+        if self._mesh() is not None:
+            workspace = self._mesh_workspace(x.shape[0], x.device)
+            mesh = self._mesh_struct(flat)
+            _capi.check(lib.dpll_step_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh),
+                                           _ptr(x), x.stride(0), x.shape[0], _ptr(x_next), x_next.stride(0),
+                                           _ptr(workspace), workspace.numel(), self._stream()))
+            return x_next
         _capi.check(lib.dpll_step(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
                                   x.shape[0], _ptr(x_next), x_next.stride(0), None, self._stream()))
         return x_next
@@ -354,6 +459,11 @@ class MultibodyLearnableSystem(Module):
         x = self._check_input(x_0, self.space.n_x, 'x_0')
         flat = self._packed()
         traj = torch.empty((x.shape[0], steps + 1, self.space.n_x), dtype=self.dtype, device=x.device)
+        if self._mesh() is not None:  # support points depend on the state: one kernel sequence per step
+            traj[:, 0] = x
+            for step in range(steps):
+                traj[:, step + 1] = self._step(traj[:, step])
+            return traj.reshape(batch_shape + (steps + 1, self.space.n_x))
         params = self._params_struct(flat)
         _capi.check(lib.dpll_simulate(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
                                       x.shape[0], steps, _ptr(traj), self._stream()))
@@ -373,6 +483,8 @@ class MultibodyLearnableSystem(Module):
 
     # ---- terms ----------------------------------------------------------------------------------
     def _terms(self, q: Tensor, v: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+        if self._mesh() is not None:
+            raise NotImplementedError('multibody_terms(q, v, u) is implemented for box geometry only')
         lib = _capi.library()
         batch_shape = q.shape[:-1]
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')

@@ -172,3 +172,5 @@ def check_supported(spec: ModelSpec) -> None:
             raise NotImplementedError('only serial chains (each link hangs off the previous one)')
         if len(body.geoms) != 1:
             raise NotImplementedError('exactly one collision geometry per body')
+        if body.geoms[0].kind == 'mesh' and spec.n_joints != 0:
+            raise NotImplementedError('mesh (DeepSupportConvex) geometry is implemented for single-body systems')

@@ -118,6 +118,40 @@ int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params,
 int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x0, int64_t ld_x,
                   int64_t batch, int64_t steps, void* traj, void* stream);
 
+/* ---- mesh geometry: DeepSupportConvex / HomogeneousICNN (geometry.py:255-325, deep_support_function.py:125-266),
+ * depth 2, width 256, one floating body.  Raw (signed) parameters, caller owned:
+ *   hidden_weight (256, 256)  network.hidden_weights.0     input_weight0 / input_weight1 (3, 256)  network.input_weights.{0,1}
+ *   output_weight (256,)      network.output_weight        perturbations (4, 3) fixed buffer, row 0 zero
+ * Gradient layout of the mesh entry points: [theta(10) | friction(2) | hidden_weight | input_weight0 | input_weight1 |
+ * output_weight] = dpll_mesh_param_count() numbers.  The box `lengths` pointer of dpll_params_t is ignored. */
+typedef struct dpll_mesh_params {
+  const void* hidden_weight;
+  const void* input_weight0;
+  const void* input_weight1;
+  const void* output_weight;
+  const void* perturbations;
+} dpll_mesh_params_t;
+
+int dpll_mesh_param_count(const dpll_model_t* model);
+int64_t dpll_mesh_workspace_bytes(const dpll_model_t* model, int64_t batch, int dtype);
+
+/* dpll_contactnets_loss with the body's collision shape given by the network: same arguments and outputs. */
+int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,
+                               const dpll_mesh_params_t* mesh, const void* x, int64_t ld_x, const void* x_plus,
+                               int64_t ld_xp, int64_t batch, const void* weights, double scale, void* loss, void* grad,
+                               void* loss_total, void* force, int32_t* iters, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+
+/* dpll_step with the network shape (one step per call: the support points depend on the current state). */
+int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                   const void* x, int64_t ld_x, int64_t batch, void* x_next, int64_t ld_next, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* DeepSupportConvex.get_vertices for the ground-contact direction of every state: points (batch, 4, 3), body frame. */
+int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_mesh_params_t* mesh, const void* x,
+                             int64_t ld_x, int64_t batch, void* points, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+
 /* MultibodyTerms.forward at (q, v) taken from x: delassus (batch, 3k, 3k), M (batch, n_v, n_v),
  * J (batch, 3k, n_v), phi (batch, k), a (batch, n_v); any output may be NULL. */
 int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,

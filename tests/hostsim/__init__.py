@@ -22,7 +22,7 @@ _lib = None
 
 def build(force: bool = False, sanitize: bool = False) -> str:
     out = _LIB if not sanitize else os.path.join(_HERE, 'libhostsim_asan.so')
-    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_CORE))
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(_CORE), os.path.getmtime(_CORE.replace('dpll_core', 'dpll_icnn')))
     if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
         flags = ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer'] if sanitize else ['-O2']
         subprocess.check_call(['g++', '-std=c++17', '-shared', '-fPIC', '-Wall', '-Wno-unknown-pragmas', *flags, '-o',
@@ -90,3 +90,22 @@ def step(desc: ModelDesc, theta, friction, lengths, x, dtype=np.float64, opts=No
         status = lib().hostsim_step_f32(*args, c_int(1 if mixed else 0))
     assert status == 0
     return x_next, iters
+
+
+def mesh(desc: ModelDesc, theta, friction, weights, pert, x, x_plus, dtype=np.float64, scale=None, opts=None,
+         want_grad=True, want_step=False):
+    """cube with a DeepSupportConvex geometry; weights = concat[Wh, Wd0, Wd1, wout] flat."""
+    dtype = np.dtype(dtype)
+    arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=dtype))
+    theta, friction, weights, pert, x, x_plus = map(arr, (theta, friction, weights, pert, x, x_plus))
+    batch = x.shape[0]
+    scale = 1.0 / batch if scale is None else scale
+    out_loss = np.zeros(batch, dtype=dtype)
+    grad = np.zeros(12 + weights.size, dtype=np.float64) if want_grad else None
+    x_next = np.zeros_like(x) if want_step else None
+    opts = opts or default_opts(dtype)
+    fn = lib().hostsim_mesh_f64 if dtype == np.float64 else lib().hostsim_mesh_f32
+    status = fn(ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction), _ptr(weights), _ptr(pert), _ptr(x),
+                _ptr(x_plus), c_int64(batch), c_double(scale), _ptr(out_loss), _ptr(grad), _ptr(x_next))
+    assert status == 0
+    return {'loss': out_loss, 'grad': grad, 'x_next': x_next}

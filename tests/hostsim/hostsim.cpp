@@ -5,7 +5,7 @@
 #include <cstdint>
 #include <vector>
 
-#include "../../dair_pll_amd/csrc/dpll_core.hpp"
+#include "../../dair_pll_amd/csrc/dpll_icnn.hpp"
 
 using namespace dpll;
 
@@ -65,6 +65,106 @@ void step_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, cons
   }
 }
 
+
+// ---- mesh (DeepSupportConvex) reference path: plain loops, cube only (one body) --------------------
+template <typename T> struct IcnnEval {
+  T q[3], m0[kIcnnWidth], m1[kIcnnWidth], u1[kIcnnWidth], u0[kIcnnWidth], p[3];
+};
+template <typename T> void icnn_forward_ref(const IcnnWeights<T>& w, const T* quat, int s, IcnnEval<T>& e) {
+  constexpr int W = kIcnnWidth;
+  icnn_query<T>(quat, w.pert + 3 * s, e.q);
+  T h0[W];
+  for (int k = 0; k < W; ++k) {
+    const T pre = e.q[0] * w.Wd0[k] + e.q[1] * w.Wd0[W + k] + e.q[2] * w.Wd0[2 * W + k];
+    h0[k] = icnn_act(pre);
+    e.m0[k] = icnn_mask(pre);
+  }
+  for (int j = 0; j < W; ++j) {
+    T pre = e.q[0] * w.Wd1[j] + e.q[1] * w.Wd1[W + j] + e.q[2] * w.Wd1[2 * W + j];
+    for (int k = 0; k < W; ++k) pre += h0[k] * tabs(w.Wh[k * W + j]);
+    e.m1[j] = icnn_mask(pre);
+    e.u1[j] = tabs(w.wout[j]) * e.m1[j];
+  }
+  for (int k = 0; k < W; ++k) {
+    T v = T(0);
+    for (int j = 0; j < W; ++j) v += tabs(w.Wh[k * W + j]) * e.u1[j];
+    e.u0[k] = v * e.m0[k];
+  }
+  for (int i = 0; i < 3; ++i) {
+    T s1 = T(0);
+    for (int j = 0; j < W; ++j) s1 += w.Wd1[i * W + j] * e.u1[j] + w.Wd0[i * W + j] * e.u0[j];
+    e.p[i] = s1;
+  }
+}
+// accumulates d/d(Wh, Wd0, Wd1, wout) (double) for upstream pbar
+template <typename T> void icnn_backward_ref(const IcnnWeights<T>& w, const IcnnEval<T>& e, const T* pbar, double* gWh,
+                                             double* gWd0, double* gWd1, double* gwout) {
+  constexpr int W = kIcnnWidth;
+  double vbar[W], u1bar[W];
+  for (int k = 0; k < W; ++k) {
+    const double u0bar = double(w.Wd0[k]) * pbar[0] + double(w.Wd0[W + k]) * pbar[1] + double(w.Wd0[2 * W + k]) * pbar[2];
+    vbar[k] = u0bar * double(e.m0[k]);
+    for (int i = 0; i < 3; ++i) { gWd0[i * W + k] += double(pbar[i]) * double(e.u0[k]); gWd1[i * W + k] += double(pbar[i]) * double(e.u1[k]); }
+  }
+  for (int j = 0; j < W; ++j) u1bar[j] = double(w.Wd1[j]) * pbar[0] + double(w.Wd1[W + j]) * pbar[1] + double(w.Wd1[2 * W + j]) * pbar[2];
+  for (int k = 0; k < W; ++k)
+    for (int j = 0; j < W; ++j) {
+      const double a = double(tabs(w.Wh[k * W + j]));
+      const double sg = w.Wh[k * W + j] > T(0) ? 1.0 : (w.Wh[k * W + j] < T(0) ? -1.0 : 0.0);
+      gWh[k * W + j] += vbar[k] * double(e.u1[j]) * sg;
+      u1bar[j] += a * vbar[k];
+    }
+  for (int j = 0; j < W; ++j) {
+    const double sg = w.wout[j] > T(0) ? 1.0 : (w.wout[j] < T(0) ? -1.0 : 0.0);
+    gwout[j] += u1bar[j] * double(e.m1[j]) * sg;
+  }
+}
+
+template <typename T, typename TA>
+void mesh_loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, const T* friction,
+                     const IcnnWeights<T>& w, const T* x, const T* xp, int64_t B, double scale, T* loss, double* grad,
+                     T* x_next) {
+  constexpr int NJ = 0, K = 4, NX = 13, W = kIcnnWidth;
+  Derived<T, NJ> dp;
+  const T zero_len[3] = {T(0), T(0), T(0)};
+  derive_params<T, NJ>(md, theta, friction, zero_len, dp);
+  double g_iota[kIota] = {}, g_mu[1] = {};
+  std::vector<double> gWh(W * W, 0.0), gWd0(3 * W, 0.0), gWd1(3 * W, 0.0), gwout(W, 0.0);
+  std::vector<IcnnEval<T>> ev(K);
+  for (int64_t i = 0; i < B; ++i) {
+    T wit[K][3], rbar[K][3];
+    if (loss) {
+      for (int s = 0; s < K; ++s) { icnn_forward_ref(w, xp + i * NX, s, ev[s]); for (int a = 0; a < 3; ++a) wit[s][a] = ev[s].p[a]; }
+      LossGrad<T, NJ> g;
+      zero_grad(g);
+      T f[K][3];
+      int it = 0;
+      loss[i] = loss_item<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, xp + i * NX, 0, T(scale), grad != nullptr, g, f, it, wit, rbar);
+      if (grad) {
+        for (int k = 0; k < kIota; ++k) g_iota[k] += double(g.g_iota[0][k]);
+        g_mu[0] += double(g.g_mu[0]);
+        for (int s = 0; s < K; ++s) icnn_backward_ref(w, ev[s], rbar[s], gWh.data(), gWd0.data(), gWd1.data(), gwout.data());
+      }
+    }
+    if (x_next) {
+      for (int s = 0; s < K; ++s) { icnn_forward_ref(w, x + i * NX, s, ev[s]); for (int a = 0; a < 3; ++a) wit[s][a] = ev[s].p[a]; }
+      T imp[K][3];
+      int it = 0;
+      step_item<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, x_next + i * NX, imp, it, wit);
+    }
+  }
+  if (!grad) return;
+  double th[10], fr[2];
+  for (int i = 0; i < 10; ++i) th[i] = double(theta[i]);
+  for (int i = 0; i < 2; ++i) fr[i] = double(friction[i]);
+  for (int k = 0; k < 10; ++k) grad[k] = theta_grad_component(md.inertia_mode, th, g_iota, k);
+  for (int k = 0; k < 2; ++k) grad[10 + k] = friction_grad_component(1, fr, g_mu, k);
+  double* out = grad + 12;  // [Wh | Wd0 | Wd1 | wout]
+  for (int i = 0; i < W * W; ++i) out[i] = gWh[i];
+  for (int i = 0; i < 3 * W; ++i) { out[W * W + i] = gWd0[i]; out[W * W + 3 * W + i] = gWd1[i]; }
+  for (int i = 0; i < W; ++i) out[W * W + 6 * W + i] = gwout[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,5 +212,22 @@ int hostsim_step_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
   return 0;
 }
 
+// mesh cube: weights = [Wh(256x256) | Wd0(3x256) | Wd1(3x256) | wout(256)], pert (4,3); grad layout [theta|friction|weights]
+int hostsim_mesh_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
+                     const double* weights, const double* pert, const double* x, const double* xp, int64_t B,
+                     double scale, double* loss, double* grad, double* x_next) {
+  constexpr int W = kIcnnWidth;
+  IcnnWeights<double> w{weights, weights + W * W, weights + W * W + 3 * W, weights + W * W + 6 * W, pert};
+  mesh_loss_batch<double, double>(*md, *opt, theta, friction, w, x, xp, B, scale, loss, grad, x_next);
+  return 0;
+}
+int hostsim_mesh_f32(const ModelDesc* md, const SolverOpts* opt, const float* theta, const float* friction,
+                     const float* weights, const float* pert, const float* x, const float* xp, int64_t B,
+                     double scale, float* loss, double* grad, float* x_next) {
+  constexpr int W = kIcnnWidth;
+  IcnnWeights<float> w{weights, weights + W * W, weights + W * W + 3 * W, weights + W * W + 6 * W, pert};
+  mesh_loss_batch<float, double>(*md, *opt, theta, friction, w, x, xp, B, scale, loss, grad, x_next);
+  return 0;
+}
 int hostsim_sizeof_model_desc() { return (int)sizeof(ModelDesc); }
 }

@@ -1,0 +1,94 @@
+"""Mesh geometry (DeepSupportConvex / HomogeneousICNN, BASELINE configs[3]) through the C ABI against the
+reference-run fixture `cube_mesh_literal` and the oracle.  Needs the MI355X: `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ASSET_DIR
+from oracle import dpll_oracle as O
+
+pytestmark = pytest.mark.gpu
+NET = 'multibody_terms.contact_terms.geometries.1.'
+
+
+def build(g, dtype):
+    from dair_pll_amd import MultibodyLearnableSystem
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube_mesh.urdf')}, float(g['dt']), dtype=dtype,
+                                      device='cuda:0')
+    system.load_state_dict({name: torch.tensor(g['param/' + name]) for name, _ in system.named_parameters()})
+    system.multibody_terms.contact_terms.geometries[1].perturbations = torch.tensor(
+        g['param/' + NET + 'perturbations'], dtype=dtype, device='cuda:0')
+    return system
+
+
+def oracle_for(g):
+    mesh = {'perturbations': torch.tensor(g['param/' + NET + 'perturbations'])}
+    for key in ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight'):
+        mesh[key] = torch.tensor(g['param/' + NET + 'network.' + key])
+    system = O.OracleSystem(os.path.join(ASSET_DIR, 'cube_mesh.urdf'), float(g['dt']), mesh_params={1: mesh})
+    system.theta = torch.tensor(g['param/multibody_terms.lagrangian_terms.inertial_parameters'])
+    system.friction = torch.tensor(g['param/multibody_terms.contact_terms.friction_params'])
+    return system
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_mesh_loss_gradients_dynamics(golden, dtype):
+    g = golden('cube_mesh_literal')
+    system = build(g, dtype)
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    f64 = dtype == torch.float64
+    # support points vs the oracle's DeepSupportConvex restatement (order-free: sort rows)
+    oracle = oracle_for(g)
+    directions = -O.quat_to_rot(torch.tensor(g['x_plus'][:, :4]))[:, 2, :]
+    ref_pts = oracle.support_points(1, directions).numpy()
+    pts = system.support_points(xp).cpu().double().numpy()
+    key = lambda a: np.sort(a.reshape(a.shape[0], -1), axis=-1)
+    assert np.abs(key(pts) - key(ref_pts)).max() < (1e-12 if f64 else 2e-6)
+    # loss: autograd.Function path
+    loss = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp)
+    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4)
+    loss.mean().backward()
+    for name, param in system.named_parameters():
+        ref = g['grad/' + name]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= (1e-9 if f64 else 2e-3) * max(np.abs(ref).max(), 1e-12 if not f64 else 1.0), (name, err)
+    # fused path
+    system.zero_grad()
+    total = system.contactnets_loss_and_grad(x, xp)
+    assert abs(total.item() - float(g['loss_mean'])) < (1e-12 if f64 else 1e-6)
+    for name, param in system.named_parameters():
+        ref = g['grad/' + name]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= (1e-9 if f64 else 2e-3) * max(np.abs(ref).max(), 1e-12 if not f64 else 1.0), (name, err)
+    # dynamics
+    x_next = system.step(x)
+    assert np.abs(x_next.cpu().double().numpy() - g['dynamics/x_next']).max() < (1e-10 if f64 else 1e-4)
+    rows = g['simulate/rows']
+    traj, _ = system.simulate(x[rows].unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), int(g['simulate/steps']))
+    assert np.abs(traj.cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4)
+
+
+def test_mesh_large_batch_matches_float64_path(golden):
+    """4096 items (16384 support queries): the float32 kernels against the float64 kernels on the same
+    inputs; tiny fractions of mask flips (a hidden unit within rounding of zero) are tolerated."""
+    g = golden('cube_mesh_literal')
+    big = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'cube_box_4096.npz'))
+    x64 = torch.tensor(big['x'], device='cuda:0')
+    xp64 = torch.tensor(big['x_plus'], device='cuda:0')
+    s64, s32 = build(g, torch.float64), build(g, torch.float32)
+    p64 = s64.support_points(xp64).cpu().numpy()
+    p32 = s32.support_points(xp64.float()).cpu().double().numpy()
+    err = np.abs(p64 - p32).max(-1).max(-1)
+    assert (err > 1e-5).mean() < 2e-3
+    l64 = s64.contact_forces(x64, xp64)[0].cpu().numpy()
+    l32 = s32.contact_forces(x64.float(), xp64.float())[0].cpu().double().numpy()
+    assert np.quantile(np.abs(l64 - l32), 0.995) < 1e-5
+    t64 = s64.contactnets_loss_and_grad(x64, xp64).item()
+    t32 = s32.contactnets_loss_and_grad(x64.float(), xp64.float()).item()
+    assert abs(t64 - t32) < 1e-5 * max(1.0, abs(t64))
+    for (name, a), (_, b) in zip(s64.named_parameters(), s32.named_parameters()):
+        ga, gb = a.grad.cpu().numpy(), b.grad.cpu().double().numpy()
+        assert np.abs(ga - gb).max() <= 5e-3 * np.abs(ga).max(), name
