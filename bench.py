@@ -29,14 +29,15 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_STEP = {('cube', 'f32'): 2 * 13 * 4 + 4, ('cube', 'f64'): 2 * 13 * 8 + 8,  # read x, x+; write loss
-                  ('elbow', 'f32'): 2 * 15 * 4 + 4, ('elbow', 'f64'): 2 * 15 * 8 + 8}
+                  ('elbow', 'f32'): 2 * 15 * 4 + 4, ('elbow', 'f64'): 2 * 15 * 8 + 8,
+                  ('mesh', 'f32'): 2 * 13 * 4 + 4, ('mesh', 'f64'): 2 * 13 * 8 + 8}
 
 
 def load_pairs(batch: int, seed: int, workload: str = 'cube'):
     """cube: the 4096 real cube pairs of the reference's data set committed as a fixture (inputs only
     are used here); other batch sizes / ranks resample them with replacement.
     elbow: the 144 synthetic elbow-toss pairs of the elbow fixture, resampled to the batch size."""
-    name = 'cube_box_4096.npz' if workload == 'cube' else 'elbow_box_literal.npz'
+    name = 'elbow_box_literal.npz' if workload == 'elbow' else 'cube_box_4096.npz'
     g = np.load(os.path.join(REPO, 'tests', 'golden', name))
     x, xp = g['x'], g['x_plus']
     if batch != x.shape[0] or seed != 0:
@@ -75,7 +76,7 @@ def main() -> None:
     parser.add_argument('--warmup', type=int, default=200)
     parser.add_argument('--dtype', choices=['f32', 'f64'], default='f32')
     parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
-    parser.add_argument('--workload', choices=['cube', 'elbow'], default='cube',
+    parser.add_argument('--workload', choices=['cube', 'elbow', 'mesh'], default='cube',
                         help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     parser.add_argument('--steps-per-graph', type=int, default=50,
@@ -102,7 +103,9 @@ def main() -> None:
 
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     x_np, xp_np, dt = load_pairs(args.batch, seed=rank, workload=args.workload)
-    system = MultibodyLearnableSystem({args.workload: os.path.join(REPO, 'assets', args.workload + '.urdf')}, dt, dtype=dtype,
+    torch.manual_seed(0)  # mesh workload: ICNN weights from the reference's init distributions
+    urdf_name = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf'}[args.workload]
+    system = MultibodyLearnableSystem({args.workload: os.path.join(REPO, 'assets', urdf_name)}, dt, dtype=dtype,
                                       device=str(device))
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
@@ -161,7 +164,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
+    ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200) if args.workload != 'mesh' else (float('nan'), float('nan'))
     total_loss = system.contactnets_loss_and_grad(x, xp).item()
 
     traffic = None
@@ -191,7 +194,9 @@ def main() -> None:
             'config': {'workload': (f'contactnets_cube.urdf, 4 friction contacts, batch={args.batch} per GPU, '
                                     f'fwd+bwd contactnets_loss') if args.workload == 'cube' else
                                    (f'contactnets_elbow.urdf, 8 friction contacts, batch={args.batch} per GPU, '
-                                    f'fwd+bwd contactnets_loss (synthetic elbow tosses, resampled)'), 'per_gpu_batch': args.batch,
+                                    f'fwd+bwd contactnets_loss (synthetic elbow tosses, resampled)') if args.workload == 'elbow' else
+                                   (f'contactnets_cube_mesh.urdf, DeepSupportConvex (ICNN 2x256) geometry, batch={args.batch} per GPU, '
+                                    f'fwd+bwd contactnets_loss incl. 67,328 network weights'), 'per_gpu_batch': args.batch,
                        'global_batch': args.batch * world, 'launch': f'hipGraph replay, {per_graph} steps per graph' if use_graph else 'eager',
                        'collective': 'one RCCL all-reduce of [loss, 15 gradients] per step' if distributed else 'none',
                        'mean_loss': total_loss},
@@ -203,7 +208,7 @@ def main() -> None:
                          'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch'},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload)
+            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload if args.workload != 'mesh' else 'cube_mesh')
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

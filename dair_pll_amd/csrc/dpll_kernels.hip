@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "../../include/dpll.h"
 
@@ -39,7 +40,6 @@ __device__ unsigned long long g_stamps[2048][8];
 #define DPLL_CORE_STAMP(slot) DPLL_STAMP(slot)
 #endif
 #include "dpll_core.hpp"
-#include "dpll_mesh_kernels.hpp"
 
 namespace {
 
@@ -96,6 +96,10 @@ template <int G> __device__ __forceinline__ double wave_sum_of_groups(double x) 
   x += __shfl_xor(x, 32);
   return x;
 }
+
+}  // namespace
+#include "dpll_mesh_kernels.hpp"
+namespace {
 
 template <typename T, int NJ> struct Dims {
   static constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NB, G = K;
@@ -545,10 +549,11 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   MeshPlan pl;
   pl.N = 4 * batch;
   pl.loss_blocks = loss_blocks<T, 0>(batch);
-  const long long tiles = (pl.N + kTileRows - 1) / kTileRows;
+  constexpr bool kMfma = std::is_same<T, float>::value;  // float: MFMA kernels on 32-row tiles
+  const long long tiles = (pl.N + (kMfma ? kMfmaRows : kTileRows) - 1) / (kMfma ? kMfmaRows : kTileRows);
   pl.gemm_blocks = (int)(tiles < 2048 ? tiles : 2048);
-  pl.b1_blocks = (int)(tiles < 256 ? tiles : 256);
-  long long slabs = pl.N / 1024;
+  pl.b1_blocks = (int)(tiles < (kMfma ? 64 : 256) ? tiles : (kMfma ? 64 : 256));
+  long long slabs = pl.N / (kMfma ? 256 : 1024);
   pl.n_slabs = (int)(slabs < 1 ? 1 : (slabs > 64 ? 64 : slabs));
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
@@ -576,10 +581,18 @@ template <typename T>
 int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, hipStream_t stream) {
   T* A = (T*)(ws + pl.off_A); T* AT = (T*)(ws + pl.off_AT); T* a = (T*)(ws + pl.off_a);
   hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a);
-  hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
-                     (uint32_t*)(ws + pl.off_M1));
-  hipLaunchKernelGGL((icnn_fwd2_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)AT,
-                     (const T*)a, (const uint32_t*)(ws + pl.off_M1), (T*)(ws + pl.off_U0), (T*)(ws + pl.off_P));
+  if constexpr (std::is_same<T, float>::value) {
+    hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)A,
+                       (uint32_t*)(ws + pl.off_M1));
+    hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)AT,
+                       (const float*)a, (const uint32_t*)(ws + pl.off_M1), (float*)(ws + pl.off_U0),
+                       (float*)(ws + pl.off_P));
+  } else {
+    hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
+                       (uint32_t*)(ws + pl.off_M1));
+    hipLaunchKernelGGL((icnn_fwd2_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)AT,
+                       (const T*)a, (const uint32_t*)(ws + pl.off_M1), (T*)(ws + pl.off_U0), (T*)(ws + pl.off_P));
+  }
   return check_launch("icnn forward");
 }
 
@@ -601,12 +614,21 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
                      want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
-  hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
-                     (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
-                     (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
-  hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
-                     (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
-                     (T*)(ws + pl.off_slabs));
+  if constexpr (std::is_same<T, float>::value) {
+    hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
+                       (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
+                       (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
+    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(2, pl.n_slabs), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
+                       (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const float*)(ws + pl.off_RB),
+                       (float*)(ws + pl.off_slabs));
+  } else {
+    hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
+                       (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
+                       (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
+    hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
+                       (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
+                       (T*)(ws + pl.off_slabs));
+  }
   const int n_out = kW * kW + 7 * kW + 16;
   hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3((n_out + 255) / 256), dim3(256), 0, stream, w,
                      (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,

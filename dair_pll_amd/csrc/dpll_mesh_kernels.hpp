@@ -286,8 +286,16 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   constexpr int kHead = 12;
   if (idx < kW * kW) {
-    double s = 0.0;
-    for (int b = 0; b < n_slabs; ++b) s += double(slabs[(long long)b * kW * kW + idx]);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 4 <= n_slabs; b += 4) {  // independent loads in flight
+      s0 += double(slabs[(long long)b * kW * kW + idx]);
+      s1 += double(slabs[(long long)(b + 1) * kW * kW + idx]);
+      s2 += double(slabs[(long long)(b + 2) * kW * kW + idx]);
+      s3 += double(slabs[(long long)(b + 3) * kW * kW + idx]);
+    }
+    for (; b < n_slabs; ++b) s0 += double(slabs[(long long)b * kW * kW + idx]);
+    const double s = (s0 + s1) + (s2 + s3);
     const T raw = w.Wh[idx];
     grad[kHead + idx] = T(s * (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0)));
   } else if (idx < kW * kW + 7 * kW) {
@@ -296,8 +304,16 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
     if (c < 3 * kW) col = 4 * kW + c;            // dWd0 lives at [4W, 7W) of the b1 row
     else if (c < 6 * kW) col = kW + (c - 3 * kW); // dWd1 at [W, 4W)
     else col = c - 6 * kW;                       // d|wout| at [0, W)
-    double s = 0.0;
-    for (int b = 0; b < b1_blocks; ++b) s += b1[(long long)b * kB1Cols + col];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = 0;
+    for (; b + 4 <= b1_blocks; b += 4) {
+      s0 += b1[(long long)b * kB1Cols + col];
+      s1 += b1[(long long)(b + 1) * kB1Cols + col];
+      s2 += b1[(long long)(b + 2) * kB1Cols + col];
+      s3 += b1[(long long)(b + 3) * kB1Cols + col];
+    }
+    for (; b < b1_blocks; ++b) s0 += b1[(long long)b * kB1Cols + col];
+    double s = (s0 + s1) + (s2 + s3);
     if (c >= 6 * kW) {
       const T raw = w.wout[c - 6 * kW];
       s *= (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0));
@@ -306,8 +322,16 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
   } else if (idx < kW * kW + 7 * kW + 16) {
     const int c = (int)(idx - kW * kW - 7 * kW);  // 0: loss, 1..12: theta, friction
     if (c <= kHead) {
-      double s = 0.0;
-      for (int r = 0; r < n_rows; ++r) s += rows[(long long)r * 16 + c];
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int r = 0;
+      for (; r + 4 <= n_rows; r += 4) {
+        s0 += rows[(long long)r * 16 + c];
+        s1 += rows[(long long)(r + 1) * 16 + c];
+        s2 += rows[(long long)(r + 2) * 16 + c];
+        s3 += rows[(long long)(r + 3) * 16 + c];
+      }
+      for (; r < n_rows; ++r) s0 += rows[(long long)r * 16 + c];
+      const double s = (s0 + s1) + (s2 + s3);
       if (c == 0) {
         if (loss_total) *loss_total = T(s);
       } else {
@@ -315,6 +339,283 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
       }
     }
   }
+}
+
+}  // namespace
+
+// =================================================================================================
+// MFMA forms (float): v_mfma_f32_32x32x2_f32, exact f32 FMA chains.  Operand maps (cdna guide, section 3):
+//   A: lane l holds A[i = l & 31][k = l >> 5]     B: lane l holds B[k = l >> 5][j = l & 31]
+//   C/D: 16 registers, col = l & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)
+// Row-tile kernels: 512 threads = 8 waves, wave v owns output columns [32 v, 32 v + 32) of a 32-row tile; the
+// X tile sits in LDS with a 257-float row stride (conflict-free column reads), the 256 x 32 column block of
+// the weight matrix is held in 128 VGPRs per lane for the whole launch.
+// =================================================================================================
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kMfmaRows = 32;
+constexpr int kXs = kW + 1;  // padded LDS row stride
+
+__device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// queries of a 32-row tile into LDS (threads 0..31)
+__device__ __forceinline__ void load_queries32(const float* __restrict__ x, long long ld, const float* __restrict__ pert,
+                                               long long n0, long long N, float (*Qs)[3]) {
+  if (threadIdx.x < kMfmaRows) {
+    const long long n = n0 + threadIdx.x;
+    float q[3] = {0.f, 0.f, 1.f};
+    if (n < N) {
+      float quat[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) quat[i] = x[(n >> 2) * ld + i];
+      icnn_query<float>(quat, pert + 3 * (n & 3), q);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Qs[threadIdx.x][i] = q[i];
+  }
+}
+
+// C(32 x 32 of this wave) = Xs(32 x 256, LDS) * Wfrag(256 x 32, registers)
+__device__ __forceinline__ f32x16 mfma_tile(const float* __restrict__ Xs, const float (&bfrag)[kW / 2], int l31, int half) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* xrow = Xs + l31 * kXs + half;
+#pragma unroll
+  for (int kk = 0; kk < kW / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[2 * kk], bfrag[kk], acc, 0, 0, 0);
+  return acc;
+}
+
+__global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ x, long long ld, long long N,
+                                                      IcnnWeights<float> w, const float* __restrict__ A,
+                                                      uint32_t* __restrict__ M1) {
+  __shared__ float Qs[kMfmaRows][3];
+  __shared__ float Xs[kMfmaRows * kXs];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int col = 32 * wv + l31;
+  float bfrag[kW / 2];
+#pragma unroll
+  for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = A[(2 * kk + half) * kW + col];
+  const float wd1[3] = {w.Wd1[col], w.Wd1[kW + col], w.Wd1[2 * kW + col]};
+  const long long tiles = (N + kMfmaRows - 1) / kMfmaRows;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long n0 = tile * kMfmaRows;
+    __syncthreads();
+    load_queries32(x, ld, w.pert, n0, N, Qs);
+    __syncthreads();
+    {  // H0 tile: thread -> column c = t & 255, rows (t >> 8) * 16 ..
+      const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
+      const float d0 = w.Wd0[c], d1 = w.Wd0[kW + c], d2 = w.Wd0[2 * kW + c];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Xs[(r0 + r) * kXs + c] = icnn_act(Qs[r0 + r][0] * d0 + Qs[r0 + r][1] * d1 + Qs[r0 + r][2] * d2);
+    }
+    __syncthreads();
+    const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = mfma_row(reg, half);
+      const float pre1 = acc[reg] + Qs[row][0] * wd1[0] + Qs[row][1] * wd1[1] + Qs[row][2] * wd1[2];
+      const unsigned long long b = __ballot(pre1 > 0.f);
+      // low word: rows of half 0, high word: rows of half 1 (= +4)
+      if (lane == 0) {
+        const int ra = mfma_row(reg, 0), rb = mfma_row(reg, 1);
+        if (n0 + ra < N) M1[(n0 + ra) * kMaskWords + wv] = (uint32_t)(b & 0xffffffffull);
+        if (n0 + rb < N) M1[(n0 + rb) * kMaskWords + wv] = (uint32_t)(b >> 32);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ x, long long ld, long long N,
+                                                      IcnnWeights<float> w, const float* __restrict__ AT,
+                                                      const float* __restrict__ a, const uint32_t* __restrict__ M1,
+                                                      float* __restrict__ U0, float* __restrict__ P) {
+  __shared__ float Qs[kMfmaRows][3];
+  __shared__ float Xs[kMfmaRows * kXs];   // U1 tile
+  __shared__ float Ys[kMfmaRows * kXs];   // U0 tile
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int col = 32 * wv + l31;
+  float bfrag[kW / 2];
+#pragma unroll
+  for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = AT[(2 * kk + half) * kW + col];
+  const float wd0[3] = {w.Wd0[col], w.Wd0[kW + col], w.Wd0[2 * kW + col]};
+  const long long tiles = (N + kMfmaRows - 1) / kMfmaRows;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long n0 = tile * kMfmaRows;
+    __syncthreads();
+    load_queries32(x, ld, w.pert, n0, N, Qs);
+    {  // U1 tile
+      const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
+      const float ac = a[c];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t word = (n0 + r0 + r < N) ? M1[(n0 + r0 + r) * kMaskWords + (c >> 5)] : 0u;
+        Xs[(r0 + r) * kXs + c] = ac * mask_factor(word, c & 31);
+      }
+    }
+    __syncthreads();
+    const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = mfma_row(reg, half);
+      const float pre0 = Qs[row][0] * wd0[0] + Qs[row][1] * wd0[1] + Qs[row][2] * wd0[2];
+      const float u0 = acc[reg] * icnn_mask(pre0);
+      Ys[row * kXs + col] = u0;
+      if (n0 + row < N) U0[(n0 + row) * kW + col] = u0;
+    }
+    __syncthreads();
+    {  // P[row][i]: thread -> (row = t >> 4, part = t & 15), columns part + 16 m
+      const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
+      float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int c = part + 16 * m;
+        const float u1 = Xs[row * kXs + c], u0 = Ys[row * kXs + c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s[i] += w.Wd1[i * kW + c] * u1 + w.Wd0[i * kW + c] * u0;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {  // sum over the 16 parts = one DPP row
+        float v = s[i];
+        v += dpp_mov<kQuadXor1>(v);
+        v += dpp_mov<kQuadXor2>(v);
+        v += dpp_mov<kRowHalfMirror>(v);
+        v += dpp_mov<kRowMirror>(v);
+        if (part == 0 && n0 + row < N) P[(n0 + row) * 3 + i] = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ x, long long ld, long long N,
+                                                      IcnnWeights<float> w, const float* __restrict__ A,
+                                                      const float* __restrict__ a, const uint32_t* __restrict__ M1,
+                                                      const float* __restrict__ U0, const float* __restrict__ RB,
+                                                      double* __restrict__ partial) {
+  __shared__ float Qs[kMfmaRows][3];
+  __shared__ float Rs[kMfmaRows][3];
+  __shared__ float Xs[kMfmaRows * kXs];  // Vb tile
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int col = 32 * wv + l31;
+  float bfrag[kW / 2];
+#pragma unroll
+  for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = A[(2 * kk + half) * kW + col];
+  const float wd1[3] = {w.Wd1[col], w.Wd1[kW + col], w.Wd1[2 * kW + col]};
+  const float acol = a[col];
+  double abar = 0.0, g1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0};
+  const long long tiles = (N + kMfmaRows - 1) / kMfmaRows;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long n0 = tile * kMfmaRows;
+    __syncthreads();
+    load_queries32(x, ld, w.pert, n0, N, Qs);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kMfmaRows * 3) {
+      const int t = threadIdx.x - 64, r = t / 3, i = t % 3;
+      Rs[r][i] = (n0 + r < N) ? RB[(n0 + r) * 3 + i] : 0.f;
+    }
+    __syncthreads();
+    {  // Vb tile
+      const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
+      const float d0 = w.Wd0[c], d1 = w.Wd0[kW + c], d2 = w.Wd0[2 * kW + c];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = r0 + r;
+        const float pre0 = Qs[rr][0] * d0 + Qs[rr][1] * d1 + Qs[rr][2] * d2;
+        Xs[rr * kXs + c] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);
+      }
+    }
+    __syncthreads();
+    const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = mfma_row(reg, half);
+      if (n0 + row < N) {
+        const float u1b = acc[reg] + Rs[row][0] * wd1[0] + Rs[row][1] * wd1[1] + Rs[row][2] * wd1[2];
+        const float mf = mask_factor(M1[(n0 + row) * kMaskWords + wv], l31);
+        const float u1 = acol * mf;
+        const float u0 = U0[(n0 + row) * kW + col];
+        abar += double(u1b * mf);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { g1[i] += double(Rs[row][i] * u1); g0[i] += double(Rs[row][i] * u0); }
+      }
+    }
+  }
+  // the two halves of the wave hold different rows of the same column
+  abar += __shfl_xor(abar, 32);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { g1[i] += __shfl_xor(g1[i], 32); g0[i] += __shfl_xor(g0[i], 32); }
+  if (half == 0) {
+    double* row = partial + (long long)blockIdx.x * kB1Cols;
+    row[col] = abar;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { row[kW + i * kW + col] = g1[i]; row[4 * kW + i * kW + col] = g0[i]; }
+  }
+}
+
+// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j]: grid (2 k-halves, n_slabs); wave v: k-tile 4 bx + (v >> 1), j-tiles
+// 4 (v & 1) .. +4; operands of a 32-query chunk staged in LDS ([n][k] and [n][j], 32 consecutive k / j per read)
+__global__ __launch_bounds__(512) void icnn_bwd2_mfma(const float* __restrict__ x, long long ld, long long N,
+                                                      IcnnWeights<float> w, const float* __restrict__ a,
+                                                      const uint32_t* __restrict__ M1, const float* __restrict__ RB,
+                                                      float* __restrict__ slabs) {
+  __shared__ float Qs[kMfmaRows][3];
+  __shared__ float Rs[kMfmaRows][3];
+  __shared__ float Vc[kMfmaRows][128];
+  __shared__ float Uc[kMfmaRows][kW];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int kbase = 128 * blockIdx.x;              // this block's k range
+  const int kt = wv >> 1, jt0 = 4 * (wv & 1);      // wave's k-tile (0..3 inside the range) and first j-tile
+  const long long per = (((N + gridDim.y - 1) / gridDim.y) + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
+  const long long n_begin = (long long)blockIdx.y * per, n_end = (n_begin + per < N) ? n_begin + per : N;
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (long long n0 = n_begin; n0 < n_end; n0 += kMfmaRows) {
+    __syncthreads();
+    load_queries32(x, ld, w.pert, n0, n_end, Qs);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kMfmaRows * 3) {
+      const int t = threadIdx.x - 64, r = t / 3, i = t % 3;
+      Rs[r][i] = (n0 + r < n_end) ? RB[(n0 + r) * 3 + i] : 0.f;
+    }
+    __syncthreads();
+    {  // Vb chunk: 128 k x 32 n (thread -> k = t & 127, rows (t >> 7) * 8 ..); rows past n_end have RB = 0
+      const int c = threadIdx.x & 127, r0 = (threadIdx.x >> 7) * 8, k = kbase + c;
+      const float d0 = w.Wd0[k], d1 = w.Wd0[kW + k], d2 = w.Wd0[2 * kW + k];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int rr = r0 + r;
+        const float pre0 = Qs[rr][0] * d0 + Qs[rr][1] * d1 + Qs[rr][2] * d2;
+        Vc[rr][c] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);
+      }
+    }
+    {  // U1 chunk: 256 j x 32 n
+      const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
+      const float ac = a[c];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t word = (n0 + r0 + r < n_end) ? M1[(n0 + r0 + r) * kMaskWords + (c >> 5)] : 0u;
+        Uc[r0 + r][c] = ac * mask_factor(word, c & 31);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kMfmaRows / 2; ++s) {
+      const float av = Vc[2 * s + half][32 * kt + l31];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Uc[2 * s + half][32 * (jt0 + t) + l31], acc[t], 0, 0, 0);
+    }
+  }
+  float* slab = slabs + (long long)blockIdx.y * kW * kW;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int k = kbase + 32 * kt + mfma_row(reg, half), j = 32 * (jt0 + t) + l31;
+      slab[k * kW + j] = acc[t][reg];
+    }
 }
 
 }  // namespace
