@@ -551,8 +551,9 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   pl.loss_blocks = loss_blocks<T, 0>(batch);
   constexpr bool kMfma = std::is_same<T, float>::value;  // float: MFMA kernels on 32-row tiles
   const long long tiles = (pl.N + (kMfma ? kMfmaRows : kTileRows) - 1) / (kMfma ? kMfmaRows : kTileRows);
-  pl.gemm_blocks = (int)(tiles < 2048 ? tiles : 2048);
-  pl.b1_blocks = (int)(tiles < (kMfma ? 64 : 256) ? tiles : (kMfma ? 64 : 256));
+  const long long cap = kMfma ? 256 : 2048;  // MFMA blocks keep their 256 x 32 weight block in registers: one per CU
+  pl.gemm_blocks = (int)(tiles < cap ? tiles : cap);
+  pl.b1_blocks = (int)(tiles < 256 ? tiles : 256);
   long long slabs = pl.N / (kMfma ? 256 : 1024);
   pl.n_slabs = (int)(slabs < 1 ? 1 : (slabs > 64 ? 64 : slabs));
   size_t off = 0;
@@ -618,7 +619,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
     hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
                        (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
                        (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
-    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(2, pl.n_slabs), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
+    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(4, pl.n_slabs), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
                        (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const float*)(ws + pl.off_RB),
                        (float*)(ws + pl.off_slabs));
   } else {

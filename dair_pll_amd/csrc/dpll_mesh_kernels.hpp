@@ -525,20 +525,29 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
       }
     }
     __syncthreads();
-    const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
+    // epilogue operands first (independent loads in flight during the MFMAs)
+    float mfv[16], u0v[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = mfma_row(reg, half);
-      if (n0 + row < N) {
-        const float u1b = acc[reg] + Rs[row][0] * wd1[0] + Rs[row][1] * wd1[1] + Rs[row][2] * wd1[2];
-        const float mf = mask_factor(M1[(n0 + row) * kMaskWords + wv], l31);
-        const float u1 = acol * mf;
-        const float u0 = U0[(n0 + row) * kW + col];
-        abar += double(u1b * mf);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { g1[i] += double(Rs[row][i] * u1); g0[i] += double(Rs[row][i] * u0); }
-      }
+      const bool ok = n0 + row < N;
+      mfv[reg] = ok ? mask_factor(M1[(n0 + row) * kMaskWords + wv], l31) : 0.f;
+      u0v[reg] = ok ? U0[(n0 + row) * kW + col] : 0.f;
     }
+    const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
+    float t_abar = 0.f, t1[3] = {0.f, 0.f, 0.f}, t0[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = mfma_row(reg, half);
+      const float u1b = acc[reg] + Rs[row][0] * wd1[0] + Rs[row][1] * wd1[1] + Rs[row][2] * wd1[2];
+      t_abar += u1b * mfv[reg];  // rows past N: mask factor 0 and RB = 0
+      const float u1 = acol * mfv[reg];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { t1[i] += Rs[row][i] * u1; t0[i] += Rs[row][i] * u0v[reg]; }
+    }
+    abar += double(t_abar);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { g1[i] += double(t1[i]); g0[i] += double(t0[i]); }
   }
   // the two halves of the wave hold different rows of the same column
   abar += __shfl_xor(abar, 32);
@@ -552,8 +561,8 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
   }
 }
 
-// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j]: grid (2 k-halves, n_slabs); wave v: k-tile 4 bx + (v >> 1), j-tiles
-// 4 (v & 1) .. +4; operands of a 32-query chunk staged in LDS ([n][k] and [n][j], 32 consecutive k / j per read)
+// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j]: grid (4 = k-half x j-half, n_slabs); wave v: k-tile (v >> 1) of the k-half,
+// two j-tiles of the j-half; operands of a 32-query chunk staged in LDS ([n][k] and [n][j], 32 consecutive k / j per read)
 __global__ __launch_bounds__(512) void icnn_bwd2_mfma(const float* __restrict__ x, long long ld, long long N,
                                                       IcnnWeights<float> w, const float* __restrict__ a,
                                                       const uint32_t* __restrict__ M1, const float* __restrict__ RB,
@@ -563,13 +572,14 @@ __global__ __launch_bounds__(512) void icnn_bwd2_mfma(const float* __restrict__ 
   __shared__ float Vc[kMfmaRows][128];
   __shared__ float Uc[kMfmaRows][kW];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-  const int kbase = 128 * blockIdx.x;              // this block's k range
-  const int kt = wv >> 1, jt0 = 4 * (wv & 1);      // wave's k-tile (0..3 inside the range) and first j-tile
+  const int kbase = 128 * (blockIdx.x & 1);                    // this block's k range
+  const int kt = wv >> 1, jt0 = 4 * (blockIdx.x >> 1) + 2 * (wv & 1);  // wave's k-tile (0..3 in the range), first of its 2 j-tiles
   const long long per = (((N + gridDim.y - 1) / gridDim.y) + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
   const long long n_begin = (long long)blockIdx.y * per, n_end = (n_begin + per < N) ? n_begin + per : N;
-  f32x16 acc[4];
+  constexpr int kJT = 2;  // j-tiles per wave
+  f32x16 acc[kJT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < kJT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (long long n0 = n_begin; n0 < n_end; n0 += kMfmaRows) {
@@ -604,13 +614,13 @@ __global__ __launch_bounds__(512) void icnn_bwd2_mfma(const float* __restrict__ 
     for (int s = 0; s < kMfmaRows / 2; ++s) {
       const float av = Vc[2 * s + half][32 * kt + l31];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < kJT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Uc[2 * s + half][32 * (jt0 + t) + l31], acc[t], 0, 0, 0);
     }
   }
   float* slab = slabs + (long long)blockIdx.y * kW * kW;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < kJT; ++t)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int k = kbase + 32 * kt + mfma_row(reg, half), j = 32 * (jt0 + t) + l31;
