@@ -125,3 +125,25 @@ print('sanitized ok')
     result = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert result.returncode == 0 and 'sanitized ok' in result.stdout, result.stderr[-2000:]
     assert 'runtime error' not in result.stderr
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_mesh_geometry_reference_path(golden, dtype):
+    """DeepSupportConvex / ICNN (cube_mesh): per-item math with the witness / r_bar plumbing plus a plain-loop
+    ICNN forward / backward (tests/hostsim) against the reference-run fixture, incl. all 67,328 weight gradients."""
+    g = golden('cube_mesh_literal')
+    spec = parse_urdf(os.path.join(ASSET_DIR, 'cube_mesh.urdf'))
+    desc = make_desc(spec, float(g['dt']), str(g['inertia_mode']))
+    net = 'multibody_terms.contact_terms.geometries.1.'
+    order = ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight')
+    weights = np.concatenate([g['param/' + net + 'network.' + k].ravel() for k in order])
+    grad_ref = np.concatenate([g['grad/' + P + 'lagrangian_terms.inertial_parameters'].ravel(),
+                               g['grad/' + P + 'contact_terms.friction_params'].ravel()] +
+                              [g['grad/' + net + 'network.' + k].ravel() for k in order])
+    out = hostsim.mesh(desc, g['param/' + P + 'lagrangian_terms.inertial_parameters'],
+                       g['param/' + P + 'contact_terms.friction_params'], weights, g['param/' + net + 'perturbations'],
+                       g['x'], g['x_plus'], dtype=dtype, want_step=True)
+    f64 = dtype == np.float64
+    assert np.abs(out['loss'] - g['loss']).max() < (1e-12 if f64 else 1e-6)
+    assert np.abs(out['grad'] - grad_ref).max() <= (1e-10 if f64 else 1e-4) * np.abs(grad_ref).max()
+    assert np.abs(out['x_next'] - g['dynamics/x_next']).max() < (1e-10 if f64 else 1e-4)
