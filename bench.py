@@ -83,6 +83,9 @@ def main() -> None:
                         help='steps captured per hipGraph (amortises the ~10 us replay floor); the timed region '
                              'still runs exactly --steps steps, serialised on one stream')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
+    parser.add_argument('--single-device', action='store_true',
+                        help='testing aid: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)')
     args = parser.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -90,13 +93,19 @@ def main() -> None:
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(args.backend)
+            args.no_graph = True  # host-staged collectives cannot be captured
 
     from dair_pll_amd import MultibodyLearnableSystem
     from dair_pll_amd.distributed import GradientAllReduce
