@@ -1,0 +1,123 @@
+"""Edge cases and size-independent properties of the HIP path (ragged batches, strides, weights, NaNs, big batches)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ASSET_DIR, GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def cube(dtype=torch.float64):
+    from dair_pll_amd import MultibodyLearnableSystem
+    return MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, 0.0068, dtype=dtype, device='cuda:0')
+
+
+def pairs(n=None, dtype=torch.float64):
+    g = np.load(os.path.join(GOLDEN_DIR, 'cube_box_4096.npz'))
+    x, xp = torch.tensor(g['x'], dtype=dtype, device='cuda:0'), torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    return (x, xp, g) if n is None else (x[:n], xp[:n], g)
+
+
+@pytest.mark.parametrize('batch', [1, 3, 16, 17, 31, 257])
+def test_ragged_batches_match_full_batch_rows(batch):
+    system = cube()
+    x, xp, g = pairs()
+    u = torch.zeros((batch, 0), device='cuda:0')
+    loss = system.contactnets_loss(x[:batch], u, xp[:batch])
+    assert loss.shape == (batch,)
+    assert np.abs(loss.detach().cpu().numpy() - g['loss'][:batch]).max() < 1e-12
+    x_next = system.step(x[:batch])
+    assert torch.equal(x_next, system.step(x)[:batch])  # per-item results do not depend on batch mates
+
+
+def test_leading_batch_dimensions_and_strided_rows():
+    system = cube()
+    x, xp, g = pairs(64)
+    u = torch.zeros((4, 16, 0), device='cuda:0')
+    loss = system.contactnets_loss(x.reshape(4, 16, 13), u, xp.reshape(4, 16, 13))
+    assert loss.shape == (4, 16)
+    assert np.abs(loss.detach().cpu().numpy().ravel() - g['loss'][:64]).max() < 1e-12
+    # rows embedded in a wider buffer: passed with their stride, no copy needed
+    wide = torch.zeros((64, 20), dtype=torch.float64, device='cuda:0')
+    wide[:, :13] = x
+    view = wide[:, :13]
+    assert view.stride(0) == 20
+    loss2 = system.contactnets_loss(view, torch.zeros((64, 0), device='cuda:0'), xp)
+    assert torch.equal(loss2, loss.reshape(-1))
+    traj, _ = system.simulate(x.reshape(4, 16, 1, 13)[:1, :3], torch.zeros((1, 3, 1), device='cuda:0'), 2)
+    assert traj.shape == (1, 3, 3, 13)
+
+
+def test_weights_are_linear_and_mean_matches_autograd():
+    system = cube()
+    x, xp, _ = pairs(1000)
+    gen = torch.Generator(device='cuda:0').manual_seed(0)
+    w1 = torch.rand(1000, dtype=torch.float64, device='cuda:0', generator=gen)
+    w2 = torch.rand(1000, dtype=torch.float64, device='cuda:0', generator=gen)
+
+    def grads(weights):
+        system.zero_grad()
+        loss = system.contactnets_loss(x, torch.zeros((1000, 0), device='cuda:0'), xp)
+        (loss * weights).sum().backward()
+        return torch.cat([p.grad.reshape(-1) for p in system.parameters()]).clone()
+
+    assert (grads(w1) + 2 * grads(w2) - grads(w1 + 2 * w2)).abs().max() < 1e-12
+    mean_autograd = grads(torch.full((1000,), 1e-3, dtype=torch.float64, device='cuda:0'))
+    system.zero_grad()
+    system.contactnets_loss_and_grad(x, xp)
+    fused = torch.cat([p.grad.reshape(-1) for p in system.parameters()])
+    assert (fused - mean_autograd).abs().max() < 1e-14
+
+
+def test_nan_and_huge_inputs_are_masked_like_the_reference():
+    """multibody_learnable_system.py:186-192: a failed solve (NaN / inf / |f| > 1e3) zeroes that item's loss
+    terms instead of raising; neighbours are unaffected."""
+    system = cube()
+    x, xp, g = pairs(32)
+    bad = xp.clone()
+    bad[5, 7:] = float('nan')   # velocities of item 5
+    loss, force, _ = system.contact_forces(x, bad)
+    ok = torch.ones(32, dtype=torch.bool)
+    ok[5] = False
+    assert np.abs(loss.cpu().numpy()[ok.numpy()] - g['loss'][:32][ok.numpy()]).max() < 1e-12
+    assert torch.isfinite(force[ok.to(force.device)]).all()
+    system.zero_grad()
+    total = system.contactnets_loss_and_grad(x[ok.to(x.device)], xp[ok.to(x.device)])
+    assert torch.isfinite(total).all()
+
+
+def test_full_size_properties_65536():
+    """BASELINE configs[4] per-GPU size and beyond: permutation invariance of the mean loss / gradient and
+    agreement of the looped-grid path (more items than one pass of the grid) with per-row results."""
+    system = cube(torch.float32)
+    x, xp, _ = pairs(dtype=torch.float32)
+    pick = torch.randint(0, 4096, (65536,), device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(1))
+    xb, xpb = x[pick], xp[pick]
+    base = system.contact_forces(x, xp)[0]
+    big = system.contact_forces(xb, xpb)[0]
+    assert torch.equal(big, base[pick])  # same item -> bitwise the same loss wherever it sits in the batch
+    t1 = system.contactnets_loss_and_grad(xb, xpb).clone()
+    g1 = system.grad_buffer().clone()
+    perm = torch.randperm(65536, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(2))
+    t2 = system.contactnets_loss_and_grad(xb[perm], xpb[perm]).clone()
+    g2 = system.grad_buffer().clone()
+    assert abs(t1.item() - t2.item()) < 1e-6 * abs(t1.item())
+    assert (g1 - g2).abs().max() <= 1e-5 * g1.abs().max()
+    # run-to-run reproducibility: fixed-order reductions, no float atomics
+    t3 = system.contactnets_loss_and_grad(xb, xpb)
+    assert torch.equal(system.grad_buffer(), g1) and torch.equal(t3, t1)
+
+
+def test_errors_are_loud():
+    from dair_pll_amd import _capi
+    system = cube()
+    x, xp, _ = pairs(8)
+    with pytest.raises(AssertionError):
+        system.contactnets_loss(x[:, :12], torch.zeros((8, 0), device='cuda:0'), xp)
+    with pytest.raises(_capi.DpllError):
+        system.contactnets_loss(x.cpu(), torch.zeros((8, 0)), xp.cpu())
+    with pytest.raises(_capi.DpllError):
+        system.contactnets_loss(x[:0], torch.zeros((0, 0), device='cuda:0'), xp[:0])
