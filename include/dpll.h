@@ -57,6 +57,12 @@ typedef struct dpll_solver_opts {
   double tol;        /* Newton decrement / (1 + |y|_M) */
   double stall_tol;  /* a decrement that stopped halving ends the solve only below this */
   double ls_tol;     /* |l'(alpha)| / |l'(0)| */
+  /* continuation in the regularisation eps: start at eps * stage_factor^(n_stages-1), divide by stage_factor when
+   * a stage reached stage_tol or stage_max_iter iterations; n_stages = 1 disables it */
+  int32_t n_stages;
+  int32_t stage_max_iter;
+  double stage_factor;
+  double stage_tol;
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;
