@@ -582,6 +582,9 @@ struct SolverOpts {
   int stage_max_iter;
   double stage_factor;
   double stage_tol;
+  double stage_ls_tol;  // line-search tolerance of the non-final stages (their iterates are only warm starts)
+  int stage_max_ls;     // line-search probes per iteration in the non-final stages
+  int pad_;
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
@@ -700,7 +703,8 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     }
     const T dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
     const T yMd = dotn<T, NV>(My, d);
-    const T slope_tol = ls_tol * dec2;  // |l'(0)| = dec2
+    const T slope_tol = (final_stage ? ls_tol : T(opt.stage_ls_tol)) * dec2;  // |l'(0)| = dec2
+    const int ls_cap = final_stage ? opt.max_ls : opt.stage_max_ls;
     T alpha = T(1), lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
     bool searching = active && (dec2 > T(0));
     for (int ls = 0; ls < opt.max_ls; ++ls) {
@@ -724,10 +728,12 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
       const bool bad = !((newton > lo_n) && (hi_n < T(0) || newton < hi_n));
       const T nxt = bad ? mid : newton;
       ok = ok || (hi_n >= T(0) && (hi_n - lo_n) <= T(4) * (sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16)) * hi_n);
+      // out of probes (non-final stages): fall back to the largest alpha known to decrease l (l' < 0 on [0, lo])
+      const bool out = searching && !ok && (ls + 1 >= ls_cap);
       lo = searching ? lo_n : lo;
       hi = searching ? hi_n : hi;
-      alpha = (searching && !ok) ? nxt : alpha;
-      searching = searching && !ok;
+      alpha = (searching && !ok) ? (out ? (lo_n > T(0) ? lo_n : nxt) : nxt) : alpha;
+      searching = searching && !ok && !out;
     }
 #if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
     if (active) printf("  it %d dec2 %.3e scale %.3e alpha %.4f conv %d stall %d\n", it, double(dec2), double(scale), double(alpha), int(converged), stall);

@@ -420,11 +420,11 @@ int check_launch(const char* what) {
 SolverOpts default_opts(int dtype) {
   SolverOpts o;
   if (dtype == DPLL_F64) {
-    o.max_iter = 100; o.max_ls = 50; o.tol = 1e-13; o.stall_tol = 1e-10; o.ls_tol = 0.1;
-    o.n_stages = 4; o.stage_max_iter = 3; o.stage_factor = 5.0; o.stage_tol = 0.1;
+    o.max_iter = 100; o.max_ls = 50; o.tol = 1e-13; o.stall_tol = 1e-10; o.ls_tol = 0.3;
+    o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.3; o.stage_max_ls = 50; o.pad_ = 0;
   } else {
-    o.max_iter = 60; o.max_ls = 30; o.tol = 1e-6; o.stall_tol = 1e-5; o.ls_tol = 0.1;
-    o.n_stages = 4; o.stage_max_iter = 3; o.stage_factor = 5.0; o.stage_tol = 0.1;
+    o.max_iter = 60; o.max_ls = 30; o.tol = 1e-6; o.stall_tol = 1e-5; o.ls_tol = 0.3;
+    o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.3; o.stage_max_ls = 50; o.pad_ = 0;
   }
   return o;
 }
@@ -722,7 +722,7 @@ void dpll_model_destroy(dpll_model_t* model) { delete model; }
 
 int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts_t* opts) {
   if (!model || !opts || (dtype != DPLL_F32 && dtype != DPLL_F64)) return fail(-1, "dpll_model_set_solver: bad argument%s");
-  if (opts->max_iter < 1 || opts->max_ls < 1 || opts->n_stages < 1 || opts->stage_max_iter < 1 || !(opts->stage_factor >= 1.0))
+  if (opts->max_iter < 1 || opts->max_ls < 1 || opts->n_stages < 1 || opts->stage_max_iter < 1 || opts->stage_max_ls < 1 || !(opts->stage_factor >= 1.0))
     return fail(-1, "dpll_model_set_solver: iteration limits must be >= 1%s");
   std::memcpy(&model->opts[dtype], opts, sizeof(SolverOpts));
   return 0;

@@ -63,6 +63,9 @@ typedef struct dpll_solver_opts {
   int32_t stage_max_iter;
   double stage_factor;
   double stage_tol;
+  double stage_ls_tol;    /* line-search tolerance and probe cap of the non-final stages */
+  int32_t stage_max_ls;
+  int32_t pad_;
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;
