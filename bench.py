@@ -84,6 +84,9 @@ def main() -> None:
                              'still runs exactly --steps steps, serialised on one stream')
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
+    parser.add_argument('--allreduce', choices=['auto', 'peer', 'collective'], default='auto',
+                        help='gradient exchange: peer = one-shot kernel over xGMI peer memory, collective = the '
+                             'backend all_reduce (RCCL); auto = peer if its start-up self-test passes')
     parser.add_argument('--single-device', action='store_true',
                         help='testing aid: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)')
     args = parser.parse_args()
@@ -98,6 +101,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     distributed = world > 1
+    host_staged = False
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -105,7 +109,7 @@ def main() -> None:
             dist.init_process_group('nccl', device_id=device)
         else:
             dist.init_process_group(args.backend)
-            args.no_graph = True  # host-staged collectives cannot be captured
+            host_staged = True  # gloo collectives cannot be captured (the peer-memory kernel can)
 
     from dair_pll_amd import MultibodyLearnableSystem
     from dair_pll_amd.distributed import GradientAllReduce
@@ -118,7 +122,7 @@ def main() -> None:
                                       device=str(device))
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
-    reducer = GradientAllReduce(system) if distributed else None
+    reducer = GradientAllReduce(system, transport=args.allreduce) if distributed else None
 
     def step():
         system.contactnets_loss_and_grad(x, xp)
@@ -130,7 +134,7 @@ def main() -> None:
         step()
     torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
+    use_graph = not args.no_graph and not (host_staged and reducer is not None and reducer.transport != 'peer')
     graph = None
     per_graph = 1
     if use_graph:
@@ -174,7 +178,10 @@ def main() -> None:
         elapsed = t.item()
 
     ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200) if args.workload != 'mesh' else (float('nan'), float('nan'))
-    total_loss = system.contactnets_loss_and_grad(x, xp).item()
+    total = system.contactnets_loss_and_grad(x, xp)
+    if reducer is not None:
+        total = reducer.all_reduce_mean()[:1]
+    total_loss = total.item()
 
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the configuration they measured
@@ -207,7 +214,10 @@ def main() -> None:
                                    (f'contactnets_cube_mesh.urdf, DeepSupportConvex (ICNN 2x256) geometry, batch={args.batch} per GPU, '
                                     f'fwd+bwd contactnets_loss incl. 67,328 network weights'), 'per_gpu_batch': args.batch,
                        'global_batch': args.batch * world, 'launch': f'hipGraph replay, {per_graph} steps per graph' if use_graph else 'eager',
-                       'collective': 'one RCCL all-reduce of [loss, 15 gradients] per step' if distributed else 'none',
+                       'collective': ('none' if not distributed else
+                                      'one-shot peer-memory all-reduce kernel (xGMI stores + in-order sum) of [loss, gradients] per step'
+                                      if reducer.transport == 'peer' else
+                                      f'one {args.backend} all-reduce of [loss, gradients] per step'),
                        'mean_loss': total_loss},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

@@ -108,6 +108,13 @@ def library() -> ctypes.CDLL:
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p]
     lib.dpll_mesh_support_points.argtypes = [c_void_p, c_int, POINTER(MeshParams), c_void_p, c_int64, c_int64, c_void_p,
                                              c_void_p, c_int64, c_void_p]
+    lib.dpll_ar_handle_bytes.restype = c_int64
+    lib.dpll_ar_create.argtypes = [c_int, c_int, c_void_p, POINTER(c_void_p)]
+    lib.dpll_ar_connect.argtypes = [c_void_p, c_void_p]
+    lib.dpll_ar_allreduce.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p]
+    lib.dpll_ar_status.argtypes = [c_void_p]
+    lib.dpll_ar_destroy.argtypes = [c_void_p]
+    lib.dpll_ar_destroy.restype = None
     lib.dpll_terms.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]
     _lib = lib
@@ -124,4 +131,5 @@ EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 
                     'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
                     'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_simulate',
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
-                    'dpll_step_mesh', 'dpll_mesh_support_points']
+                    'dpll_step_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
+                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy']

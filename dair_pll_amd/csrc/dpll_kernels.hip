@@ -40,6 +40,7 @@ __device__ unsigned long long g_stamps[2048][8];
 #define DPLL_CORE_STAMP(slot) DPLL_STAMP(slot)
 #endif
 #include "dpll_core.hpp"
+#include "dpll_allreduce.hpp"
 
 namespace {
 
@@ -859,6 +860,104 @@ int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params
   if (!x) return fail(-1, "dpll_terms: null state pointer%s");
   if (ld_x < dpll_n_x(model)) return fail(-1, "dpll_terms: row stride smaller than n_x%s");
   DPLL_DISPATCH(launch_terms, model, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- one-shot all-reduce over peer memory (dpll_allreduce.hpp) -------------------------------------
+struct dpll_ar {
+  int rank, world;
+  void* local;             // this rank's receive buffer (uncached device memory)
+  uint32_t* state;         // [0] call counter, [1] error word (device)
+  dpll_arx::Peers peers;
+  void* opened[dpll_arx::kMaxWorld];
+};
+
+extern "C" {
+
+int64_t dpll_ar_handle_bytes(void) { return (int64_t)sizeof(hipIpcMemHandle_t); }
+
+/* Allocates this rank's receive buffer and writes its IPC handle (dpll_ar_handle_bytes() bytes) to handle_out. */
+int dpll_ar_create(int rank, int world, void* handle_out, dpll_ar_t** out) {
+  if (!handle_out || !out || world < 1 || world > dpll_arx::kMaxWorld || rank < 0 || rank >= world)
+    return fail(-1, "dpll_ar_create: bad argument%s");
+  dpll_ar* ar = new (std::nothrow) dpll_ar;
+  if (!ar) return fail(-4, "dpll_ar_create: out of memory%s");
+  std::memset(ar, 0, sizeof(*ar));
+  ar->rank = rank;
+  ar->world = world;
+  const size_t bytes = sizeof(unsigned long long) * 2 * (size_t)world * dpll_arx::kMaxWords;
+  if (hipExtMallocWithFlags(&ar->local, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    delete ar;
+    return fail(-5, "dpll_ar_create: hipExtMallocWithFlags(uncached) failed%s");
+  }
+  if (hipMemset(ar->local, 0, bytes) != hipSuccess || hipMalloc((void**)&ar->state, 2 * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(ar->state, 0, 2 * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    delete ar;
+    return fail(-5, "dpll_ar_create: buffer setup failed%s");
+  }
+  hipIpcMemHandle_t handle;
+  if (hipIpcGetMemHandle(&handle, ar->local) != hipSuccess) {
+    delete ar;
+    return fail(-5, "dpll_ar_create: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 needed)%s");
+  }
+  std::memcpy(handle_out, &handle, sizeof(handle));
+  *out = ar;
+  return 0;
+}
+
+/* handles: world * dpll_ar_handle_bytes() bytes, the handle of rank r at offset r * dpll_ar_handle_bytes(). */
+int dpll_ar_connect(dpll_ar_t* ar, const void* handles) {
+  if (!ar || !handles) return fail(-1, "dpll_ar_connect: bad argument%s");
+  for (int r = 0; r < ar->world; ++r) {
+    if (r == ar->rank) {
+      ar->peers.recv[r] = (unsigned long long*)ar->local;
+      continue;
+    }
+    hipIpcMemHandle_t handle;
+    std::memcpy(&handle, (const char*)handles + (size_t)r * sizeof(handle), sizeof(handle));
+    void* ptr = nullptr;
+    if (hipIpcOpenMemHandle(&ptr, handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+      return fail(-5, "dpll_ar_connect: hipIpcOpenMemHandle failed%s");
+    ar->opened[r] = ptr;
+    ar->peers.recv[r] = (unsigned long long*)ptr;
+  }
+  return 0;
+}
+
+/* In-place SUM over the ranks of `n` elements (device pointer, dtype float or double); every rank must call it the
+ * same number of times.  Launches one small kernel on `stream` (graph-capturable).  n * sizeof(element) <= 1 KiB. */
+int dpll_ar_allreduce(dpll_ar_t* ar, int dtype, void* data, int n, void* stream) {
+  if (!ar || !data || n < 1) return fail(-1, "dpll_ar_allreduce: bad argument%s");
+  const int words = n * (dtype == DPLL_F64 ? 2 : 1);
+  if (words > dpll_arx::kMaxWords) return fail(-1, "dpll_ar_allreduce: message too long%s");
+  if (dtype == DPLL_F64)
+    hipLaunchKernelGGL(dpll_arx::allreduce_kernel<double>, dim3(1), dim3(256), 0, (hipStream_t)stream, (double*)data, n,
+                       ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
+  else if (dtype == DPLL_F32)
+    hipLaunchKernelGGL(dpll_arx::allreduce_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, (float*)data, n,
+                       ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
+  else
+    return fail(-1, "dpll_ar_allreduce: bad dtype%s");
+  return check_launch("allreduce_kernel");
+}
+
+/* Synchronises the device and returns 0 if no call timed out so far, 1 otherwise. */
+int dpll_ar_status(dpll_ar_t* ar) {
+  if (!ar) return -1;
+  uint32_t host[2] = {0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, ar->state, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(-5, "dpll_ar_status: device error%s");
+  return host[1] ? 1 : 0;
+}
+
+void dpll_ar_destroy(dpll_ar_t* ar) {
+  if (!ar) return;
+  for (int r = 0; r < ar->world; ++r)
+    if (ar->opened[r]) (void)hipIpcCloseMemHandle(ar->opened[r]);
+  if (ar->local) (void)hipFree(ar->local);
+  if (ar->state) (void)hipFree(ar->state);
+  delete ar;
 }
 
 }  // extern "C"

@@ -1,19 +1,30 @@
-"""Data-parallel sharding of trajectory batches: one process per GPU, one collective per step.
+"""Data-parallel sharding of trajectory batches: one process per GPU, one exchange per step.
 
 The reference has no distributed code; the path shards trivially because
 every (x, x+) pair is independent given the (tiny, replicated) parameters.  Rank ``r`` of ``N`` owns
 the contiguous rows ``shard_bounds(B, r, N)``; after the fused loss+gradient kernels each rank holds
 ``[sum_i w_i loss_i | sum_i w_i dloss_i/dparams]`` for its rows in ONE contiguous buffer, and a
-single ``all_reduce(SUM)`` of that buffer (16 numbers for the cube, 30 for the elbow: latency
-bound, RCCL's LL protocol over xGMI) makes every rank hold the global mean loss and gradient, so
-identical optimizer steps keep the replicas in sync with no broadcast.
+single SUM all-reduce of that buffer (16 numbers for the cube, 30 for the elbow) makes every rank hold
+the global mean loss and gradient, so identical optimizer steps keep the replicas in sync.
+
+The message is pure latency, so the default transport is :class:`PeerAllReduce` -- every rank
+stores its vector straight into every peer's IPC-shared receive buffer over xGMI and sums what arrived
+(``csrc/dpll_allreduce.hpp``, one ~2 us kernel inside the step's hipGraph) -- verified against
+``torch.distributed.all_reduce`` at start-up and replaced by it (RCCL) if the self-test fails or the
+message is too long for it (mesh systems: 67 k gradients are bandwidth, not latency, bound).
 """
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+from . import _capi
+
+_DTYPES = {torch.float32: _capi.F32, torch.float64: _capi.F64}
+PEER_MAX_BYTES = 1024  # dpll_allreduce.hpp kMaxWords * 4
 
 
 def shard_bounds(batch: int, rank: int, world: int) -> Tuple[int, int]:
@@ -23,21 +34,99 @@ def shard_bounds(batch: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+class PeerAllReduce:
+    """One-shot all-reduce over peer memory for vectors of at most 1 KiB.  Construction is collective
+    (handles travel through ``all_gather_object`` of the given process group)."""
+
+    def __init__(self, group=None) -> None:
+        lib = _capi.library()
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        size = lib.dpll_ar_handle_bytes()
+        handle = (ctypes.c_char * size)()
+        self._ar = ctypes.c_void_p()
+        _capi.check(lib.dpll_ar_create(self.rank, self.world, ctypes.cast(handle, ctypes.c_void_p),
+                                       ctypes.byref(self._ar)))
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, bytes(handle), group=group)
+        blob = b''.join(gathered)
+        _capi.check(lib.dpll_ar_connect(self._ar, ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p)))
+        dist.barrier(group=group)
+
+    def all_reduce(self, tensor: torch.Tensor) -> None:
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() * tensor.element_size() <= PEER_MAX_BYTES
+        _capi.check(_capi.library().dpll_ar_allreduce(self._ar, _DTYPES[tensor.dtype], tensor.data_ptr(), tensor.numel(),
+                                                      torch.cuda.current_stream().cuda_stream))
+
+    def healthy(self) -> bool:
+        """Synchronises; False once any call hit its spin limit."""
+        return _capi.library().dpll_ar_status(self._ar) == 0
+
+    def self_test(self, rounds: int = 4) -> bool:
+        """A few reductions of rank-dependent data checked against the closed-form sum; collective."""
+        ok = True
+        for step in range(rounds):
+            probe = torch.arange(16, dtype=torch.float32, device='cuda') * (self.rank + 1) + step
+            self.all_reduce(probe)
+            expect = torch.arange(16, dtype=torch.float32, device='cuda') * (self.world * (self.world + 1) / 2) + \
+                step * self.world
+            ok = ok and self.healthy() and bool(torch.equal(probe, expect))
+        flag = [None] * self.world
+        dist.all_gather_object(flag, ok, group=self.group)
+        return all(flag)
+
+    def close(self) -> None:
+        if self._ar is not None and _capi._lib is not None:
+            _capi._lib.dpll_ar_destroy(self._ar)
+        self._ar = None
+
+
 class GradientAllReduce:
-    """Binds a :class:`MultibodyLearnableSystem` to the default process group.
+    """Binds a :class:`MultibodyLearnableSystem` to a process group.
 
     ``system.contactnets_loss_and_grad`` then scales every item by ``1 / (local_batch * world)``
     so that the SUM all-reduce yields the global batch mean directly (no extra scaling kernel);
-    with unequal shards pass ``global_batch`` to weight by ``1 / global_batch`` instead."""
+    with unequal shards pass ``global_batch`` to weight by ``1 / global_batch`` instead.
 
-    def __init__(self, system, group=None, global_batch: int = 0) -> None:
+    ``transport``: ``'auto'`` (peer-memory one-shot kernel if the buffer fits and its self-test passes,
+    else the backend's collective), ``'peer'`` or ``'collective'``."""
+
+    def __init__(self, system, group=None, global_batch: int = 0, transport: str = 'auto') -> None:
         self.system = system
         self.group = group
         self.world = dist.get_world_size(group)
         system.grad_world = self.world
         system.global_batch = global_batch
+        self.peer: Optional[PeerAllReduce] = None
+        buf = system.grad_buffer()
+        fits = buf.is_cuda and buf.numel() * buf.element_size() <= PEER_MAX_BYTES
+        if transport not in ('auto', 'peer', 'collective'):
+            raise ValueError(transport)
+        if transport == 'peer' and not fits:
+            raise ValueError('gradient buffer too long for the peer-memory all-reduce')
+        if transport != 'collective' and fits and self.world > 1:
+            try:
+                peer = PeerAllReduce(group)
+                if peer.self_test():
+                    self.peer = peer
+                else:
+                    peer.close()
+            except _capi.DpllError:
+                self.peer = None
+            decided = [None] * self.world  # every rank must take the same route
+            dist.all_gather_object(decided, self.peer is not None, group=group)
+            if not all(decided) and self.peer is not None:
+                self.peer.close()
+                self.peer = None
+            if transport == 'peer' and self.peer is None:
+                raise _capi.DpllError('peer-memory all-reduce unavailable')
+        self.transport = 'peer' if self.peer is not None else 'collective'
 
     def all_reduce_mean(self) -> torch.Tensor:
         buf = self.system.grad_buffer()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if self.peer is not None:
+            self.peer.all_reduce(buf)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         return buf

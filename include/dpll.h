@@ -166,6 +166,20 @@ int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_me
 int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
                int64_t batch, void* delassus, void* M, void* J, void* phi, void* a, void* stream);
 
+/* ---- one-shot all-reduce of the tiny [loss | gradients] vector over xGMI peer memory (one process per GPU).
+ * The reference has no distributed code; this is the path's single exchange step.  Every rank
+ * pushes its vector into every peer's uncached, IPC-shared receive buffer and sums what arrived in rank order
+ * (bitwise identical on all ranks).  Setup: dpll_ar_create on every rank -> exchange the handles by any means
+ * (e.g. torch.distributed.all_gather) -> dpll_ar_connect.  dpll_ar_allreduce launches one kernel on `stream`
+ * and may be captured into a hipGraph; spins are bounded and a timeout is reported by dpll_ar_status. */
+typedef struct dpll_ar dpll_ar_t;
+int64_t dpll_ar_handle_bytes(void);
+int dpll_ar_create(int rank, int world, void* handle_out, dpll_ar_t** out);
+int dpll_ar_connect(dpll_ar_t* ar, const void* handles);
+int dpll_ar_allreduce(dpll_ar_t* ar, int dtype, void* data, int n, void* stream);
+int dpll_ar_status(dpll_ar_t* ar);
+void dpll_ar_destroy(dpll_ar_t* ar);
+
 #ifdef __cplusplus
 }
 #endif
