@@ -481,6 +481,30 @@ class MultibodyLearnableSystem(Module):
         x, carry = self.preprocess_initial_condition(x_0, carry_0)
         return self.integrator.simulate(x, carry, steps)
 
+    # ---- reporting (host side, off the hot path) -------------------------------------------------
+    def scalars(self) -> Dict[str, float]:
+        """Scalar description of the learned parameters with the reference's key scheme
+        (``dair_pll/multibody_terms.py:536-582``: ``{body}_{m, com_*, I_*}`` from ``pi_cm``
+        (``inertia.py:444-458``), ``{body}_len_*`` full box lengths (``geometry.py:405-411``),
+        ``{body}_mu``); mesh extraction of learned shapes is out of scope."""
+        from .inertia import theta_to_pi_cm
+        theta = self.multibody_terms.lagrangian_terms.inertial_parameters.detach().double().cpu().numpy()
+        friction = self.multibody_terms.contact_terms.get_friction_coefficients().detach().cpu()
+        out: Dict[str, float] = {}
+        for index, body in enumerate(self.spec.bodies):
+            pi_cm = theta_to_pi_cm(theta[index])
+            out[f'{body.name}_m'] = float(pi_cm[0])
+            for axis, value in zip('xyz', pi_cm[1:4] / pi_cm[0]):
+                out[f'{body.name}_com_{axis}'] = float(value)
+            for name, value in zip(('I_xx', 'I_yy', 'I_zz', 'I_xy', 'I_xz', 'I_yz'), pi_cm[4:]):
+                out[f'{body.name}_{name}'] = float(value)
+            geometry = self.multibody_terms.contact_terms.geometries[index + 1]
+            if isinstance(geometry, Box):
+                for axis, value in zip('xyz', geometry.get_half_lengths().detach().cpu().reshape(-1)):
+                    out[f'{body.name}_len_{axis}'] = 2 * float(value)
+            out[f'{body.name}_mu'] = float(friction[index + 1])
+        return out
+
     # ---- terms ----------------------------------------------------------------------------------
     def _terms(self, q: Tensor, v: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
         if self._mesh() is not None:

@@ -61,6 +61,15 @@ def test_state_dict_contract_matches_reference_names(golden):
     assert system.carry_callback().tolist() == [False]
 
 
+def test_scalars_summary_uses_reference_keys():
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, 0.0068, device='cpu',
+                                      dtype=torch.float64)
+    scalars = system.scalars()
+    assert abs(scalars['body_m'] - 0.37) < 1e-12 and abs(scalars['body_I_xx'] - 0.00081) < 1e-12
+    assert abs(scalars['body_len_x'] - 0.1048) < 1e-12 and scalars['body_mu'] == 0.15
+    assert abs(scalars['body_com_x']) < 1e-15
+
+
 def test_compute_calls_fail_loudly_without_gpu_tensors():
     system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, 0.0068, device='cpu')
     x = torch.zeros(2, 13)
