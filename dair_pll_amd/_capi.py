@@ -96,6 +96,8 @@ def library() -> ctypes.CDLL:
                                                   POINTER(ctypes.c_float), POINTER(ctypes.c_float)]
     lib.dpll_step.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_void_p, c_void_p]
+    lib.dpll_step_backward.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                       c_void_p, c_void_p, c_int64, c_void_p]
     lib.dpll_simulate.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                   c_void_p]
     lib.dpll_mesh_param_count.argtypes = [c_void_p]
@@ -129,7 +131,7 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_model_destroy',
                     'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
-                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_simulate',
+                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_step_backward', 'dpll_simulate',
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
                     'dpll_step_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
                     'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy']

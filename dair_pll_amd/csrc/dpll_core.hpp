@@ -1118,6 +1118,177 @@ DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const Solv
   DPLL_UNROLL for (int i = 0; i < NV; ++i) x_next[NQ + i] = vn[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Adjoint of one simulation step with respect to the learnable parameters (state treated as data): what
+// back-propagating a one-step prediction loss through dair_pll's forward_dynamics needs (experiment.py:292-320
+// with the default t_prediction = 1; there the cone solve's backward is sappy's, unpinned -- here it is the
+// implicit-function derivative of the stationarity condition G(y) = M y - sum_c J_c^T P_K(z_c) = 0).
+// With s = d/d v+ (including the pull-back of d/d q+ through the Lie-group Euler update), H lambda = s at the
+// solution, gamma_c = P_K(z_c), kappa_c = dP_c (J_c lambda) / eps:
+//   dL = -B(S lambda, S y; d iota) + sum_c [gamma_c^T dJ_c lambda - kappa_c^T dJ_c v+ - kappa_c,n dphi_c / dt]
+//        + (s - sum_c J_c^T kappa_c)^T dt da,          da = M^-1 (dF - dM a)
+// ---------------------------------------------------------------------------------------------
+template <typename T> DPLL_HD void quat_exp_mul_adjoint(const T* q, const T (&r)[3], const T* obar, T (&rbar)[3]) {
+  const T n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const T n = tsqrt(n2);
+  T sh, c;
+  tsincos(n * T(0.5), sh, c);
+  const bool small = !(n > T(1e-6));
+  const T sfac = small ? T(0.5) : sh / n;                       // e_v = r * sfac
+  const T dsfac = small ? T(-1.0 / 24.0) : (T(0.5) * c - sfac) / n2;  // d sfac / d r = dsfac * r
+  const T qv[3] = {q[1], q[2], q[3]}, ov[3] = {obar[1], obar[2], obar[3]};
+  const T e0bar = q[0] * obar[0] + dot3(qv, ov);
+  T x[3];
+  cross(ov, qv, x);
+  T evbar[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) evbar[i] = -qv[i] * obar[0] + q[0] * ov[i] + x[i];
+  const T rdot = dot3(r, evbar);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar[i] = -T(0.5) * sfac * r[i] * e0bar + sfac * evbar[i] + dsfac * rdot * r[i];
+}
+
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
+                                int first_contact, const T* xbar_next, LossGrad<T, NJ>& grad,
+                                const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr) {
+  constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
+  const T dt = T(md.dt), eps = T(kDynamicsEps), ieps = fast_rcp(eps);
+  const T* q = x;
+  const T* v = x + NQ;
+  // ---- forward (recomputed, nothing is stored between the passes) --------------------------------
+  Terms<T, NJ> t;
+  Kin<TA, NJ> kinA;
+  compute_terms<T, TA, NJ>(md, dp, q, v, t, kinA);
+  T vm[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];
+  ContactGeom<T, NJ> cg[KPL];
+  CJac<T, NJ> Jc[KPL];
+  T mu[KPL], qc[KPL][3];
+  const T idt = T(1) / dt;
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr);
+    Jc[c] = cg[c].J;
+    mu[c] = cg[c].mu;
+    T jv[3];
+    cjac_apply<T, T, NJ>(Jc[c], vm, jv);
+    qc[c][0] = mu[c] * jv[0];
+    qc[c][1] = mu[c] * jv[1];
+    qc[c][2] = jv[2] + cg[c].phi * idt;
+  }
+  TA y[NV];
+  T gam[KPL][3];
+  sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, gam);
+  T yT[NV], vn[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) { yT[i] = T(y[i]); vn[i] = T(TA(vm[i]) + y[i]); }
+  // ---- seed: d/d v+ plus the pull-back of d/d q+ through q+ = q (+) v+ dt ------------------------
+  T sv[NV];
+  {
+    const T r[3] = {vn[0] * dt, vn[1] * dt, vn[2] * dt};
+    T rbar[3];
+    quat_exp_mul_adjoint<T>(q, r, xbar_next, rbar);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) sv[i] = xbar_next[NQ + i] + dt * rbar[i];
+    DPLL_UNROLL for (int i = 3; i < NV; ++i) sv[i] = xbar_next[NQ + i] + dt * xbar_next[4 + (i - 3)];
+  }
+  // ---- H lambda = s at the solution ---------------------------------------------------------------
+  Proj<T> pr[KPL];
+  T H[NV][NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i)
+    DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] = T(0);
+  T dPc[KPL][6];
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    TA jy[3];
+    cjac_apply<T, TA, NJ>(Jc[c], y, jy);
+    const T z[3] = {-T(TA(mu[c]) * jy[0] + TA(qc[c][0])) * ieps, -T(TA(mu[c]) * jy[1] + TA(qc[c][1])) * ieps,
+                    -T(jy[2] + TA(qc[c][2])) * ieps};
+    lorentz_project(z, pr[c]);
+    proj_jacobian(pr[c], dPc[c]);
+    const T(&dP)[6] = dPc[c];
+    const T m1 = mu[c] * ieps, m2 = mu[c] * m1;
+    const T C[3][3] = {{dP[0] * m2, dP[3] * m2, dP[4] * m1}, {dP[3] * m2, dP[1] * m2, dP[5] * m1}, {dP[4] * m1, dP[5] * m1, dP[2] * ieps}};
+    T CA[3][3];
+    mat3_mul(C, Jc[c].A, CA);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+      DPLL_UNROLL for (int j = 0; j <= i; ++j) {
+        H[i][j] += Jc[c].A[0][i] * CA[0][j] + Jc[c].A[1][i] * CA[1][j] + Jc[c].A[2][i] * CA[2][j];
+        H[3 + i][3 + j] += C[i][j];
+      }
+      DPLL_UNROLL for (int j = 0; j < 3; ++j) H[3 + i][j] += CA[i][j];
+    }
+    DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) {
+      T u[3];
+      mat3_vec(C, Jc[c].j[jj], u);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+        H[6 + jj][i] += Jc[c].A[0][i] * u[0] + Jc[c].A[1][i] * u[1] + Jc[c].A[2][i] * u[2];
+        H[6 + jj][3 + i] += u[i];
+      }
+      DPLL_UNROLL for (int kk = 0; kk <= jj; ++kk) H[6 + jj][6 + kk] += dot3(Jc[c].j[kk], u);
+    }
+  }
+  DPLL_UNROLL for (int i = 0; i < NV; ++i)
+    DPLL_UNROLL for (int j = 0; j <= i; ++j) {
+      H[i][j] = t.M[i][j] + Lanes::group_sum(H[i][j]);
+      H[j][i] = H[i][j];
+    }
+  T L[NV][NV], invd[NV], lam[NV];
+  cholesky<T, NV>(H, L, invd);
+  chol_solve<T, NV>(L, invd, sv, lam);
+  // ---- per-contact pieces: kappa_c, friction and witness gradients; s' = s - sum_c J_c^T kappa_c ---
+  T jtk[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) jtk[i] = T(0);
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    T pl[3], pv[3];
+    cjac_apply<T, T, NJ>(Jc[c], lam, pl);  // Jp lambda
+    cjac_apply<T, T, NJ>(Jc[c], vn, pv);   // Jp v+
+    const T jl[3] = {mu[c] * pl[0], mu[c] * pl[1], pl[2]};
+    const T(&dP)[6] = dPc[c];
+    const T kap[3] = {ieps * (dP[0] * jl[0] + dP[3] * jl[1] + dP[4] * jl[2]),
+                      ieps * (dP[3] * jl[0] + dP[1] * jl[1] + dP[5] * jl[2]),
+                      ieps * (dP[4] * jl[0] + dP[5] * jl[1] + dP[2] * jl[2])};
+    const T ak[3] = {mu[c] * kap[0], mu[c] * kap[1], kap[2]};
+    cjac_apply_t_add<T, NJ>(Jc[c], ak, jtk);
+    const T(&g)[3] = pr[c].g;
+    const T gmu = g[0] * pl[0] + g[1] * pl[1] - kap[0] * pv[0] - kap[1] * pv[1];
+    const T ag[3] = {mu[c] * g[0], mu[c] * g[1], g[2]};
+    T ol[3], ov[3], c1[3], c2[3], rhobar[3], rbar[3];
+    world_omega<T, NJ>(t.kin, cg[c].body, lam, ol);
+    world_omega<T, NJ>(t.kin, cg[c].body, vn, ov);
+    cross(ag, ol, c1);
+    cross(ak, ov, c2);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) rhobar[i] = c1[i] - c2[i];
+    rhobar[2] -= kap[2] * idt;
+    mat3t_vec(cg[c].R, rhobar, rbar);
+    if (rbar_out) {
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = rbar[i];
+    }
+    DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+      const bool mine = (cg[c].body == b);
+      grad.g_mu[b] += mine ? gmu : T(0);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[b][i] += mine ? cg[c].sgn[i] * rbar[i] : T(0);
+    }
+  }
+  T abar[NV], bvec[NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) abar[i] = dt * (sv[i] - Lanes::group_sum(jtk[i]));
+  chol_solve<T, NV>(t.LM, t.invdM, abar, bvec);
+  // ---- inertial part --------------------------------------------------------------------------------
+  T Lw[NB][3], Lu[NB][3], Yw[NB][3], Yu[NB][3], Bw[NB][3], Bu[NB][3], Aw[NB][3], Au[NB][3];
+  body_twists<T, NJ>(t.kin, lam, Lw, Lu);
+  body_twists<T, NJ>(t.kin, yT, Yw, Yu);
+  body_twists<T, NJ>(t.kin, bvec, Bw, Bu);
+  body_twists<T, NJ>(t.kin, t.a, Aw, Au);
+  DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+    inertia_bilinear_grad<T>(T(-1), Lw[b], Lu[b], Yw[b], Yu[b], grad.g_iota[b]);
+    T accw[3], accu[3];
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { accw[i] = Aw[b][i] + t.AGw[b][i]; accu[i] = Au[b][i] + t.AGu[b][i]; }
+    inertia_bilinear_grad<T>(T(-1), Bw[b], Bu[b], accw, accu, grad.g_iota[b]);
+    T cw[3], c1[3], c2[3], cu[3];
+    cross(t.Vw[b], Bw[b], cw);
+    cross(t.Vw[b], Bu[b], c1);
+    cross(t.Vu[b], Bw[b], c2);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) cu[i] = c1[i] + c2[i];
+    inertia_bilinear_grad<T>(T(1), cw, cu, t.Vw[b], t.Vu[b], grad.g_iota[b]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // chain from the batch-reduced gradients (d/d iota, d/d mu_pair, d/d |length|) to the learnable
 // parameters (theta, friction_params, length_params); double precision, a handful of flops.

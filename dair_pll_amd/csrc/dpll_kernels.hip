@@ -117,6 +117,49 @@ template <typename T, int NJ> struct Dims {
 template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
 
 
+// Wave reduction of the items' d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
+// parameter per lane (lane l >= 1 carries d iota / d theta_(l-1) in `diota`): the row written is in parameter space.
+template <typename T, int NJ>
+__device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, double loss_acc,
+                                                const T (&diota)[NJ + 1][kIota], const T* __restrict__ friction,
+                                                const T* __restrict__ lengths, double* __restrict__ partials) {
+  using D = Dims<T, NJ>;
+  using Lanes = GpuLanes<D::G>;
+  const int lane = threadIdx.x;
+  const double loss_sum = wave_sum_of_groups<D::G>(Lanes::group_sum(loss_acc));
+  double s_mu[D::NB], s_len[D::NB * 3];
+  double theta_bar = 0.0;
+#pragma unroll
+  for (int b = 0; b < D::NB; ++b) {
+#pragma unroll
+    for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
+      theta_bar += wave_sum_of_groups<D::G>(double(acc.g_iota[b][i])) * double(diota[b][i]);
+    s_mu[b] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_mu[b])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_len[b][i])));
+  }
+  const int k = lane - 1;
+  double fr[D::NB + 1], ln[D::NB * 3];
+#pragma unroll
+  for (int i = 0; i < D::NB + 1; ++i) fr[i] = double(friction[i]);
+#pragma unroll
+  for (int i = 0; i < D::NB * 3; ++i) ln[i] = lengths ? double(lengths[i]) : 0.0;
+  double val = loss_sum;
+  if (k >= 0 && k < D::NB * 10) val = theta_bar;
+  // friction and length components: evaluate all (a handful of flops) and select, no runtime indexing
+#pragma unroll
+  for (int i = 0; i < D::NB + 1; ++i) {
+    const double c = friction_grad_component(D::NB, fr, s_mu, i);
+    val = (k == D::NB * 10 + i) ? c : val;
+  }
+#pragma unroll
+  for (int i = 0; i < D::NB * 3; ++i) {
+    const double c = length_grad_component(ln, s_len, i);
+    val = (k == D::NB * 10 + D::NB + 1 + i) ? c : val;
+  }
+  if (lane < D::PI) partials[(long long)blockIdx.x * D::PI + lane] = val;
+}
+
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
 template <typename T, int NJ>
 __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
@@ -189,40 +232,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     DPLL_STAMP(2);
   }
   if (!want_grad) return;
-  // wave reduction of d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
-  // parameter per lane: the row this wave writes is already in parameter space
-  const double loss_sum = wave_sum_of_groups<D::G>(Lanes::group_sum(loss_acc));
-  double s_mu[D::NB], s_len[D::NB * 3];
-  double theta_bar = 0.0;
-#pragma unroll
-  for (int b = 0; b < D::NB; ++b) {
-#pragma unroll
-    for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
-      theta_bar += wave_sum_of_groups<D::G>(double(acc.g_iota[b][i])) * double(diota[b][i]);
-    s_mu[b] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_mu[b])));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_len[b][i])));
-  }
-  const int k = lane - 1;
-  double fr[D::NB + 1], ln[D::NB * 3];
-#pragma unroll
-  for (int i = 0; i < D::NB + 1; ++i) fr[i] = double(friction[i]);
-#pragma unroll
-  for (int i = 0; i < D::NB * 3; ++i) ln[i] = lengths ? double(lengths[i]) : 0.0;
-  double val = loss_sum;
-  if (k >= 0 && k < D::NB * 10) val = theta_bar;
-  // friction and length components: evaluate all (a handful of flops) and select, no runtime indexing
-#pragma unroll
-  for (int i = 0; i < D::NB + 1; ++i) {
-    const double c = friction_grad_component(D::NB, fr, s_mu, i);
-    val = (k == D::NB * 10 + i) ? c : val;
-  }
-#pragma unroll
-  for (int i = 0; i < D::NB * 3; ++i) {
-    const double c = length_grad_component(ln, s_len, i);
-    val = (k == D::NB * 10 + D::NB + 1 + i) ? c : val;
-  }
-  if (lane < D::PI) partials[(long long)blockIdx.x * D::PI + lane] = val;
+  store_param_row<T, NJ>(acc, loss_acc, diota, friction, lengths, partials);
   DPLL_STAMP(3);
 }
 
@@ -318,6 +328,53 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
     }
     if (iters && valid && cidx == 0) iters[it] = total;
   }
+}
+
+// ---- adjoint of one simulation step with respect to the parameters (state = data) -----------------------
+template <typename T, int NJ>
+__global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+                                                              const T* __restrict__ friction,
+                                                              const T* __restrict__ lengths, const T* __restrict__ x,
+                                                              long long ld_x, const T* __restrict__ gx,
+                                                              long long ld_g, long long batch,
+                                                              double* __restrict__ partials) {
+  using D = Dims<T, NJ>;
+  using Lanes = GpuLanes<D::G>;
+  const int lane = threadIdx.x;
+  const int cidx = lane % D::G;
+  const int slot = lane / D::G;
+  Derived<T, NJ> dp;
+  T diota[D::NB][kIota];
+  derive_params_seeded<T, NJ>(md, theta, friction, lengths, lane - 1, dp, diota);
+  LossGrad<T, NJ> acc;
+  zero_grad(acc);
+  const long long stride = (long long)gridDim.x * D::IPW;
+  for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
+    const long long item = base + slot;
+    const bool valid = item < batch;
+    const long long it = valid ? item : batch - 1;
+    T xr[D::NX], gr[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; gr[i] = valid ? gx[it * ld_g + i] : T(0); }
+    LossGrad<T, NJ> g;
+    zero_grad(g);
+    step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
+    // every lane of the group holds the item's d/d iota; d/d mu and d/d length are per contact
+#pragma unroll
+    for (int b = 0; b < D::NB; ++b) {
+#pragma unroll
+      for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] += (cidx == 0) ? g.g_iota[b][i] : T(0);
+      acc.g_mu[b] += g.g_mu[b];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc.g_len[b][i] += g.g_len[b][i];
+    }
+  }
+  // g_iota here is NOT replicated (only the group leader kept it): spread it so the shared tail applies
+#pragma unroll
+  for (int b = 0; b < D::NB; ++b)
+#pragma unroll
+    for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] = Lanes::group_sum(acc.g_iota[b][i]);
+  store_param_row<T, NJ>(acc, 0.0, diota, friction, lengths, partials);
 }
 
 // ---- MultibodyTerms.forward for API parity (off the hot path: the loss / step kernels never form D) ----
@@ -526,6 +583,23 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
                      (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)witness);
   return check_launch("simulate_kernel");
+}
+
+template <typename T, int NJ>
+int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x,
+                         const void* gx, long long ld_g, long long batch, void* grad, void* workspace,
+                         long long workspace_bytes, hipStream_t stream) {
+  using D = Dims<T, NJ>;
+  const int blocks = loss_blocks<T, NJ>(batch);
+  if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+    return fail(-3, "dpll_step_backward: workspace too small%s");
+  hipLaunchKernelGGL((step_backward_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
+                     ld_g, batch, (double*)workspace);
+  if (int rc = check_launch("step_backward_kernel")) return rc;
+  hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
+                     (T*)grad, (T*)nullptr);
+  return check_launch("finalize_kernel");
 }
 
 template <typename T, int NJ>
@@ -789,6 +863,17 @@ int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params,
   if (ld_x < nx || ld_next < nx) return fail(-1, "dpll_step: row stride smaller than n_x%s");
   DPLL_DISPATCH(launch_simulate, model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters,
                 (hipStream_t)stream);
+}
+
+int dpll_step_backward(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
+                       const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_step_backward")) return rc;
+  if (batch == 0 || !x || !grad_x_next || !grad) return fail(-1, "dpll_step_backward: bad argument%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx || ld_g < nx) return fail(-1, "dpll_step_backward: row stride smaller than n_x%s");
+  DPLL_DISPATCH(launch_step_backward, model, dtype, params, x, ld_x, grad_x_next, ld_g, batch, grad, workspace,
+                workspace_bytes, (hipStream_t)stream);
 }
 
 int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x0, int64_t ld_x,

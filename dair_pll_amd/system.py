@@ -150,6 +150,23 @@ class _LossFunction(torch.autograd.Function):
         return (None, None, None) + tuple(system._split_flat(flat_grad.clone()))
 
 
+class _StepFunction(torch.autograd.Function):
+    """One ``VelocityIntegrator.step``; backward = ``dpll_step_backward`` (gradient with respect to the
+    parameters by implicit differentiation of the cone solve; the input state is treated as data)."""
+
+    @staticmethod
+    def forward(ctx, system, x, *params):  # pylint: disable=arguments-differ
+        ctx.system = system
+        ctx.save_for_backward(x)
+        return system._step(x)
+
+    @staticmethod
+    def backward(ctx, grad_x_next):  # pylint: disable=arguments-differ
+        (x,) = ctx.saved_tensors
+        flat_grad = ctx.system._step_backward(x, grad_x_next.contiguous())
+        return (None, None) + tuple(ctx.system._split_flat(flat_grad))
+
+
 class MultibodyLearnableSystem(Module):
     """Drop-in for ``dair_pll.multibody_learnable_system.MultibodyLearnableSystem``."""
 
@@ -435,13 +452,36 @@ class MultibodyLearnableSystem(Module):
                                   x.shape[0], _ptr(x_next), x_next.stride(0), None, self._stream()))
         return x_next
 
+    def _step_backward(self, x: Tensor, grad_x_next: Tensor) -> Tensor:
+        if self._mesh() is not None:
+            raise NotImplementedError('the backward of step() is implemented for box geometry')
+        lib = _capi.library()
+        flat = self._packed()
+        grad = torch.empty(flat.numel(), dtype=self.dtype, device=x.device)
+        ws_bytes = lib.dpll_workspace_bytes(self._model(), x.shape[0])
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        params = self._params_struct(flat)
+        gx = grad_x_next.to(self.dtype)
+        _capi.check(lib.dpll_step_backward(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
+                                           _ptr(gx), gx.stride(0), x.shape[0], _ptr(grad), _ptr(workspace), ws_bytes,
+                                           self._stream()))
+        return grad
+
+    def _differentiable_step(self, x: Tensor) -> Tensor:
+        self._packed()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()) and self._mesh() is None:
+            return _StepFunction.apply(self, x, *self._param_list())
+        return self._step(x)
+
     def forward_dynamics(self, q: Tensor, v: Tensor, u: Tensor, dynamics_pool=None) -> Tensor:
         """``(*, n_q), (*, n_v), (*, ?) -> (*, n_v)`` next velocity by Anitescu's convex contact
-        model (``multibody_learnable_system.py:199-304``).  Not differentiable yet (forward only)."""
+        model (``multibody_learnable_system.py:199-304``).  Differentiable with respect to the module's
+        parameters (implicit differentiation of the cone solve, ``dpll_step_backward``); ``q, v`` are
+        treated as data, which is what one-step prediction losses need."""
         del u, dynamics_pool
         batch_shape = q.shape[:-1]
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
-        return self._step(x)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))
+        return self._differentiable_step(x)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))
 
     def sim_step(self, x: Tensor, carry: Tensor) -> Tuple[Tensor, Tensor]:
         """``Integrator.partial_step`` callback (``multibody_learnable_system.py:306-313``)."""
@@ -451,13 +491,18 @@ class MultibodyLearnableSystem(Module):
     def step(self, x: Tensor) -> Tensor:
         """One fused ``VelocityIntegrator.step``: ``(*, n_x) -> (*, n_x)``."""
         batch_shape = x.shape[:-1]
-        return self._step(self._check_input(x, self.space.n_x, 'x')).reshape(batch_shape + (self.space.n_x,))
+        return self._differentiable_step(self._check_input(x, self.space.n_x, 'x')).reshape(batch_shape + (self.space.n_x,))
 
     def _fused_simulate(self, x_0: Tensor, steps: int) -> Tensor:
         lib = _capi.library()
         batch_shape = x_0.shape[:-1]
         x = self._check_input(x_0, self.space.n_x, 'x_0')
         flat = self._packed()
+        if steps == 1 and self._mesh() is None and torch.is_grad_enabled() and \
+                any(p.requires_grad for p in self._param_list()):
+            # one-step prediction (the reference's default horizon): keep the parameter gradient
+            traj1 = torch.stack((x, self._differentiable_step(x)), dim=1)
+            return traj1.reshape(batch_shape + (2, self.space.n_x))
         traj = torch.empty((x.shape[0], steps + 1, self.space.n_x), dtype=self.dtype, device=x.device)
         if self._mesh() is not None:  # support points depend on the state: one kernel sequence per step
             traj[:, 0] = x

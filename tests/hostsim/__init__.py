@@ -111,3 +111,16 @@ def mesh(desc: ModelDesc, theta, friction, weights, pert, x, x_plus, dtype=np.fl
                 _ptr(x_plus), c_int64(batch), c_double(scale), _ptr(out_loss), _ptr(grad), _ptr(x_next))
     assert status == 0
     return {'loss': out_loss, 'grad': grad, 'x_next': x_next}
+
+
+def step_backward(desc: ModelDesc, theta, friction, lengths, x, xbar_next, opts=None):
+    """d(sum xbar_next . x_next)/d[theta | friction | lengths] (float64)."""
+    arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    theta, friction, lengths, x, xbar_next = map(arr, (theta, friction, lengths, x, xbar_next))
+    n_b = desc.n_joints + 1
+    grad = np.zeros(14 * n_b + 1, dtype=np.float64)
+    opts = opts or default_opts(np.float64)
+    status = lib().hostsim_step_backward_f64(ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction),
+                                             _ptr(lengths), _ptr(x), _ptr(xbar_next), c_int64(x.shape[0]), _ptr(grad))
+    assert status == 0
+    return grad

@@ -165,6 +165,34 @@ void mesh_loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta,
   for (int i = 0; i < W; ++i) out[W * W + 6 * W + i] = gwout[i];
 }
 
+
+template <typename T, typename TA, int NJ>
+void step_backward_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
+                         const T* x, const T* xbar_next, int64_t B, double* grad) {
+  constexpr int NB = NJ + 1, K = kQuery * NB, NX = 13 + 2 * NJ;
+  Derived<T, NJ> dp;
+  derive_params<T, NJ>(md, theta, friction, lengths, dp);
+  double g_iota[NB][kIota] = {}, g_mu[NB] = {}, g_len[NB][3] = {};
+  for (int64_t i = 0; i < B; ++i) {
+    LossGrad<T, NJ> g;
+    zero_grad(g);
+    step_item_backward<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, xbar_next + i * NX, g);
+    for (int b = 0; b < NB; ++b) {
+      for (int k = 0; k < kIota; ++k) g_iota[b][k] += double(g.g_iota[b][k]);
+      g_mu[b] += double(g.g_mu[b]);
+      for (int k = 0; k < 3; ++k) g_len[b][k] += double(g.g_len[b][k]);
+    }
+  }
+  double th[NB * 10], fr[NB + 1], ln[NB * 3];
+  for (int i = 0; i < NB * 10; ++i) th[i] = double(theta[i]);
+  for (int i = 0; i < NB + 1; ++i) fr[i] = double(friction[i]);
+  for (int i = 0; i < NB * 3; ++i) ln[i] = double(lengths[i]);
+  for (int b = 0; b < NB; ++b)
+    for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
+  for (int k = 0; k < NB + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NB, fr, g_mu, k);
+  for (int k = 0; k < NB * 3; ++k) grad[NB * 10 + NB + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
+}
+
 }  // namespace
 
 extern "C" {
@@ -229,5 +257,13 @@ int hostsim_mesh_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
   mesh_loss_batch<float, double>(*md, *opt, theta, friction, w, x, xp, B, scale, loss, grad, x_next);
   return 0;
 }
+int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
+                              const double* lengths, const double* x, const double* xbar_next, int64_t B, double* grad) {
+  if (md->n_joints == 0) step_backward_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad);
+  else if (md->n_joints == 1) step_backward_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad);
+  else return -1;
+  return 0;
+}
+
 int hostsim_sizeof_model_desc() { return (int)sizeof(ModelDesc); }
 }

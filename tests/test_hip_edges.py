@@ -29,8 +29,8 @@ def test_ragged_batches_match_full_batch_rows(batch):
     loss = system.contactnets_loss(x[:batch], u, xp[:batch])
     assert loss.shape == (batch,)
     assert np.abs(loss.detach().cpu().numpy() - g['loss'][:batch]).max() < 1e-12
-    x_next = system.step(x[:batch])
-    assert torch.equal(x_next, system.step(x)[:batch])  # per-item results do not depend on batch mates
+    x_next = system.step(x[:batch]).detach()
+    assert torch.equal(x_next, system.step(x).detach()[:batch])  # per-item results do not depend on batch mates
 
 
 def test_leading_batch_dimensions_and_strided_rows():

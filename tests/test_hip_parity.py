@@ -138,19 +138,19 @@ def test_dynamics_match_reference_run(golden, case, dtype):
     tol = 1e-10 if dtype == torch.float64 else 1e-4
     q, v = system.space.q_v(x)
     v_next = system.forward_dynamics(q, v, torch.zeros(x.shape[:-1] + (0,), device='cuda:0'))
-    assert np.abs(v_next.cpu().double().numpy() - g['dynamics/v_next']).max() < tol
-    x_next = system.step(x)
+    assert np.abs(v_next.detach().cpu().double().numpy() - g['dynamics/v_next']).max() < tol
+    x_next = system.step(x).detach()
     assert np.abs(x_next.cpu().double().numpy() - g['dynamics/x_next']).max() < tol
     # the generic Integrator path (python loop over sim_step) and the fused kernel agree with the fixture
     x_loop, _ = system.integrator.step(x, torch.zeros(x.shape[:-1] + (1,), device='cuda:0'))
-    assert np.abs(x_loop.cpu().double().numpy() - g['dynamics/x_next']).max() < tol
+    assert np.abs(x_loop.detach().cpu().double().numpy() - g['dynamics/x_next']).max() < tol
     rows = g['simulate/rows']
     steps = int(g['simulate/steps'])
     x_0 = x[rows].unsqueeze(-2)
     traj, carry = system.simulate(x_0, torch.zeros((len(rows), 1), device='cuda:0'), steps)
     assert traj.shape == (len(rows), steps + 1, system.space.n_x)
     assert carry.shape == (len(rows), steps + 1, 1)
-    assert np.abs(traj.cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if dtype == torch.float64 else 5e-4)
+    assert np.abs(traj.detach().cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if dtype == torch.float64 else 5e-4)
 
 
 def _canonical(J, phi, D, k):
@@ -190,3 +190,46 @@ def test_terms_match_reference_run(golden, case):
     assert np.abs(Dm[good] - Dr[good]).max() < 1e-8 * max(1.0, np.abs(Dr).max())
     # permutation-invariant check on every item
     assert np.abs(np.sort(phi, -1) - np.sort(g['terms/phi'], -1)).max() < 1e-12
+
+
+def test_step_backward_matches_finite_differences(golden):
+    """d(sum w . x_next)/d params through dpll_step_backward (implicit differentiation of the cone solve) against
+    central differences of the forward kernel, float64; components whose finite difference is corrupted by a
+    kink (resting contacts) are the only ones allowed to disagree."""
+    for case in ('cube_box_literal', 'elbow_box_literal'):
+        g = golden(case)
+        system = build_system(g, torch.float64)
+        with torch.no_grad():
+            for p in system.parameters():
+                p.add_(0.01 * torch.randn(p.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(p.device))
+        x = dev(g['x'][::3], torch.float64)
+        w = torch.randn(x.shape, generator=torch.Generator().manual_seed(0), dtype=torch.float64).to(x.device)
+        system.zero_grad()
+        (system.step(x) * w).sum().backward()
+        analytic = torch.cat([p.grad.reshape(-1) for p in system._param_list()]).cpu().numpy()
+        flat = system._packed()
+        fd = np.zeros_like(analytic)
+        with torch.no_grad():
+            for k in range(flat.numel()):
+                old = flat[k].item()
+                flat[k] = old + 1e-6
+                up = (system.step(x) * w).sum().item()
+                flat[k] = old - 1e-6
+                down = (system.step(x) * w).sum().item()
+                flat[k] = old
+                fd[k] = (up - down) / 2e-6
+        rel = np.abs(analytic - fd) / (np.abs(fd) + 1e-6 * np.abs(fd).max())
+        assert np.median(rel) < 1e-6
+        assert (rel < 1e-4).sum() >= len(rel) - 3, (case, rel)
+        # forward_dynamics and one-step simulate carry the same gradient
+        system.zero_grad()
+        q, v = system.space.q_v(x)
+        (system.forward_dynamics(q, v, torch.zeros(x.shape[:-1] + (0,), device='cuda:0')) * w[:, system.space.n_q:]).sum().backward()
+        g_fd = torch.cat([p.grad.reshape(-1) for p in system._param_list()]).clone()
+        system.zero_grad()
+        traj, _ = system.simulate(x.unsqueeze(-2), torch.zeros((x.shape[0], 1), device='cuda:0'), 1)
+        w0 = w.clone()
+        w0[:, :system.space.n_q] = 0
+        (traj[:, 1] * w0).sum().backward()
+        g_sim = torch.cat([p.grad.reshape(-1) for p in system._param_list()])
+        assert torch.allclose(g_fd, g_sim, rtol=1e-12, atol=1e-14)

@@ -147,3 +147,28 @@ def test_mesh_geometry_reference_path(golden, dtype):
     assert np.abs(out['loss'] - g['loss']).max() < (1e-12 if f64 else 1e-6)
     assert np.abs(out['grad'] - grad_ref).max() <= (1e-10 if f64 else 1e-4) * np.abs(grad_ref).max()
     assert np.abs(out['x_next'] - g['dynamics/x_next']).max() < (1e-10 if f64 else 1e-4)
+
+
+@pytest.mark.parametrize('case', ['cube_box_literal', 'elbow_box_literal'])
+def test_step_adjoint_matches_finite_differences(golden, case):
+    """step_item_backward (implicit differentiation of the cone solve w.r.t. the parameters) vs central
+    differences of step_item, float64; finite differences are invalid at contact kinks, so a couple of
+    length components may disagree."""
+    g = golden(case)
+    desc, theta, friction, lengths, _ = setup(g)
+    n_b = desc.n_joints + 1
+    rng = np.random.default_rng(0)
+    params = np.concatenate([theta.ravel() + 0.01 * rng.normal(size=theta.size), friction.ravel(), lengths.ravel()])
+    split = lambda p: (p[:10 * n_b].reshape(n_b, 10), p[10 * n_b:11 * n_b + 1], p[11 * n_b + 1:].reshape(n_b, 3))
+    x = g['x'][::3]
+    w = rng.normal(size=x.shape)
+    analytic = hostsim.step_backward(desc, *split(params), x, w)
+    fd = np.zeros_like(analytic)
+    for k in range(params.size):
+        up, down = params.copy(), params.copy()
+        up[k] += 1e-6
+        down[k] -= 1e-6
+        fd[k] = ((hostsim.step(desc, *split(up), x)[0] - hostsim.step(desc, *split(down), x)[0]) * w).sum() / 2e-6
+    rel = np.abs(analytic - fd) / (np.abs(fd) + 1e-6 * np.abs(fd).max())
+    assert np.median(rel) < 1e-7
+    assert (rel < 1e-4).sum() >= rel.size - 3, rel
