@@ -176,6 +176,15 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
   const int cidx = lane % D::G;
   const int slot = lane / D::G;
   DPLL_STAMP(0);
+  // the first item's state rows are requested before the parameter math so that their memory latency hides behind it
+  const long long stride = (long long)gridDim.x * D::IPWL;
+  long long base = (long long)blockIdx.x * D::IPWL;
+  long long item = base + slot % D::IPWL;  // lane groups beyond IPWL shadow the first ones (same trip counts)
+  bool valid = item < batch && slot < D::IPWL;
+  long long it = valid ? item : batch - 1;  // idle groups shadow the last item: keeps every lane live for DPP
+  T xr[D::NX], xpr[D::NX];
+#pragma unroll
+  for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
   // lane l >= 1 owns learnable parameter l - 1 of the output row and carries d iota / d theta_(l-1)
   Derived<T, NJ> dp;
   T diota[D::NB][kIota];
@@ -183,14 +192,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
   LossGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
-  const long long stride = (long long)gridDim.x * D::IPWL;
-  for (long long base = (long long)blockIdx.x * D::IPWL; base < batch; base += stride) {
-    const long long item = base + slot % D::IPWL;  // lane groups beyond IPWL shadow the first ones (same trip counts)
-    const bool valid = item < batch && slot < D::IPWL;
-    const long long it = valid ? item : batch - 1;  // idle groups shadow the last item: keeps every lane live for DPP
-    T xr[D::NX], xpr[D::NX];
-#pragma unroll
-    for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
+  while (true) {
     const T w = valid ? T(scale) * (weights ? weights[it] : T(1)) : T(0);
     T f[1][3];
     int n_it = 0;
@@ -230,6 +232,13 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     }
 #endif
     DPLL_STAMP(2);
+    base += stride;
+    if (base >= batch) break;
+    item = base + slot % D::IPWL;
+    valid = item < batch && slot < D::IPWL;
+    it = valid ? item : batch - 1;
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
   }
   if (!want_grad) return;
   store_param_row<T, NJ>(acc, loss_acc, diota, friction, lengths, partials);
