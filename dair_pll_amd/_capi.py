@@ -31,7 +31,7 @@ class SolverOpts(ctypes.Structure):
     """``dpll_solver_opts_t``"""
     _fields_ = [('max_iter', c_int32), ('max_ls', c_int32), ('tol', c_double), ('stall_tol', c_double),
                 ('ls_tol', c_double), ('n_stages', c_int32), ('stage_max_iter', c_int32), ('stage_factor', c_double),
-                ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('pad_', c_int32)]
+                ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('fast_ls', c_int32)]
 
 
 class Params(ctypes.Structure):

@@ -24,6 +24,9 @@
 #pragma once
 
 #include <math.h>
+#if defined(DPLL_TRACE)
+#include <cstdio>
+#endif
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -33,6 +36,11 @@
 #endif
 
 #define DPLL_UNROLL _Pragma("unroll")
+#ifndef DPLL_PHASE_BEGIN
+#define DPLL_PHASE_BEGIN() do {} while (0)
+#define DPLL_PHASE(slot) do {} while (0)
+#define DPLL_PHASE_END() do {} while (0)
+#endif
 #ifndef DPLL_CORE_STAMP
 #define DPLL_CORE_STAMP(slot) do {} while (0)
 #endif
@@ -584,7 +592,11 @@ struct SolverOpts {
   double stage_tol;
   double stage_ls_tol;  // line-search tolerance of the non-final stages (their iterates are only warm starts)
   int stage_max_ls;     // line-search probes per iteration in the non-final stages
-  int pad_;
+  // probes per iteration while the decrement keeps falling (0: always max_ls / stage_max_ls).  Exact line searches
+  // rarely change the Newton path but a wave pays for its slowest item's probes on every iteration, so an iteration
+  // only gets the full search once the decrement has failed to drop by 4x twice in a row (the safeguard that keeps
+  // the method globally convergent).
+  int fast_ls;
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
@@ -617,7 +629,9 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
   DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = TA(0);
   T best = T(3.0e38);
   int stall = 0;
+  DPLL_PHASE_BEGIN();
   for (int it = 0; it < opt.max_iter; ++it) {
+    DPLL_PHASE(5);
     const T ieps = fast_rcp(eps_c);
     const bool final_stage = stage >= last_stage;
     // cone residuals z = -(J y + q) / eps, projections, J^T gamma
@@ -638,6 +652,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     T My[NV], grad[NV];
     symv<T, NV>(M, yT, My);
     DPLL_UNROLL for (int i = 0; i < NV; ++i) grad[i] = My[i] - Lanes::group_sum(jtg[i]);
+    DPLL_PHASE(0);
     // Hessian H = M + sum_c [A 1 j]^T C [A 1 j],  C = D_mu dP D_mu / eps
     T H[NV][NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
@@ -671,10 +686,12 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
         H[i][j] = M[i][j] + Lanes::group_sum(H[i][j]);
         H[j][i] = H[i][j];
       }
+    DPLL_PHASE(1);
     T L[NV][NV], invd[NV], d[NV];
     cholesky_fast<T, NV>(H, L, invd);
     chol_solve<T, NV>(L, invd, grad, d);
     DPLL_UNROLL for (int i = 0; i < NV; ++i) d[i] = -d[i];
+    DPLL_PHASE(2);
     // Newton decrement and stopping rule (the step below is still taken: it only improves y)
     const T dec2 = -dotn<T, NV>(grad, d);
     const T ynorm2 = dotn<T, NV>(yT, My);
@@ -704,9 +721,11 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     const T dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
     const T yMd = dotn<T, NV>(My, d);
     const T slope_tol = (final_stage ? ls_tol : T(opt.stage_ls_tol)) * dec2;  // |l'(0)| = dec2
-    const int ls_cap = final_stage ? opt.max_ls : opt.stage_max_ls;
+    const int ls_full = final_stage ? opt.max_ls : opt.stage_max_ls;
+    const int ls_cap = (opt.fast_ls > 0 && stall < 2) ? (opt.fast_ls < ls_full ? opt.fast_ls : ls_full) : ls_full;
     T alpha = T(1), lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
     bool searching = active && (dec2 > T(0));
+    DPLL_PHASE(3);
     for (int ls = 0; ls < opt.max_ls; ++ls) {
       if (!Lanes::wave_any(searching)) break;
       T part1 = T(0), part2 = T(0);
@@ -735,8 +754,17 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
       alpha = (searching && !ok) ? (out ? (lo_n > T(0) ? lo_n : nxt) : nxt) : alpha;
       searching = searching && !ok && !out;
     }
+    DPLL_PHASE(4);
 #if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
-    if (active) printf("  it %d dec2 %.3e scale %.3e alpha %.4f conv %d stall %d\n", it, double(dec2), double(scale), double(alpha), int(converged), stall);
+    if (active) {
+      printf("  it %2d stage %d eps %.2e dec2 %.3e scale %.3e alpha %.4f conv %d stall %d regions", it, stage, double(eps_c), double(dec2), double(scale), double(alpha), int(converged), stall);
+      for (int c = 0; c < KPL; ++c) printf(" %c", pr[c].inside ? 'I' : (pr[c].polar ? '0' : 'M'));
+      for (int c = 0; c < KPL; ++c) if (!pr[c].inside && !pr[c].polar) {
+        const double r = sqrt(double(z[c][0]) * z[c][0] + double(z[c][1]) * z[c][1]);
+        printf(" | c%d r %.4e n %.4e ang %.4f dz_t (%.3e %.3e) dz_n %.3e", c, r, double(z[c][2]), atan2(double(z[c][1]), double(z[c][0])), -double(ieps * jd[c][0]), -double(ieps * jd[c][1]), -double(ieps * jd[c][2]));
+      }
+      printf("\n");
+    }
 #endif
     const bool move = active && (dec2 > T(0));
     DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += move ? TA(alpha) * TA(d[i]) : TA(0);
@@ -751,6 +779,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     stall = advance ? 0 : stall;
     if (!Lanes::wave_any(active)) break;
   }
+  DPLL_PHASE_END();
   // forces at the final iterate, with the reference's eps
   const T ieps = fast_rcp(eps);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {

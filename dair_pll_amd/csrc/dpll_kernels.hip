@@ -38,6 +38,21 @@ __device__ unsigned long long g_stamps[2048][8];
 #endif
 #ifdef DPLL_STAMPS
 #define DPLL_CORE_STAMP(slot) DPLL_STAMP(slot)
+// cycles per phase of the Newton iteration, summed over the iterations of a wave (rows 1024.. of g_stamps)
+__device__ __forceinline__ unsigned long long dpll_clock_() {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t_;
+}
+#define DPLL_PHASE_BEGIN() unsigned long long ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = dpll_clock_()
+#define DPLL_PHASE(slot) do { const unsigned long long t_ = dpll_clock_(); ph_acc_[slot] += t_ - ph_last_; ph_last_ = t_; } while (0)
+#define DPLL_PHASE_END()                                                                                   \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 1024)                                                             \
+      for (int k_ = 0; k_ < 8; ++k_) g_stamps[1024 + blockIdx.x][k_] = ph_acc_[k_];                        \
+  } while (0)
 #endif
 #include "dpll_core.hpp"
 #include "dpll_allreduce.hpp"
@@ -487,11 +502,11 @@ int check_launch(const char* what) {
 SolverOpts default_opts(int dtype) {
   SolverOpts o;
   if (dtype == DPLL_F64) {
-    o.max_iter = 100; o.max_ls = 50; o.tol = 1e-13; o.stall_tol = 1e-10; o.ls_tol = 0.3;
-    o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.3; o.stage_max_ls = 50; o.pad_ = 0;
+    o.max_iter = 100; o.max_ls = 50; o.tol = 1e-13; o.stall_tol = 1e-10; o.ls_tol = 0.9;
+    o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.9; o.stage_max_ls = 50; o.fast_ls = 1;
   } else {
-    o.max_iter = 60; o.max_ls = 30; o.tol = 1e-6; o.stall_tol = 1e-5; o.ls_tol = 0.3;
-    o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.3; o.stage_max_ls = 50; o.pad_ = 0;
+    o.max_iter = 60; o.max_ls = 30; o.tol = 1e-6; o.stall_tol = 1e-5; o.ls_tol = 0.9;
+    o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.9; o.stage_max_ls = 50; o.fast_ls = 1;
   }
   return o;
 }

@@ -65,7 +65,7 @@ typedef struct dpll_solver_opts {
   double stage_tol;
   double stage_ls_tol;    /* line-search tolerance and probe cap of the non-final stages */
   int32_t stage_max_ls;
-  int32_t pad_;
+  int32_t fast_ls;        /* probes per iteration while the decrement keeps falling; 0 = always the full search */
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;

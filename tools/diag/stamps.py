@@ -22,10 +22,11 @@ for _ in range(50): s.contactnets_loss_and_grad(x, xp)
 e1.record(); torch.cuda.synchronize(); print('eager us per call', e0.elapsed_time(e1) * 20)
 torch.cuda.synchronize()
 lib = _capi.library()
-NR = int(os.environ.get('DPLL_DIAG_ROWS', '256')); out = np.zeros((NR, 8), dtype=np.uint64)
+NR = int(os.environ.get('DPLL_DIAG_ROWS', '256')); out = np.zeros((2048, 8), dtype=np.uint64)
 lib.dpll_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-assert lib.dpll_debug_read_stamps(out.ctypes.data_as(ctypes.c_void_p), NR) == 0
-t = out.astype(np.int64)
+assert lib.dpll_debug_read_stamps(out.ctypes.data_as(ctypes.c_void_p), 2048) == 0
+phases = out[1024:1024 + NR].astype(np.int64)
+t = out[:NR].astype(np.int64)
 names = ['params(0->1)', 'loads+terms+contacts(1->4)', 'newton(4->5)', 'adjoint(5->2)', 'reduce+store(2->3)']
 seg = np.stack([t[:, 1] - t[:, 0], t[:, 4] - t[:, 1], t[:, 5] - t[:, 4], t[:, 2] - t[:, 5], t[:, 3] - t[:, 2]], 1)
 total = t[:, 3] - t[:, 0]
@@ -37,3 +38,8 @@ for label, idx in (('slowest', order[-1]), ('median', order[len(order) // 2]), (
 print('mean per segment', dict(zip(names, seg.mean(0).round(0))), 'mean total', total.mean())
 print('newton ticks per iteration (slowest wave)', seg[order[-1], 2] / max(1, its[order[-1]]))
 print('launch skew: last start', t[:, 0].max() - t[:, 0].min(), 'last end', t[:, 3].max() - t[:, 0].min())
+
+pn = ['residual+proj+grad', 'hessian+reduce', 'cholesky+solve', 'decrement+ls-setup', 'line-search', 'update+stage-logic']
+w = order[-1]
+print('phase cycles, slowest wave (sum over its iterations):', dict(zip(pn, phases[w, :6])), 'per iteration:', dict(zip(pn, (phases[w, :6] / max(1, its[w])).round(0))))
+print('phase cycles, mean over waves per iteration:', dict(zip(pn, (phases[:, :6].sum(0) / max(1, its.sum())).round(0))))
