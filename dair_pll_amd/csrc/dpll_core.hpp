@@ -40,6 +40,7 @@
 #define DPLL_PHASE_BEGIN() do {} while (0)
 #define DPLL_PHASE(slot) do {} while (0)
 #define DPLL_PHASE_END() do {} while (0)
+#define DPLL_PHASE_COUNT(slot) do {} while (0)
 #endif
 #ifndef DPLL_CORE_STAMP
 #define DPLL_CORE_STAMP(slot) do {} while (0)
@@ -627,6 +628,11 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
   bool active = true;
   int iters = 0;
   DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = TA(0);
+  // every lane of the group starts its share of the Hessian from M / group size (a power of two, so exact): the
+  // group sum then returns M + sum_c ... without a separate addition per entry
+  T Mshare[NV][NV];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i)
+    DPLL_UNROLL for (int j = 0; j <= i; ++j) Mshare[i][j] = M[i][j] * T(1.0 / Lanes::kGroup);
   T best = T(3.0e38);
   int stall = 0;
   DPLL_PHASE_BEGIN();
@@ -656,7 +662,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     // Hessian H = M + sum_c [A 1 j]^T C [A 1 j],  C = D_mu dP D_mu / eps
     T H[NV][NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
-      DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] = T(0);
+      DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] = Mshare[i][j];
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
       T dP[6];
       proj_jacobian(pr[c], dP);
@@ -683,7 +689,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     }
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
       DPLL_UNROLL for (int j = 0; j <= i; ++j) {
-        H[i][j] = M[i][j] + Lanes::group_sum(H[i][j]);
+        H[i][j] = Lanes::group_sum(H[i][j]);
         H[j][i] = H[i][j];
       }
     DPLL_PHASE(1);
@@ -726,8 +732,8 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     T alpha = T(1), lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
     bool searching = active && (dec2 > T(0));
     DPLL_PHASE(3);
-    for (int ls = 0; ls < opt.max_ls; ++ls) {
-      if (!Lanes::wave_any(searching)) break;
+    // one probe: l'(alpha) and l''(alpha) by re-projecting the cone residuals, then a safeguarded Newton step on l'
+    auto probe = [&](int ls) {
       T part1 = T(0), part2 = T(0);
       const T step = alpha * ieps;
       DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
@@ -747,12 +753,18 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
       const bool bad = !((newton > lo_n) && (hi_n < T(0) || newton < hi_n));
       const T nxt = bad ? mid : newton;
       ok = ok || (hi_n >= T(0) && (hi_n - lo_n) <= T(4) * (sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16)) * hi_n);
-      // out of probes (non-final stages): fall back to the largest alpha known to decrease l (l' < 0 on [0, lo])
+      // out of probes: fall back to the largest alpha known to decrease l (l' < 0 on [0, lo])
       const bool out = searching && !ok && (ls + 1 >= ls_cap);
       lo = searching ? lo_n : lo;
       hi = searching ? hi_n : hi;
       alpha = (searching && !ok) ? (out ? (lo_n > T(0) ? lo_n : nxt) : nxt) : alpha;
       searching = searching && !ok && !out;
+    };
+    probe(0);  // alpha = 1 is probed unconditionally (straight-line code); more probes are the exception
+    for (int ls = 1; ls < opt.max_ls; ++ls) {
+      if (!Lanes::wave_any(searching)) break;
+      DPLL_PHASE_COUNT(6);
+      probe(ls);
     }
     DPLL_PHASE(4);
 #if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
@@ -1353,6 +1365,7 @@ DPLL_HD double length_grad_component(const double* lengths, const double* g_len,
 
 // host/one-lane implementation of the lane-group primitives
 struct OneLane {
+  static constexpr int kGroup = 1;  // lanes that share one item
   template <typename T> static DPLL_HD T group_sum(T x) { return x; }
   static DPLL_HD bool group_any(bool x) { return x; }
   static DPLL_HD bool wave_any(bool x) { return x; }

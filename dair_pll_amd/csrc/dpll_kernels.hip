@@ -48,6 +48,7 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
 }
 #define DPLL_PHASE_BEGIN() unsigned long long ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = dpll_clock_()
 #define DPLL_PHASE(slot) do { const unsigned long long t_ = dpll_clock_(); ph_acc_[slot] += t_ - ph_last_; ph_last_ = t_; } while (0)
+#define DPLL_PHASE_COUNT(slot) do { ph_acc_[slot] += 1; } while (0)
 #define DPLL_PHASE_END()                                                                                   \
   do {                                                                                                     \
     if (threadIdx.x == 0 && blockIdx.x < 1024)                                                             \
@@ -89,6 +90,7 @@ constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
 
 template <int G> struct GpuLanes {
   static_assert(G == 4 || G == 8, "one lane per contact: 4 (one body) or 8 (two bodies)");
+  static constexpr int kGroup = G;
   template <typename T> static __device__ __forceinline__ T group_sum(T x) {
     x += dpp_mov<kQuadXor1>(x);
     x += dpp_mov<kQuadXor2>(x);
@@ -104,13 +106,36 @@ template <int G> struct GpuLanes {
 };
 
 // sum over the whole wave of a value that is already uniform inside each group of G lanes, counting every
-// group once; the result is valid in every lane
-template <int G> __device__ __forceinline__ double wave_sum_of_groups(double x) {
+// group once; the result is valid in every lane.  Rows of 16 lanes are closed with the mirror controls, the four
+// rows with row_bcast:15 / row_bcast:31 (the total lands in lane 63) and one v_readlane: no LDS permutes.
+constexpr int kRowBcast15 = 0x142;  // lane 15 of each row -> every lane of the next row (row_mask 0xA)
+constexpr int kRowBcast31 = 0x143;  // lane 31 -> rows 2 and 3 (row_mask 0xC)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_rows(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_rows(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int lo = (int)(unsigned)(u & 0xffffffffull), hi = (int)(unsigned)(u >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+  return __builtin_bit_cast(double, r);  // +0.0 in the rows outside ROW_MASK
+}
+__device__ __forceinline__ float read_lane63(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ double read_lane63(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x) {
   if (G == 4) x += dpp_mov<kRowHalfMirror>(x);
   x += dpp_mov<kRowMirror>(x);
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+  x += dpp_rows<kRowBcast15, 0xA>(x);
+  x += dpp_rows<kRowBcast31, 0xC>(x);
+  return read_lane63(x);
 }
 
 }  // namespace
@@ -148,10 +173,10 @@ __device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, doub
   for (int b = 0; b < D::NB; ++b) {
 #pragma unroll
     for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
-      theta_bar += wave_sum_of_groups<D::G>(double(acc.g_iota[b][i])) * double(diota[b][i]);
-    s_mu[b] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_mu[b])));
+      theta_bar += double(wave_sum_of_groups<D::G>(acc.g_iota[b][i])) * double(diota[b][i]);
+    s_mu[b] = double(wave_sum_of_groups<D::G>(Lanes::group_sum(acc.g_mu[b])));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = wave_sum_of_groups<D::G>(Lanes::group_sum(double(acc.g_len[b][i])));
+    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = double(wave_sum_of_groups<D::G>(Lanes::group_sum(acc.g_len[b][i])));
   }
   const int k = lane - 1;
   double fr[D::NB + 1], ln[D::NB * 3];

@@ -43,3 +43,4 @@ pn = ['residual+proj+grad', 'hessian+reduce', 'cholesky+solve', 'decrement+ls-se
 w = order[-1]
 print('phase cycles, slowest wave (sum over its iterations):', dict(zip(pn, phases[w, :6])), 'per iteration:', dict(zip(pn, (phases[w, :6] / max(1, its[w])).round(0))))
 print('phase cycles, mean over waves per iteration:', dict(zip(pn, (phases[:, :6].sum(0) / max(1, its.sum())).round(0))))
+print('line-search probes per iteration: slowest wave', phases[w, 6] / max(1, its[w]), 'mean', phases[:, 6].sum() / max(1, its.sum()))
