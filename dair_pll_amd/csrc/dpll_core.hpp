@@ -522,46 +522,53 @@ template <typename T, int NJ> DPLL_HD void world_omega(const Kin<T, NJ>& k, int 
 // ---------------------------------------------------------------------------------------------
 // Lorentz-cone projection, z = [t_x, t_y, n] (tensor_utils.py:460-497 ordering), unit cone
 // ---------------------------------------------------------------------------------------------
+// The three regions share one parametrisation of the generalised Jacobian,
+//   dP = cp p p^T + a (t t^T + e3 e3^T) + b (t e3^T + e3 t^T),   t = z_t / |z_t|,  p = (-t_y, t_x, 0):
+// identity region (cp, a, b) = (1, 1, 0), cone surface (s / r, 1/2, 1/2), polar region (0, 0, 0); the projection
+// itself is g = (cp z_t, inside ? n : s) with s = max((n + r) / 2, 0).  Everything downstream is select free.
 template <typename T> struct Proj {
   T g[3];       // projection
-  T that[2];    // unit tangential direction (mid region)
-  T ratio;      // s / r in the mid region
+  T that[2];    // unit tangential direction ((1, 0) where z_t = 0)
+  T cp, a, b;   // coefficients above
   bool inside;  // identity region
   bool polar;   // zero region (neither: the "mid" region, projection onto the cone surface)
 };
 template <typename T> DPLL_HD void lorentz_project(const T (&z)[3], Proj<T>& p) {
   const T r2 = z[0] * z[0] + z[1] * z[1];
-  const T ir = r2 > T(0) ? fast_rsqrt(r2) : T(0);
+  const bool pos = r2 > T(0);
+  const T ir = pos ? fast_rsqrt(r2) : T(0);
   const T r = r2 * ir;
   const T n = z[2];
+  const T sraw = T(0.5) * (n + r);
   p.inside = r <= n;
-  p.polar = (r <= -n) && !p.inside;
-  const T s = T(0.5) * (n + r);
-  p.that[0] = z[0] * ir;
+  p.polar = !(sraw > T(0)) && !p.inside;
+  const T s = tmax(sraw, T(0));
+  p.that[0] = pos ? z[0] * ir : T(1);
   p.that[1] = z[1] * ir;
-  p.ratio = s * ir;
-  p.g[0] = p.inside ? z[0] : (p.polar ? T(0) : p.that[0] * s);
-  p.g[1] = p.inside ? z[1] : (p.polar ? T(0) : p.that[1] * s);
-  p.g[2] = p.inside ? z[2] : (p.polar ? T(0) : s);
+  const T half = (sraw > T(0)) ? T(0.5) : T(0);
+  p.cp = p.inside ? T(1) : s * ir;
+  p.a = p.inside ? T(1) : half;
+  p.b = p.inside ? T(0) : half;
+  p.g[0] = p.cp * z[0];
+  p.g[1] = p.cp * z[1];
+  p.g[2] = p.inside ? n : s;
 }
-// w^T dP w for the generalised Jacobian dP of the projection; in the mid region
-// dP = ratio p p^T + 1/2 n n^T with p = (-t_y, t_x, 0), n = (t_x, t_y, 1)
+// w^T dP w
 template <typename T> DPLL_HD T proj_quadratic(const Proj<T>& p, const T (&w)[3]) {
-  const T full = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const T a = p.that[0] * w[1] - p.that[1] * w[0];
-  const T b = p.that[0] * w[0] + p.that[1] * w[1] + w[2];
-  const T mid = p.ratio * a * a + T(0.5) * b * b;
-  return p.inside ? full : (p.polar ? T(0) : mid);
+  const T a1 = p.that[0] * w[1] - p.that[1] * w[0];
+  const T u = p.that[0] * w[0] + p.that[1] * w[1];
+  return p.cp * a1 * a1 + p.a * (u * u + w[2] * w[2]) + (p.b + p.b) * u * w[2];
 }
 // dP as a symmetric 3x3 (xx, yy, zz, xy, xz, yz)
 template <typename T> DPLL_HD void proj_jacobian(const Proj<T>& p, T (&d)[6]) {
-  const T tx = p.that[0], ty = p.that[1], ra = p.ratio;
-  const T m[6] = {ra * ty * ty + T(0.5) * tx * tx, ra * tx * tx + T(0.5) * ty * ty, T(0.5),
-                  (T(0.5) - ra) * tx * ty, T(0.5) * tx, T(0.5) * ty};
-  DPLL_UNROLL for (int i = 0; i < 6; ++i) {
-    const T ident = (i < 3) ? T(1) : T(0);
-    d[i] = p.inside ? ident : (p.polar ? T(0) : m[i]);
-  }
+  const T tx = p.that[0], ty = p.that[1];
+  const T txx = tx * tx, tyy = ty * ty, txy = tx * ty;
+  d[0] = p.cp * tyy + p.a * txx;
+  d[1] = p.cp * txx + p.a * tyy;
+  d[2] = p.a;
+  d[3] = (p.a - p.cp) * txy;
+  d[4] = p.b * tx;
+  d[5] = p.b * ty;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -778,8 +785,8 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
       printf("\n");
     }
 #endif
-    const bool move = active && (dec2 > T(0));
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += move ? TA(alpha) * TA(d[i]) : TA(0);
+    const TA alpha_move = (active && (dec2 > T(0))) ? TA(alpha) : TA(0);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += alpha_move * TA(d[i]);
     iters = active ? it + 1 : iters;
     const bool stage_done = converged || stalled || (!final_stage && it_stage + 1 >= opt.stage_max_iter);
     const bool advance = active && !final_stage && stage_done && !force_free;
