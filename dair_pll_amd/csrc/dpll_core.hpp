@@ -664,7 +664,9 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     }
     T My[NV], grad[NV];
     symv<T, NV>(M, yT, My);
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) grad[i] = My[i] - Lanes::group_sum(jtg[i]);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) { jtg[i] = Lanes::group_sum(jtg[i]); grad[i] = My[i] - jtg[i]; }
+    // jtg[5] is now the sum of the normal forces: zero exactly when every contact sits in the polar region
+    const bool any_force = jtg[5] > T(0);
     DPLL_PHASE(0);
     // Hessian H = M + sum_c [A 1 j]^T C [A 1 j],  C = D_mu dP D_mu / eps
     T H[NV][NV];
@@ -716,9 +718,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     best = tmin(best, dec2);
     const bool stalled = stall >= 3 && !(dec2 > (final_stage ? stol2 : stage_tol2) * scale2);
     // no force at all and y stationary: the answer (y = 0 region-wise) does not depend on eps, skip the other stages
-    bool nonpolar = false;
-    DPLL_UNROLL for (int c = 0; c < KPL; ++c) nonpolar = nonpolar || !pr[c].polar;
-    const bool force_free = !(dec2 > T(0)) && !Lanes::group_any(nonpolar);
+    const bool force_free = !(dec2 > T(0)) && !any_force;
     // line search on l'(alpha) = y.Md + alpha d.Md - sum_c gamma_c(alpha) . (J_c d); from H d = -grad:
     //   d.Md = dec2 - (1/eps) sum_c (J_c d)^T dP_c (J_c d)
     T jd[KPL][3];
