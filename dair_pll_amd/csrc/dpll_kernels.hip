@@ -201,7 +201,9 @@ __device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, doub
 }
 
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
-template <typename T, int NJ>
+// MESH: the contact's support point is read from `witness` (ICNN kernels) and its adjoint written to `rbar_out`;
+// a template flag so that the box kernels carry none of it (a run-time choice of array put both in scratch).
+template <typename T, int NJ, bool MESH = false>
 __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
                                                      const T* __restrict__ x, long long ld_x,
@@ -239,15 +241,17 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     DPLL_STAMP(1);
     // mesh geometry: this contact's support point comes from the ICNN kernels; its adjoint goes back to them
     T wit[1][3] = {{T(0), T(0), T(0)}}, rb[1][3] = {{T(0), T(0), T(0)}};
-    if (witness) {
+    T L;
+    if constexpr (MESH) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
-    }
-    const T L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it,
-                                                                  witness ? wit : nullptr, rbar_out ? rb : nullptr);
-    if (rbar_out && valid) {
+      L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, wit, rb);
+      if (rbar_out && valid) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
+        for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
+      }
+    } else {
+      L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it);
     }
     if (valid) {
       if (cidx == 0) {
@@ -291,6 +295,21 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
 constexpr int kFinalizeThreads = 1024;
 constexpr int kFinalizeLoads = kMaxLossBlocks / 32;  // rows per thread at the largest grid
 
+// rows rowg, rowg + 32, ... of one column, all loads issued before the first add (fixed summation order)
+template <int LOADS>
+__device__ __forceinline__ double finalize_column(const double* __restrict__ partials, int n_rows, int width, int col, int rowg) {
+  double v[LOADS];
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) {
+    const int r = rowg + 32 * i;
+    v[i] = (col < width && r < n_rows) ? partials[(long long)r * width + col] : 0.0;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < LOADS; ++i) s += v[i];
+  return s;
+}
+
 template <typename T, int NJ>
 __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double* __restrict__ partials, int n_rows,
                                                                     T* __restrict__ grad, T* __restrict__ loss_total) {
@@ -298,19 +317,9 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
   static_assert(D::PI <= 32, "partial row must fit 32 columns");
   __shared__ double red[32][33];
   const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
-  double v[kFinalizeLoads];
-#pragma unroll
-  for (int i = 0; i < kFinalizeLoads; ++i) {
-    const int r = rowg + 32 * i;
-    v[i] = (col < D::PI && r < n_rows) ? partials[(long long)r * D::PI + col] : 0.0;
-    if (32 * (i + 1) >= n_rows) break;  // uniform: n_rows is a kernel argument
-  }
-  double s = 0.0;
-#pragma unroll
-  for (int i = 0; i < kFinalizeLoads; ++i) {
-    s += v[i];
-    if (32 * (i + 1) >= n_rows) break;
-  }
+  // uniform branch (n_rows is a kernel argument): the headline grid has 256 rows = 8 per thread
+  const double s = n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, col, rowg)
+                                 : finalize_column<kFinalizeLoads>(partials, n_rows, D::PI, col, rowg);
   red[rowg][col] = s;
   __syncthreads();
   if (threadIdx.x < D::PI) {
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
 }
 
 // ---- simulation: `steps` VelocityIntegrator steps per item, trajectory written as it goes ---------
-template <typename T, int NJ>
+template <typename T, int NJ, bool MESH = false>
 __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
                                                          const T* __restrict__ x0, long long ld_x, long long batch,
@@ -360,12 +369,14 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
     for (long long s = 0; s < steps; ++s) {
       T xn[D::NX], imp[1][3];
       int n_it = 0;
-      T wit[1][3] = {{T(0), T(0), T(0)}};
-      if (witness) {  // mesh geometry: support points of the CURRENT state, one step per launch
+      if constexpr (MESH) {  // mesh geometry: support points of the CURRENT state, one step per launch
+        T wit[1][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
+        step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it, wit);
+      } else {
+        step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it);
       }
-      step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it, witness ? wit : nullptr);
       total += n_it;
 #pragma unroll
       for (int i = 0; i < D::NX; ++i) xr[i] = xn[i];
@@ -628,9 +639,14 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   using D = Dims<T, NJ>;
   long long blocks = (batch + D::IPW - 1) / D::IPW;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL((simulate_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
-                     (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)witness);
+  if (witness)
+    hipLaunchKernelGGL((simulate_kernel<T, NJ, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
+                       (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)witness);
+  else
+    hipLaunchKernelGGL((simulate_kernel<T, NJ, false>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
+                       (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
   return check_launch("simulate_kernel");
 }
 
@@ -735,7 +751,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   const IcnnWeights<T> w = mesh_weights<T>(mp);
   if (int rc = mesh_forward<T>(pl, w, ws, (const T*)xp, ld_xp, stream)) return rc;  // terms live at the NEXT state
   const int want_grad = grad != nullptr;
-  hipLaunchKernelGGL((loss_kernel<T, 0>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+  hipLaunchKernelGGL((loss_kernel<T, 0, true>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
                      want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);

@@ -1,0 +1,54 @@
+"""Turns the raw rocprofv3 output of tools/diag/refresh_profiles.sh (gpurun_out/r01p) into the files kept under profiles/."""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r01p')
+DST = os.path.join(REPO, 'profiles')
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r01'
+KERNEL = 'loss_kernel<float, 0>'
+
+
+def counter_means(path):
+    sums, counts = defaultdict(float), defaultdict(int)
+    for row in csv.DictReader(open(path)):
+        if KERNEL in row['Kernel_Name']:
+            sums[row['Counter_Name']] += float(row['Counter_Value'])
+            counts[row['Counter_Name']] += 1
+    return {k: (sums[k] / counts[k], counts[k]) for k in sums}
+
+
+shutil.copy(os.path.join(SRC, 'stats', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_f32_kernel_stats.csv'))
+shutil.copy(os.path.join(SRC, 'stats_mesh', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_mesh_f32_kernel_stats.csv'))
+with open(os.path.join(SRC, 'stats', 'run_kernel_trace.csv')) as f:
+    lines = f.readlines()
+with open(os.path.join(DST, f'{TAG}_bench_f32_kernel_trace_tail.csv'), 'w') as f:
+    f.writelines(lines[:1] + lines[-40:])
+means = {}
+for sub in ('pmc_sq1', 'pmc_sq2'):
+    means.update(counter_means(os.path.join(SRC, sub, 'run_counter_collection.csv')))
+with open(os.path.join(DST, f'{TAG}_loss_kernel_pmc.csv'), 'w') as f:
+    f.write('counter,mean_per_dispatch,dispatches\n')
+    for name, (mean, n) in means.items():
+        f.write(f'{name},{mean:g},{n}\n')
+traffic = {}
+for sub, name in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+    path = os.path.join(SRC, sub, 'run_counter_collection.csv')
+    traffic[name] = counter_means(path)[name]
+    rows = [r for r in csv.reader(open(path))]
+    keep = [rows[0]] + [r for r in rows[1:] if KERNEL in r[8]]
+    with open(os.path.join(DST, f'{TAG}_pmc_{name.lower()}.csv'), 'w', newline='') as f:
+        csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(keep)
+fetch_kb, n_f = traffic['FETCH_SIZE']
+write_kb, n_w = traffic['WRITE_SIZE']
+old = json.load(open(os.path.join(DST, f'{TAG}_hbm_traffic.json')))
+old.update({'FETCH_SIZE_KB_per_launch': round(fetch_kb, 2), 'WRITE_SIZE_KB_per_launch': round(write_kb, 2),
+            'traffic_bytes_per_launch': int(round((fetch_kb + write_kb) * 1024)),
+            'method': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no trace domains), means over {n_f} / {n_w} '
+                      'dispatches of python3 bench.py --steps 20 --no-graph; unit KB as reported.'})
+json.dump(old, open(os.path.join(DST, f'{TAG}_hbm_traffic.json'), 'w'), indent=1)
+with open(os.path.join(SRC, 'stamps.txt')) as f:
+    text = [l for l in f.read().splitlines() if 'amdgpu.ids' not in l]
+with open(os.path.join(DST, f'{TAG}_loss_kernel_stamps.txt'), 'w') as f:
+    f.write('tools/diag/stamps.py, f32, B=4096 (256 one-wave workgroups, 16 items per wave); units: shader cycles (s_memtime); '
+            'the stamped build runs ~10 % slower than the shipped one\n' + '\n'.join(text).replace('np.int64(', '').replace('np.float64(', '').replace(')', '') + '\n')
+print(json.dumps(old, indent=1)); print(open(os.path.join(DST, f'{TAG}_loss_kernel_pmc.csv')).read())
