@@ -14,6 +14,7 @@ on a ROCm device and the HIP library is built.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -549,6 +550,76 @@ class MultibodyLearnableSystem(Module):
                     out[f'{body.name}_len_{axis}'] = 2 * float(value)
             out[f'{body.name}_mu'] = float(friction[index + 1])
         return out
+
+    def _pi_cm(self) -> np.ndarray:
+        from .inertia import theta_to_pi_cm
+        theta = self.multibody_terms.lagrangian_terms.inertial_parameters.detach().double().cpu().numpy()
+        return np.stack([theta_to_pi_cm(row) for row in theta])
+
+    def extract_meshes(self) -> Dict[str, Tuple[np.ndarray, np.ndarray]]:
+        """``{body name: (vertices (V, 3), faces (F, 3))}`` for every body whose geometry is a learned convex
+        shape (``multibody_terms.py:561-563`` with ``deep_support_function.py:93-123``)."""
+        from . import export
+        meshes = {}
+        for index, body in enumerate(self.spec.bodies):
+            geometry = self.multibody_terms.contact_terms.geometries[index + 1]
+            if isinstance(geometry, DeepSupportConvex):
+                def support(directions: np.ndarray) -> np.ndarray:
+                    # the HIP kernels evaluate the network (dpll_mesh_support_points): a state whose rotation takes
+                    # the direction to -e_z makes the kernel's first query (perturbation row 0 = 0) that direction
+                    param = geometry.network.output_weight
+                    d = torch.tensor(directions, dtype=torch.float64)
+                    w = 1.0 - d[:, 2]                                    # 1 + d . (-e_z)
+                    axis = torch.stack((-d[:, 1], d[:, 0], torch.zeros_like(w)), -1)  # d x (-e_z)
+                    flip = w < 1e-12                                     # d = +e_z: half turn about x
+                    quat = torch.cat((w[:, None], axis), -1)
+                    quat[flip] = torch.tensor([0.0, 1.0, 0.0, 0.0], dtype=torch.float64)
+                    quat = quat / quat.norm(dim=-1, keepdim=True)
+                    x = torch.zeros((d.shape[0], self.space.n_x), dtype=torch.float64)
+                    x[:, :4] = quat
+                    with torch.no_grad():
+                        points = self.support_points(x.to(device=param.device, dtype=param.dtype))
+                    return points[:, 0, :].double().cpu().numpy()
+                meshes[body.name] = export.extract_mesh(support)
+        return meshes
+
+    def scalars_and_meshes(self) -> Tuple[Dict[str, float], Dict[str, Tuple[np.ndarray, np.ndarray]]]:
+        """``MultibodyTerms.scalars_and_meshes`` (``multibody_terms.py:536-582``): :meth:`scalars` plus, for a
+        learned convex shape, its mesh and the ``{body}_diameter_*`` / ``{body}_center_*`` of the vertices."""
+        scalars = self.scalars()
+        meshes = self.extract_meshes()
+        for name, (vertices, _) in meshes.items():
+            low, high = vertices.min(axis=0), vertices.max(axis=0)
+            for axis, diameter, centre in zip('xyz', high - low, low + (high - low) / 2):
+                scalars[f'{name}_diameter_{axis}'] = float(diameter)
+                scalars[f'{name}_center_{axis}'] = float(centre)
+        return scalars, meshes
+
+    def generate_updated_urdfs(self) -> Dict[str, str]:
+        """Writes the current parameters as URDFs with the original base names into ``output_urdfs_dir`` and
+        returns ``{urdf name: path}`` (``multibody_learnable_system.py:82-102``, ``urdf_utils.py:317-384``);
+        a learned convex shape is written next to them as ``test.obj`` (``urdf_utils.py:244-252``)."""
+        from . import export
+        assert self.output_urdfs_dir is not None
+        pi_cm = self._pi_cm()
+        friction = self.multibody_terms.contact_terms.get_friction_coefficients().detach().double().cpu().numpy()
+        meshes = self.extract_meshes()
+        bodies = []
+        for index, body in enumerate(self.spec.bodies):
+            geometry = self.multibody_terms.contact_terms.geometries[index + 1]
+            if isinstance(geometry, Box):
+                half = geometry.get_half_lengths().detach().double().cpu().numpy().reshape(-1)
+                shape = ('box', {'size': ' '.join(repr(2.0 * float(h)) for h in half)})
+            else:
+                export.save_string(os.path.join(self.output_urdfs_dir, export.MESH_FILE), export.mesh_to_obj(*meshes[body.name]))
+                shape = ('mesh', {'filename': export.MESH_FILE})
+            bodies.append((body.name, pi_cm[index], shape, float(friction[index + 1])))
+        new_urdfs = {}
+        for name, source in self.urdfs.items():
+            target = os.path.join(self.output_urdfs_dir, os.path.basename(source))
+            export.save_string(target, export.render_urdf(source, bodies))
+            new_urdfs[name] = target
+        return new_urdfs
 
     # ---- terms ----------------------------------------------------------------------------------
     def _terms(self, q: Tensor, v: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:

@@ -92,3 +92,34 @@ def test_mesh_large_batch_matches_float64_path(golden):
     for (name, a), (_, b) in zip(s64.named_parameters(), s32.named_parameters()):
         ga, gb = a.grad.cpu().numpy(), b.grad.cpu().double().numpy()
         assert np.abs(ga - gb).max() <= 5e-3 * np.abs(ga).max(), name
+
+
+def test_learned_shape_export(golden, tmp_path):
+    """scalars_and_meshes / generate_updated_urdfs for a DeepSupportConvex body (multibody_terms.py:536-582,
+    urdf_utils.py:244-252): the mesh vertices are the network's support points over the reference's 296
+    surface directions (evaluated by the HIP kernels, checked against the oracle's network)."""
+    from dair_pll_amd import export
+    from dair_pll_amd.urdf import parse_urdf
+    g = golden('cube_mesh_literal')
+    system = build(g, torch.float64)
+    system.output_urdfs_dir = str(tmp_path)
+    scalars, meshes = system.scalars_and_meshes()
+    vertices, faces = meshes['body']
+    weights = {key: torch.tensor(g['param/' + NET + 'network.' + key]) for key in
+               ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight')}
+    directions = torch.tensor(export.surface_directions())
+    expect = O.icnn_support_point(weights, directions).numpy()
+    # every vertex is one of the oracle's support points, and every support point is a vertex
+    dist = np.abs(vertices[:, None, :] - expect[None, :, :]).max(axis=2)
+    assert dist.min(axis=1).max() < 1e-12 and dist.min(axis=0).max() < 1e-12
+    # support function of the hull = the network's value f(d) = d . grad f(d) (positive homogeneity)
+    value = O.icnn_value(weights, directions).numpy()
+    assert np.abs((vertices @ directions.numpy().T).max(axis=0) - value).max() < 1e-10
+    normals, backwards, _ = export.outward_normals(vertices, faces)
+    assert not backwards.any()
+    for axis, lo, hi in zip('xyz', vertices.min(axis=0), vertices.max(axis=0)):
+        assert scalars[f'body_diameter_{axis}'] == pytest.approx(hi - lo) and scalars[f'body_center_{axis}'] == pytest.approx((hi + lo) / 2)
+    new = system.generate_updated_urdfs()
+    spec = parse_urdf(new['cube'])
+    assert spec.bodies[0].geoms[0].kind == 'mesh' and spec.bodies[0].geoms[0].mesh_file == 'test.obj'
+    assert np.allclose(np.array(spec.bodies[0].geoms[0].vertices), vertices, atol=0, rtol=1e-15)

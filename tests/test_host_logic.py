@@ -136,3 +136,50 @@ def test_shard_bounds_cover_batch():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_generate_updated_urdfs_round_trip(tmp_path):
+    """multibody_learnable_system.py:82-102: same base name in the output directory; the written values
+    are the current parameters (mass / com / central inertia from pi_cm, full box lengths, |friction|)."""
+    system = MultibodyLearnableSystem({'elbow': os.path.join(ASSET_DIR, 'elbow.urdf')}, 0.0068,
+                                      output_urdfs_dir=str(tmp_path), dtype=torch.float64, device='cpu')
+    with torch.no_grad():
+        system.multibody_terms.contact_terms.geometries[2].length_params.mul_(-1.25)  # sign must not matter
+        system.multibody_terms.contact_terms.friction_params[1] = -0.22
+        pi_cm = np.array([0.5, 0.5 * 0.01, -0.5 * 0.02, 0.0, 2e-3, 3e-3, 4e-3, 1e-4, -2e-4, 3e-4])
+        system.multibody_terms.lagrangian_terms.inertial_parameters[1] = torch.tensor(pi_cm_to_theta(pi_cm))
+    new = system.generate_updated_urdfs()
+    assert new == {'elbow': os.path.join(str(tmp_path), 'elbow.urdf')}
+    text = open(new['elbow']).read()
+    assert text.startswith('<?xml version="1.0"?>') and 'drake:mu_static' in text
+    spec, old = parse_urdf(new['elbow']), parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf'))
+    assert abs(spec.bodies[0].geoms[0].mu - 0.22) < 1e-15 and spec.bodies[1].geoms[0].mu == old.bodies[1].geoms[0].mu
+    assert np.allclose(spec.bodies[1].geoms[0].half_lengths, 1.25 * np.array(old.bodies[1].geoms[0].half_lengths), rtol=1e-14)
+    assert abs(spec.bodies[1].mass - 0.5) < 1e-12 and np.allclose(spec.bodies[1].com, [0.01, -0.02, 0.0], atol=1e-12)
+    assert np.allclose(spec.bodies[1].inertia_cm, pi_cm[4:], atol=1e-12)
+    assert spec.bodies[1].joint_origin == old.bodies[1].joint_origin and spec.bodies[0].mass == pytest.approx(old.bodies[0].mass)
+    # a system built on the exported URDF starts from the exported parameters
+    again = MultibodyLearnableSystem(new, 0.0068, dtype=torch.float64, device='cpu')
+    assert torch.allclose(again.multibody_terms.lagrangian_terms.inertial_parameters,
+                          system.multibody_terms.lagrangian_terms.inertial_parameters, atol=1e-9)
+    scalars, meshes = system.scalars_and_meshes()
+    assert meshes == {}
+
+
+def test_extract_mesh_of_an_analytic_support_function():
+    """deep_support_function.py:93-123 on the support function of a box: its 8 corners, 12 outward
+    counter-clockwise triangles; the OBJ text carries one normal per face."""
+    from dair_pll_amd import export
+    half = np.array([0.1, 0.2, 0.3])
+    directions = export.surface_directions()
+    assert directions.shape == (296, 3) and np.allclose(np.linalg.norm(directions, axis=1), 1.0)
+    vertices, faces = export.extract_mesh(lambda d: np.sign(d) * half)
+    assert vertices.shape == (8, 3) and faces.shape == (12, 3)
+    normals, backwards, offsets = export.outward_normals(vertices, faces)
+    assert not backwards.any() and np.allclose(np.abs(normals).max(axis=1), 1.0)
+    v_a, v_b, v_c = (vertices[faces[:, i]] for i in range(3))
+    assert (np.einsum('fi,fi->f', np.cross(v_b - v_a, v_c - v_a), normals) > 0).all()  # ccw seen from outside
+    assert np.allclose(sorted(offsets), sorted([0.1, 0.1, 0.1, 0.1, 0.2, 0.2, 0.2, 0.2, 0.3, 0.3, 0.3, 0.3]))
+    lines = export.mesh_to_obj(vertices, faces).splitlines()
+    assert sum(l.startswith('v ') for l in lines) == 8 and sum(l.startswith('vn ') for l in lines) == 12
+    assert [l for l in lines if l.startswith('f ')][3].count('//4') == 3
