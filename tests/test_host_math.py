@@ -172,3 +172,17 @@ def test_step_adjoint_matches_finite_differences(golden, case):
     rel = np.abs(analytic - fd) / (np.abs(fd) + 1e-6 * np.abs(fd).max())
     assert np.median(rel) < 1e-7
     assert (rel < 1e-4).sum() >= rel.size - 3, rel
+
+
+def test_one_probe_line_search_is_safeguarded(golden):
+    """fast_ls = 1 (one probe per Newton iteration) must reach the same optimum as the exact search on
+    every schedule: without the escalation to the full search after two non-halving decrements the
+    no-continuation schedule cycles on a handful of the 4096 items (60 iterations, loss error 4e-3)."""
+    g = golden('cube_box_4096')
+    desc, theta, friction, lengths, _ = setup(g)
+    for n_stages, factor in ((1, 3.0), (3, 10.0), (6, 3.0)):
+        opts = hostsim.default_opts(np.float32)
+        opts.n_stages, opts.stage_factor, opts.stage_max_iter, opts.fast_ls = n_stages, factor, 1, 1
+        out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float32, opts=opts, want_grad=False)
+        assert out['iters'].max() < 40
+        assert np.abs(out['loss'] - g['loss']).max() < 5e-6
