@@ -772,8 +772,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
                        (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
                        (T*)(ws + pl.off_slabs));
   }
-  const int n_out = kW * kW + 7 * kW + 16;
-  hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3((n_out + 255) / 256), dim3(256), 0, stream, w,
+  hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3(kRedBlocks), dim3(256), 0, stream, w,
                      (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,
                      (const T*)(ws + pl.off_slabs), pl.n_slabs, (T*)grad, (T*)loss_total);
   return check_launch("icnn backward");

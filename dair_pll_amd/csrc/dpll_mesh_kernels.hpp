@@ -278,65 +278,78 @@ __global__ __launch_bounds__(256) void icnn_bwd2_kernel(const T* __restrict__ x,
 }
 
 // final fixed-order reduction + sign chain.  grad layout: [theta(10) | friction(2) | Wh | Wd0 | Wd1 | wout]
+// The sums are over 64 slabs of 256 KB and 256 partial rows: a block owns 64 consecutive outputs and splits the
+// summands over 16 thread groups (thread = 4 consecutive outputs x every 16th summand, all of its loads in flight
+// at once), then combines the 16 groups through LDS in a fixed order => bitwise reproducible at full bandwidth.
+constexpr int kRedOut = 64;     // outputs per block
+constexpr int kRedGroups = 16;  // summand groups per block
+constexpr int kRedWhBlocks = kW * kW / kRedOut;
+constexpr int kRedB1Blocks = 7 * kW / kRedOut;
+constexpr int kRedBlocks = kRedWhBlocks + kRedB1Blocks + 1;
+
+template <typename S>
+__device__ __forceinline__ void reduce_strided4(const S* __restrict__ base, long long stride, int n, int first, double (&acc)[4]) {
+  // summands first, first + 16, ... < n of 4 consecutive columns; unrolled by 4 so that 4 vector loads are in flight
+  struct alignas(4 * sizeof(S)) V4 { S v[4]; };
+  int s = first;
+  for (; s + 3 * kRedGroups < n; s += 4 * kRedGroups) {
+    const V4 a = *(const V4*)(base + (long long)s * stride);
+    const V4 b = *(const V4*)(base + (long long)(s + kRedGroups) * stride);
+    const V4 c = *(const V4*)(base + (long long)(s + 2 * kRedGroups) * stride);
+    const V4 d = *(const V4*)(base + (long long)(s + 3 * kRedGroups) * stride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += (double(a.v[i]) + double(b.v[i])) + (double(c.v[i]) + double(d.v[i]));
+  }
+  for (; s < n; s += kRedGroups) {
+    const V4 a = *(const V4*)(base + (long long)s * stride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += double(a.v[i]);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, const double* __restrict__ rows,
                                                           int n_rows, const double* __restrict__ b1, int b1_blocks,
                                                           const T* __restrict__ slabs, int n_slabs,
                                                           T* __restrict__ grad, T* __restrict__ loss_total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   constexpr int kHead = 12;
-  if (idx < kW * kW) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = 0;
-    for (; b + 4 <= n_slabs; b += 4) {  // independent loads in flight
-      s0 += double(slabs[(long long)b * kW * kW + idx]);
-      s1 += double(slabs[(long long)(b + 1) * kW * kW + idx]);
-      s2 += double(slabs[(long long)(b + 2) * kW * kW + idx]);
-      s3 += double(slabs[(long long)(b + 3) * kW * kW + idx]);
-    }
-    for (; b < n_slabs; ++b) s0 += double(slabs[(long long)b * kW * kW + idx]);
-    const double s = (s0 + s1) + (s2 + s3);
+  __shared__ double red[kRedGroups][kRedOut + 1];
+  const int cg = threadIdx.x & 15, sg = threadIdx.x >> 4;
+  const int b = blockIdx.x;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (b < kRedWhBlocks) {
+    reduce_strided4<T>(slabs + (long long)b * kRedOut + 4 * cg, (long long)kW * kW, n_slabs, sg, acc);
+  } else if (b < kRedWhBlocks + kRedB1Blocks) {
+    // output c: 0..767 Wd0 (b1 columns [4W, 7W)), 768..1535 Wd1 ([W, 4W)), 1536..1791 wout ([0, W)); 64 | 768, 256
+    const int c0 = (b - kRedWhBlocks) * kRedOut;
+    const int col0 = c0 < 3 * kW ? 4 * kW + c0 : (c0 < 6 * kW ? kW + (c0 - 3 * kW) : c0 - 6 * kW);
+    reduce_strided4<double>(b1 + col0 + 4 * cg, (long long)kB1Cols, b1_blocks, sg, acc);
+  } else if (cg < 4) {  // head: 16 columns of the loss kernel's rows = 4 column groups
+    reduce_strided4<double>(rows + 4 * cg, 16, n_rows, sg, acc);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[sg][4 * cg + i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x >= kRedOut) return;
+  double s = 0.0;
+#pragma unroll
+  for (int g = 0; g < kRedGroups; ++g) s += red[g][threadIdx.x];
+  if (b < kRedWhBlocks) {
+    const long long idx = (long long)b * kRedOut + threadIdx.x;
     const T raw = w.Wh[idx];
     grad[kHead + idx] = T(s * (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0)));
-  } else if (idx < kW * kW + 7 * kW) {
-    const int c = (int)(idx - kW * kW);  // 0..767 Wd0, 768..1535 Wd1, 1536..1791 wout
-    int col;
-    if (c < 3 * kW) col = 4 * kW + c;            // dWd0 lives at [4W, 7W) of the b1 row
-    else if (c < 6 * kW) col = kW + (c - 3 * kW); // dWd1 at [W, 4W)
-    else col = c - 6 * kW;                       // d|wout| at [0, W)
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = 0;
-    for (; b + 4 <= b1_blocks; b += 4) {
-      s0 += b1[(long long)b * kB1Cols + col];
-      s1 += b1[(long long)(b + 1) * kB1Cols + col];
-      s2 += b1[(long long)(b + 2) * kB1Cols + col];
-      s3 += b1[(long long)(b + 3) * kB1Cols + col];
-    }
-    for (; b < b1_blocks; ++b) s0 += b1[(long long)b * kB1Cols + col];
-    double s = (s0 + s1) + (s2 + s3);
+  } else if (b < kRedWhBlocks + kRedB1Blocks) {
+    const int c = (b - kRedWhBlocks) * kRedOut + threadIdx.x;
     if (c >= 6 * kW) {
       const T raw = w.wout[c - 6 * kW];
       s *= (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0));
     }
     grad[kHead + kW * kW + c] = T(s);
-  } else if (idx < kW * kW + 7 * kW + 16) {
-    const int c = (int)(idx - kW * kW - 7 * kW);  // 0: loss, 1..12: theta, friction
-    if (c <= kHead) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int r = 0;
-      for (; r + 4 <= n_rows; r += 4) {
-        s0 += rows[(long long)r * 16 + c];
-        s1 += rows[(long long)(r + 1) * 16 + c];
-        s2 += rows[(long long)(r + 2) * 16 + c];
-        s3 += rows[(long long)(r + 3) * 16 + c];
-      }
-      for (; r < n_rows; ++r) s0 += rows[(long long)r * 16 + c];
-      const double s = (s0 + s1) + (s2 + s3);
-      if (c == 0) {
-        if (loss_total) *loss_total = T(s);
-      } else {
-        grad[c - 1] = T(s);
-      }
+  } else if (threadIdx.x <= kHead) {  // 0: loss, 1..12: theta, friction
+    if (threadIdx.x == 0) {
+      if (loss_total) *loss_total = T(s);
+    } else {
+      grad[threadIdx.x - 1] = T(s);
     }
   }
 }
