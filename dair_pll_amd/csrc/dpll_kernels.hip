@@ -684,7 +684,8 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
 struct MeshPlan {
   long long N;
   int loss_blocks, gemm_blocks, b1_blocks, n_slabs;
-  size_t off_A, off_AT, off_a, off_P, off_RB, off_M1, off_U0, off_rows, off_b1, off_slabs, total;
+  size_t off_A, off_AT, off_a, off_P, off_RB, off_M1, off_U0, off_Vb, off_U1, off_rows, off_b1, off_slabs, total;
+  long long n_tiles;
 };
 
 template <typename T> MeshPlan mesh_plan(long long batch) {
@@ -707,6 +708,10 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   pl.off_RB = take(sizeof(T) * 3 * pl.N);
   pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
   pl.off_U0 = take(sizeof(T) * kW * pl.N);
+  pl.n_tiles = tiles;
+  // MFMA path: Vb (icnn_bwd1) and U1 (icnn_fwd2) as operand tiles for icnn_bwd2, whole 32-row tiles
+  pl.off_Vb = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
+  pl.off_U1 = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
   pl.off_rows = take(sizeof(double) * 16 * pl.loss_blocks);
   pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
   pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
@@ -721,7 +726,8 @@ template <typename T> IcnnWeights<T> mesh_weights(const dpll_mesh_params_t* mp) 
 
 // forward half: prep + the two forward GEMMs -> P (and M1, U0 for the backward half)
 template <typename T>
-int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, hipStream_t stream) {
+int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, hipStream_t stream,
+                 bool for_backward = false) {
   T* A = (T*)(ws + pl.off_A); T* AT = (T*)(ws + pl.off_AT); T* a = (T*)(ws + pl.off_a);
   hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a);
   if constexpr (std::is_same<T, float>::value) {
@@ -729,7 +735,7 @@ int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T*
                        (uint32_t*)(ws + pl.off_M1));
     hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)AT,
                        (const float*)a, (const uint32_t*)(ws + pl.off_M1), (float*)(ws + pl.off_U0),
-                       (float*)(ws + pl.off_P));
+                       (float*)(ws + pl.off_P), for_backward ? (float*)(ws + pl.off_U1) : (float*)nullptr);
   } else {
     hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
                        (uint32_t*)(ws + pl.off_M1));
@@ -749,8 +755,8 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   if (!grad && loss_total) return fail(-3, "dpll_contactnets_loss_mesh: loss_total requires grad%s");
   char* ws = (char*)workspace;
   const IcnnWeights<T> w = mesh_weights<T>(mp);
-  if (int rc = mesh_forward<T>(pl, w, ws, (const T*)xp, ld_xp, stream)) return rc;  // terms live at the NEXT state
   const int want_grad = grad != nullptr;
+  if (int rc = mesh_forward<T>(pl, w, ws, (const T*)xp, ld_xp, stream, want_grad != 0)) return rc;  // terms live at the NEXT state
   hipLaunchKernelGGL((loss_kernel<T, 0, true>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
@@ -760,10 +766,10 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   if constexpr (std::is_same<T, float>::value) {
     hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
                        (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
-                       (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
-    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(4, pl.n_slabs), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
-                       (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const float*)(ws + pl.off_RB),
-                       (float*)(ws + pl.off_slabs));
+                       (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1),
+                       (float*)(ws + pl.off_Vb));
+    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
+                       (const float*)(ws + pl.off_Vb), (const float*)(ws + pl.off_U1), (float*)(ws + pl.off_slabs));
   } else {
     hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
                        (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),

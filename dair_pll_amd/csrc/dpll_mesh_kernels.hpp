@@ -8,7 +8,7 @@
 //   icnn_fwd2      U1 = a . m1;  V = U1 A^T;  U0 = V . m0;  P = U1 Wd1^T + U0 Wd0^T   GEMM  N x 256 x 256
 //   loss_kernel_mesh   the ContactNets loss with witnesses P; emits r_bar (N x 3)
 //   icnn_bwd1      Vb = (RB Wd0) . m0;  U1b = Vb A + RB Wd1;  partial d|wout|, dWd1, dWd0   GEMM  N x 256 x 256
-//   icnn_bwd2      d|Wh| = Vb^T U1                                                          GEMM  256 x 256 x N
+//   icnn_bwd2      d|Wh| = Vb^T U1  (float: Vb (N x 256) is stored by icnn_bwd1)                GEMM  256 x 256 x N
 //   icnn_reduce    fixed-order sums of all partials, sign chain, cast to the parameter dtype
 //
 // The GEMM kernels exist in two forms: a generic register-tiled VALU form (any T; the float64 path and the
@@ -372,6 +372,25 @@ constexpr int kXs = kW + 1;  // padded LDS row stride
 
 __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// "Operand-tile" layout of an (N, 256) activation matrix for icnn_bwd2_mfma: 4 KB blocks (row tile t of 32 rows,
+// column tile c of 32 columns) at float offset (t * 8 + c) * 1024, inside a block the float4 with index
+// (q * 32 + col) * 2 + half holds rows 2 (4 q + e) + half, e = 0..3, of column col -- exactly what lane
+// (col, half) feeds to MFMA steps 4 q .. 4 q + 3, so a wave fetches four steps with one contiguous 1 KB read.
+// A thread of the tile kernels owns column c and rows r0 .. r0 + 15 (r0 = 0 or 16): four float4 stores.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void store_operand_tile(float* __restrict__ base, long long tile, int c, int r0, const float (&v)[16]) {
+  f32x4* blk = (f32x4*)(base + (tile * 8 + (c >> 5)) * 1024);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      f32x4 val;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = v[2 * (4 * qq + e) + h];
+      blk[((r0 / 8 + qq) * 32 + (c & 31)) * 2 + h] = val;
+    }
+}
+
 // queries of a 32-row tile into LDS (threads 0..31)
 __device__ __forceinline__ void load_queries32(const float* __restrict__ x, long long ld, const float* __restrict__ pert,
                                                long long n0, long long N, float (*Qs)[3]) {
@@ -443,9 +462,10 @@ __global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ 
 __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ x, long long ld, long long N,
                                                       IcnnWeights<float> w, const float* __restrict__ AT,
                                                       const float* __restrict__ a, const uint32_t* __restrict__ M1,
-                                                      float* __restrict__ U0, float* __restrict__ P) {
+                                                      float* __restrict__ U0, float* __restrict__ P,
+                                                      float* __restrict__ U1t) {
   __shared__ float Qs[kMfmaRows][3];
-  __shared__ float Xs[kMfmaRows * kXs];   // U1 tile
+  __shared__ float Xs[kMfmaRows * kXs];   // U1 tile (also written as operand tiles `U1t` when the backward will run)
   __shared__ float Ys[kMfmaRows * kXs];   // U0 tile
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
@@ -461,11 +481,14 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
     {  // U1 tile
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
       const float ac = a[c];
+      float u1v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const uint32_t word = (n0 + r0 + r < N) ? M1[(n0 + r0 + r) * kMaskWords + (c >> 5)] : 0u;
-        Xs[(r0 + r) * kXs + c] = ac * mask_factor(word, c & 31);
+        u1v[r] = ac * mask_factor(word, c & 31);
+        Xs[(r0 + r) * kXs + c] = u1v[r];
       }
+      if (U1t) store_operand_tile(U1t, tile, c, r0, u1v);
     }
     __syncthreads();
     const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
@@ -505,10 +528,10 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
                                                       IcnnWeights<float> w, const float* __restrict__ A,
                                                       const float* __restrict__ a, const uint32_t* __restrict__ M1,
                                                       const float* __restrict__ U0, const float* __restrict__ RB,
-                                                      double* __restrict__ partial) {
+                                                      double* __restrict__ partial, float* __restrict__ Vb) {
   __shared__ float Qs[kMfmaRows][3];
   __shared__ float Rs[kMfmaRows][3];
-  __shared__ float Xs[kMfmaRows * kXs];  // Vb tile
+  __shared__ float Xs[kMfmaRows * kXs];  // Vb tile (also written to `Vb` as operand tiles for icnn_bwd2_mfma)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
   float bfrag[kW / 2];
@@ -530,12 +553,15 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
     {  // Vb tile
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
       const float d0 = w.Wd0[c], d1 = w.Wd0[kW + c], d2 = w.Wd0[2 * kW + c];
+      float vbv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = r0 + r;
         const float pre0 = Qs[rr][0] * d0 + Qs[rr][1] * d1 + Qs[rr][2] * d2;
-        Xs[rr * kXs + c] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);
+        vbv[r] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);  // rows past N: RB = 0
+        Xs[rr * kXs + c] = vbv[r];
       }
+      store_operand_tile(Vb, tile, c, r0, vbv);
     }
     __syncthreads();
     // epilogue operands first (independent loads in flight during the MFMAs)
@@ -574,71 +600,65 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
   }
 }
 
-// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j]: grid (4 = k-half x j-half, n_slabs); wave v: k-tile (v >> 1) of the k-half,
-// two j-tiles of the j-half; operands of a 32-query chunk staged in LDS ([n][k] and [n][j], 32 consecutive k / j per read)
-__global__ __launch_bounds__(512) void icnn_bwd2_mfma(const float* __restrict__ x, long long ld, long long N,
-                                                      IcnnWeights<float> w, const float* __restrict__ a,
-                                                      const uint32_t* __restrict__ M1, const float* __restrict__ RB,
-                                                      float* __restrict__ slabs) {
-  __shared__ float Qs[kMfmaRows][3];
-  __shared__ float Rs[kMfmaRows][3];
-  __shared__ float Vc[kMfmaRows][128];
-  __shared__ float Uc[kMfmaRows][kW];
+// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j] as a plain split-K GEMM on the operand tiles that icnn_bwd1_mfma (Vb) and
+// icnn_fwd2_mfma (U1) left behind.  Grid (4 = k-half x j-half, n_slabs): a block owns a 128 x 128 piece over its slab
+// of row tiles; wave v the k-tile v >> 1 and the two j-tiles 2 (v & 1), 2 (v & 1) + 1 of the piece (two accumulator
+// sets).  Per row tile the block copies 4 + 4 operand tiles (32 KB) global -> registers -> LDS, double buffered:
+// the next tile's loads are in flight during this tile's 32 MFMAs per wave, one barrier per tile.  Per MFMA a wave
+// issues 3/8 LDS reads (ds_read_b128) and almost no VALU, which is what the f32 MFMA pipe needs to stay busy
+// (PMC on the previous forms: 14 VALU instructions per MFMA, MFMA busy 43 %).
+constexpr int kB2Pieces = 4;
+__global__ __launch_bounds__(512) void icnn_bwd2_mfma(long long n_tiles, const float* __restrict__ VbT,
+                                                      const float* __restrict__ U1T, float* __restrict__ slabs) {
+  __shared__ f32x4 Ls[2][8][256];  // [buffer][0..3: Vb k-tiles, 4..7: U1 j-tiles][4 KB operand tile]
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-  const int kbase = 128 * (blockIdx.x & 1);                    // this block's k range
-  const int kt = wv >> 1, jt0 = 4 * (blockIdx.x >> 1) + 2 * (wv & 1);  // wave's k-tile (0..3 in the range), first of its 2 j-tiles
-  const long long per = (((N + gridDim.y - 1) / gridDim.y) + kMfmaRows - 1) / kMfmaRows * kMfmaRows;
-  const long long n_begin = (long long)blockIdx.y * per, n_end = (n_begin + per < N) ? n_begin + per : N;
-  constexpr int kJT = 2;  // j-tiles per wave
-  f32x16 acc[kJT];
+  const int kq = blockIdx.x & 1, jq = blockIdx.x >> 1;
+  const int ktl = wv >> 1, jtl = 2 * (wv & 1);
+  const long long per = (n_tiles + gridDim.y - 1) / gridDim.y;
+  const long long t_begin = (long long)blockIdx.y * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int t = 0; t < kJT; ++t)
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  // copy assignment: float4 number threadIdx.x + 512 m of the chunk's 2048 (slot = number >> 8, index = number & 255)
+  f32x4 stage[4];
+  auto fetch = [&](long long t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  for (long long n0 = n_begin; n0 < n_end; n0 += kMfmaRows) {
-    __syncthreads();
-    load_queries32(x, ld, w.pert, n0, n_end, Qs);
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + kMfmaRows * 3) {
-      const int t = threadIdx.x - 64, r = t / 3, i = t % 3;
-      Rs[r][i] = (n0 + r < n_end) ? RB[(n0 + r) * 3 + i] : 0.f;
+    for (int m = 0; m < 4; ++m) {
+      const int slot = 2 * m + (threadIdx.x >> 8), idx = threadIdx.x & 255;
+      const float* src = slot < 4 ? VbT + (t * 8 + 4 * kq + slot) * 1024 : U1T + (t * 8 + 4 * jq + (slot - 4)) * 1024;
+      stage[m] = ((const f32x4*)src)[idx];
     }
-    __syncthreads();
-    {  // Vb chunk: 128 k x 32 n (thread -> k = t & 127, rows (t >> 7) * 8 ..); rows past n_end have RB = 0
-      const int c = threadIdx.x & 127, r0 = (threadIdx.x >> 7) * 8, k = kbase + c;
-      const float d0 = w.Wd0[k], d1 = w.Wd0[kW + k], d2 = w.Wd0[2 * kW + k];
+  };
+  auto commit = [&](int buf) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int rr = r0 + r;
-        const float pre0 = Qs[rr][0] * d0 + Qs[rr][1] * d1 + Qs[rr][2] * d2;
-        Vc[rr][c] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);
+    for (int m = 0; m < 4; ++m) Ls[buf][2 * m + (threadIdx.x >> 8)][threadIdx.x & 255] = stage[m];
+  };
+  if (t_begin < t_end) { fetch(t_begin); commit(0); }
+  __syncthreads();
+  for (long long t = t_begin; t < t_end; ++t) {
+    const int cur = (int)((t - t_begin) & 1);
+    const bool more = t + 1 < t_end;
+    if (more) fetch(t + 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = (q * 32 + l31) * 2 + half;
+      const f32x4 a4 = Ls[cur][ktl][idx], b0 = Ls[cur][4 + jtl][idx], b1 = Ls[cur][5 + jtl][idx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b0[e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b1[e], acc1, 0, 0, 0);
       }
     }
-    {  // U1 chunk: 256 j x 32 n
-      const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
-      const float ac = a[c];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t word = (n0 + r0 + r < n_end) ? M1[(n0 + r0 + r) * kMaskWords + (c >> 5)] : 0u;
-        Uc[r0 + r][c] = ac * mask_factor(word, c & 31);
-      }
-    }
+    if (more) commit(cur ^ 1);
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < kMfmaRows / 2; ++s) {
-      const float av = Vc[2 * s + half][32 * kt + l31];
-#pragma unroll
-      for (int t = 0; t < kJT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Uc[2 * s + half][32 * (jt0 + t) + l31], acc[t], 0, 0, 0);
-    }
   }
   float* slab = slabs + (long long)blockIdx.y * kW * kW;
 #pragma unroll
-  for (int t = 0; t < kJT; ++t)
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int k = kbase + 32 * kt + mfma_row(reg, half), j = 32 * (jt0 + t) + l31;
-      slab[k * kW + j] = acc[t][reg];
-    }
+  for (int reg = 0; reg < 16; ++reg) {
+    const int k = 128 * kq + 32 * ktl + mfma_row(reg, half);
+    slab[k * kW + 128 * jq + 32 * jtl + l31] = acc0[reg];
+    slab[k * kW + 128 * jq + 32 * (jtl + 1) + l31] = acc1[reg];
+  }
 }
 
 }  // namespace
