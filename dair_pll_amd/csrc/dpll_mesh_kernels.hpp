@@ -367,8 +367,16 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kMfmaRows = 32;
-constexpr int kXs = kW + 1;  // padded LDS row stride
+constexpr int kXs = kW + 1;  // padded LDS row stride of tiles that are not MFMA operands
+// LDS image of a 32 x 256 MFMA A-operand tile: element (row, k) at xop(row, k); the four values lane (row, half)
+// feeds to the steps 4 kq .. 4 kq + 3 (k = 2 (4 kq + e) + half) are one aligned float4, the 64 lanes of a wave read a
+// contiguous 1 KB with one ds_read_b128 per four MFMAs; the 8-float pad per kq keeps the column-wise fills
+// (64 consecutive k of one row per wave) on 64 distinct banks.
+constexpr int kXq = 32 * 8 + 8;
+constexpr int kXopFloats = 32 * kXq;
+__device__ __forceinline__ int xop(int row, int k) { return (k >> 3) * kXq + row * 8 + (k & 1) * 4 + ((k >> 1) & 3); }
 
 __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
@@ -377,7 +385,6 @@ __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 
 // (q * 32 + col) * 2 + half holds rows 2 (4 q + e) + half, e = 0..3, of column col -- exactly what lane
 // (col, half) feeds to MFMA steps 4 q .. 4 q + 3, so a wave fetches four steps with one contiguous 1 KB read.
 // A thread of the tile kernels owns column c and rows r0 .. r0 + 15 (r0 = 0 or 16): four float4 stores.
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 __device__ __forceinline__ void store_operand_tile(float* __restrict__ base, long long tile, int c, int r0, const float (&v)[16]) {
   f32x4* blk = (f32x4*)(base + (tile * 8 + (c >> 5)) * 1024);
 #pragma unroll
@@ -408,14 +415,18 @@ __device__ __forceinline__ void load_queries32(const float* __restrict__ x, long
   }
 }
 
-// C(32 x 32 of this wave) = Xs(32 x 256, LDS) * Wfrag(256 x 32, registers)
+// C(32 x 32 of this wave) = Xs(32 x 256, LDS in the xop layout) * Wfrag(256 x 32, registers)
 __device__ __forceinline__ f32x16 mfma_tile(const float* __restrict__ Xs, const float (&bfrag)[kW / 2], int l31, int half) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const float* xrow = Xs + l31 * kXs + half;
+  const f32x4* xq = (const f32x4*)(Xs + l31 * 8 + half * 4);
 #pragma unroll
-  for (int kk = 0; kk < kW / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[2 * kk], bfrag[kk], acc, 0, 0, 0);
+  for (int kq = 0; kq < kW / 8; ++kq) {
+    const f32x4 x4 = xq[kq * (kXq / 4)];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[e], bfrag[4 * kq + e], acc, 0, 0, 0);
+  }
   return acc;
 }
 
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ 
                                                       IcnnWeights<float> w, const float* __restrict__ A,
                                                       uint32_t* __restrict__ M1) {
   __shared__ float Qs[kMfmaRows][3];
-  __shared__ float Xs[kMfmaRows * kXs];
+  __shared__ __attribute__((aligned(16))) float Xs[kXopFloats];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
   float bfrag[kW / 2];
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ 
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
       const float d0 = w.Wd0[c], d1 = w.Wd0[kW + c], d2 = w.Wd0[2 * kW + c];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) Xs[(r0 + r) * kXs + c] = icnn_act(Qs[r0 + r][0] * d0 + Qs[r0 + r][1] * d1 + Qs[r0 + r][2] * d2);
+      for (int r = 0; r < 16; ++r) Xs[xop(r0 + r, c)] = icnn_act(Qs[r0 + r][0] * d0 + Qs[r0 + r][1] * d1 + Qs[r0 + r][2] * d2);
     }
     __syncthreads();
     const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
                                                       float* __restrict__ U0, float* __restrict__ P,
                                                       float* __restrict__ U1t) {
   __shared__ float Qs[kMfmaRows][3];
-  __shared__ float Xs[kMfmaRows * kXs];   // U1 tile (also written as operand tiles `U1t` when the backward will run)
+  __shared__ __attribute__((aligned(16))) float Xs[kXopFloats];   // U1 tile, xop layout (also written as operand tiles `U1t` when the backward will run)
   __shared__ float Ys[kMfmaRows * kXs];   // U0 tile
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         const uint32_t word = (n0 + r0 + r < N) ? M1[(n0 + r0 + r) * kMaskWords + (c >> 5)] : 0u;
         u1v[r] = ac * mask_factor(word, c & 31);
-        Xs[(r0 + r) * kXs + c] = u1v[r];
+        Xs[xop(r0 + r, c)] = u1v[r];
       }
       if (U1t) store_operand_tile(U1t, tile, c, r0, u1v);
     }
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int c = part + 16 * m;
-        const float u1 = Xs[row * kXs + c], u0 = Ys[row * kXs + c];
+        const float u1 = Xs[xop(row, c)], u0 = Ys[row * kXs + c];
 #pragma unroll
         for (int i = 0; i < 3; ++i) s[i] += w.Wd1[i * kW + c] * u1 + w.Wd0[i * kW + c] * u0;
       }
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
                                                       double* __restrict__ partial, float* __restrict__ Vb) {
   __shared__ float Qs[kMfmaRows][3];
   __shared__ float Rs[kMfmaRows][3];
-  __shared__ float Xs[kMfmaRows * kXs];  // Vb tile (also written to `Vb` as operand tiles for icnn_bwd2_mfma)
+  __shared__ __attribute__((aligned(16))) float Xs[kXopFloats];  // Vb tile, xop layout (also written to `Vb` as operand tiles for icnn_bwd2_mfma)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
   float bfrag[kW / 2];
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
         const int rr = r0 + r;
         const float pre0 = Qs[rr][0] * d0 + Qs[rr][1] * d1 + Qs[rr][2] * d2;
         vbv[r] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);  // rows past N: RB = 0
-        Xs[rr * kXs + c] = vbv[r];
+        Xs[xop(rr, c)] = vbv[r];
       }
       store_operand_tile(Vb, tile, c, r0, vbv);
     }
