@@ -28,6 +28,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix rate: 256 CUs x 256 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32: 64 cyc/SIMD)
+VALU_F64_PEAK_TFLOPS = 78.6   # f64 vector FMA rate
 BYTES_PER_STEP = {('cube', 'f32'): 2 * 13 * 4 + 4, ('cube', 'f64'): 2 * 13 * 8 + 8,  # read x, x+; write loss
                   ('elbow', 'f32'): 2 * 15 * 4 + 4, ('elbow', 'f64'): 2 * 15 * 8 + 8,
                   ('mesh', 'f32'): 2 * 13 * 4 + 4, ('mesh', 'f64'): 2 * 13 * 8 + 8}
@@ -177,7 +179,12 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
-    ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200) if args.workload != 'mesh' else (float('nan'), float('nan'))
+    mesh_ms = None
+    if args.workload == 'mesh':
+        mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
+        ms_loss, ms_fin = mesh_ms['loss_kernel'], mesh_ms['icnn_reduce']
+    else:
+        ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
     total = system.contactnets_loss_and_grad(x, xp)
     if reducer is not None:
         total = reducer.all_reduce_mean()[:1]
@@ -226,6 +233,20 @@ def main() -> None:
                          'algorithmic_bytes_per_launch': alg_bytes,
                          'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch'},
         }
+        if mesh_ms is not None:
+            # the mesh pipeline is bounded by its four N x 256 x 256 f32 GEMMs (MFMA); the dominant kernel is
+            # the slowest of them, its algorithmic work 2 * N * 256 * 256 flop with N = 4 * batch support queries
+            gemms = {k: mesh_ms[k] for k in ('icnn_fwd1', 'icnn_fwd2', 'icnn_bwd1', 'icnn_bwd2')}
+            dominant = max(gemms, key=gemms.get)
+            flops = 2.0 * (4 * args.batch) * 256 * 256
+            tflops = flops / (gemms[dominant] * 1e-3) / 1e12
+            peak = MFMA_F32_PEAK_TFLOPS if args.dtype == 'f32' else VALU_F64_PEAK_TFLOPS
+            line['roofline'] = {'bound': 'mfma', 'achieved': tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tflops / peak,
+                                'traffic': None, 'kernel': dominant, 'kernel_ms': gemms[dominant],
+                                'algorithmic_flops_per_launch': flops, 'all_kernels_ms': mesh_ms,
+                                'pipeline_gemm_tflops': 4 * flops / (sum(gemms.values()) * 1e-3) / 1e12,
+                                'note': 'v_mfma_f32_32x32x2_f32 (exact f32); peak = dense f32 matrix rate of MI355X_MICROARCH.md'
+                                        if args.dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload if args.workload != 'mesh' else 'cube_mesh')
         print(json.dumps(line), flush=True)

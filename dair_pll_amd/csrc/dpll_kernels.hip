@@ -719,6 +719,15 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   return pl;
 }
 
+// measuring aid of dpll_profile_contactnets_loss_mesh: when set, an event is recorded on the launch stream after each
+// kernel of the mesh pipeline (order: prep, fwd1, fwd2, loss, bwd1, bwd2, reduce)
+constexpr int kMeshKernels = 7;
+thread_local hipEvent_t* t_mesh_marks = nullptr;
+thread_local int t_mesh_mark = 0;
+inline void mesh_mark(hipStream_t stream) {
+  if (t_mesh_marks && t_mesh_mark < kMeshKernels) (void)hipEventRecord(t_mesh_marks[t_mesh_mark++], stream);
+}
+
 template <typename T> IcnnWeights<T> mesh_weights(const dpll_mesh_params_t* mp) {
   return IcnnWeights<T>{(const T*)mp->hidden_weight, (const T*)mp->input_weight0, (const T*)mp->input_weight1,
                         (const T*)mp->output_weight, (const T*)mp->perturbations};
@@ -730,18 +739,22 @@ int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T*
                  bool for_backward = false) {
   T* A = (T*)(ws + pl.off_A); T* AT = (T*)(ws + pl.off_AT); T* a = (T*)(ws + pl.off_a);
   hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a);
+  mesh_mark(stream);
   if constexpr (std::is_same<T, float>::value) {
     hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)A,
                        (uint32_t*)(ws + pl.off_M1));
+    mesh_mark(stream);
     hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)AT,
                        (const float*)a, (const uint32_t*)(ws + pl.off_M1), (float*)(ws + pl.off_U0),
                        (float*)(ws + pl.off_P), for_backward ? (float*)(ws + pl.off_U1) : (float*)nullptr);
   } else {
     hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
                        (uint32_t*)(ws + pl.off_M1));
+    mesh_mark(stream);
     hipLaunchKernelGGL((icnn_fwd2_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)AT,
                        (const T*)a, (const uint32_t*)(ws + pl.off_M1), (T*)(ws + pl.off_U0), (T*)(ws + pl.off_P));
   }
+  mesh_mark(stream);
   return check_launch("icnn forward");
 }
 
@@ -761,6 +774,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
                      (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
                      want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);
+  mesh_mark(stream);
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
   if constexpr (std::is_same<T, float>::value) {
@@ -768,19 +782,23 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
                        (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
                        (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1),
                        (float*)(ws + pl.off_Vb));
+    mesh_mark(stream);
     hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
                        (const float*)(ws + pl.off_Vb), (const float*)(ws + pl.off_U1), (float*)(ws + pl.off_slabs));
   } else {
     hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
                        (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
                        (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
+    mesh_mark(stream);
     hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
                        (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
                        (T*)(ws + pl.off_slabs));
   }
+  mesh_mark(stream);
   hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3(kRedBlocks), dim3(256), 0, stream, w,
                      (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,
                      (const T*)(ws + pl.off_slabs), pl.n_slabs, (T*)grad, (T*)loss_total);
+  mesh_mark(stream);
   return check_launch("icnn backward");
 }
 
@@ -845,7 +863,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 3; }
+int dpll_abi_version(void) { return 4; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -980,6 +998,44 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
                                    loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
   return launch_mesh_loss<double>(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
                                   loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,
+                                       const dpll_mesh_params_t* mesh, const void* x, int64_t ld_x, const void* x_plus,
+                                       int64_t ld_xp, int64_t batch, double scale, void* grad, void* workspace,
+                                       int64_t workspace_bytes, void* stream, int32_t reps, float* ms_kernels) {
+  if (!grad || !ms_kernels || reps < 1 || reps > 10000) return fail(-1, "dpll_profile_contactnets_loss_mesh: bad argument%s");
+  const int per = kMeshKernels + 1;
+  hipEvent_t* ev = new (std::nothrow) hipEvent_t[(size_t)per * reps];
+  if (!ev) return fail(-4, "dpll_profile_contactnets_loss_mesh: out of memory%s");
+  for (int i = 0; i < per * reps; ++i) (void)hipEventCreate(&ev[i]);
+  int rc = 0;
+  for (int r = 0; r < reps && rc == 0; ++r) {
+    (void)hipEventRecord(ev[per * r], (hipStream_t)stream);
+    t_mesh_marks = ev + per * r + 1;
+    t_mesh_mark = 0;
+    rc = dpll_contactnets_loss_mesh(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, nullptr, scale, nullptr, grad,
+                                    nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+    if (rc == 0 && t_mesh_mark != kMeshKernels) rc = fail(-5, "dpll_profile_contactnets_loss_mesh: pipeline recorded an unexpected number of kernels%s");
+  }
+  t_mesh_marks = nullptr;
+  if (rc == 0) {
+    (void)hipEventSynchronize(ev[per * reps - 1]);
+    for (int k = 0; k < kMeshKernels; ++k) {
+      double total = 0.0;
+      for (int r = 0; r < reps; ++r) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[per * r + k], ev[per * r + k + 1]);
+        total += ms;
+      }
+      ms_kernels[k] = (float)(total / reps);
+    }
+  } else {
+    (void)hipStreamSynchronize((hipStream_t)stream);
+  }
+  for (int i = 0; i < per * reps; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
 }
 
 int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,

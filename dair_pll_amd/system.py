@@ -425,6 +425,25 @@ class MultibodyLearnableSystem(Module):
             self._stream(), reps, ctypes.byref(ms_loss), ctypes.byref(ms_fin)))
         return ms_loss.value, ms_fin.value
 
+    MESH_KERNELS = ('icnn_prep', 'icnn_fwd1', 'icnn_fwd2', 'loss_kernel', 'icnn_bwd1', 'icnn_bwd2', 'icnn_reduce')
+
+    def profile_mesh_kernels(self, x: Tensor, x_plus: Tensor, reps: int = 50) -> Dict[str, float]:
+        """Average duration in ms of each kernel of the mesh-geometry loss pipeline, HIP events on the launch
+        stream (``dpll_profile_contactnets_loss_mesh``).  Synchronises."""
+        lib = _capi.library()
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        self._launch_loss(xf, xpf, None, 1.0 / xf.shape[0], True, want_loss=False)  # allocates grad buffers
+        flat = self._packed()
+        params, mesh = self._params_struct(flat), self._mesh_struct(flat)
+        workspace = self._mesh_workspace(xf.shape[0], xf.device)
+        out = (ctypes.c_float * len(self.MESH_KERNELS))()
+        _capi.check(lib.dpll_profile_contactnets_loss_mesh(
+            self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(xf), xf.stride(0), _ptr(xpf),
+            xpf.stride(0), xf.shape[0], 1.0 / xf.shape[0], _ptr(self._flat_grad), _ptr(workspace), workspace.numel(),
+            self._stream(), reps, out))
+        return dict(zip(self.MESH_KERNELS, (float(v) for v in out)))
+
     def contact_forces(self, x: Tensor, x_plus: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         """Loss, the detached contact impulses ``(*, 3k)`` (``[normals | (t_x, t_y) per contact]``)
         and solver iteration counts; diagnostic twin of :meth:`contactnets_loss`."""

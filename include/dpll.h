@@ -160,6 +160,14 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
                                void* loss_total, void* force, int32_t* iters, void* workspace, int64_t workspace_bytes,
                                void* stream);
 
+/* Measuring utility, mesh pipeline: `reps` calls of dpll_contactnets_loss_mesh (with grad) with HIP events on the
+ * launch stream after each of its kernels; ms_kernels[7] = average duration of
+ * {prep, fwd1, fwd2, loss, bwd1, bwd2, reduce}.  Synchronises. */
+int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,
+                                       const dpll_mesh_params_t* mesh, const void* x, int64_t ld_x, const void* x_plus,
+                                       int64_t ld_xp, int64_t batch, double scale, void* grad, void* workspace,
+                                       int64_t workspace_bytes, void* stream, int32_t reps, float* ms_kernels);
+
 /* dpll_step with the network shape (one step per call: the support points depend on the current state). */
 int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                    const void* x, int64_t ld_x, int64_t batch, void* x_next, int64_t ld_next, void* workspace,
