@@ -97,7 +97,7 @@ def library() -> ctypes.CDLL:
     lib.dpll_step.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_int64,
                               c_void_p, c_void_p]
     lib.dpll_step_backward.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64, c_int64,
-                                       c_void_p, c_void_p, c_int64, c_void_p]
+                                       c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
     lib.dpll_simulate.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_int64, c_void_p,
                                   c_void_p]
     lib.dpll_mesh_param_count.argtypes = [c_void_p]

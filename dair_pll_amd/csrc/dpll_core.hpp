@@ -158,6 +158,25 @@ template <typename T> DPLL_HD DualT<T> operator/(const DualT<T>& a, const DualT<
   const T q = a.v / b.v;
   return DualT<T>(q, (a.d - q * b.d) / b.v);
 }
+template <typename T> DPLL_HD DualT<T> operator-(const DualT<T>& a) { return DualT<T>(-a.v, -a.d); }
+template <typename T> DPLL_HD DualT<T>& operator+=(DualT<T>& a, const DualT<T>& b) { a.v += b.v; a.d += b.d; return a; }
+template <typename T> DPLL_HD DualT<T>& operator-=(DualT<T>& a, const DualT<T>& b) { a.v -= b.v; a.d -= b.d; return a; }
+template <typename T> DPLL_HD DualT<T>& operator*=(DualT<T>& a, const DualT<T>& b) { a = a * b; return a; }
+// comparisons look at the value only: branches of the primal computation are piecewise constant in the seed
+template <typename T> DPLL_HD bool operator<(const DualT<T>& a, const DualT<T>& b) { return a.v < b.v; }
+template <typename T> DPLL_HD bool operator>(const DualT<T>& a, const DualT<T>& b) { return a.v > b.v; }
+template <typename T> DPLL_HD bool operator<=(const DualT<T>& a, const DualT<T>& b) { return a.v <= b.v; }
+template <typename T> DPLL_HD bool operator>=(const DualT<T>& a, const DualT<T>& b) { return a.v >= b.v; }
+template <typename T> DPLL_HD DualT<T> tsqrt(DualT<T> x) {
+  const T r = tsqrt(x.v);
+  return DualT<T>(r, x.d == T(0) ? T(0) : x.d / (r + r));  // a constant keeps derivative 0 even at sqrt(0)
+}
+template <typename T> DPLL_HD void tsincos(DualT<T> x, DualT<T>& s, DualT<T>& c) {
+  T sv, cv;
+  tsincos(x.v, sv, cv);
+  s = DualT<T>(sv, cv * x.d);
+  c = DualT<T>(cv, -sv * x.d);
+}
 DPLL_HD float s_exp(const float& x) { return expf(x); }
 DPLL_HD double s_exp(const double& x) { return exp(x); }
 template <typename T> DPLL_HD DualT<T> s_exp(const DualT<T>& x) { const T e = s_exp(x.v); return DualT<T>(e, e * x.d); }
@@ -1196,9 +1215,15 @@ template <typename T> DPLL_HD void quat_exp_mul_adjoint(const T* q, const T (&r)
 }
 
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, const T* x, int first_contact,
+                                const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
+                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ]);
+
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
                                 int first_contact, const T* xbar_next, LossGrad<T, NJ>& grad,
-                                const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr) {
+                                const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr,
+                                T (*xbar)[13 + 2 * NJ] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kDynamicsEps), ieps = fast_rcp(eps);
   const T* q = x;
@@ -1280,6 +1305,7 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
   T L[NV][NV], invd[NV], lam[NV];
   cholesky<T, NV>(H, L, invd);
   chol_solve<T, NV>(L, invd, sv, lam);
+  if (xbar) step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar);
   // ---- per-contact pieces: kappa_c, friction and witness gradients; s' = s - sum_c J_c^T kappa_c ---
   T jtk[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) jtk[i] = T(0);
@@ -1334,6 +1360,77 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
     cross(t.Vu[b], Bw[b], c2);
     DPLL_UNROLL for (int i = 0; i < 3; ++i) cu[i] = c1[i] + c2[i];
     inertia_bilinear_grad<T>(T(1), cw, cu, t.Vw[b], t.Vu[b], grad.g_iota[b]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adjoint of one simulation step with respect to the STATE (back-propagation through time over several steps).
+// With the optimum y*, the seed s = d/d v+ and H lambda = s of step_item_backward held fixed, d(total)/dx is the
+// partial derivative of the scalar
+//     Phi(x) = xbar+_q . q+(q, v+ fixed) + s . v-(x) - lambda . G(x, y*),     G = M(q) y* - sum_c J_c(q)^T D_mu P_K(z_c(x, y*)),
+// (implicit-function theorem on G = 0: dy*/dx = -H^-1 dG/dx).  Phi is pushed through the same templates as the
+// forward pass with forward-mode duals, one state component per pass: n_x passes of (terms + contact geometry) in
+// the accumulation type.  The witness corner of a box is piecewise constant in q; a learned (mesh) witness would
+// need the network's input Jacobian and is not handled.
+// ---------------------------------------------------------------------------------------------
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, const T* x, int first_contact,
+                                const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
+                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ]) {
+  constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = NQ + NV;
+  using S = DualT<TA>;
+  Derived<S, NJ> dps;
+  DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+    DPLL_UNROLL for (int i = 0; i < kIota; ++i) dps.iota[b][i] = S(TA(dp.iota[b][i]));
+    dps.mu[b] = S(TA(dp.mu[b]));
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dps.habs[b][i] = S(TA(dp.habs[b][i]));
+  }
+  const S dt = S(TA(md.dt)), idt = S(TA(1) / TA(md.dt)), mieps = S(TA(-1) / TA(kDynamicsEps));
+  for (int k = 0; k < NX; ++k) {  // deliberately not unrolled: one copy of the dual forward pass
+    S xs[NX];
+    DPLL_UNROLL for (int i = 0; i < NX; ++i) xs[i] = S(TA(x[i]), i == k ? TA(1) : TA(0));
+    Terms<S, NJ> t;
+    Kin<S, NJ> kin;
+    compute_terms<S, S, NJ>(md, dps, xs, xs + NQ, t, kin);
+    S vm[NV], ys[NV], ls[NV];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) { vm[i] = xs[NQ + i] + dt * t.a[i]; ys[i] = S(y[i]); ls[i] = S(TA(lam[i])); }
+    // q+ with the rotation vector v+ dt held fixed (linear in q), s . v-, -lambda . M y*
+    const S r[3] = {S(TA(vn[0]) * TA(md.dt)), S(TA(vn[1]) * TA(md.dt)), S(TA(vn[2]) * TA(md.dt))};
+    S qn[4];
+    quat_exp_mul<S>(xs, r, qn);
+    S phi = S(TA(0));
+    DPLL_UNROLL for (int i = 0; i < 4; ++i) phi += S(TA(xbar_next[i])) * qn[i];
+    DPLL_UNROLL for (int i = 0; i < 3 + NJ; ++i) phi += S(TA(xbar_next[4 + i])) * xs[4 + i];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) phi += S(TA(sv[i])) * vm[i];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) {
+      S my = S(TA(0));
+      DPLL_UNROLL for (int j = 0; j < NV; ++j) my += t.M[i][j] * ys[j];
+      phi -= ls[i] * my;
+    }
+    // + sum_c (J_c lambda) . D_mu P_K(z_c)
+    S phic = S(TA(0));
+    DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+      ContactGeom<S, NJ> cg;
+      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg);
+      S jy[3], jv[3], jl[3];
+      cjac_apply<S, S, NJ>(cg.J, ys, jy);
+      cjac_apply<S, S, NJ>(cg.J, vm, jv);
+      cjac_apply<S, S, NJ>(cg.J, ls, jl);
+      const S z[3] = {(cg.mu * jy[0] + cg.mu * jv[0]) * mieps, (cg.mu * jy[1] + cg.mu * jv[1]) * mieps,
+                      (jy[2] + jv[2] + cg.phi * idt) * mieps};
+      // projection of a dual: value through lorentz_project, derivative through its generalised Jacobian
+      const TA zv[3] = {z[0].v, z[1].v, z[2].v};
+      Proj<TA> pr;
+      lorentz_project(zv, pr);
+      TA dP[6];
+      proj_jacobian(pr, dP);
+      const S f[3] = {S(pr.g[0], dP[0] * z[0].d + dP[3] * z[1].d + dP[4] * z[2].d),
+                      S(pr.g[1], dP[3] * z[0].d + dP[1] * z[1].d + dP[5] * z[2].d),
+                      S(pr.g[2], dP[4] * z[0].d + dP[5] * z[1].d + dP[2] * z[2].d)};
+      phic += cg.mu * (f[0] * jl[0] + f[1] * jl[1]) + f[2] * jl[2];
+    }
+    const TA total = phi.d + Lanes::group_sum(phic.d);
+    DPLL_UNROLL for (int i = 0; i < NX; ++i) xbar[i] = (i == k) ? T(total) : xbar[i];
   }
 }
 

@@ -391,13 +391,15 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
 }
 
 // ---- adjoint of one simulation step with respect to the parameters (state = data) -----------------------
-template <typename T, int NJ>
+// STATE: also the adjoint of the input state (n_x forward-mode passes of the terms, core step_state_adjoint)
+template <typename T, int NJ, bool STATE = false>
 __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                               const T* __restrict__ friction,
                                                               const T* __restrict__ lengths, const T* __restrict__ x,
                                                               long long ld_x, const T* __restrict__ gx,
                                                               long long ld_g, long long batch,
-                                                              double* __restrict__ partials) {
+                                                              double* __restrict__ partials, T* __restrict__ xbar_out,
+                                                              long long ld_xb) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<D::G>;
   const int lane = threadIdx.x;
@@ -418,7 +420,18 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; gr[i] = valid ? gx[it * ld_g + i] : T(0); }
     LossGrad<T, NJ> g;
     zero_grad(g);
-    step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
+    if constexpr (STATE) {
+      T xb[D::NX];
+#pragma unroll
+      for (int i = 0; i < D::NX; ++i) xb[i] = T(0);
+      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, nullptr, nullptr, &xb);
+      if (valid && cidx == 0) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) xbar_out[it * ld_xb + i] = xb[i];
+      }
+    } else {
+      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
+    }
     // every lane of the group holds the item's d/d iota; d/d mu and d/d length are per contact
 #pragma unroll
     for (int b = 0; b < D::NB; ++b) {
@@ -653,14 +666,19 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
 template <typename T, int NJ>
 int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x,
                          const void* gx, long long ld_g, long long batch, void* grad, void* workspace,
-                         long long workspace_bytes, hipStream_t stream) {
+                         long long workspace_bytes, hipStream_t stream, void* grad_x, long long ld_gx) {
   using D = Dims<T, NJ>;
   const int blocks = loss_blocks<T, NJ>(batch);
   if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
     return fail(-3, "dpll_step_backward: workspace too small%s");
-  hipLaunchKernelGGL((step_backward_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
-                     ld_g, batch, (double*)workspace);
+  if (grad_x)
+    hipLaunchKernelGGL((step_backward_kernel<T, NJ, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
+                       ld_g, batch, (double*)workspace, (T*)grad_x, ld_gx);
+  else
+    hipLaunchKernelGGL((step_backward_kernel<T, NJ, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
+                       ld_g, batch, (double*)workspace, (T*)nullptr, 0LL);
   if (int rc = check_launch("step_backward_kernel")) return rc;
   hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
                      (T*)grad, (T*)nullptr);
@@ -863,7 +881,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 4; }
+int dpll_abi_version(void) { return 5; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -954,14 +972,14 @@ int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params,
 }
 
 int dpll_step_backward(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
-                       const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad, void* workspace,
-                       int64_t workspace_bytes, void* stream) {
+                       const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad, void* grad_x, int64_t ld_gx,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_step_backward")) return rc;
   if (batch == 0 || !x || !grad_x_next || !grad) return fail(-1, "dpll_step_backward: bad argument%s");
   const int nx = dpll_n_x(model);
-  if (ld_x < nx || ld_g < nx) return fail(-1, "dpll_step_backward: row stride smaller than n_x%s");
+  if (ld_x < nx || ld_g < nx || (grad_x && ld_gx < nx)) return fail(-1, "dpll_step_backward: row stride smaller than n_x%s");
   DPLL_DISPATCH(launch_step_backward, model, dtype, params, x, ld_x, grad_x_next, ld_g, batch, grad, workspace,
-                workspace_bytes, (hipStream_t)stream);
+                workspace_bytes, (hipStream_t)stream, grad_x, ld_gx);
 }
 
 int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x0, int64_t ld_x,

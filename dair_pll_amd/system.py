@@ -152,8 +152,9 @@ class _LossFunction(torch.autograd.Function):
 
 
 class _StepFunction(torch.autograd.Function):
-    """One ``VelocityIntegrator.step``; backward = ``dpll_step_backward`` (gradient with respect to the
-    parameters by implicit differentiation of the cone solve; the input state is treated as data)."""
+    """One ``VelocityIntegrator.step``; backward = ``dpll_step_backward``: gradient with respect to the
+    parameters and -- when the input state carries a graph (multi-step rollouts) -- to the state, both by
+    implicit differentiation of the cone solve."""
 
     @staticmethod
     def forward(ctx, system, x, *params):  # pylint: disable=arguments-differ
@@ -164,8 +165,8 @@ class _StepFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_x_next):  # pylint: disable=arguments-differ
         (x,) = ctx.saved_tensors
-        flat_grad = ctx.system._step_backward(x, grad_x_next.contiguous())
-        return (None, None) + tuple(ctx.system._split_flat(flat_grad))
+        flat_grad, grad_x = ctx.system._step_backward(x, grad_x_next.contiguous(), want_state=ctx.needs_input_grad[1])
+        return (None, grad_x) + tuple(ctx.system._split_flat(flat_grad))
 
 
 class MultibodyLearnableSystem(Module):
@@ -310,12 +311,13 @@ class MultibodyLearnableSystem(Module):
             setattr(opts, key, value)
         _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
 
-    def _check_input(self, tensor: Tensor, width: int, what: str) -> Tensor:
+    def _check_input(self, tensor: Tensor, width: int, what: str, keep_graph: bool = False) -> Tensor:
         if tensor.shape[-1] != width:
             raise AssertionError(f'{what}: last dimension {tensor.shape[-1]} != {width}')
         if not tensor.is_cuda:
             raise _capi.DpllError(f'{what} must live on a ROCm device: the HIP kernels are the only implementation')
-        tensor = tensor.detach()
+        if not keep_graph:
+            tensor = tensor.detach()
         if tensor.dtype != self.dtype:
             tensor = tensor.to(self.dtype)
         tensor = tensor.reshape(-1, width)
@@ -472,7 +474,7 @@ class MultibodyLearnableSystem(Module):
                                   x.shape[0], _ptr(x_next), x_next.stride(0), None, self._stream()))
         return x_next
 
-    def _step_backward(self, x: Tensor, grad_x_next: Tensor) -> Tensor:
+    def _step_backward(self, x: Tensor, grad_x_next: Tensor, want_state: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
         if self._mesh() is not None:
             raise NotImplementedError('the backward of step() is implemented for box geometry')
         lib = _capi.library()
@@ -482,25 +484,29 @@ class MultibodyLearnableSystem(Module):
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         params = self._params_struct(flat)
         gx = grad_x_next.to(self.dtype)
+        grad_x = torch.empty_like(x, memory_format=torch.contiguous_format) if want_state else None
         _capi.check(lib.dpll_step_backward(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
-                                           _ptr(gx), gx.stride(0), x.shape[0], _ptr(grad), _ptr(workspace), ws_bytes,
-                                           self._stream()))
-        return grad
+                                           _ptr(gx), gx.stride(0), x.shape[0], _ptr(grad), _ptr(grad_x),
+                                           grad_x.stride(0) if want_state else 0, _ptr(workspace), ws_bytes, self._stream()))
+        return grad, grad_x
+
+    def _wants_graph(self, x: Tensor) -> bool:
+        return torch.is_grad_enabled() and self._mesh() is None and \
+            (x.requires_grad or any(p.requires_grad for p in self._param_list()))
 
     def _differentiable_step(self, x: Tensor) -> Tensor:
         self._packed()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()) and self._mesh() is None:
+        if self._wants_graph(x):
             return _StepFunction.apply(self, x, *self._param_list())
-        return self._step(x)
+        return self._step(x.detach())
 
     def forward_dynamics(self, q: Tensor, v: Tensor, u: Tensor, dynamics_pool=None) -> Tensor:
         """``(*, n_q), (*, n_v), (*, ?) -> (*, n_v)`` next velocity by Anitescu's convex contact
         model (``multibody_learnable_system.py:199-304``).  Differentiable with respect to the module's
-        parameters (implicit differentiation of the cone solve, ``dpll_step_backward``); ``q, v`` are
-        treated as data, which is what one-step prediction losses need."""
+        parameters and to ``q, v`` (implicit differentiation of the cone solve, ``dpll_step_backward``)."""
         del u, dynamics_pool
         batch_shape = q.shape[:-1]
-        x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
+        x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state', keep_graph=True)
         return self._differentiable_step(x)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))
 
     def sim_step(self, x: Tensor, carry: Tensor) -> Tuple[Tensor, Tensor]:
@@ -511,18 +517,23 @@ class MultibodyLearnableSystem(Module):
     def step(self, x: Tensor) -> Tensor:
         """One fused ``VelocityIntegrator.step``: ``(*, n_x) -> (*, n_x)``."""
         batch_shape = x.shape[:-1]
-        return self._differentiable_step(self._check_input(x, self.space.n_x, 'x')).reshape(batch_shape + (self.space.n_x,))
+        return self._differentiable_step(self._check_input(x, self.space.n_x, 'x', keep_graph=True)).reshape(
+            batch_shape + (self.space.n_x,))
 
     def _fused_simulate(self, x_0: Tensor, steps: int) -> Tensor:
         lib = _capi.library()
         batch_shape = x_0.shape[:-1]
-        x = self._check_input(x_0, self.space.n_x, 'x_0')
+        x = self._check_input(x_0, self.space.n_x, 'x_0', keep_graph=True)
         flat = self._packed()
-        if steps == 1 and self._mesh() is None and torch.is_grad_enabled() and \
-                any(p.requires_grad for p in self._param_list()):
-            # one-step prediction (the reference's default horizon): keep the parameter gradient
-            traj1 = torch.stack((x, self._differentiable_step(x)), dim=1)
-            return traj1.reshape(batch_shape + (2, self.space.n_x))
+        if steps >= 1 and self._wants_graph(x):
+            # prediction losses (experiment.py:292-320): one autograd node per step, parameter gradient and state
+            # adjoint from dpll_step_backward (back-propagation through time); the fused rollout kernel below is
+            # the inference path
+            states = [x]
+            for _ in range(steps):
+                states.append(self._differentiable_step(states[-1]))
+            return torch.stack(states, dim=1).reshape(batch_shape + (steps + 1, self.space.n_x))
+        x = x.detach()
         traj = torch.empty((x.shape[0], steps + 1, self.space.n_x), dtype=self.dtype, device=x.device)
         if self._mesh() is not None:  # support points depend on the state: one kernel sequence per step
             traj[:, 0] = x

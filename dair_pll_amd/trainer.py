@@ -32,6 +32,32 @@ def slice_pairs(trajectories: Iterable[Tensor]) -> Tuple[Tensor, Tensor]:
     return torch.cat(xs), torch.cat(xps)
 
 
+def slice_windows(trajectories: Iterable[Tensor], t_prediction: int) -> Tuple[Tensor, Tensor]:
+    """The same slicing with a prediction horizon (``dataset_management.py:43-59`` with ``t_skip=0,
+    t_history=1``): ``x_past (S, 1, n_x)`` and ``x_future (S, t_prediction, n_x)`` for every start index
+    ``i`` in ``[0, T - t_prediction)``."""
+    past, future = [], []
+    for trajectory in trajectories:
+        assert trajectory.dim() == 2 and trajectory.shape[0] > t_prediction >= 1
+        for i in range(trajectory.shape[0] - t_prediction):
+            past.append(trajectory[i:i + 1])
+            future.append(trajectory[i + 1:i + 1 + t_prediction])
+    return torch.stack(past), torch.stack(future)
+
+
+def prediction_loss(system, x_past: Tensor, x_future: Tensor) -> Tensor:
+    """``SupervisedLearningExperiment.prediction_loss`` (``experiment.py:292-320``): roll the model out from
+    the last state of ``x_past (B, T_0, n_x)`` for ``x_future.shape[-2]`` steps and average the squared
+    velocity error over batch, horizon and velocity components.  Differentiable with respect to the system's
+    parameters through every step (``dpll_step_backward``: parameter gradient + state adjoint)."""
+    steps = x_future.shape[-2]
+    carry = torch.zeros(x_past.shape[:-2] + (1,), device=x_past.device)
+    predicted, _ = system.simulate(x_past, carry, steps)
+    v_predicted = system.space.v(predicted[..., 1:, :])
+    v_future = system.space.v(x_future)
+    return ((v_future - v_predicted)**2).sum() / v_predicted.numel()
+
+
 @dataclass
 class TrainLog:
     epoch_losses: List[float]
@@ -42,7 +68,9 @@ class ContactNetsTrainer:
     (``lr=1e-3``, ``weight_decay`` as in ``examples/contactnets_simple.py:78-86``)."""
 
     def __init__(self, system, lr: float = 1e-3, weight_decay: float = 0.0, batch_size: int = 4096,
-                 seed: int = 0) -> None:
+                 seed: int = 0, loss: str = 'contactnets') -> None:
+        assert loss in ('contactnets', 'prediction')  # MultibodyLosses of drake_experiment.py:47-52
+        self.loss = loss
         self.system = system
         self.batch_size = batch_size
         self.optimizer = torch.optim.Adam(system.parameters(), lr=lr, weight_decay=weight_decay)
@@ -55,7 +83,11 @@ class ContactNetsTrainer:
     def train_epoch(self, x: Tensor, x_plus: Tensor) -> float:
         """One pass over the (device-resident) pairs in shuffled mini-batches; returns the mean of the
         batch losses (``experiment.py:348-363``).  With a process group every rank must hold the SAME
-        pairs: each batch is sharded by contiguous rows and gradients are all-reduced."""
+        pairs: each batch is sharded by contiguous rows and gradients are all-reduced.
+        ``loss='prediction'``: ``x`` is ``x_past (S, T_0, n_x)``, ``x_plus`` is ``x_future (S, T, n_x)``
+        (:func:`slice_windows`) and the batch loss is :func:`prediction_loss` through autograd."""
+        if self.loss == 'prediction':
+            return self._train_epoch_prediction(x, x_plus)
         n = x.shape[0]
         order = torch.randperm(n, generator=self.generator).to(x.device)
         losses = []
@@ -70,6 +102,20 @@ class ContactNetsTrainer:
                 self.reducer.all_reduce_mean()
             self.optimizer.step()
             losses.append(total.clone())
+        return torch.stack(losses).mean().item()
+
+    def _train_epoch_prediction(self, x_past: Tensor, x_future: Tensor) -> float:
+        if self.reducer is not None:
+            raise NotImplementedError('prediction-loss training is single process (its gradients live in .grad)')
+        order = torch.randperm(x_past.shape[0], generator=self.generator).to(x_past.device)
+        losses = []
+        for start in range(0, x_past.shape[0], self.batch_size):
+            idx = order[start:start + self.batch_size]
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = prediction_loss(self.system, x_past[idx], x_future[idx])
+            loss.backward()
+            self.optimizer.step()
+            losses.append(loss.detach())
         return torch.stack(losses).mean().item()
 
     def fit(self, x: Tensor, x_plus: Tensor, epochs: int) -> TrainLog:

@@ -123,14 +123,16 @@ int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dp
 int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
               int64_t batch, void* x_next, int64_t ld_next, int32_t* iters, void* stream);
 
-/* Backward of dpll_step with respect to the learnable parameters, the state treated as data: given
- * grad_x_next (batch, n_x) = d(total)/d x_next, writes grad (dpll_param_count,) = d(total)/d params.  This is what
- * back-propagating a one-step prediction loss through forward_dynamics needs (experiment.py:292-320 with the default
- * t_prediction = 1); the cone solve is differentiated implicitly at its optimum (dair_pll delegates that to sappy).
- * Recomputes the forward pass; workspace as for dpll_contactnets_loss.  Box geometry only. */
+/* Backward of dpll_step: given grad_x_next (batch, n_x) = d(total)/d x_next, writes grad (dpll_param_count,) =
+ * d(total)/d params and, when grad_x is not NULL, grad_x (batch, n_x) = d(total)/d x (row stride ld_gx; the four
+ * quaternion components are independent variables, as they are for torch autograd in the reference).  This is what
+ * back-propagating a prediction loss through forward_dynamics / Integrator.simulate needs (experiment.py:292-320):
+ * the parameter gradient of every step plus the state adjoint that carries the loss from step t + 1 to step t.  The
+ * cone solve is differentiated implicitly at its optimum (dair_pll delegates that to sappy).  Recomputes the forward
+ * pass; workspace as for dpll_contactnets_loss.  Box geometry only. */
 int dpll_step_backward(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,
-                       const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad, void* workspace,
-                       int64_t workspace_bytes, void* stream);
+                       const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad, void* grad_x, int64_t ld_gx,
+                       void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Integrator.simulate: x0 (batch, n_x) -> traj (batch, steps + 1, n_x) contiguous, traj[:, 0] = x0. */
 int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x0, int64_t ld_x,

@@ -113,14 +113,15 @@ def mesh(desc: ModelDesc, theta, friction, weights, pert, x, x_plus, dtype=np.fl
     return {'loss': out_loss, 'grad': grad, 'x_next': x_next}
 
 
-def step_backward(desc: ModelDesc, theta, friction, lengths, x, xbar_next, opts=None):
-    """d(sum xbar_next . x_next)/d[theta | friction | lengths] (float64)."""
+def step_backward(desc: ModelDesc, theta, friction, lengths, x, xbar_next, opts=None, want_state=False):
+    """d(sum xbar_next . x_next)/d[theta | friction | lengths] (float64); with want_state also d/dx (B, n_x)."""
     arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     theta, friction, lengths, x, xbar_next = map(arr, (theta, friction, lengths, x, xbar_next))
     n_b = desc.n_joints + 1
     grad = np.zeros(14 * n_b + 1, dtype=np.float64)
     opts = opts or default_opts(np.float64)
+    xbar = np.zeros_like(x) if want_state else None
     status = lib().hostsim_step_backward_f64(ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction),
-                                             _ptr(lengths), _ptr(x), _ptr(xbar_next), c_int64(x.shape[0]), _ptr(grad))
+                                             _ptr(lengths), _ptr(x), _ptr(xbar_next), c_int64(x.shape[0]), _ptr(grad), _ptr(xbar))
     assert status == 0
-    return grad
+    return (grad, xbar) if want_state else grad

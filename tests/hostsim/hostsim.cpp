@@ -168,7 +168,7 @@ void mesh_loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta,
 
 template <typename T, typename TA, int NJ>
 void step_backward_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
-                         const T* x, const T* xbar_next, int64_t B, double* grad) {
+                         const T* x, const T* xbar_next, int64_t B, double* grad, T* xbar) {
   constexpr int NB = NJ + 1, K = kQuery * NB, NX = 13 + 2 * NJ;
   Derived<T, NJ> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
@@ -176,7 +176,10 @@ void step_backward_batch(const ModelDesc& md, const SolverOpts& opt, const T* th
   for (int64_t i = 0; i < B; ++i) {
     LossGrad<T, NJ> g;
     zero_grad(g);
-    step_item_backward<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, xbar_next + i * NX, g);
+    T xb[NX] = {};
+    step_item_backward<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, xbar_next + i * NX, g, nullptr, nullptr,
+                                              xbar ? &xb : nullptr);
+    if (xbar) for (int k = 0; k < NX; ++k) xbar[i * NX + k] = xb[k];
     for (int b = 0; b < NB; ++b) {
       for (int k = 0; k < kIota; ++k) g_iota[b][k] += double(g.g_iota[b][k]);
       g_mu[b] += double(g.g_mu[b]);
@@ -258,9 +261,10 @@ int hostsim_mesh_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
   return 0;
 }
 int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
-                              const double* lengths, const double* x, const double* xbar_next, int64_t B, double* grad) {
-  if (md->n_joints == 0) step_backward_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad);
-  else if (md->n_joints == 1) step_backward_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad);
+                              const double* lengths, const double* x, const double* xbar_next, int64_t B, double* grad,
+                              double* xbar) {
+  if (md->n_joints == 0) step_backward_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
+  else if (md->n_joints == 1) step_backward_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else return -1;
   return 0;
 }

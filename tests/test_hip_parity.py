@@ -233,3 +233,52 @@ def test_step_backward_matches_finite_differences(golden):
         (traj[:, 1] * w0).sum().backward()
         g_sim = torch.cat([p.grad.reshape(-1) for p in system._param_list()])
         assert torch.allclose(g_fd, g_sim, rtol=1e-12, atol=1e-14)
+
+
+def test_rollout_gradient_matches_finite_differences(golden):
+    """Back-propagation through time: d(sum w . x_T)/d x_0 and /d params of a 3-step rollout through
+    dpll_step_backward's state adjoint (implicit differentiation of every step's cone solve) against central
+    differences of the fused rollout kernel, float64.  Items whose rollout crosses a kink within the difference
+    step are the only ones allowed to disagree."""
+    steps = 3
+    for case in ('cube_box_literal', 'elbow_box_literal'):
+        g = golden(case)
+        system = build_system(g, torch.float64)
+        x0 = dev(g['x'][::4], torch.float64).clone().requires_grad_(True)
+        carry = torch.zeros((x0.shape[0], 1), device='cuda:0')
+        w = torch.randn(x0.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(x0.device)
+        system.zero_grad()
+        traj, _ = system.simulate(x0.unsqueeze(-2), carry, steps)
+        assert traj.shape == (x0.shape[0], steps + 1, x0.shape[1]) and traj.requires_grad
+        (traj[:, -1] * w).sum().backward()
+        with torch.no_grad():
+            fused, _ = system.simulate(x0.detach().unsqueeze(-2), carry, steps)
+            assert torch.allclose(fused, traj.detach(), rtol=0, atol=1e-12)  # same forward as the fused kernel
+
+            def total(x):
+                return (system.simulate(x.unsqueeze(-2), carry, steps)[0][:, -1] * w).sum(-1)
+            fd = torch.zeros_like(x0)
+            h = 1e-6
+            for k in range(x0.shape[1]):
+                e = torch.zeros_like(x0)
+                e[:, k] = h
+                fd[:, k] = (total(x0.detach() + e) - total(x0.detach() - e)) / (2 * h)
+        rel = ((x0.grad - fd).abs().max(-1).values / (fd.abs().max(-1).values + 1e-9)).cpu().numpy()
+        assert np.median(rel) < 1e-6, (case, rel)
+        assert (rel < 1e-4).sum() >= len(rel) - 2, (case, rel)
+        # parameter gradient of the same rollout
+        analytic = torch.cat([p.grad.reshape(-1) for p in system._param_list()]).cpu().numpy()
+        flat = system._packed()
+        fdp = np.zeros_like(analytic)
+        with torch.no_grad():
+            for k in range(flat.numel()):
+                old = flat[k].item()
+                flat[k] = old + 1e-6
+                up = total(x0.detach()).sum().item()
+                flat[k] = old - 1e-6
+                down = total(x0.detach()).sum().item()
+                flat[k] = old
+                fdp[k] = (up - down) / 2e-6
+        relp = np.abs(analytic - fdp) / (np.abs(fdp) + 1e-6 * np.abs(fdp).max())
+        assert np.median(relp) < 1e-5, (case, relp)
+        assert (relp < 1e-3).sum() >= len(relp) - 3, (case, relp)

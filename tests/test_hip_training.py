@@ -47,3 +47,42 @@ def test_training_reduces_loss_and_matches_autograd_path():
     o2.step()
     for (name, p1), (_, p2) in zip(s1.named_parameters(), s2.named_parameters()):
         assert torch.allclose(p1, p2, rtol=1e-5, atol=1e-7), name
+
+
+def test_prediction_loss_training_through_rollouts():
+    """MultibodyLosses.PREDICTION_LOSS (drake_experiment.py:47-52, experiment.py:292-320): multi-step rollouts
+    of the model itself give the targets, a model started from a wrong friction coefficient is trained through
+    the rollouts (parameter gradient + state adjoint of every step) and moves back towards the truth."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.trainer import ContactNetsTrainer, prediction_loss, slice_windows
+    g = np.load(os.path.join(GOLDEN_DIR, 'cube_box_4096.npz'))
+    dt = float(g['dt'])
+    urdf = {'cube': os.path.join(ASSET_DIR, 'cube.urdf')}
+    truth = MultibodyLearnableSystem(urdf, dt, dtype=torch.float64, device='cuda:0')
+    x0 = torch.tensor(g['x'][:256], dtype=torch.float64, device='cuda:0')
+    with torch.no_grad():
+        trajectories, _ = truth.simulate(x0.unsqueeze(-2), torch.zeros((256, 1), device='cuda:0'), 8)
+    past, future = slice_windows(list(trajectories), 3)
+    assert past.shape == (256 * 6, 1, 13) and future.shape == (256 * 6, 3, 13)
+    assert torch.equal(past[1, 0], trajectories[0, 1]) and torch.equal(future[1], trajectories[0, 2:5])
+    with torch.no_grad():
+        assert prediction_loss(truth, past, future).item() < 1e-20  # the generating model predicts its own data
+    model = MultibodyLearnableSystem(urdf, dt, dtype=torch.float64, device='cuda:0')
+    with torch.no_grad():
+        model.multibody_terms.contact_terms.friction_params[1] = 0.45
+    # prediction losses through stiff contact are badly conditioned in the inertial and shape parameters (the
+    # reason ContactNets exists); the friction coefficient alone is a well-posed one-dimensional check
+    model.multibody_terms.lagrangian_terms.inertial_parameters.requires_grad_(False)
+    model.multibody_terms.contact_terms.geometries[1].length_params.requires_grad_(False)
+    first = prediction_loss(model, past, future)
+    first.backward()
+    grad_mu = model.multibody_terms.contact_terms.friction_params.grad[1].item()
+    assert grad_mu > 0  # too much friction: the loss falls when it is reduced
+    model.zero_grad()
+    trainer = ContactNetsTrainer(model, lr=1e-2, batch_size=512, loss='prediction')
+    log = trainer.fit(past, future, epochs=10)
+    mu = model.multibody_terms.contact_terms.friction_params[1].abs().item()
+    with torch.no_grad():
+        last = prediction_loss(model, past, future).item()
+    assert last < 0.7 * first.item(), (first.item(), last, log.epoch_losses, mu)
+    assert abs(mu - 0.15) < abs(0.45 - 0.15), mu

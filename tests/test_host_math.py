@@ -186,3 +186,25 @@ def test_one_probe_line_search_is_safeguarded(golden):
         out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float32, opts=opts, want_grad=False)
         assert out['iters'].max() < 40
         assert np.abs(out['loss'] - g['loss']).max() < 5e-6
+
+
+@pytest.mark.parametrize('case', ['cube_box_4096', 'elbow_box_literal'])
+def test_step_state_adjoint_matches_finite_differences(golden, case):
+    """d(sum w . x_next)/d x from the implicit-function adjoint (core step_state_adjoint: n_x forward-mode
+    passes of terms + contact geometry at fixed y*, lambda) against central differences of the step, float64."""
+    g = golden(case)
+    desc, theta, friction, lengths, _ = setup(g)
+    x = np.array(g['x'][:24], dtype=np.float64)
+    w = np.random.default_rng(0).standard_normal(x.shape)
+    _, xbar = hostsim.step_backward(desc, theta, friction, lengths, x, w, want_state=True)
+    fd = np.zeros_like(x)
+    h = 1e-6
+    for k in range(x.shape[1]):
+        e = np.zeros_like(x)
+        e[:, k] = h
+        up, _ = hostsim.step(desc, theta, friction, lengths, x + e, dtype=np.float64)
+        down, _ = hostsim.step(desc, theta, friction, lengths, x - e, dtype=np.float64)
+        fd[:, k] = ((up - down) * w).sum(1) / (2 * h)
+    rel = np.abs(fd - xbar).max(1) / (np.abs(fd).max(1) + 1e-9)
+    assert np.median(rel) < 1e-8
+    assert rel.max() < 1e-5, rel
