@@ -1,11 +1,11 @@
 """Turns the raw rocprofv3 output of tools/diag/refresh_profiles.sh (gpurun_out/r01p) into the files kept under profiles/."""
-import csv, json, os, shutil, sys
+import csv, json, os, re, shutil, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r01p')
 DST = os.path.join(REPO, 'profiles')
 TAG = sys.argv[2] if len(sys.argv) > 2 else 'r01'
-KERNEL = 'loss_kernel<float, 0>'
+KERNEL = 'loss_kernel<float, 0, false>'
 
 
 def counter_means(path):
@@ -50,5 +50,5 @@ with open(os.path.join(SRC, 'stamps.txt')) as f:
     text = [l for l in f.read().splitlines() if 'amdgpu.ids' not in l]
 with open(os.path.join(DST, f'{TAG}_loss_kernel_stamps.txt'), 'w') as f:
     f.write('tools/diag/stamps.py, f32, B=4096 (256 one-wave workgroups, 16 items per wave); units: shader cycles (s_memtime); '
-            'the stamped build runs ~10 % slower than the shipped one\n' + '\n'.join(text).replace('np.int64(', '').replace('np.float64(', '').replace(')', '') + '\n')
+            'the stamped build runs ~10 % slower than the shipped one\n' + re.sub(r'np\.(?:int64|float64)\(([^)]*)\)', r'\1', '\n'.join(text)) + '\n')
 print(json.dumps(old, indent=1)); print(open(os.path.join(DST, f'{TAG}_loss_kernel_pmc.csv')).read())
