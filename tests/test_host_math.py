@@ -118,6 +118,7 @@ desc, theta, friction, lengths, grad_ref = setup(g)
 for dtype in (np.float64, np.float32):
     out = hostsim.loss(desc, theta, friction, lengths, g['x'][:32], g['x_plus'][:32], dtype=dtype)
     hostsim.step(desc, theta, friction, lengths, g['x'][:32], dtype=dtype)
+hostsim.step_backward(desc, theta, friction, lengths, g['x'][:8], np.ones_like(g['x'][:8]), want_state=True)
 print('sanitized ok')
 '''
     asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so']).decode().strip()
