@@ -199,6 +199,15 @@ def main() -> None:
     except (OSError, KeyError, ValueError):
         pass
 
+    valu_frac = None
+    try:  # VALU issue-slot occupancy from the committed SQ counter pass (same configuration only)
+        if traffic is not None:
+            with open(os.path.join(REPO, 'profiles', 'r01_loss_kernel_pmc.csv')) as handle:
+                counters = {row.split(',')[0]: float(row.split(',')[1]) for row in handle.read().splitlines()[1:]}
+            valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * 2.4e9 * 1024)
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         alg_bytes = BYTES_PER_STEP[(args.workload, args.dtype)] * args.batch
@@ -231,7 +240,10 @@ def main() -> None:
                          'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' if traffic else None,
                          'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
                          'algorithmic_bytes_per_launch': alg_bytes,
-                         'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch'},
+                         'valu_issue_frac': valu_frac,
+                         'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch; valu_issue_frac = '
+                                 'SQ_INSTS_VALU per launch (profiles/r01_loss_kernel_pmc.csv) x 4 cycles / (kernel time x 2.4 GHz x '
+                                 '1024 SIMDs): the launch is 256 one-wave workgroups, one wave on every fourth SIMD'},
         }
         if mesh_ms is not None:
             # the mesh pipeline is bounded by its four N x 256 x 256 f32 GEMMs (MFMA); the dominant kernel is
