@@ -68,12 +68,19 @@ class ContactNetsTrainer:
     (``lr=1e-3``, ``weight_decay`` as in ``examples/contactnets_simple.py:78-86``)."""
 
     def __init__(self, system, lr: float = 1e-3, weight_decay: float = 0.0, batch_size: int = 4096,
-                 seed: int = 0, loss: str = 'contactnets') -> None:
+                 seed: int = 0, loss: str = 'contactnets', use_graph: bool = False) -> None:
+        """``use_graph``: one training step (packing the parameters, fused loss + gradients, gradient exchange, Adam)
+        is captured once as a hipGraph and replayed per full batch -- the step is a dozen launch-bound small
+        kernels, most of them the optimizer's."""
         assert loss in ('contactnets', 'prediction')  # MultibodyLosses of drake_experiment.py:47-52
         self.loss = loss
         self.system = system
         self.batch_size = batch_size
-        self.optimizer = torch.optim.Adam(system.parameters(), lr=lr, weight_decay=weight_decay)
+        self.use_graph = use_graph and loss == 'contactnets'
+        self.optimizer = torch.optim.Adam(system.parameters(), lr=lr, weight_decay=weight_decay,
+                                          capturable=self.use_graph)
+        self._graph = None
+        self._static = None
         self.generator = torch.Generator().manual_seed(seed)
         self.reducer: Optional[GradientAllReduce] = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
@@ -97,12 +104,65 @@ class ContactNetsTrainer:
                 lo, hi = shard_bounds(idx.numel(), torch.distributed.get_rank(), self.reducer.world)
                 self.system.global_batch = idx.numel()
                 idx = idx[lo:hi]
+            if self.use_graph and idx.numel() == self._graph_rows():
+                losses.append(self._graph_step(x, x_plus, idx))
+                continue
             total = self.system.contactnets_loss_and_grad(x[idx], x_plus[idx])
             if self.reducer is not None:
                 self.reducer.all_reduce_mean()
             self.optimizer.step()
             losses.append(total.clone())
         return torch.stack(losses).mean().item()
+
+    # ---- hipGraph replay of the training step ----------------------------------------------------------
+    def _graph_rows(self) -> int:
+        """Rows of a full batch on this rank (the captured step has static shapes; a ragged tail runs eagerly)."""
+        if self.reducer is None:
+            return self.batch_size
+        lo, hi = shard_bounds(self.batch_size, torch.distributed.get_rank(), self.reducer.world)
+        return hi - lo
+
+    def _step_body(self, x: Tensor, x_plus: Tensor) -> Tensor:
+        total = self.system.contactnets_loss_and_grad(x, x_plus)
+        if self.reducer is not None:
+            self.reducer.all_reduce_mean()
+        self.optimizer.step()
+        return total
+
+    def _graph_step(self, x: Tensor, x_plus: Tensor, idx: Tensor) -> Tensor:
+        if self._graph is None:
+            if self.reducer is not None and self.reducer.transport != 'peer' and \
+                    torch.distributed.get_backend() != 'nccl':
+                raise NotImplementedError('graph capture needs a capturable gradient exchange (peer kernel or RCCL)')
+            rows = self._graph_rows()
+            xs = torch.empty((rows, x.shape[1]), dtype=x.dtype, device=x.device)
+            xps = torch.empty_like(xs)
+            xs.copy_(x[idx])
+            xps.copy_(x_plus[idx])
+            # the state an eager warm-up changes (parameters, Adam moments and step count) is restored afterwards,
+            # so that captured training is step for step the eager training
+            params = [p.detach().clone() for p in self.system.parameters()]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._step_body(xs, xps)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                total = self._step_body(xs, xps)
+            with torch.no_grad():
+                for p, saved in zip(self.system.parameters(), params):
+                    p.copy_(saved)
+                for k, st in self.optimizer.state.items():
+                    for n, v in st.items():
+                        if torch.is_tensor(v):
+                            v.zero_()  # first real step starts from zero moments / step 0
+            self._graph, self._static = graph, (xs, xps, total)
+        xs, xps, total = self._static
+        torch.index_select(x, 0, idx, out=xs)
+        torch.index_select(x_plus, 0, idx, out=xps)
+        self._graph.replay()
+        return total.clone()
 
     def _train_epoch_prediction(self, x_past: Tensor, x_future: Tensor) -> float:
         if self.reducer is not None:
