@@ -46,13 +46,30 @@ class PeerAllReduce:
         size = lib.dpll_ar_handle_bytes()
         handle = (ctypes.c_char * size)()
         self._ar = ctypes.c_void_p()
-        _capi.check(lib.dpll_ar_create(self.rank, self.world, ctypes.cast(handle, ctypes.c_void_p),
-                                       ctypes.byref(self._ar)))
+        # every rank goes through the same collectives whether or not its own set-up worked, and all of them raise
+        # together: a rank that bailed out alone would leave the others waiting in the next collective
+        error = ''
+        try:
+            _capi.check(lib.dpll_ar_create(self.rank, self.world, ctypes.cast(handle, ctypes.c_void_p),
+                                           ctypes.byref(self._ar)))
+        except _capi.DpllError as exc:
+            error = str(exc) or 'dpll_ar_create failed'
+            self._ar = None
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, bytes(handle), group=group)
-        blob = b''.join(gathered)
-        _capi.check(lib.dpll_ar_connect(self._ar, ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p)))
-        dist.barrier(group=group)
+        dist.all_gather_object(gathered, (error, bytes(handle)), group=group)
+        errors = [e for e, _ in gathered if e]
+        if not errors:
+            blob = b''.join(h for _, h in gathered)
+            try:
+                _capi.check(lib.dpll_ar_connect(self._ar, ctypes.cast(ctypes.c_char_p(blob), ctypes.c_void_p)))
+            except _capi.DpllError as exc:
+                error = str(exc) or 'dpll_ar_connect failed'
+            connected = [None] * self.world
+            dist.all_gather_object(connected, error, group=group)
+            errors = [e for e in connected if e]
+        if errors:
+            self.close()
+            raise _capi.DpllError('peer-memory all-reduce set-up failed on some rank: ' + errors[0])
 
     def all_reduce(self, tensor: torch.Tensor) -> None:
         assert tensor.is_cuda and tensor.is_contiguous() and tensor.numel() * tensor.element_size() <= PEER_MAX_BYTES
