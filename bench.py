@@ -89,6 +89,8 @@ def main() -> None:
     parser.add_argument('--allreduce', choices=['auto', 'peer', 'collective'], default='auto',
                         help='gradient exchange: peer = one-shot kernel over xGMI peer memory, collective = the '
                              'backend all_reduce (RCCL); auto = peer if its start-up self-test passes')
+    parser.add_argument('--no-fuse', action='store_true',
+                        help='peer transport: run the exchange as its own kernel after the loss launch instead of inside its finalize kernel')
     parser.add_argument('--single-device', action='store_true',
                         help='testing aid: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)')
     args = parser.parse_args()
@@ -124,7 +126,7 @@ def main() -> None:
                                       device=str(device))
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
-    reducer = GradientAllReduce(system, transport=args.allreduce) if distributed else None
+    reducer = GradientAllReduce(system, transport=args.allreduce, fuse=not args.no_fuse) if distributed else None
 
     def step():
         system.contactnets_loss_and_grad(x, xp)
@@ -231,7 +233,8 @@ def main() -> None:
                                     f'fwd+bwd contactnets_loss incl. 67,328 network weights'), 'per_gpu_batch': args.batch,
                        'global_batch': args.batch * world, 'launch': f'hipGraph replay, {per_graph} steps per graph' if use_graph else 'eager',
                        'collective': ('none' if not distributed else
-                                      'one-shot peer-memory all-reduce kernel (xGMI stores + in-order sum) of [loss, gradients] per step'
+                                      ('one-shot peer-memory all-reduce (xGMI stores + in-order sum) of [loss, gradients] per step, '
+                                       + ('inside the finalize kernel of the loss launch' if reducer.fused else 'one kernel after the loss launch'))
                                       if reducer.transport == 'peer' else
                                       f'one {args.backend} all-reduce of [loss, gradients] per step'),
                        'mean_loss': total_loss},

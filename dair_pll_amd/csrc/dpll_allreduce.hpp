@@ -38,19 +38,12 @@ __device__ __forceinline__ unsigned long long load_granule(unsigned long long* p
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// data: n elements of T (float or double), summed in place over the ranks.  One workgroup of 256 threads.
-template <typename T>
-__global__ __launch_bounds__(256) void allreduce_kernel(T* __restrict__ data, int n, Peers peers, int rank, int world,
-                                                        uint32_t* __restrict__ seq_ptr, uint32_t* __restrict__ err) {
-  constexpr int kWordsPer = sizeof(T) / 4;
-  __shared__ uint32_t words[kMaxWords];
-  __shared__ uint32_t gathered[kMaxWorld][kMaxWords];
-  const int n_words = n * kWordsPer;
-  const uint32_t seq = *seq_ptr + 1u;
+// The exchange itself, for one workgroup: `words` (LDS, n_words 32-bit words of this rank) go to every rank's
+// receive buffer, then `gathered[from][i]` (LDS) is filled with every rank's words of call `seq`.  Ends with a
+// barrier.  Shared by the stand-alone kernel and by the finalize kernel that ends a loss launch (fused form).
+__device__ __forceinline__ void exchange_words(const uint32_t* words, uint32_t (*gathered)[kMaxWords], int n_words,
+                                               const Peers& peers, int rank, int world, uint32_t seq, uint32_t* err) {
   const int slot = (int)(seq & 1u);
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(data);
-  for (int i = threadIdx.x; i < n_words; i += blockDim.x) words[i] = src[i];
-  __syncthreads();
   // push: one 8-byte store per (peer, word)
   for (int idx = threadIdx.x; idx < world * n_words; idx += blockDim.x) {
     const int peer = idx / n_words, i = idx % n_words;
@@ -73,16 +66,34 @@ __global__ __launch_bounds__(256) void allreduce_kernel(T* __restrict__ data, in
   }
   if (timed_out) atomicExch(err, 1u);
   __syncthreads();
-  // reduce in rank order: every rank computes bitwise the same sum
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    double s = 0.0;
-    for (int from = 0; from < world; ++from) {
-      T v;
-      __builtin_memcpy(&v, &gathered[from][e * kWordsPer], sizeof(T));
-      s += double(v);
-    }
-    data[e] = T(s);
+}
+
+// element e of the exchanged vectors summed in rank order: every rank computes bitwise the same value
+template <typename T> __device__ __forceinline__ T sum_over_ranks(uint32_t (*gathered)[kMaxWords], int world, int e) {
+  constexpr int kWordsPer = sizeof(T) / 4;
+  double s = 0.0;
+  for (int from = 0; from < world; ++from) {
+    T v;
+    __builtin_memcpy(&v, &gathered[from][e * kWordsPer], sizeof(T));
+    s += double(v);
   }
+  return T(s);
+}
+
+// data: n elements of T (float or double), summed in place over the ranks.  One workgroup of 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void allreduce_kernel(T* __restrict__ data, int n, Peers peers, int rank, int world,
+                                                        uint32_t* __restrict__ seq_ptr, uint32_t* __restrict__ err) {
+  constexpr int kWordsPer = sizeof(T) / 4;
+  __shared__ uint32_t words[kMaxWords];
+  __shared__ uint32_t gathered[kMaxWorld][kMaxWords];
+  const int n_words = n * kWordsPer;
+  const uint32_t seq = *seq_ptr + 1u;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(data);
+  for (int i = threadIdx.x; i < n_words; i += blockDim.x) words[i] = src[i];
+  __syncthreads();
+  exchange_words(words, gathered, n_words, peers, rank, world, seq, err);
+  for (int e = threadIdx.x; e < n; e += blockDim.x) data[e] = sum_over_ranks<T>(gathered, world, e);
   if (threadIdx.x == 0) *seq_ptr = seq;
 }
 

@@ -310,9 +310,14 @@ __device__ __forceinline__ double finalize_column(const double* __restrict__ par
   return s;
 }
 
-template <typename T, int NJ>
+// FUSED: the row [loss | gradients] is summed over the ranks of a data-parallel job before it is written, with the
+// one-shot peer-memory exchange of dpll_allreduce.hpp (same protocol and call counter as dpll_ar_allreduce): the
+// gradient exchange costs no launch of its own.
+template <typename T, int NJ, bool FUSED = false>
 __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double* __restrict__ partials, int n_rows,
-                                                                    T* __restrict__ grad, T* __restrict__ loss_total) {
+                                                                    T* __restrict__ grad, T* __restrict__ loss_total,
+                                                                    dpll_arx::Peers peers, int rank, int world,
+                                                                    uint32_t* __restrict__ seq_ptr, uint32_t* __restrict__ err) {
   using D = Dims<T, NJ>;
   static_assert(D::PI <= 32, "partial row must fit 32 columns");
   __shared__ double red[32][33];
@@ -322,14 +327,29 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
                                  : finalize_column<kFinalizeLoads>(partials, n_rows, D::PI, col, rowg);
   red[rowg][col] = s;
   __syncthreads();
+  T value = T(0);
   if (threadIdx.x < D::PI) {
     double t = 0.0;
 #pragma unroll
     for (int r = 0; r < 32; ++r) t += red[r][col];
+    value = T(t);
+  }
+  if constexpr (FUSED) {
+    constexpr int kWordsPer = sizeof(T) / 4;
+    __shared__ uint32_t words[D::PI * kWordsPer];
+    __shared__ uint32_t gathered[dpll_arx::kMaxWorld][dpll_arx::kMaxWords];
+    const uint32_t seq = *seq_ptr + 1u;
+    if (threadIdx.x < D::PI) __builtin_memcpy(&words[threadIdx.x * kWordsPer], &value, sizeof(T));
+    __syncthreads();
+    dpll_arx::exchange_words(words, gathered, D::PI * kWordsPer, peers, rank, world, seq, err);
+    if (threadIdx.x < D::PI) value = dpll_arx::sum_over_ranks<T>(gathered, world, threadIdx.x);
+    if (threadIdx.x == 0) *seq_ptr = seq;
+  }
+  if (threadIdx.x < D::PI) {
     if (threadIdx.x == 0) {
-      if (loss_total) *loss_total = T(t);
+      if (loss_total) *loss_total = value;
     } else {
-      grad[threadIdx.x - 1] = T(t);
+      grad[threadIdx.x - 1] = value;
     }
   }
 }
@@ -570,6 +590,14 @@ template <typename T, int NJ> int loss_blocks(long long batch) {
 
 }  // namespace
 
+struct dpll_ar {
+  int rank, world;
+  void* local;             // this rank's receive buffer (uncached device memory)
+  uint32_t* state;         // [0] call counter, [1] error word (device)
+  dpll_arx::Peers peers;
+  void* opened[dpll_arx::kMaxWorld];
+};
+
 struct dpll_model {
   ModelDesc desc;
   SolverOpts opts[2];
@@ -581,7 +609,7 @@ template <typename T, int NJ>
 int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
                 long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* grad,
                 void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
-                hipStream_t stream) {
+                hipStream_t stream, const dpll_ar* ar = nullptr) {
   using D = Dims<T, NJ>;
   const int blocks = loss_blocks<T, NJ>(batch);
   const int want_grad = grad != nullptr;
@@ -597,8 +625,12 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                      want_grad, (const T*)nullptr, (T*)nullptr);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
-    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
-                       (T*)grad, (T*)loss_total);
+    if (ar)
+      hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
+                         blocks, (T*)grad, (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
+    else
+      hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
+                         blocks, (T*)grad, (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (int rc = check_launch("finalize_kernel")) return rc;
   }
   return 0;
@@ -624,8 +656,8 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
                        (const T*)xp, ld_xp, batch, (const T*)nullptr, scale, (T*)nullptr, (T*)nullptr, (int*)nullptr,
                        (double*)workspace, 1, (const T*)nullptr, (T*)nullptr);
     (void)hipEventRecord(ev[3 * r + 1], stream);
-    hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
-                       (T*)grad, (T*)nullptr);
+    hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
+                       blocks, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
     (void)hipEventRecord(ev[3 * r + 2], stream);
   }
   int rc = check_launch("profile launches");
@@ -680,8 +712,8 @@ int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p,
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
                        ld_g, batch, (double*)workspace, (T*)nullptr, 0LL);
   if (int rc = check_launch("step_backward_kernel")) return rc;
-  hipLaunchKernelGGL((finalize_kernel<T, NJ>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
-                     (T*)grad, (T*)nullptr);
+  hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
+                     (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
   return check_launch("finalize_kernel");
 }
 
@@ -881,7 +913,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 5; }
+int dpll_abi_version(void) { return 6; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -948,6 +980,21 @@ int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_param
   if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss: row stride smaller than n_x%s");
   DPLL_DISPATCH(launch_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total,
                 force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                                    int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                                    double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
+                                    dpll_ar_t* ar, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_loss_allreduce")) return rc;
+  if (batch == 0) return fail(-1, "dpll_contactnets_loss_allreduce: empty batch%s");
+  if (!x || !x_plus || !grad || !loss_total || !ar) return fail(-1, "dpll_contactnets_loss_allreduce: null argument%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss_allreduce: row stride smaller than n_x%s");
+  if ((dpll_param_count(model) + 1) * (dtype == DPLL_F64 ? 2 : 1) > dpll_arx::kMaxWords)
+    return fail(-1, "dpll_contactnets_loss_allreduce: gradient row too long for the one-shot exchange%s");
+  DPLL_DISPATCH(launch_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total,
+                nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, ar);
 }
 
 int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
@@ -1094,13 +1141,6 @@ int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params
 }  // extern "C"
 
 // ---- one-shot all-reduce over peer memory (dpll_allreduce.hpp) -------------------------------------
-struct dpll_ar {
-  int rank, world;
-  void* local;             // this rank's receive buffer (uncached device memory)
-  uint32_t* state;         // [0] call counter, [1] error word (device)
-  dpll_arx::Peers peers;
-  void* opened[dpll_arx::kMaxWorld];
-};
 
 extern "C" {
 

@@ -107,9 +107,10 @@ class GradientAllReduce:
     with unequal shards pass ``global_batch`` to weight by ``1 / global_batch`` instead.
 
     ``transport``: ``'auto'`` (peer-memory one-shot kernel if the buffer fits and its self-test passes,
-    else the backend's collective), ``'peer'`` or ``'collective'``."""
+    else the backend's collective), ``'peer'`` or ``'collective'``.  ``fuse`` (peer transport): the exchange is
+    done by the loss launch's own finalize kernel instead of a kernel after it."""
 
-    def __init__(self, system, group=None, global_batch: int = 0, transport: str = 'auto') -> None:
+    def __init__(self, system, group=None, global_batch: int = 0, transport: str = 'auto', fuse: bool = True) -> None:
         self.system = system
         self.group = group
         self.world = dist.get_world_size(group)
@@ -139,9 +140,16 @@ class GradientAllReduce:
             if transport == 'peer' and self.peer is None:
                 raise _capi.DpllError('peer-memory all-reduce unavailable')
         self.transport = 'peer' if self.peer is not None else 'collective'
+        # fuse: with the peer transport the exchange runs inside the finalize kernel of the loss launch
+        # (dpll_contactnets_loss_allreduce); all_reduce_mean() then has nothing left to launch
+        self.fused = bool(fuse and self.peer is not None and getattr(system, '_mesh', lambda: None)() is None)
+        system._fused_ar = self.peer._ar if self.fused else None
 
     def all_reduce_mean(self) -> torch.Tensor:
         buf = self.system.grad_buffer()
+        if self.fused and self.system._grad_reduced:
+            self.system._grad_reduced = False  # already summed by the loss launch
+            return buf
         if self.peer is not None:
             self.peer.all_reduce(buf)
         else:

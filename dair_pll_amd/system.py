@@ -204,6 +204,8 @@ class MultibodyLearnableSystem(Module):
         self._loss_total: Optional[Tensor] = None
         self.grad_world = 1      # set by distributed.GradientAllReduce
         self.global_batch = 0
+        self._fused_ar: Optional[ctypes.c_void_p] = None  # peer all-reduce handle: the exchange rides in the loss launch
+        self._grad_reduced = False  # the last contactnets_loss_and_grad already summed [loss | gradients] over the ranks
 
     # ---- parameters ---------------------------------------------------------------------------
     def _param_list(self) -> List[Parameter]:
@@ -335,7 +337,7 @@ class MultibodyLearnableSystem(Module):
     # ---- ContactNets loss -----------------------------------------------------------------------
     def _launch_loss(self, x: Tensor, x_plus: Tensor, weights: Optional[Tensor], scale: float, want_grad: bool,
                      force: Optional[Tensor] = None, iters: Optional[Tensor] = None,
-                     loss: Optional[Tensor] = None, want_loss: bool = True):
+                     loss: Optional[Tensor] = None, want_loss: bool = True, fused_ar=None):
         lib = _capi.library()
         flat = self._packed()
         batch = x.shape[0]
@@ -359,6 +361,13 @@ class MultibodyLearnableSystem(Module):
                 self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(x), x.stride(0),
                 _ptr(x_plus), x_plus.stride(0), batch, _ptr(weights), float(scale), _ptr(loss), _ptr(grad), _ptr(total),
                 _ptr(force), _ptr(iters), _ptr(workspace), workspace.numel(), self._stream()))
+            return loss, grad, total
+        if fused_ar is not None and want_grad and loss is None and force is None and iters is None:
+            _capi.check(lib.dpll_contactnets_loss_allreduce(
+                self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0), _ptr(x_plus),
+                x_plus.stride(0), batch, _ptr(weights), float(scale), _ptr(grad), _ptr(total), _ptr(workspace), ws_bytes,
+                fused_ar, self._stream()))
+            self._grad_reduced = True
             return loss, grad, total
         _capi.check(lib.dpll_contactnets_loss(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x),
                                               x.stride(0), _ptr(x_plus), x_plus.stride(0), batch, _ptr(weights),
@@ -386,7 +395,8 @@ class MultibodyLearnableSystem(Module):
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
         denom = self.global_batch if self.global_batch > 0 else xf.shape[0] * self.grad_world
-        _, grad, total = self._launch_loss(xf, xpf, None, 1.0 / denom, True, want_loss=False)
+        self._grad_reduced = False
+        _, grad, total = self._launch_loss(xf, xpf, None, 1.0 / denom, True, want_loss=False, fused_ar=self._fused_ar)
         for param, piece in zip(self._param_list(), self._split_flat(grad)):
             if accumulate and param.grad is not None:
                 param.grad = param.grad + piece

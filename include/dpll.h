@@ -199,6 +199,15 @@ int dpll_ar_allreduce(dpll_ar_t* ar, int dtype, void* data, int n, void* stream)
 int dpll_ar_status(dpll_ar_t* ar);
 void dpll_ar_destroy(dpll_ar_t* ar);
 
+/* dpll_contactnets_loss (forward + backward, no per-item outputs) whose last kernel also sums the row
+ * [loss_total | grad] over the ranks of `ar` before writing it: data-parallel training's only collective rides in the
+ * launch that produces the gradients (no kernel of its own).  Counts as one call of dpll_ar_allreduce on every
+ * rank.  `scale` should already carry 1 / global batch. */
+int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                                    int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                                    double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
+                                    dpll_ar_t* ar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,31 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
     reduced = reducer.all_reduce_mean()
     assert (reduced - full_grad).abs().max() < 1e-15
+    assert reducer.fused and system._fused_ar is not None  # the exchange ran inside the loss launch's finalize kernel
+    fused_result = reduced.clone()
+    # the fused step under hipGraph replay
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
+        reducer.all_reduce_mean()
+    torch.cuda.current_stream().wait_stream(side)
+    dist.barrier()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
+        reducer.all_reduce_mean()
+    for _ in range(3):
+        system.grad_buffer().zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(system.grad_buffer(), fused_result)
+    assert reducer.peer.healthy()
+    # a separate exchange kernel after the launch gives bitwise the same row
+    unfused = GradientAllReduce(system, global_batch=batch, fuse=False)
+    assert unfused.transport == 'peer' and not unfused.fused and system._fused_ar is None
+    system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
+    assert torch.equal(unfused.all_reduce_mean(), fused_result)
     np.save(os.path.join(out_dir, f'rank{rank}.npy'), reduced.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
