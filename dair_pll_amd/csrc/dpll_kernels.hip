@@ -476,7 +476,8 @@ __global__ __launch_bounds__(kWave) void terms_kernel(ModelDesc md, const T* __r
                                                       const T* __restrict__ friction, const T* __restrict__ lengths,
                                                       const T* __restrict__ x, long long ld_x, long long batch,
                                                       T* __restrict__ Dout, T* __restrict__ Mout, T* __restrict__ Jout,
-                                                      T* __restrict__ phiout, T* __restrict__ aout) {
+                                                      T* __restrict__ phiout, T* __restrict__ aout,
+                                                      const T* __restrict__ witness) {
   using D = Dims<T, NJ>;
   constexpr int NV = D::NV, K = D::K;
   __shared__ T Jrows[D::IPW][3 * K][NV];
@@ -497,7 +498,12 @@ __global__ __launch_bounds__(kWave) void terms_kernel(ModelDesc md, const T* __r
     Kin<typename Acc<T>::type, NJ> kinA;
     compute_terms<T, typename Acc<T>::type, NJ>(md, dp, xr, xr + D::NQ, t, kinA);
     ContactGeom<T, NJ> cg;
-    compute_contact<T, typename Acc<T>::type, NJ>(md, dp, t.kin, kinA, cidx, cg);
+    T wit[3] = {T(0), T(0), T(0)};  // mesh geometry: the support point from the ICNN kernels (off the hot path)
+    if (witness) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) wit[i] = witness[(it * K + cidx) * 3 + i];
+    }
+    compute_contact<T, typename Acc<T>::type, NJ>(md, dp, t.kin, kinA, cidx, cg, witness ? wit : nullptr);
     // rows of J in the reference order [normals | mu (t_x, t_y) per contact] (multibody_terms.py:415-426)
     T mine[3][NV];
 #pragma unroll
@@ -719,13 +725,13 @@ int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p,
 
 template <typename T, int NJ>
 int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm,
-                 void* M, void* J, void* phi, void* a, hipStream_t stream) {
+                 void* M, void* J, void* phi, void* a, hipStream_t stream, const void* witness = nullptr) {
   using D = Dims<T, NJ>;
   long long blocks = (batch + D::IPW - 1) / D::IPW;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL((terms_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, (const T*)p->theta,
                      (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J,
-                     (T*)phi, (T*)a);
+                     (T*)phi, (T*)a, (const T*)witness);
   return check_launch("terms_kernel");
 }
 
@@ -1127,6 +1133,28 @@ int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_me
   if (batch < 1 || !x || !points || ld_x < 4) return fail(-1, "dpll_mesh_support_points: bad arguments%s");
   if (dtype == DPLL_F32) return launch_mesh_support<float>(mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
   return launch_mesh_support<double>(mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dpll_terms_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                    const void* x, int64_t ld_x, int64_t batch, void* delassus, void* M, void* J, void* phi, void* a,
+                    void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!model) return fail(-1, "dpll_terms_mesh: null model%s");
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_terms_mesh: bad dtype%s");
+  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_terms_mesh: null parameter pointer%s");
+  if (int rc = check_mesh(model, mesh, "dpll_terms_mesh")) return rc;
+  if (batch < 1 || !x || ld_x < 13) return fail(-1, "dpll_terms_mesh: bad state arguments%s");
+  dpll_params_t q = *params;
+  q.lengths = nullptr;
+  if (dtype == DPLL_F32) {
+    const MeshPlan pl = mesh_plan<float>(batch);
+    if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_terms_mesh: workspace too small%s");
+    if (int rc = mesh_forward<float>(pl, mesh_weights<float>(mesh), (char*)workspace, (const float*)x, ld_x, (hipStream_t)stream)) return rc;
+    return launch_terms<float, 0>(model, &q, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream, (char*)workspace + pl.off_P);
+  }
+  const MeshPlan pl = mesh_plan<double>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_terms_mesh: workspace too small%s");
+  if (int rc = mesh_forward<double>(pl, mesh_weights<double>(mesh), (char*)workspace, (const double*)x, ld_x, (hipStream_t)stream)) return rc;
+  return launch_terms<double, 0>(model, &q, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream, (char*)workspace + pl.off_P);
 }
 
 int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,

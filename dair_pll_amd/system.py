@@ -663,8 +663,6 @@ class MultibodyLearnableSystem(Module):
 
     # ---- terms ----------------------------------------------------------------------------------
     def _terms(self, q: Tensor, v: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
-        if self._mesh() is not None:
-            raise NotImplementedError('multibody_terms(q, v, u) is implemented for box geometry only')
         lib = _capi.library()
         batch_shape = q.shape[:-1]
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
@@ -673,7 +671,14 @@ class MultibodyLearnableSystem(Module):
         new = lambda *shape: torch.empty((n,) + shape, dtype=self.dtype, device=x.device)
         delassus, mass, jac, phi, acc = new(3 * k, 3 * k), new(n_v, n_v), new(3 * k, n_v), new(k), new(n_v)
         params = self._params_struct(flat)
-        _capi.check(lib.dpll_terms(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0), n,
-                                   _ptr(delassus), _ptr(mass), _ptr(jac), _ptr(phi), _ptr(acc), self._stream()))
+        if self._mesh() is not None:
+            workspace = self._mesh_workspace(n, x.device)
+            mesh = self._mesh_struct(flat)
+            _capi.check(lib.dpll_terms_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh),
+                                            _ptr(x), x.stride(0), n, _ptr(delassus), _ptr(mass), _ptr(jac), _ptr(phi),
+                                            _ptr(acc), _ptr(workspace), workspace.numel(), self._stream()))
+        else:
+            _capi.check(lib.dpll_terms(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0), n,
+                                       _ptr(delassus), _ptr(mass), _ptr(jac), _ptr(phi), _ptr(acc), self._stream()))
         shape = lambda t: t.reshape(batch_shape + t.shape[1:])
         return shape(delassus), shape(mass), shape(jac), shape(phi), shape(acc)

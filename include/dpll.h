@@ -162,6 +162,11 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
                                void* loss_total, void* force, int32_t* iters, void* workspace, int64_t workspace_bytes,
                                void* stream);
 
+/* dpll_terms with the network shape (support points of the CURRENT state as witnesses). */
+int dpll_terms_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                    const void* x, int64_t ld_x, int64_t batch, void* delassus, void* M, void* J, void* phi, void* a,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Measuring utility, mesh pipeline: `reps` calls of dpll_contactnets_loss_mesh (with grad) with HIP events on the
  * launch stream after each of its kernels; ms_kernels[7] = average duration of
  * {prep, fwd1, fwd2, loss, bwd1, bwd2, reduce}.  Synchronises. */

@@ -123,3 +123,23 @@ def test_learned_shape_export(golden, tmp_path):
     spec = parse_urdf(new['cube'])
     assert spec.bodies[0].geoms[0].kind == 'mesh' and spec.bodies[0].geoms[0].mesh_file == 'test.obj'
     assert np.allclose(np.array(spec.bodies[0].geoms[0].vertices), vertices, atol=0, rtol=1e-15)
+
+
+def test_mesh_terms_match_reference_run(golden):
+    """MultibodyTerms.forward (D, M, J, phi, a) with the learned shape; the reference's top-k leaves the order of
+    the four witness points unspecified, so contacts are put in a canonical order first (as for the boxes)."""
+    from test_hip_parity import _canonical
+    g = golden('cube_mesh_literal')
+    system = build(g, torch.float64)
+    xp = torch.tensor(g['x_plus'], dtype=torch.float64, device='cuda:0')
+    q, v = system.space.q_v(xp)
+    D, M, J, phi, a = [t.cpu().numpy() for t in system.multibody_terms(q, v, torch.zeros(q.shape[:-1] + (0,)))]
+    k = phi.shape[-1]
+    assert np.abs(M - g['terms/M']).max() < 1e-12 and np.abs(a - g['terms/a']).max() < 1e-9
+    assert np.abs(np.sort(phi, -1) - np.sort(g['terms/phi'], -1)).max() < 1e-12
+    Jm, pm, Dm = _canonical(J, phi, D, k)
+    Jr, pr, Dr = _canonical(g['terms/J'], g['terms/phi'], g['terms/D'], k)
+    good = np.abs(Jm - Jr).reshape(J.shape[0], -1).max(-1) < 1e-9
+    assert good.mean() > 0.9
+    assert np.abs(pm[good] - pr[good]).max() < 1e-12
+    assert np.abs(Dm[good] - Dr[good]).max() < 1e-8 * max(1.0, np.abs(Dr).max())
