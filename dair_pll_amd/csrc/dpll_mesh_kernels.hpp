@@ -385,16 +385,23 @@ __device__ __forceinline__ int mfma_row(int reg, int half) { return (reg & 3) + 
 // (q * 32 + col) * 2 + half holds rows 2 (4 q + e) + half, e = 0..3, of column col -- exactly what lane
 // (col, half) feeds to MFMA steps 4 q .. 4 q + 3, so a wave fetches four steps with one contiguous 1 KB read.
 // A thread of the tile kernels owns column c and rows r0 .. r0 + 15 (r0 = 0 or 16): four float4 stores.
-__device__ __forceinline__ void store_operand_tile(float* __restrict__ base, long long tile, int c, int r0, const float (&v)[16]) {
-  f32x4* blk = (f32x4*)(base + (tile * 8 + (c >> 5)) * 1024);
+template <class ValueOfRow>
+__device__ __forceinline__ void fill_operand_tile(float* __restrict__ base, long long tile, int c, int r0, float* __restrict__ Xs,
+                                                  ValueOfRow value_of_row) {
+  // rows in float4 order (four values live at a time): LDS image Xs in the xop layout, global operand tile if `base`
+  f32x4* blk = base ? (f32x4*)(base + (tile * 8 + (c >> 5)) * 1024) : nullptr;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
       f32x4 val;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = v[2 * (4 * qq + e) + h];
-      blk[((r0 / 8 + qq) * 32 + (c & 31)) * 2 + h] = val;
+      for (int e = 0; e < 4; ++e) {
+        const int rr = r0 + 2 * (4 * qq + e) + h;
+        val[e] = value_of_row(rr);
+        Xs[xop(rr, c)] = val[e];
+      }
+      if (blk) blk[((r0 / 8 + qq) * 32 + (c & 31)) * 2 + h] = val;
     }
 }
 
@@ -484,6 +491,15 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
 #pragma unroll
   for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = AT[(2 * kk + half) * kW + col];
   const float wd0[3] = {w.Wd0[col], w.Wd0[kW + col], w.Wd0[2 * kW + col]};
+  // input weights of both layers by column for the support-point product below: [c] = (Wd1[0..2][c], 0 | Wd0[0..2][c], 0);
+  // read back as two float4 per column (the 96 global loads per thread and tile they replace kept the vector-memory
+  // pipe busier than the MFMAs)
+  __shared__ f32x4 Wds[kW][2];
+  if (threadIdx.x < kW) {
+    const int c = threadIdx.x;
+    Wds[c][0] = f32x4{w.Wd1[c], w.Wd1[kW + c], w.Wd1[2 * kW + c], 0.f};
+    Wds[c][1] = f32x4{w.Wd0[c], w.Wd0[kW + c], w.Wd0[2 * kW + c], 0.f};
+  }
   const long long tiles = (N + kMfmaRows - 1) / kMfmaRows;
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kMfmaRows;
@@ -492,14 +508,10 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
     {  // U1 tile
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
       const float ac = a[c];
-      float u1v[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t word = (n0 + r0 + r < N) ? M1[(n0 + r0 + r) * kMaskWords + (c >> 5)] : 0u;
-        u1v[r] = ac * mask_factor(word, c & 31);
-        Xs[xop(r0 + r, c)] = u1v[r];
-      }
-      if (U1t) store_operand_tile(U1t, tile, c, r0, u1v);
+      fill_operand_tile(U1t, tile, c, r0, Xs, [&](int rr) {
+        const uint32_t word = (n0 + rr < N) ? M1[(n0 + rr) * kMaskWords + (c >> 5)] : 0u;
+        return ac * mask_factor(word, c & 31);
+      });
     }
     __syncthreads();
     const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
@@ -515,12 +527,13 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
     {  // P[row][i]: thread -> (row = t >> 4, part = t & 15), columns part + 16 m
       const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
       float s[3] = {0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 2  // (the weight fragment leaves few registers: a full unroll hoists 32 float4 loads and spills)
       for (int m = 0; m < 16; ++m) {
         const int c = part + 16 * m;
         const float u1 = Xs[xop(row, c)], u0 = Ys[row * kXs + c];
+        const f32x4 w1 = Wds[c][0], w0 = Wds[c][1];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s[i] += w.Wd1[i * kW + c] * u1 + w.Wd0[i * kW + c] * u0;
+        for (int i = 0; i < 3; ++i) s[i] += w1[i] * u1 + w0[i] * u0;
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {  // sum over the 16 parts = one DPP row
@@ -564,15 +577,10 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
     {  // Vb tile
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
       const float d0 = w.Wd0[c], d1 = w.Wd0[kW + c], d2 = w.Wd0[2 * kW + c];
-      float vbv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = r0 + r;
+      fill_operand_tile(Vb, tile, c, r0, Xs, [&](int rr) {
         const float pre0 = Qs[rr][0] * d0 + Qs[rr][1] * d1 + Qs[rr][2] * d2;
-        vbv[r] = (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);  // rows past N: RB = 0
-        Xs[xop(rr, c)] = vbv[r];
-      }
-      store_operand_tile(Vb, tile, c, r0, vbv);
+        return (Rs[rr][0] * d0 + Rs[rr][1] * d1 + Rs[rr][2] * d2) * icnn_mask(pre0);  // rows past N: RB = 0
+      });
     }
     __syncthreads();
     // epilogue operands first (independent loads in flight during the MFMAs)
