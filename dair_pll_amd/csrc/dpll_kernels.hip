@@ -145,11 +145,6 @@ namespace {
 template <typename T, int NJ> struct Dims {
   static constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NB, G = K;
   static constexpr int IPW = kWave / G;                       // items per wave
-#ifdef DPLL_LOSS_IPW
-  static constexpr int IPWL = DPLL_LOSS_IPW < IPW ? DPLL_LOSS_IPW : IPW;  // distinct items per wave in the loss kernel
-#else
-  static constexpr int IPWL = IPW;
-#endif
   static constexpr int P = NB * 10 + (NB + 1) + NB * 3;       // learnable parameters [theta | friction | lengths]
   static constexpr int PI = 1 + P;                            // partial-sum row: [loss | d/d params]
 };
@@ -219,10 +214,10 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
   const int slot = lane / D::G;
   DPLL_STAMP(0);
   // the first item's state rows are requested before the parameter math so that their memory latency hides behind it
-  const long long stride = (long long)gridDim.x * D::IPWL;
-  long long base = (long long)blockIdx.x * D::IPWL;
-  long long item = base + slot % D::IPWL;  // lane groups beyond IPWL shadow the first ones (same trip counts)
-  bool valid = item < batch && slot < D::IPWL;
+  const long long stride = (long long)gridDim.x * D::IPW;
+  long long base = (long long)blockIdx.x * D::IPW;
+  long long item = base + slot;
+  bool valid = item < batch;
   long long it = valid ? item : batch - 1;  // idle groups shadow the last item: keeps every lane live for DPP
   T xr[D::NX], xpr[D::NX];
 #pragma unroll
@@ -278,8 +273,8 @@ __global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts op
     DPLL_STAMP(2);
     base += stride;
     if (base >= batch) break;
-    item = base + slot % D::IPWL;
-    valid = item < batch && slot < D::IPWL;
+    item = base + slot;
+    valid = item < batch;
     it = valid ? item : batch - 1;
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
@@ -588,7 +583,7 @@ SolverOpts default_opts(int dtype) {
 
 template <typename T, int NJ> int loss_blocks(long long batch) {
   using D = Dims<T, NJ>;
-  long long blocks = (batch + D::IPWL - 1) / D::IPWL;
+  long long blocks = (batch + D::IPW - 1) / D::IPW;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -965,9 +960,6 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (!model || batch < 0) return -1;
   const int nb = model->desc.n_joints + 1;
   int64_t ipw = kWave / (kQuery * nb);
-#ifdef DPLL_LOSS_IPW
-  if (DPLL_LOSS_IPW < ipw) ipw = DPLL_LOSS_IPW;
-#endif
   int64_t blocks = (batch + ipw - 1) / ipw;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;

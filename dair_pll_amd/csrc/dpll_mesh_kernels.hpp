@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void icnn_fwd2_kernel(const T* __restrict__ x,
   __shared__ T Pp[4][kTileRows][3];
   const int j = threadIdx.x;
   const T wd0[3] = {w.Wd0[j], w.Wd0[kW + j], w.Wd0[2 * kW + j]};
-  const T wd1[3] = {w.Wd1[j], w.Wd1[kW + j], w.Wd1[2 * kW + j]};
   const T aj = a[j];
   const long long tiles = (N + kTileRows - 1) / kTileRows;
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {

@@ -54,7 +54,6 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     torch.cuda.synchronize()
     assert peer.healthy()
     total = world * (world + 1) / 2
-    expect = total * world**6  # 1 eager + 1 capture-time? (capture does not run) -> see below
     # t was reduced once eagerly (-> total), then 5 replays each multiply the common value by `world`
     assert torch.allclose(t, torch.full((16,), total * world**5, device='cuda')), (t[0].item(), total * world**5)
     peer.close()
