@@ -647,32 +647,33 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
   const int blocks = loss_blocks<T, NJ>(batch);
   if (!grad || !workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
     return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
-  hipEvent_t* ev = new (std::nothrow) hipEvent_t[3 * (size_t)reps];
-  if (!ev) return fail(-4, "dpll_profile_contactnets_loss: out of memory%s");
-  for (int i = 0; i < 3 * reps; ++i) (void)hipEventCreate(&ev[i]);
-  for (int r = 0; r < reps; ++r) {
-    (void)hipEventRecord(ev[3 * r], stream);
+  // two passes, two events each (an event between every pair of kernels costs several microseconds of its own):
+  // `reps` loss kernels back to back, then `reps` (loss, finalize) pairs; finalize = the difference
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; ++i) (void)hipEventCreate(&ev[i]);
+  auto launch_loss_only = [&]() {
     hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x,
                        (const T*)xp, ld_xp, batch, (const T*)nullptr, scale, (T*)nullptr, (T*)nullptr, (int*)nullptr,
                        (double*)workspace, 1, (const T*)nullptr, (T*)nullptr);
-    (void)hipEventRecord(ev[3 * r + 1], stream);
+  };
+  (void)hipEventRecord(ev[0], stream);
+  for (int r = 0; r < reps; ++r) launch_loss_only();
+  (void)hipEventRecord(ev[1], stream);
+  (void)hipEventRecord(ev[2], stream);
+  for (int r = 0; r < reps; ++r) {
+    launch_loss_only();
     hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
                        blocks, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
-    (void)hipEventRecord(ev[3 * r + 2], stream);
   }
+  (void)hipEventRecord(ev[3], stream);
   int rc = check_launch("profile launches");
-  (void)hipEventSynchronize(ev[3 * reps - 1]);
-  double t_loss = 0.0, t_fin = 0.0;
-  for (int r = 0; r < reps; ++r) {
-    float a = 0.f, b = 0.f;
-    (void)hipEventElapsedTime(&a, ev[3 * r], ev[3 * r + 1]);
-    (void)hipEventElapsedTime(&b, ev[3 * r + 1], ev[3 * r + 2]);
-    t_loss += a;
-    t_fin += b;
-  }
-  for (int i = 0; i < 3 * reps; ++i) (void)hipEventDestroy(ev[i]);
-  delete[] ev;
+  (void)hipEventSynchronize(ev[3]);
+  float t_loss = 0.f, t_pair = 0.f;
+  (void)hipEventElapsedTime(&t_loss, ev[0], ev[1]);
+  (void)hipEventElapsedTime(&t_pair, ev[2], ev[3]);
+  const double t_fin = t_pair > t_loss ? t_pair - t_loss : 0.0;
+  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
   if (ms_loss) *ms_loss = (float)(t_loss / reps);
   if (ms_finalize) *ms_finalize = (float)(t_fin / reps);
   return rc;

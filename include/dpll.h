@@ -111,9 +111,10 @@ int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_param
                           double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
-/* Measuring utility (synchronises; not for graph capture): `reps` loss + finalize launches on `stream` with
- * HIP events recorded on that stream around each kernel; returns the average duration of the loss kernel
- * and of the finalize kernel in milliseconds.  Same arguments as dpll_contactnets_loss with uniform weights. */
+/* Measuring utility (synchronises; not for graph capture), HIP events on `stream`: `reps` loss kernels back to back
+ * between two events give the average loss-kernel launch duration; `reps` (loss, finalize) pairs between two more
+ * give the finalize kernel as the difference (an event between every two kernels would add microseconds of its own).
+ * Milliseconds.  Same arguments as dpll_contactnets_loss with uniform weights. */
 int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
                                   int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, double scale,
                                   void* grad, void* workspace, int64_t workspace_bytes, void* stream, int32_t reps,
