@@ -1217,7 +1217,7 @@ template <typename T> DPLL_HD void quat_exp_mul_adjoint(const T* q, const T (&r)
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
-                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ]);
+                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3] = nullptr);
 
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
@@ -1305,7 +1305,7 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
   T L[NV][NV], invd[NV], lam[NV];
   cholesky<T, NV>(H, L, invd);
   chol_solve<T, NV>(L, invd, sv, lam);
-  if (xbar) step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar);
+  if (xbar) step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar, witness);
   // ---- per-contact pieces: kappa_c, friction and witness gradients; s' = s - sum_c J_c^T kappa_c ---
   T jtk[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) jtk[i] = T(0);
@@ -1370,13 +1370,13 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
 //     Phi(x) = xbar+_q . q+(q, v+ fixed) + s . v-(x) - lambda . G(x, y*),     G = M(q) y* - sum_c J_c(q)^T D_mu P_K(z_c(x, y*)),
 // (implicit-function theorem on G = 0: dy*/dx = -H^-1 dG/dx).  Phi is pushed through the same templates as the
 // forward pass with forward-mode duals, one state component per pass: n_x passes of (terms + contact geometry) in
-// the accumulation type.  The witness corner of a box is piecewise constant in q; a learned (mesh) witness would
-// need the network's input Jacobian and is not handled.
+// the accumulation type.  The witness is piecewise constant in q in both geometries: a box corner, or the support
+// point of a LeakyReLU network (piecewise linear support function => piecewise constant gradient), passed in.
 // ---------------------------------------------------------------------------------------------
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
-                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ]) {
+                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3]) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = NQ + NV;
   using S = DualT<TA>;
   Derived<S, NJ> dps;
@@ -1411,7 +1411,11 @@ DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, c
     S phic = S(TA(0));
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
       ContactGeom<S, NJ> cg;
-      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg);
+      S wit[3] = {S(TA(0)), S(TA(0)), S(TA(0))};
+      if (witness) {
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = S(TA(witness[c][i]));
+      }
+      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg, witness ? wit : nullptr);
       S jy[3], jv[3], jl[3];
       cjac_apply<S, S, NJ>(cg.J, ys, jy);
       cjac_apply<S, S, NJ>(cg.J, vm, jv);

@@ -407,14 +407,16 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
 
 // ---- adjoint of one simulation step with respect to the parameters (state = data) -----------------------
 // STATE: also the adjoint of the input state (n_x forward-mode passes of the terms, core step_state_adjoint)
-template <typename T, int NJ, bool STATE = false>
+// MESH: witnesses from the ICNN kernels in, their adjoint r_bar out (as in the loss kernel)
+template <typename T, int NJ, bool STATE = false, bool MESH = false>
 __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                               const T* __restrict__ friction,
                                                               const T* __restrict__ lengths, const T* __restrict__ x,
                                                               long long ld_x, const T* __restrict__ gx,
                                                               long long ld_g, long long batch,
                                                               double* __restrict__ partials, T* __restrict__ xbar_out,
-                                                              long long ld_xb) {
+                                                              long long ld_xb, const T* __restrict__ witness,
+                                                              T* __restrict__ rbar_out) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<D::G>;
   const int lane = threadIdx.x;
@@ -435,17 +437,33 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; gr[i] = valid ? gx[it * ld_g + i] : T(0); }
     LossGrad<T, NJ> g;
     zero_grad(g);
-    if constexpr (STATE) {
-      T xb[D::NX];
+    T wit[1][3] = {{T(0), T(0), T(0)}}, rb[1][3] = {{T(0), T(0), T(0)}};
+    if constexpr (MESH) {
 #pragma unroll
-      for (int i = 0; i < D::NX; ++i) xb[i] = T(0);
+      for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
+    }
+    T xb[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) xb[i] = T(0);
+    if constexpr (STATE && MESH)
+      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, wit, rb, &xb);
+    else if constexpr (STATE)
       step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, nullptr, nullptr, &xb);
+    else if constexpr (MESH)
+      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, wit, rb);
+    else
+      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
+    if constexpr (STATE) {
       if (valid && cidx == 0) {
 #pragma unroll
         for (int i = 0; i < D::NX; ++i) xbar_out[it * ld_xb + i] = xb[i];
       }
-    } else {
-      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
+    }
+    if constexpr (MESH) {
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
+      }
     }
     // every lane of the group holds the item's d/d iota; d/d mu and d/d length are per contact
 #pragma unroll
@@ -708,11 +726,11 @@ int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p,
   if (grad_x)
     hipLaunchKernelGGL((step_backward_kernel<T, NJ, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
-                       ld_g, batch, (double*)workspace, (T*)grad_x, ld_gx);
+                       ld_g, batch, (double*)workspace, (T*)grad_x, ld_gx, (const T*)nullptr, (T*)nullptr);
   else
     hipLaunchKernelGGL((step_backward_kernel<T, NJ, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
-                       ld_g, batch, (double*)workspace, (T*)nullptr, 0LL);
+                       ld_g, batch, (double*)workspace, (T*)nullptr, 0LL, (const T*)nullptr, (T*)nullptr);
   if (int rc = check_launch("step_backward_kernel")) return rc;
   hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
                      (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
@@ -810,6 +828,36 @@ int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T*
   return check_launch("icnn forward");
 }
 
+// backward half shared by the loss and by the step backward: r_bar (ws.RB) and the row partials (ws.rows) are in
+// place, `state` is the state the support points were evaluated at
+template <typename T>
+int mesh_backward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, void* grad,
+                  void* loss_total, hipStream_t stream) {
+  if constexpr (std::is_same<T, float>::value) {
+    hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)state, ld, pl.N, w,
+                       (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
+                       (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1),
+                       (float*)(ws + pl.off_Vb));
+    mesh_mark(stream);
+    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
+                       (const float*)(ws + pl.off_Vb), (const float*)(ws + pl.off_U1), (float*)(ws + pl.off_slabs));
+  } else {
+    hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)state, ld, pl.N, w,
+                       (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
+                       (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
+    mesh_mark(stream);
+    hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)state, ld, pl.N, w,
+                       (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
+                       (T*)(ws + pl.off_slabs));
+  }
+  mesh_mark(stream);
+  hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3(kRedBlocks), dim3(256), 0, stream, w,
+                     (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,
+                     (const T*)(ws + pl.off_slabs), pl.n_slabs, (T*)grad, (T*)loss_total);
+  mesh_mark(stream);
+  return check_launch("icnn backward");
+}
+
 template <typename T>
 int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
                      long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
@@ -829,29 +877,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   mesh_mark(stream);
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
-  if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)xp, ld_xp, pl.N, w,
-                       (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
-                       (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1),
-                       (float*)(ws + pl.off_Vb));
-    mesh_mark(stream);
-    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
-                       (const float*)(ws + pl.off_Vb), (const float*)(ws + pl.off_U1), (float*)(ws + pl.off_slabs));
-  } else {
-    hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
-                       (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
-                       (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
-    mesh_mark(stream);
-    hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)xp, ld_xp, pl.N, w,
-                       (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
-                       (T*)(ws + pl.off_slabs));
-  }
-  mesh_mark(stream);
-  hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3(kRedBlocks), dim3(256), 0, stream, w,
-                     (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,
-                     (const T*)(ws + pl.off_slabs), pl.n_slabs, (T*)grad, (T*)loss_total);
-  mesh_mark(stream);
-  return check_launch("icnn backward");
+  return mesh_backward<T>(pl, w, ws, (const T*)xp, ld_xp, grad, loss_total, stream);
 }
 
 template <typename T>
@@ -865,6 +891,29 @@ int launch_mesh_step(const dpll_model* m, int dtype, const dpll_params_t* p, con
   dpll_params_t q = *p;
   q.lengths = nullptr;
   return launch_simulate<T, 0>(m, dtype, &q, x, ld_x, batch, 1, x_next, ld_next, 0, 0, nullptr, stream, ws + pl.off_P);
+}
+
+// backward of dpll_step_mesh: support points at x, step backward (emits r_bar and the theta / friction row partials),
+// then the ICNN backward kernels as for the loss
+template <typename T>
+int launch_mesh_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp,
+                              const void* x, long long ld_x, const void* gx, long long ld_g, long long batch, void* grad,
+                              void* grad_x, long long ld_gx, void* workspace, long long workspace_bytes, hipStream_t stream) {
+  const MeshPlan pl = mesh_plan<T>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_step_backward_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  const IcnnWeights<T> w = mesh_weights<T>(mp);
+  if (int rc = mesh_forward<T>(pl, w, ws, (const T*)x, ld_x, stream, true)) return rc;
+#define DPLL_LAUNCH_SB(STATE_)                                                                                             \
+  hipLaunchKernelGGL((step_backward_kernel<T, 0, STATE_, true>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc,    \
+                     m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x,      \
+                     (const T*)gx, ld_g, batch, (double*)(ws + pl.off_rows), (T*)grad_x, ld_gx, (const T*)(ws + pl.off_P), \
+                     (T*)(ws + pl.off_RB))
+  if (grad_x) DPLL_LAUNCH_SB(true);
+  else DPLL_LAUNCH_SB(false);
+#undef DPLL_LAUNCH_SB
+  if (int rc = check_launch("step_backward_kernel (mesh)")) return rc;
+  return mesh_backward<T>(pl, w, ws, (const T*)x, ld_x, grad, nullptr, stream);
 }
 
 template <typename T>
@@ -915,7 +964,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 6; }
+int dpll_abi_version(void) { return 7; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1115,6 +1164,22 @@ int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* pa
                                    (hipStream_t)stream);
   return launch_mesh_step<double>(model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
                                   (hipStream_t)stream);
+}
+
+int dpll_step_backward_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                            const void* x, int64_t ld_x, const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad,
+                            void* grad_x, int64_t ld_gx, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!model) return fail(-1, "dpll_step_backward_mesh: null model%s");
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_step_backward_mesh: bad dtype%s");
+  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_step_backward_mesh: null parameter pointer%s");
+  if (int rc = check_mesh(model, mesh, "dpll_step_backward_mesh")) return rc;
+  if (batch < 1 || !x || !grad_x_next || !grad || ld_x < 13 || ld_g < 13 || (grad_x && ld_gx < 13))
+    return fail(-1, "dpll_step_backward_mesh: bad arguments%s");
+  if (dtype == DPLL_F32)
+    return launch_mesh_step_backward<float>(model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
+                                            workspace, workspace_bytes, (hipStream_t)stream);
+  return launch_mesh_step_backward<double>(model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
+                                           workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_mesh_params_t* mesh, const void* x,

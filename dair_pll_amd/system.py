@@ -485,24 +485,29 @@ class MultibodyLearnableSystem(Module):
         return x_next
 
     def _step_backward(self, x: Tensor, grad_x_next: Tensor, want_state: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
-        if self._mesh() is not None:
-            raise NotImplementedError('the backward of step() is implemented for box geometry')
         lib = _capi.library()
         flat = self._packed()
         grad = torch.empty(flat.numel(), dtype=self.dtype, device=x.device)
-        ws_bytes = lib.dpll_workspace_bytes(self._model(), x.shape[0])
-        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         params = self._params_struct(flat)
         gx = grad_x_next.to(self.dtype)
         grad_x = torch.empty_like(x, memory_format=torch.contiguous_format) if want_state else None
+        ld_gx = grad_x.stride(0) if want_state else 0
+        if self._mesh() is not None:
+            workspace = self._mesh_workspace(x.shape[0], x.device)
+            mesh = self._mesh_struct(flat)
+            _capi.check(lib.dpll_step_backward_mesh(
+                self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(x), x.stride(0), _ptr(gx),
+                gx.stride(0), x.shape[0], _ptr(grad), _ptr(grad_x), ld_gx, _ptr(workspace), workspace.numel(), self._stream()))
+            return grad, grad_x
+        ws_bytes = lib.dpll_workspace_bytes(self._model(), x.shape[0])
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         _capi.check(lib.dpll_step_backward(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),
-                                           _ptr(gx), gx.stride(0), x.shape[0], _ptr(grad), _ptr(grad_x),
-                                           grad_x.stride(0) if want_state else 0, _ptr(workspace), ws_bytes, self._stream()))
+                                           _ptr(gx), gx.stride(0), x.shape[0], _ptr(grad), _ptr(grad_x), ld_gx,
+                                           _ptr(workspace), ws_bytes, self._stream()))
         return grad, grad_x
 
     def _wants_graph(self, x: Tensor) -> bool:
-        return torch.is_grad_enabled() and self._mesh() is None and \
-            (x.requires_grad or any(p.requires_grad for p in self._param_list()))
+        return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._param_list()))
 
     def _differentiable_step(self, x: Tensor) -> Tensor:
         self._packed()

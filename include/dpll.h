@@ -163,6 +163,13 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
                                void* loss_total, void* force, int32_t* iters, void* workspace, int64_t workspace_bytes,
                                void* stream);
 
+/* dpll_step_backward with the network shape: grad has the layout of dpll_contactnets_loss_mesh's
+ * ([theta | friction | hidden | input0 | input1 | output weights], dpll_mesh_param_count entries); the support point is
+ * piecewise constant in the state (LeakyReLU network), so grad_x needs no network Jacobian. */
+int dpll_step_backward_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                            const void* x, int64_t ld_x, const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad,
+                            void* grad_x, int64_t ld_gx, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* dpll_terms with the network shape (support points of the CURRENT state as witnesses). */
 int dpll_terms_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                     const void* x, int64_t ld_x, int64_t batch, void* delassus, void* M, void* J, void* phi, void* a,

@@ -64,11 +64,11 @@ def test_mesh_loss_gradients_dynamics(golden, dtype):
         err = np.abs(param.grad.cpu().double().numpy() - ref).max()
         assert err <= (1e-9 if f64 else 2e-3) * max(np.abs(ref).max(), 1e-12 if not f64 else 1.0), (name, err)
     # dynamics
-    x_next = system.step(x)
+    x_next = system.step(x).detach()
     assert np.abs(x_next.cpu().double().numpy() - g['dynamics/x_next']).max() < (1e-10 if f64 else 1e-4)
     rows = g['simulate/rows']
     traj, _ = system.simulate(x[rows].unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), int(g['simulate/steps']))
-    assert np.abs(traj.cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4)
+    assert np.abs(traj.detach().cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4)
 
 
 def test_mesh_large_batch_matches_float64_path(golden):
@@ -143,3 +143,48 @@ def test_mesh_terms_match_reference_run(golden):
     assert good.mean() > 0.9
     assert np.abs(pm[good] - pr[good]).max() < 1e-12
     assert np.abs(Dm[good] - Dr[good]).max() < 1e-8 * max(1.0, np.abs(Dr).max())
+
+
+def test_mesh_step_gradients_match_finite_differences(golden):
+    """dpll_step_backward_mesh: d(sum w . x_next)/d(theta, friction, network weights) and /dx for the learned-shape
+    body against central differences of dpll_step_mesh, float64 (the support point is piecewise constant in the
+    state and piecewise linear in every weight tensor, so differences are exact away from mask flips)."""
+    g = golden('cube_mesh_literal')
+    system = build(g, torch.float64)
+    x = torch.tensor(g['x'][::2], dtype=torch.float64, device='cuda:0').clone().requires_grad_(True)
+    w = torch.randn(x.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(x.device)
+    system.zero_grad()
+    (system.step(x) * w).sum().backward()
+
+    def total(xs):
+        with torch.no_grad():
+            return (system.step(xs) * w).sum(-1)
+    h = 1e-6
+    fd = torch.zeros_like(x)
+    for k in range(x.shape[1]):
+        e = torch.zeros_like(x)
+        e[:, k] = h
+        fd[:, k] = (total(x.detach() + e) - total(x.detach() - e)) / (2 * h)
+    rel = ((x.grad - fd).abs().max(-1).values / (fd.abs().max(-1).values + 1e-9)).cpu().numpy()
+    assert np.median(rel) < 1e-6 and (rel < 1e-4).sum() >= len(rel) - 2, rel
+    # parameters: all of theta and friction, a sample of every network tensor
+    gen = torch.Generator().manual_seed(4)
+    for name, p in system.named_parameters():
+        flat, grad = p.data.view(-1), p.grad.reshape(-1)
+        picks = range(flat.numel()) if flat.numel() <= 16 else torch.randint(0, flat.numel(), (6,), generator=gen).tolist()
+        for k in picks:
+            old = flat[k].item()
+            flat[k] = old + 1e-6
+            up = total(x.detach()).sum().item()
+            flat[k] = old - 1e-6
+            down = total(x.detach()).sum().item()
+            flat[k] = old
+            fdk = (up - down) / 2e-6
+            assert abs(grad[k].item() - fdk) <= 1e-5 * max(1.0, abs(fdk)) + 1e-7 * grad.abs().max().item(), (name, k, grad[k].item(), fdk)
+    # a 2-step rollout carries the graph through both steps
+    system.zero_grad()
+    x2 = x.detach().clone().requires_grad_(True)
+    traj, _ = system.simulate(x2.unsqueeze(-2), torch.zeros((x2.shape[0], 1), device='cuda:0'), 2)
+    (traj[:, -1] * w).sum().backward()
+    assert x2.grad is not None and torch.isfinite(x2.grad).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in system.parameters())

@@ -88,7 +88,7 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dpll_abi_version() == 6
+    assert lib.dpll_abi_version() == 7
     assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
