@@ -154,10 +154,10 @@ template <typename T> struct Acc { using type = double; };  // cone residual / y
 
 // Wave reduction of the items' d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
 // parameter per lane (lane l >= 1 carries d iota / d theta_(l-1) in `diota`): the row written is in parameter space.
-template <typename T, int NJ>
+template <typename T, int NJ, typename P = T>
 __device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, double loss_acc,
-                                                const T (&diota)[NJ + 1][kIota], const T* __restrict__ friction,
-                                                const T* __restrict__ lengths, double* __restrict__ partials) {
+                                                const T (&diota)[NJ + 1][kIota], const P* __restrict__ friction,
+                                                const P* __restrict__ lengths, double* __restrict__ partials) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<D::G>;
   const int lane = threadIdx.x;
@@ -408,6 +408,9 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
 // ---- adjoint of one simulation step with respect to the parameters (state = data) -----------------------
 // STATE: also the adjoint of the input state (n_x forward-mode passes of the terms, core step_state_adjoint)
 // MESH: witnesses from the ICNN kernels in, their adjoint r_bar out (as in the loss kernel)
+// The arithmetic is double for float storage too: lambda = H^-1 s at the dynamics' eps = 1e-4 amplifies float rounding of
+// H by its condition number (float32 state adjoints were off by 1e-3 .. 0.2 on items in contact), and this kernel is
+// not on the hot path.  The float loss kernel keeps its float arithmetic; only the step's backward pays for double.
 template <typename T, int NJ, bool STATE = false, bool MESH = false>
 __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                               const T* __restrict__ friction,
@@ -418,58 +421,66 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
                                                               long long ld_xb, const T* __restrict__ witness,
                                                               T* __restrict__ rbar_out) {
   using D = Dims<T, NJ>;
+  using C = double;
   using Lanes = GpuLanes<D::G>;
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
   const int slot = lane / D::G;
-  Derived<T, NJ> dp;
-  T diota[D::NB][kIota];
-  derive_params_seeded<T, NJ>(md, theta, friction, lengths, lane - 1, dp, diota);
-  LossGrad<T, NJ> acc;
+  C theta_c[D::NB * 10], friction_c[D::NB + 1], lengths_c[D::NB * 3];
+#pragma unroll
+  for (int i = 0; i < D::NB * 10; ++i) theta_c[i] = C(theta[i]);
+#pragma unroll
+  for (int i = 0; i < D::NB + 1; ++i) friction_c[i] = C(friction[i]);
+#pragma unroll
+  for (int i = 0; i < D::NB * 3; ++i) lengths_c[i] = lengths ? C(lengths[i]) : C(0);
+  Derived<C, NJ> dp;
+  C diota[D::NB][kIota];
+  derive_params_seeded<C, NJ>(md, theta_c, friction_c, lengths ? lengths_c : nullptr, lane - 1, dp, diota);
+  LossGrad<C, NJ> acc;
   zero_grad(acc);
   const long long stride = (long long)gridDim.x * D::IPW;
   for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
     const long long item = base + slot;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;
-    T xr[D::NX], gr[D::NX];
+    C xr[D::NX], gr[D::NX];
 #pragma unroll
-    for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; gr[i] = valid ? gx[it * ld_g + i] : T(0); }
-    LossGrad<T, NJ> g;
+    for (int i = 0; i < D::NX; ++i) { xr[i] = C(x[it * ld_x + i]); gr[i] = valid ? C(gx[it * ld_g + i]) : C(0); }
+    LossGrad<C, NJ> g;
     zero_grad(g);
-    T wit[1][3] = {{T(0), T(0), T(0)}}, rb[1][3] = {{T(0), T(0), T(0)}};
+    C wit[1][3] = {{C(0), C(0), C(0)}}, rb[1][3] = {{C(0), C(0), C(0)}};
     if constexpr (MESH) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
+      for (int i = 0; i < 3; ++i) wit[0][i] = C(witness[(it * D::K + cidx) * 3 + i]);
     }
-    T xb[D::NX];
+    C xb[D::NX];
 #pragma unroll
-    for (int i = 0; i < D::NX; ++i) xb[i] = T(0);
+    for (int i = 0; i < D::NX; ++i) xb[i] = C(0);
     if constexpr (STATE && MESH)
-      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, wit, rb, &xb);
+      step_item_backward<C, C, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, wit, rb, &xb);
     else if constexpr (STATE)
-      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, nullptr, nullptr, &xb);
+      step_item_backward<C, C, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, nullptr, nullptr, &xb);
     else if constexpr (MESH)
-      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, wit, rb);
+      step_item_backward<C, C, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g, wit, rb);
     else
-      step_item_backward<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
+      step_item_backward<C, C, NJ, 1, Lanes>(md, dp, opt, xr, cidx, gr, g);
     if constexpr (STATE) {
       if (valid && cidx == 0) {
 #pragma unroll
-        for (int i = 0; i < D::NX; ++i) xbar_out[it * ld_xb + i] = xb[i];
+        for (int i = 0; i < D::NX; ++i) xbar_out[it * ld_xb + i] = T(xb[i]);
       }
     }
     if constexpr (MESH) {
       if (valid) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
+        for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = T(rb[0][i]);
       }
     }
     // every lane of the group holds the item's d/d iota; d/d mu and d/d length are per contact
 #pragma unroll
     for (int b = 0; b < D::NB; ++b) {
 #pragma unroll
-      for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] += (cidx == 0) ? g.g_iota[b][i] : T(0);
+      for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] += (cidx == 0) ? g.g_iota[b][i] : C(0);
       acc.g_mu[b] += g.g_mu[b];
 #pragma unroll
       for (int i = 0; i < 3; ++i) acc.g_len[b][i] += g.g_len[b][i];
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
   for (int b = 0; b < D::NB; ++b)
 #pragma unroll
     for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] = Lanes::group_sum(acc.g_iota[b][i]);
-  store_param_row<T, NJ>(acc, 0.0, diota, friction, lengths, partials);
+  store_param_row<C, NJ, T>(acc, 0.0, diota, friction, lengths, partials);
 }
 
 // ---- MultibodyTerms.forward for API parity (off the hot path: the loss / step kernels never form D) ----
@@ -724,11 +735,11 @@ int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p,
   if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
     return fail(-3, "dpll_step_backward: workspace too small%s");
   if (grad_x)
-    hipLaunchKernelGGL((step_backward_kernel<T, NJ, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+    hipLaunchKernelGGL((step_backward_kernel<T, NJ, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[DPLL_F64],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
                        ld_g, batch, (double*)workspace, (T*)grad_x, ld_gx, (const T*)nullptr, (T*)nullptr);
   else
-    hipLaunchKernelGGL((step_backward_kernel<T, NJ, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+    hipLaunchKernelGGL((step_backward_kernel<T, NJ, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[DPLL_F64],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
                        ld_g, batch, (double*)workspace, (T*)nullptr, 0LL, (const T*)nullptr, (T*)nullptr);
   if (int rc = check_launch("step_backward_kernel")) return rc;
@@ -906,7 +917,7 @@ int launch_mesh_step_backward(const dpll_model* m, int dtype, const dpll_params_
   if (int rc = mesh_forward<T>(pl, w, ws, (const T*)x, ld_x, stream, true)) return rc;
 #define DPLL_LAUNCH_SB(STATE_)                                                                                             \
   hipLaunchKernelGGL((step_backward_kernel<T, 0, STATE_, true>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc,    \
-                     m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x,      \
+                     m->opts[DPLL_F64], (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x,      \
                      (const T*)gx, ld_g, batch, (double*)(ws + pl.off_rows), (T*)grad_x, ld_gx, (const T*)(ws + pl.off_P), \
                      (T*)(ws + pl.off_RB))
   if (grad_x) DPLL_LAUNCH_SB(true);

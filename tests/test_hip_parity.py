@@ -335,3 +335,23 @@ def test_random_states_and_parameters_match_oracle(urdf):
         x_next = system.step(xd).detach().cpu().double()
         step_err = (x_next - x_next_ref).abs().max(-1).values
         assert step_err.max().item() < TOL[dtype] * 10, (urdf, dtype, step_err.max().item())
+
+
+def test_state_adjoint_float32_matches_float64(golden):
+    """The float32 kernels' state adjoint and parameter gradient of one step against the float64 kernels on the
+    same inputs (the forward-mode passes run in double in both; what differs is y*, lambda and the seed)."""
+    for case in ('cube_box_literal', 'elbow_box_literal'):
+        g = golden(case)
+        grads = {}
+        for dtype in (torch.float64, torch.float32):
+            system = build_system(g, dtype)
+            x = dev(g['x'][::2], dtype).clone().requires_grad_(True)
+            w = torch.randn(x.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64).to(device=x.device, dtype=dtype)
+            system.zero_grad()
+            (system.step(x) * w).sum().backward()
+            grads[dtype] = (x.grad.double().cpu(), torch.cat([p.grad.reshape(-1) for p in system._param_list()]).double().cpu())
+        gx64, gp64 = grads[torch.float64]
+        gx32, gp32 = grads[torch.float32]
+        rel = ((gx32 - gx64).abs().max(-1).values / (gx64.abs().max(-1).values + 1e-9)).numpy()
+        assert np.median(rel) < 1e-4 and (rel < 5e-3).mean() > 0.9, (case, np.sort(rel)[-5:])
+        assert ((gp32 - gp64).abs() <= 5e-3 * gp64.abs().max()).all(), (case, (gp32 - gp64).abs().max(), gp64.abs().max())
