@@ -49,7 +49,9 @@ def load_pairs(batch: int, seed: int, workload: str = 'cube'):
 
 
 def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
-    """Oracle timing (checker code; measured, never shipped): float64 PyTorch CPU fwd+bwd."""
+    """Oracle timing (checker code; measured, never shipped): PyTorch CPU fwd+bwd of the restated reference path on
+    the box's host threads in float64 (the reference's dtype, dair_pll/inertia.py:96; the oracle's solver is not
+    tuned for float32, where it runs 10x slower), 3 warm-up passes then >= 10 timed passes."""
     from oracle import dpll_oracle as O
     threads = torch.get_num_threads()
     sample = min(1024, x.shape[0])
@@ -60,14 +62,15 @@ def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
         system.zero_grad()
         system.contactnets_loss(xs, xps).mean().backward()
 
-    one()
+    for _ in range(3):
+        one()
     reps, t0 = 0, time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t0 < budget_s and reps < 50):
+    while reps < 10 or (time.perf_counter() - t0 < budget_s and reps < 50):
         one()
         reps += 1
     elapsed = time.perf_counter() - t0
     return {'value': sample * reps / elapsed, 'unit': 'trajectory-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{reps} fwd+bwd passes over the first {sample} pairs of the workload, float64, '
+            'sample': f'{reps} fwd+bwd passes over the first {sample} pairs of the workload after 3 warm-up passes, float64, '
                       f'oracle/dpll_oracle.py (PyTorch CPU, {threads} threads)'}
 
 
