@@ -37,12 +37,16 @@ BYTES_PER_STEP = {('cube', 'f32'): 2 * 13 * 4 + 4, ('cube', 'f64'): 2 * 13 * 8 +
 
 def load_pairs(batch: int, seed: int, workload: str = 'cube'):
     """cube: the 4096 real cube pairs of the reference's data set committed as a fixture (inputs only
-    are used here); other batch sizes / ranks resample them with replacement.
+    are used here); ranks > 0 take them in a permuted order (weak scaling: every GPU gets the same mix of easy
+    and hard pairs), other batch sizes resample them with replacement.
     elbow: the 144 synthetic elbow-toss pairs of the elbow fixture, resampled to the batch size."""
     name = 'elbow_box_literal.npz' if workload == 'elbow' else 'cube_box_4096.npz'
     g = np.load(os.path.join(REPO, 'tests', 'golden', name))
     x, xp = g['x'], g['x_plus']
-    if batch != x.shape[0] or seed != 0:
+    if batch == x.shape[0] and seed != 0:
+        pick = np.random.default_rng(seed).permutation(batch)  # other ranks: the same pairs in another order
+        x, xp = x[pick], xp[pick]
+    elif batch != x.shape[0]:
         pick = np.random.default_rng(seed).integers(0, x.shape[0], size=batch)
         x, xp = x[pick], xp[pick]
     return x, xp, float(g['dt'])
@@ -233,7 +237,7 @@ def main() -> None:
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype + (' (cone residual accumulated in f64)' if args.dtype == 'f32' else ''),
             'data': ('fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set '
-                     '(tests/golden/cube_box_4096.npz, seed 0); ranks > 0 resample with replacement; URDF-initial parameters')
+                     '(tests/golden/cube_box_4096.npz, seed 0); ranks > 0 take the same pairs in a permuted order, other batch sizes resample with replacement; URDF-initial parameters')
             if args.workload == 'cube' else 'synthetic elbow tosses (tests/golden/elbow_box_literal.npz) resampled with replacement',
             'config': {'workload': (f'contactnets_cube.urdf, 4 friction contacts, batch={args.batch} per GPU, '
                                     f'fwd+bwd contactnets_loss') if args.workload == 'cube' else
