@@ -68,6 +68,7 @@ static_assert(kMaxJoints == DPLL_MAX_JOINTS && kMaxBodies == DPLL_MAX_BODIES, "l
 
 constexpr int kWave = 64;
 constexpr int kMaxLossBlocks = 2048;  // partial-sum rows; 8 one-wave workgroups per CU
+constexpr int kSimds = 1024;          // 256 CUs x 4
 
 // ---- cross-lane primitives --------------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
@@ -198,8 +199,11 @@ __device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, doub
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
 // MESH: the contact's support point is read from `witness` (ICNN kernels) and its adjoint written to `rbar_out`;
 // a template flag so that the box kernels carry none of it (a run-time choice of array put both in scratch).
-template <typename T, int NJ, bool MESH = false>
-__global__ __launch_bounds__(kWave) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+// DENSE: built for two waves per SIMD (<= 256 registers, a few spills) -- for launches with more waves than SIMDs, where
+// a second resident wave fills the issue slots a lone wave leaves empty (65,536 pairs: 800 -> 944 M steps/s); the
+// headline launch (256 waves) keeps the roomier one-wave build (it is 1 % faster there).
+template <typename T, int NJ, bool MESH = false, bool DENSE = false>
+__global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
                                                      const T* __restrict__ x, long long ld_x,
                                                      const T* __restrict__ xp, long long ld_xp, long long batch,
@@ -649,10 +653,16 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   } else if (loss_total) {
     return fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
   }
-  hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                     ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                     want_grad, (const T*)nullptr, (T*)nullptr);
+  if (blocks > kSimds)  // more waves than SIMDs: the two-waves-per-SIMD build
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
+  else
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
     if (ar)
