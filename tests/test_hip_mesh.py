@@ -188,3 +188,28 @@ def test_mesh_step_gradients_match_finite_differences(golden):
     (traj[:, -1] * w).sum().backward()
     assert x2.grad is not None and torch.isfinite(x2.grad).all()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in system.parameters())
+
+
+@pytest.mark.parametrize('batch', [1, 5, 33])
+def test_mesh_ragged_batches(golden, batch):
+    """Batches that do not fill a 32-row query tile or a slab: per-item losses equal those of the full fixture
+    batch, and the gradient of their mean equals the weighted full-batch gradient (float32 MFMA path and float64)."""
+    g = golden('cube_mesh_literal')
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        system = build(g, dtype)
+        x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+        xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+        u = torch.zeros((x.shape[0], 0), device='cuda:0')
+        full = system.contactnets_loss(x, u, xp).detach()
+        part = system.contactnets_loss(x[:batch], u[:batch], xp[:batch])
+        assert (part.detach() - full[:batch]).abs().max().item() <= tol * max(1.0, full.abs().max().item())
+        system.zero_grad()
+        part.mean().backward()
+        g_part = [p.grad.clone() for p in system.parameters()]
+        system.zero_grad()
+        weights = torch.zeros(x.shape[0], dtype=dtype, device='cuda:0')
+        weights[:batch] = 1.0 / batch
+        (system.contactnets_loss(x, u, xp) * weights).sum().backward()
+        for a, (name, p) in zip(g_part, system.named_parameters()):
+            scale = max(p.grad.abs().max().item(), 1e-12)
+            assert (a - p.grad).abs().max().item() <= (1e-9 if dtype == torch.float64 else 5e-3) * scale, (name, batch, dtype)
