@@ -1,0 +1,51 @@
+// Diagnostic: issue cost (cycles per instruction) of the instruction kinds of the Newton loop for ONE wave per SIMD.
+//   hipcc -O3 --offload-arch=gfx950 -o issue_cost issue_cost.hip && ./issue_cost
+#include <hip/hip_runtime.h>
+#include <cstdio>
+template <int MODE> __global__ void cost(float* out, unsigned long long* cycles, int iters) {
+  float a[16]; double d[16];
+  for (int i = 0; i < 16; ++i) { a[i] = threadIdx.x * 1e-3f + i + 1.f; d[i] = threadIdx.x * 1e-3 + i + 1.0; }
+  unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (MODE == 0) a[i] = __builtin_fmaf(a[i], 1.0001f, 1e-3f);
+      if (MODE == 1) d[i] = __builtin_fma(d[i], 1.0001, 1e-3);
+      if (MODE == 2) d[i] = d[i] + 1e-3;
+      if (MODE == 3) a[i] = __builtin_amdgcn_rsqf(a[i]) + 1.f;               // rsq + add
+      if (MODE == 4) a[i] = (float)((double)a[i] + 1e-3);                    // cvt f32->f64, add f64, cvt back
+      if (MODE == 5) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0xB1, 0xF, 0xF, true));  // DPP add
+      if (MODE == 6) a[i] = a[i] > 8.f ? a[i] * 0.5f : a[i] + 1.f;           // cmp + cndmask + 2 alu
+    }
+  }
+  unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += a[i] + (float)d[i];
+  out[blockIdx.x * 64 + threadIdx.x] = s;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+int main() {
+  float* out; unsigned long long* cyc; unsigned long long h[256];
+  (void)hipMalloc(&out, 256 * 64 * 4); (void)hipMalloc(&cyc, 256 * 8);
+  const int iters = 2048;
+  const char* names[7] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add"};
+  const int per[7] = {1, 1, 1, 2, 3, 1, 4};
+  for (int mode = 0; mode < 7; ++mode) {
+    for (int rep = 0; rep < 2; ++rep) {
+      switch (mode) {
+        case 0: hipLaunchKernelGGL(cost<0>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 1: hipLaunchKernelGGL(cost<1>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 2: hipLaunchKernelGGL(cost<2>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 3: hipLaunchKernelGGL(cost<3>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 4: hipLaunchKernelGGL(cost<4>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 5: hipLaunchKernelGGL(cost<5>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        default: hipLaunchKernelGGL(cost<6>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+      }
+      (void)hipDeviceSynchronize();
+    }
+    (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double mean = 0; for (int i = 0; i < 256; ++i) mean += (double)h[i]; mean /= 256;
+    printf("%-44s %.2f cycles per group of %d instruction(s) (16 independent chains)\n", names[mode], mean / iters / 16, per[mode]);
+  }
+  return 0;
+}
