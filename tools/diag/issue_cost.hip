@@ -16,6 +16,10 @@ template <int MODE> __global__ void cost(float* out, unsigned long long* cycles,
       if (MODE == 4) a[i] = (float)((double)a[i] + 1e-3);                    // cvt f32->f64, add f64, cvt back
       if (MODE == 5) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0xB1, 0xF, 0xF, true));  // DPP add
       if (MODE == 6) a[i] = a[i] > 8.f ? a[i] * 0.5f : a[i] + 1.f;           // cmp + cndmask + 2 alu
+      if (MODE == 7) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x141, 0xF, 0xF, true));  // row_half_mirror
+      if (MODE == 8) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x111, 0xF, 0xF, true));  // row_shr:1
+      if (MODE == 9) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a[i]), 0x80B1));                   // ds_swizzle quad xor 1 + add
+      if (MODE == 10) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((threadIdx.x ^ 1) << 2), __builtin_bit_cast(int, a[i])));  // ds_bpermute + add
     }
   }
   unsigned long long t1 = __builtin_readcyclecounter();
@@ -28,9 +32,9 @@ int main() {
   float* out; unsigned long long* cyc; unsigned long long h[256];
   (void)hipMalloc(&out, 256 * 64 * 4); (void)hipMalloc(&cyc, 256 * 8);
   const int iters = 2048;
-  const char* names[7] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add"};
-  const int per[7] = {1, 1, 1, 2, 3, 1, 4};
-  for (int mode = 0; mode < 7; ++mode) {
+  const char* names[11] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add", "v_add_f32_dpp (row_half_mirror)", "v_add_f32_dpp (row_shr:1)", "ds_swizzle_b32 + v_add_f32", "ds_bpermute_b32 + v_add_f32"};
+  const int per[11] = {1, 1, 1, 2, 3, 1, 4, 1, 1, 2, 2};
+  for (int mode = 0; mode < 11; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       switch (mode) {
         case 0: hipLaunchKernelGGL(cost<0>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
@@ -39,7 +43,11 @@ int main() {
         case 3: hipLaunchKernelGGL(cost<3>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
         case 4: hipLaunchKernelGGL(cost<4>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
         case 5: hipLaunchKernelGGL(cost<5>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        default: hipLaunchKernelGGL(cost<6>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 6: hipLaunchKernelGGL(cost<6>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 7: hipLaunchKernelGGL(cost<7>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 8: hipLaunchKernelGGL(cost<8>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 9: hipLaunchKernelGGL(cost<9>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        default: hipLaunchKernelGGL(cost<10>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
       }
       (void)hipDeviceSynchronize();
     }
