@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 #include <type_traits>
 
 #include "../../include/dpll.h"
@@ -90,15 +91,17 @@ constexpr int kRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
 constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
 
 template <int G> struct GpuLanes {
-  static_assert(G == 4 || G == 8, "one lane per contact: 4 (one body) or 8 (two bodies)");
+  static_assert(G == 1 || G == 4 || G == 8, "lanes per item: one per contact (4 or 8), or 1 (wide build)");
   static constexpr int kGroup = G;
   template <typename T> static __device__ __forceinline__ T group_sum(T x) {
+    if (G == 1) return x;
     x += dpp_mov<kQuadXor1>(x);
     x += dpp_mov<kQuadXor2>(x);
     if (G == 8) x += dpp_mov<kRowHalfMirror>(x);  // both quads hold their own sum -> mirror pairs them
     return x;
   }
   static __device__ __forceinline__ bool group_any(bool x) {
+    if (G == 1) return x;
     const unsigned long long b = __ballot(x);
     const int base = (threadIdx.x & (kWave - 1)) & ~(G - 1);
     return ((b >> base) & ((1ull << G) - 1ull)) != 0ull;
@@ -132,7 +135,11 @@ __device__ __forceinline__ double read_lane63(double x) {
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x) {
-  if (G == 4) x += dpp_mov<kRowHalfMirror>(x);
+  if (G == 1) {
+    x += dpp_mov<kQuadXor1>(x);
+    x += dpp_mov<kQuadXor2>(x);
+  }
+  if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
   x += dpp_mov<kRowMirror>(x);
   x += dpp_rows<kRowBcast15, 0xA>(x);
   x += dpp_rows<kRowBcast31, 0xC>(x);
@@ -155,24 +162,24 @@ template <typename T> struct Acc { using type = double; };  // cone residual / y
 
 // Wave reduction of the items' d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
 // parameter per lane (lane l >= 1 carries d iota / d theta_(l-1) in `diota`): the row written is in parameter space.
-template <typename T, int NJ, typename P = T>
+template <typename T, int NJ, typename P = T, int G = Dims<T, NJ>::G>
 __device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, double loss_acc,
                                                 const T (&diota)[NJ + 1][kIota], const P* __restrict__ friction,
                                                 const P* __restrict__ lengths, double* __restrict__ partials) {
   using D = Dims<T, NJ>;
-  using Lanes = GpuLanes<D::G>;
+  using Lanes = GpuLanes<G>;
   const int lane = threadIdx.x;
-  const double loss_sum = wave_sum_of_groups<D::G>(Lanes::group_sum(loss_acc));
+  const double loss_sum = wave_sum_of_groups<G>(Lanes::group_sum(loss_acc));
   double s_mu[D::NB], s_len[D::NB * 3];
   double theta_bar = 0.0;
 #pragma unroll
   for (int b = 0; b < D::NB; ++b) {
 #pragma unroll
     for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
-      theta_bar += double(wave_sum_of_groups<D::G>(acc.g_iota[b][i])) * double(diota[b][i]);
-    s_mu[b] = double(wave_sum_of_groups<D::G>(Lanes::group_sum(acc.g_mu[b])));
+      theta_bar += double(wave_sum_of_groups<G>(acc.g_iota[b][i])) * double(diota[b][i]);
+    s_mu[b] = double(wave_sum_of_groups<G>(Lanes::group_sum(acc.g_mu[b])));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = double(wave_sum_of_groups<D::G>(Lanes::group_sum(acc.g_len[b][i])));
+    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = double(wave_sum_of_groups<G>(Lanes::group_sum(acc.g_len[b][i])));
   }
   const int k = lane - 1;
   double fr[D::NB + 1], ln[D::NB * 3];
@@ -286,6 +293,58 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
   if (!want_grad) return;
   store_param_row<T, NJ>(acc, loss_acc, diota, friction, lengths, partials);
   DPLL_STAMP(3);
+}
+
+// Wide build: ONE lane per item, all of its contacts in that lane (the core templates with KPL = K, as the host build
+// runs them).  No cross-lane sums inside the solver (a DPP add costs 9.5 cycles against 4 for plain arithmetic, DESIGN
+// section 4) and 64 items per wave instead of 16, at the price of a ~2x longer serial chain per iteration: for launches
+// far beyond one wave per SIMD only (launch_loss picks it from 65,536 pairs of the one-body model).
+template <typename T, int NJ>
+__global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                          const T* __restrict__ x, long long ld_x,
+                                                          const T* __restrict__ xp, long long ld_xp, long long batch,
+                                                          const T* __restrict__ weights, double scale, T* __restrict__ loss,
+                                                          T* __restrict__ force, int* __restrict__ iters,
+                                                          double* __restrict__ partials, int want_grad) {
+  using D = Dims<T, NJ>;
+  using Lanes = GpuLanes<1>;
+  const int lane = threadIdx.x;
+  Derived<T, NJ> dp;
+  T diota[D::NB][kIota];
+  derive_params_seeded<T, NJ>(md, theta, friction, lengths, lane - 1, dp, diota);
+  LossGrad<T, NJ> acc;
+  zero_grad(acc);
+  double loss_acc = 0.0;
+  const long long stride = (long long)gridDim.x * kWave;
+  for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
+    const long long item = base + lane;
+    const bool valid = item < batch;
+    const long long it = valid ? item : batch - 1;
+    T xr[D::NX], xpr[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
+    const T w = valid ? T(scale) * (weights ? weights[it] : T(1)) : T(0);
+    T f[D::K][3];
+    int n_it = 0;
+    const T L = loss_item<T, typename Acc<T>::type, NJ, D::K, Lanes>(md, dp, opt, xr, xpr, 0, w, want_grad != 0, acc, f, n_it);
+    if (valid) {
+      if (loss) loss[it] = L;
+      if (iters) iters[it] = n_it;
+      if (force) {
+        T* row = force + it * (3 * D::K);
+#pragma unroll
+        for (int c = 0; c < D::K; ++c) {
+          row[c] = f[c][2];
+          row[D::K + 2 * c] = f[c][0];
+          row[D::K + 2 * c + 1] = f[c][1];
+        }
+      }
+    }
+    loss_acc += double(w) * double(L);
+  }
+  if (!want_grad) return;
+  store_param_row<T, NJ, T, 1>(acc, loss_acc, diota, friction, lengths, partials);
 }
 
 // sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype.
@@ -653,7 +712,20 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   } else if (loss_total) {
     return fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
   }
-  if (blocks > kSimds)  // more waves than SIMDs: the two-waves-per-SIMD build
+  // wide build (one lane per item): from 65,536 pairs of the one-body float model, where it has a wave for every SIMD
+  // (measured: 16,384 pairs 398 vs 524 M steps/s, 32,768 pairs level, 65,536 pairs 1340 vs 934, 262,144 pairs 1723 vs 1221);
+  // the two-body and double instantiations spill (1.4-3.2 KB of scratch) and stay on the lane-per-contact builds
+  const char* wide_env = std::getenv("DPLL_WIDE");  // diagnostic override: 1 = always the wide build, 0 = never
+  const bool wide = wide_env ? wide_env[0] == '1' : (std::is_same<T, float>::value && NJ == 0 && batch >= 65536);
+  int rows = blocks;
+  if (wide) {
+    long long wb = (batch + kWave - 1) / kWave;
+    rows = (int)(wb > kMaxLossBlocks ? kMaxLossBlocks : wb);
+    hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), dim3(rows), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad);
+  } else if (blocks > kSimds)  // more waves than SIMDs: the two-waves-per-SIMD build
     hipLaunchKernelGGL((loss_kernel<T, NJ, false, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
@@ -667,10 +739,10 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   if (want_grad) {
     if (ar)
       hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         blocks, (T*)grad, (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
+                         rows, (T*)grad, (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
     else
       hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         blocks, (T*)grad, (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                         rows, (T*)grad, (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (int rc = check_launch("finalize_kernel")) return rc;
   }
   return 0;

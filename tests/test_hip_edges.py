@@ -98,7 +98,14 @@ def test_full_size_properties_65536():
     xb, xpb = x[pick], xp[pick]
     base = system.contact_forces(x, xp)[0]
     big = system.contact_forces(xb, xpb)[0]
-    assert torch.equal(big, base[pick])  # same item -> bitwise the same loss wherever it sits in the batch
+    # 65,536 pairs run the one-lane-per-item build, 4096 the lane-per-contact build: same item, same loss to float
+    # rounding (the sums over its contacts are taken in a different order) ...
+    assert (big - base[pick]).abs().max() <= 2e-6 * base.abs().max()
+    # ... and bitwise the same wherever it sits in a batch of the same size
+    where = torch.randperm(65536, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(3))
+    assert torch.equal(system.contact_forces(xb[where], xpb[where])[0], big[where])
+    small = system.contact_forces(x[:1000], xp[:1000])[0]
+    assert torch.equal(small, base[:1000])
     t1 = system.contactnets_loss_and_grad(xb, xpb).clone()
     g1 = system.grad_buffer().clone()
     perm = torch.randperm(65536, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(2))
