@@ -698,20 +698,12 @@ struct dpll_model {
 
 namespace {
 
+// Picks the build of the loss kernel for this launch and launches it; returns the number of partial rows written.
 template <typename T, int NJ>
-int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
-                long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* grad,
-                void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
-                hipStream_t stream, const dpll_ar* ar = nullptr) {
-  using D = Dims<T, NJ>;
+int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
+                       long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* force,
+                       int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
   const int blocks = loss_blocks<T, NJ>(batch);
-  const int want_grad = grad != nullptr;
-  if (want_grad) {
-    if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
-      return fail(-3, "dpll_contactnets_loss: workspace too small%s");
-  } else if (loss_total) {
-    return fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
-  }
   // wide build (one lane per item): from 65,536 pairs of the one-body float model, where it has a wave for every SIMD
   // (measured: 16,384 pairs 398 vs 524 M steps/s, 32,768 pairs level, 65,536 pairs 1340 vs 934, 262,144 pairs 1723 vs 1221);
   // the two-body and double instantiations spill (1.4-3.2 KB of scratch) and stay on the lane-per-contact builds
@@ -735,6 +727,25 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
+  return rows;
+}
+
+template <typename T, int NJ>
+int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
+                long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* grad,
+                void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
+                hipStream_t stream, const dpll_ar* ar = nullptr) {
+  using D = Dims<T, NJ>;
+  const int blocks = loss_blocks<T, NJ>(batch);
+  const int want_grad = grad != nullptr;
+  if (want_grad) {
+    if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+      return fail(-3, "dpll_contactnets_loss: workspace too small%s");
+  } else if (loss_total) {
+    return fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
+  }
+  const int rows = launch_loss_kernel<T, NJ>(m, dtype, p, x, ld_x, xp, ld_xp, batch, weights, scale, loss, force, iters, workspace,
+                                             want_grad, stream);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
     if (ar)
@@ -762,11 +773,10 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
   // `reps` loss kernels back to back, then `reps` (loss, finalize) pairs; finalize = the difference
   hipEvent_t ev[4];
   for (int i = 0; i < 4; ++i) (void)hipEventCreate(&ev[i]);
+  int rows = blocks;
   auto launch_loss_only = [&]() {
-    hipLaunchKernelGGL((loss_kernel<T, NJ>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x,
-                       (const T*)xp, ld_xp, batch, (const T*)nullptr, scale, (T*)nullptr, (T*)nullptr, (int*)nullptr,
-                       (double*)workspace, 1, (const T*)nullptr, (T*)nullptr);
+    rows = launch_loss_kernel<T, NJ>(m, dtype, p, x, ld_x, xp, ld_xp, batch, nullptr, scale, nullptr, nullptr, nullptr, workspace, 1,
+                                     stream);
   };
   (void)hipEventRecord(ev[0], stream);
   for (int r = 0; r < reps; ++r) launch_loss_only();
@@ -775,7 +785,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
   for (int r = 0; r < reps; ++r) {
     launch_loss_only();
     hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                       blocks, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       rows, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
   }
   (void)hipEventRecord(ev[3], stream);
   int rc = check_launch("profile launches");
