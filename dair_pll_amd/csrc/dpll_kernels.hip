@@ -382,7 +382,8 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
   const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
   // uniform branch (n_rows is a kernel argument): the headline grid has 256 rows = 8 per thread
   const double s = n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, col, rowg)
-                                 : finalize_column<kFinalizeLoads>(partials, n_rows, D::PI, col, rowg);
+                   : n_rows <= 1024 ? finalize_column<32>(partials, n_rows, D::PI, col, rowg)
+                                    : finalize_column<kFinalizeLoads>(partials, n_rows, D::PI, col, rowg);
   red[rowg][col] = s;
   __syncthreads();
   T value = T(0);
