@@ -128,3 +128,23 @@ def test_errors_are_loud():
         system.contactnets_loss(x.cpu(), torch.zeros((8, 0)), xp.cpu())
     with pytest.raises(_capi.DpllError):
         system.contactnets_loss(x[:0], torch.zeros((0, 0), device='cuda:0'), xp[:0])
+
+
+def test_wide_build_matches_chunks_with_weights():
+    """70,001 pairs (the one-lane-per-item build, a ragged last wave) with per-item upstream gradients through the
+    autograd path against the same pairs in chunks of 4096 (lane-per-contact build): same weighted gradient."""
+    system = cube(torch.float32)
+    x, xp, _ = pairs(dtype=torch.float32)
+    n = 70001
+    pick = torch.randint(0, 4096, (n,), device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(5))
+    xb, xpb = x[pick], xp[pick]
+    w = torch.rand(n, device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(6))
+    u = torch.zeros((n, 0), device='cuda:0')
+    system.zero_grad()
+    (system.contactnets_loss(xb, u, xpb) * w).sum().backward()
+    whole = torch.cat([p.grad.reshape(-1) for p in system._param_list()]).clone()
+    system.zero_grad()
+    for i in range(0, n, 4096):
+        (system.contactnets_loss(xb[i:i + 4096], u[i:i + 4096], xpb[i:i + 4096]) * w[i:i + 4096]).sum().backward()
+    chunks = torch.cat([p.grad.reshape(-1) for p in system._param_list()])
+    assert (whole - chunks).abs().max() <= 1e-5 * chunks.abs().max()
