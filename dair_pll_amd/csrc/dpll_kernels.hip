@@ -705,11 +705,12 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* force,
                        int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
   const int blocks = loss_blocks<T, NJ>(batch);
-  // wide build (one lane per item): from 65,536 pairs of the one-body float model, where it has a wave for every SIMD
-  // (measured: 16,384 pairs 398 vs 524 M steps/s, 32,768 pairs level, 65,536 pairs 1340 vs 934, 262,144 pairs 1723 vs 1221);
-  // the two-body and double instantiations spill (1.4-3.2 KB of scratch) and stay on the lane-per-contact builds
+  // wide build (one lane per item): from 65,536 pairs, where it has a wave for every SIMD.  Measured, lane-per-contact
+  // builds vs wide, M steps/s: cube f32 16,384 pairs 524 vs 398, 32,768 level, 65,536 934 vs 1340, 262,144 1221 vs 1723;
+  // at 65,536: cube f64 423 vs 684, elbow f32 293 vs 476 (0.5-1.4 KB of scratch spills and still ahead); elbow f64
+  // 118 vs 85 (3.2 KB of spills): that one stays on the lane-per-contact builds
   const char* wide_env = std::getenv("DPLL_WIDE");  // diagnostic override: 1 = always the wide build, 0 = never
-  const bool wide = wide_env ? wide_env[0] == '1' : (std::is_same<T, float>::value && NJ == 0 && batch >= 65536);
+  const bool wide = wide_env ? wide_env[0] == '1' : (batch >= 65536 && !(std::is_same<T, double>::value && NJ == 1));
   int rows = blocks;
   if (wide) {
     long long wb = (batch + kWave - 1) / kWave;
