@@ -148,3 +148,28 @@ def test_wide_build_matches_chunks_with_weights():
         (system.contactnets_loss(xb[i:i + 4096], u[i:i + 4096], xpb[i:i + 4096]) * w[i:i + 4096]).sum().backward()
     chunks = torch.cat([p.grad.reshape(-1) for p in system._param_list()])
     assert (whole - chunks).abs().max() <= 1e-5 * chunks.abs().max()
+
+
+@pytest.mark.parametrize('urdf,case,dtype', [('cube.urdf', 'cube_box_literal', torch.float64),
+                                             ('elbow.urdf', 'elbow_box_literal', torch.float32),
+                                             ('elbow.urdf', 'elbow_box_literal', torch.float64)])
+def test_wide_and_lane_per_contact_builds_agree(monkeypatch, urdf, case, dtype):
+    """DPLL_WIDE forces the one-lane-per-item build (1) or forbids it (0) for any batch size: per-item losses, forces,
+    iteration counts and the batch gradient of both builds agree to rounding on the reference-run fixtures."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    g = np.load(os.path.join(GOLDEN_DIR, case + '.npz'))
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, urdf)}, float(g['dt']), dtype=dtype, device='cuda:0')
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    out = {}
+    for wide in ('0', '1'):
+        monkeypatch.setenv('DPLL_WIDE', wide)
+        loss, force, iters = system.contact_forces(x, xp)
+        system.contactnets_loss_and_grad(x, xp)
+        out[wide] = (loss.clone(), force.clone(), iters.clone(), system.grad_buffer().clone())
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    assert (out['0'][0] - out['1'][0]).abs().max() <= tol * max(1.0, out['0'][0].abs().max().item())
+    assert (out['0'][1] - out['1'][1]).abs().max() <= (1e-8 if dtype == torch.float64 else 1e-3) * max(1.0, out['0'][1].abs().max().item())
+    assert (out['0'][2] - out['1'][2]).abs().max() <= 1
+    assert (out['0'][3] - out['1'][3]).abs().max() <= (1e-9 if dtype == torch.float64 else 2e-3) * out['0'][3].abs().max()
+    assert np.abs(out['1'][0].cpu().double().numpy() - g['loss']).max() < (1e-10 if dtype == torch.float64 else 1e-4)
