@@ -14,6 +14,7 @@ from .urdf import ModelSpec, check_supported
 MAX_JOINTS = 2
 MAX_BODIES = 3
 F32, F64 = 0, 1
+ABI_VERSION = 8  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,7 +32,8 @@ class SolverOpts(ctypes.Structure):
     """``dpll_solver_opts_t``"""
     _fields_ = [('max_iter', c_int32), ('max_ls', c_int32), ('tol', c_double), ('stall_tol', c_double),
                 ('ls_tol', c_double), ('n_stages', c_int32), ('stage_max_iter', c_int32), ('stage_factor', c_double),
-                ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('fast_ls', c_int32)]
+                ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('fast_ls', c_int32),
+                ('warm_start', c_int32), ('wide', c_int32)]
 
 
 class Params(ctypes.Structure):
@@ -79,6 +81,9 @@ def library() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     lib.dpll_last_error.restype = c_char_p
     lib.dpll_abi_version.restype = c_int
+    if lib.dpll_abi_version() != ABI_VERSION:  # a stale build with another argument layout must not load silently
+        raise DpllError(f'{LIB_PATH} has ABI version {lib.dpll_abi_version()}, this binding needs {ABI_VERSION}: rebuild it '
+                        f'(`make -C {os.path.join(_HERE, "csrc")}`)')
     lib.dpll_model_create.argtypes = [POINTER(ModelDesc), POINTER(c_void_p)]
     lib.dpll_model_destroy.argtypes = [c_void_p]
     lib.dpll_model_destroy.restype = None

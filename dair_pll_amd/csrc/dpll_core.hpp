@@ -36,6 +36,11 @@
 #endif
 
 #define DPLL_UNROLL _Pragma("unroll")
+#if defined(__clang__)
+#define DPLL_NOUNROLL _Pragma("clang loop unroll(disable)")
+#else
+#define DPLL_NOUNROLL _Pragma("GCC unroll 1")
+#endif
 #ifndef DPLL_PHASE_BEGIN
 #define DPLL_PHASE_BEGIN() do {} while (0)
 #define DPLL_PHASE(slot) do {} while (0)
@@ -44,6 +49,9 @@
 #endif
 #ifndef DPLL_CORE_STAMP
 #define DPLL_CORE_STAMP(slot) do {} while (0)
+#endif
+#ifndef DPLL_ITER_HOOK  // host-side statistics of the solver (tests/hostsim): (iteration, item still active, step length taken)
+#define DPLL_ITER_HOOK(it, active, alpha) do {} while (0)
 #endif
 
 namespace dpll {
@@ -624,6 +632,11 @@ struct SolverOpts {
   // only gets the full search once the decrement has failed to drop by 4x twice in a row (the safeguard that keeps
   // the method globally convergent).
   int fast_ls;
+  // loss solve starts from y0 = dv, the observed velocity jump beyond free flight (on data the model explains,
+  // y* = M^-1 J^T f is close to it), instead of from zero; the dynamics solve has no such observation and ignores it
+  int warm_start;
+  // build of the loss kernel: -1 picked from the batch size, 0 always one lane per contact, 1 always one lane per item
+  int wide;
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
@@ -641,9 +654,44 @@ template <typename T, int N> DPLL_HD void cholesky_fast(const T (&A)[N][N], T (&
   }
 }
 
+// State of the solve at one iterate y, kept free of the regularisation: zs = -(J y + q) = eps z and gs = P_K(zs) =
+// eps P_K(z) (the cone is scale invariant, and so are the coefficients cp, a, b, that of the projection's Jacobian),
+// so a change of eps between continuation stages needs no re-evaluation.
+template <typename T, int NV, int KPL> struct SapPoint {
+  T zs[KPL][3];
+  Proj<T> pr[KPL];  // pr.g = gs
+  T yT[NV], My[NV];
+  T jtg[NV];        // sum_c J_c^T D_mu gs_c, summed over the lane group; [5] = sum of the normal components
+};
+
+template <typename T, typename TA, int NJ, int KPL, class Lanes>
+DPLL_HD void sap_evaluate(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL], const T (&mu)[KPL],
+                          const T (&qc)[KPL][3], const TA (&y)[6 + NJ], SapPoint<T, 6 + NJ, KPL>& p) {
+  constexpr int NV = 6 + NJ;
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) { p.yT[i] = T(y[i]); p.jtg[i] = T(0); }
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    TA jy[3];
+    cjac_apply<T, TA, NJ>(Jc[c], y, jy);
+    p.zs[c][0] = -T(TA(mu[c]) * jy[0] + TA(qc[c][0]));
+    p.zs[c][1] = -T(TA(mu[c]) * jy[1] + TA(qc[c][1]));
+    p.zs[c][2] = -T(jy[2] + TA(qc[c][2]));
+    lorentz_project(p.zs[c], p.pr[c]);
+    const T a[3] = {mu[c] * p.pr[c].g[0], mu[c] * p.pr[c].g[1], p.pr[c].g[2]};
+    cjac_apply_t_add<T, NJ>(Jc[c], a, p.jtg);
+  }
+  symv<T, NV>(M, p.yT, p.My);
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) p.jtg[i] = Lanes::group_sum(p.jtg[i]);
+}
+
+// One iteration: Newton direction d from the state at y, then the state at y + d is evaluated -- it is both the line
+// search's probe of alpha = 1 (l'(1) = grad(y + d) . d) and, when that step is accepted (99 % of the item-iterations on
+// the benchmark batch), the next iteration's starting state, so an accepted iteration costs one evaluation, one
+// Hessian and one Cholesky and nothing else.  Only when some item of the wave rejects alpha = 1 does the wave run the
+// derivative-based safeguarded search (re-projections of zs - alpha J d) and evaluate the state again at y + alpha d.
 template <typename T, typename TA, int NJ, int KPL, class Lanes>
 DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL], const T (&mu)[KPL],
-                       const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3]) {
+                       const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3],
+                       const T (&y0)[6 + NJ], bool use_y0) {
   constexpr int NV = 6 + NJ;
   const T tol2 = T(opt.tol * opt.tol), stol2 = T(opt.stall_tol * opt.stall_tol), ls_tol = T(opt.ls_tol);
   const T stage_tol2 = T(opt.stage_tol * opt.stage_tol), inv_factor = T(1.0 / opt.stage_factor);
@@ -653,7 +701,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
   int stage = 0, it_stage = 0;
   bool active = true;
   int iters = 0;
-  DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = TA(0);
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = use_y0 ? TA(y0[i]) : TA(0);
   // every lane of the group starts its share of the Hessian from M / group size (a power of two, so exact): the
   // group sum then returns M + sum_c ... without a separate addition per entry
   T Mshare[NV][NV];
@@ -661,39 +709,27 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     DPLL_UNROLL for (int j = 0; j <= i; ++j) Mshare[i][j] = M[i][j] * T(1.0 / Lanes::kGroup);
   T best = T(3.0e38);
   int stall = 0;
+  // two point states that swap roles every iteration (the loop below is unrolled by two so that "the state at y + d
+  // becomes the current state" costs no register moves)
+  SapPoint<T, NV, KPL> pa, pb;
+  sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, y, pa);
   DPLL_PHASE_BEGIN();
-  for (int it = 0; it < opt.max_iter; ++it) {
+  // one iteration from the state `cur` at y; leaves the state at the new y in `trial`; false = every item of the wave is done
+  auto iterate = [&](int it, const SapPoint<T, NV, KPL>& cur, SapPoint<T, NV, KPL>& trial) -> bool {
     DPLL_PHASE(5);
     const T ieps = fast_rcp(eps_c);
     const bool final_stage = stage >= last_stage;
-    // cone residuals z = -(J y + q) / eps, projections, J^T gamma
-    T z[KPL][3];
-    Proj<T> pr[KPL];
-    T yT[NV], jtg[NV];
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) { yT[i] = T(y[i]); jtg[i] = T(0); }
-    DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-      TA jy[3];
-      cjac_apply<T, TA, NJ>(Jc[c], y, jy);
-      z[c][0] = -T(TA(mu[c]) * jy[0] + TA(qc[c][0])) * ieps;
-      z[c][1] = -T(TA(mu[c]) * jy[1] + TA(qc[c][1])) * ieps;
-      z[c][2] = -T(jy[2] + TA(qc[c][2])) * ieps;
-      lorentz_project(z[c], pr[c]);
-      const T a[3] = {mu[c] * pr[c].g[0], mu[c] * pr[c].g[1], pr[c].g[2]};
-      cjac_apply_t_add<T, NJ>(Jc[c], a, jtg);
-    }
-    T My[NV], grad[NV];
-    symv<T, NV>(M, yT, My);
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) { jtg[i] = Lanes::group_sum(jtg[i]); grad[i] = My[i] - jtg[i]; }
-    // jtg[5] is now the sum of the normal forces: zero exactly when every contact sits in the polar region
-    const bool any_force = jtg[5] > T(0);
-    DPLL_PHASE(0);
+    T grad[NV];
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) grad[i] = cur.My[i] - ieps * cur.jtg[i];
+    // the sum of the normal forces is zero exactly when every contact sits in the polar region
+    const bool any_force = cur.jtg[5] > T(0);
     // Hessian H = M + sum_c [A 1 j]^T C [A 1 j],  C = D_mu dP D_mu / eps
     T H[NV][NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
       DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] = Mshare[i][j];
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
       T dP[6];
-      proj_jacobian(pr[c], dP);
+      proj_jacobian(cur.pr[c], dP);
       const T m1 = mu[c] * ieps, m2 = mu[c] * m1;
       const T C[3][3] = {{dP[0] * m2, dP[3] * m2, dP[4] * m1}, {dP[3] * m2, dP[1] * m2, dP[5] * m1}, {dP[4] * m1, dP[5] * m1, dP[2] * ieps}};
       T CA[3][3];
@@ -720,15 +756,15 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
         H[i][j] = Lanes::group_sum(H[i][j]);
         H[j][i] = H[i][j];
       }
-    DPLL_PHASE(1);
+    DPLL_PHASE(0);
     T L[NV][NV], invd[NV], d[NV];
     cholesky_fast<T, NV>(H, L, invd);
     chol_solve<T, NV>(L, invd, grad, d);
     DPLL_UNROLL for (int i = 0; i < NV; ++i) d[i] = -d[i];
-    DPLL_PHASE(2);
+    DPLL_PHASE(1);
     // Newton decrement and stopping rule (the step below is still taken: it only improves y)
     const T dec2 = -dotn<T, NV>(grad, d);
-    const T ynorm2 = dotn<T, NV>(yT, My);
+    const T ynorm2 = dotn<T, NV>(cur.yT, cur.My);
     const T scale = T(1) + tsqrt(tmax(ynorm2, T(0)));
     const T scale2 = scale * scale;
     const bool converged = !(dec2 > (final_stage ? tol2 : stage_tol2) * scale2);
@@ -738,74 +774,99 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     const bool stalled = stall >= 3 && !(dec2 > (final_stage ? stol2 : stage_tol2) * scale2);
     // no force at all and y stationary: the answer (y = 0 region-wise) does not depend on eps, skip the other stages
     const bool force_free = !(dec2 > T(0)) && !any_force;
-    // line search on l'(alpha) = y.Md + alpha d.Md - sum_c gamma_c(alpha) . (J_c d); from H d = -grad:
-    //   d.Md = dec2 - (1/eps) sum_c (J_c d)^T dP_c (J_c d)
-    T jd[KPL][3];
-    T curv = T(0);
-    DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-      T t[3];
-      cjac_apply<T, T, NJ>(Jc[c], d, t);
-      jd[c][0] = mu[c] * t[0];
-      jd[c][1] = mu[c] * t[1];
-      jd[c][2] = t[2];
-      curv += proj_quadratic(pr[c], jd[c]);
-    }
-    const T dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
-    const T yMd = dotn<T, NV>(My, d);
+    const bool moving = active && (dec2 > T(0));
     const T slope_tol = (final_stage ? ls_tol : T(opt.stage_ls_tol)) * dec2;  // |l'(0)| = dec2
     const int ls_full = final_stage ? opt.max_ls : opt.stage_max_ls;
     const int ls_cap = (opt.fast_ls > 0 && stall < 2) ? (opt.fast_ls < ls_full ? opt.fast_ls : ls_full) : ls_full;
-    T alpha = T(1), lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
-    bool searching = active && (dec2 > T(0));
+    DPLL_PHASE(2);
+    // The state at y + d: l'(1) = grad(y + d) . d.
+    TA yt[NV];
+    T alpha = T(1);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) yt[i] = y[i] + (moving ? TA(d[i]) : TA(0));
+    sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
+    T first1 = T(0);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) first1 += (trial.My[i] - ieps * trial.jtg[i]) * d[i];
+    // alpha = 1 stands when the slope there is small enough, and also -- while the search is capped at one probe --
+    // when l is still descending at 1 (the capped search would stop at its lower bracket, alpha = 1)
+    const bool reject = moving && !(tabs(first1) <= slope_tol) && (first1 > T(0) || ls_cap > 1);
     DPLL_PHASE(3);
-    // one probe: l'(alpha) and l''(alpha) by re-projecting the cone residuals, then a safeguarded Newton step on l'
-    auto probe = [&](int ls) {
-      T part1 = T(0), part2 = T(0);
-      const T step = alpha * ieps;
-      DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-        const T za[3] = {z[c][0] - step * jd[c][0], z[c][1] - step * jd[c][1], z[c][2] - step * jd[c][2]};
-        Proj<T> pa;
-        lorentz_project(za, pa);
-        part1 += pa.g[0] * jd[c][0] + pa.g[1] * jd[c][1] + pa.g[2] * jd[c][2];
-        part2 += proj_quadratic(pa, jd[c]);
-      }
-      const T first = yMd + alpha * dMd - Lanes::group_sum(part1);
-      const T second = dMd + ieps * Lanes::group_sum(part2);
-      bool ok = tabs(first) <= slope_tol;
-      const T lo_n = first < T(0) ? alpha : lo;
-      const T hi_n = first >= T(0) ? alpha : hi;
-      const T newton = alpha - first * fast_rcp(second);
-      const T mid = hi_n < T(0) ? T(2) * alpha : T(0.5) * (lo_n + hi_n);
-      const bool bad = !((newton > lo_n) && (hi_n < T(0) || newton < hi_n));
-      const T nxt = bad ? mid : newton;
-      ok = ok || (hi_n >= T(0) && (hi_n - lo_n) <= T(4) * (sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16)) * hi_n);
-      // out of probes: fall back to the largest alpha known to decrease l (l' < 0 on [0, lo])
-      const bool out = searching && !ok && (ls + 1 >= ls_cap);
-      lo = searching ? lo_n : lo;
-      hi = searching ? hi_n : hi;
-      alpha = (searching && !ok) ? (out ? (lo_n > T(0) ? lo_n : nxt) : nxt) : alpha;
-      searching = searching && !ok && !out;
-    };
-    probe(0);  // alpha = 1 is probed unconditionally (straight-line code); more probes are the exception
-    for (int ls = 1; ls < opt.max_ls; ++ls) {
-      if (!Lanes::wave_any(searching)) break;
+    if (Lanes::wave_any(reject)) {
       DPLL_PHASE_COUNT(6);
-      probe(ls);
+      // l'(alpha) = y.Md + alpha d.Md - sum_c gamma_c(alpha) . (J_c d); from H d = -grad:
+      //   d.Md = dec2 - (1/eps) sum_c (J_c d)^T dP_c (J_c d),      l''(alpha) = d.Md + (1/eps) sum_c (J_c d)^T dP_c(alpha) (J_c d)
+      T jd[KPL][3];
+      T curv = T(0), curv1 = T(0);
+      DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+        T t[3];
+        cjac_apply<T, T, NJ>(Jc[c], d, t);
+        jd[c][0] = mu[c] * t[0];
+        jd[c][1] = mu[c] * t[1];
+        jd[c][2] = t[2];
+        curv += proj_quadratic(cur.pr[c], jd[c]);
+        curv1 += proj_quadratic(trial.pr[c], jd[c]);
+      }
+      const T dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
+      // capped search, l'(1) > 0 (overshoot): one safeguarded Newton step on l' back from alpha = 1, whose projections
+      // are the trial state's
+      {
+        const T second1 = dMd + ieps * Lanes::group_sum(curv1);
+        const T newton = T(1) - first1 * fast_rcp(second1);
+        const T capped = (newton > T(0) && newton < T(1)) ? newton : T(0.5);
+        alpha = reject ? capped : alpha;
+      }
+      const bool full = reject && ls_cap > 1;
+      if (Lanes::wave_any(full)) {
+        // stalled items: the derivative-based bracketing search, re-projecting the cone residuals at every probe
+        const T yMd = dotn<T, NV>(cur.My, d);
+        T lo = T(0), hi = T(-1);  // hi < 0: no upper bracket yet
+        bool searching = full;
+        T a_s = T(1);
+        // one probe: l'(a) and l''(a) by re-projecting the cone residuals, then a safeguarded Newton step on l'
+        for (int ls = 0; ls < opt.max_ls; ++ls) {
+          if (!Lanes::wave_any(searching)) break;
+          DPLL_PHASE_COUNT(6);
+          T part1 = T(0), part2 = T(0);
+          DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+            const T za[3] = {cur.zs[c][0] - a_s * jd[c][0], cur.zs[c][1] - a_s * jd[c][1], cur.zs[c][2] - a_s * jd[c][2]};
+            Proj<T> pa;
+            lorentz_project(za, pa);
+            part1 += pa.g[0] * jd[c][0] + pa.g[1] * jd[c][1] + pa.g[2] * jd[c][2];
+            part2 += proj_quadratic(pa, jd[c]);
+          }
+          const T first = yMd + a_s * dMd - ieps * Lanes::group_sum(part1);
+          const T second = dMd + ieps * Lanes::group_sum(part2);
+          bool ok = tabs(first) <= slope_tol;
+          const T lo_n = first < T(0) ? a_s : lo;
+          const T hi_n = first >= T(0) ? a_s : hi;
+          const T newton = a_s - first * fast_rcp(second);
+          const T mid = hi_n < T(0) ? T(2) * a_s : T(0.5) * (lo_n + hi_n);
+          const bool bad = !((newton > lo_n) && (hi_n < T(0) || newton < hi_n));
+          const T nxt = bad ? mid : newton;
+          ok = ok || (hi_n >= T(0) && (hi_n - lo_n) <= T(4) * (sizeof(T) == 4 ? T(1.2e-7) : T(2.3e-16)) * hi_n);
+          // out of probes: fall back to the largest step known to decrease l (l' < 0 on [0, lo])
+          const bool out = searching && !ok && (ls + 1 >= ls_cap);
+          lo = searching ? lo_n : lo;
+          hi = searching ? hi_n : hi;
+          a_s = (searching && !ok) ? (out ? (lo_n > T(0) ? lo_n : nxt) : nxt) : a_s;
+          searching = searching && !ok && !out;
+        }
+        alpha = full ? a_s : alpha;
+      }
+      // The state at y + alpha d.  Items that kept alpha = 1 recompute the state they already have (same expressions,
+      // same values): an item's result does not depend on which other items share its wave.
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) yt[i] = y[i] + (moving ? TA(alpha) * TA(d[i]) : TA(0));
+      sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
     }
     DPLL_PHASE(4);
 #if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
     if (active) {
       printf("  it %2d stage %d eps %.2e dec2 %.3e scale %.3e alpha %.4f conv %d stall %d regions", it, stage, double(eps_c), double(dec2), double(scale), double(alpha), int(converged), stall);
-      for (int c = 0; c < KPL; ++c) printf(" %c", pr[c].inside ? 'I' : (pr[c].polar ? '0' : 'M'));
-      for (int c = 0; c < KPL; ++c) if (!pr[c].inside && !pr[c].polar) {
-        const double r = sqrt(double(z[c][0]) * z[c][0] + double(z[c][1]) * z[c][1]);
-        printf(" | c%d r %.4e n %.4e ang %.4f dz_t (%.3e %.3e) dz_n %.3e", c, r, double(z[c][2]), atan2(double(z[c][1]), double(z[c][0])), -double(ieps * jd[c][0]), -double(ieps * jd[c][1]), -double(ieps * jd[c][2]));
-      }
+      for (int c = 0; c < KPL; ++c) printf(" %c", cur.pr[c].inside ? 'I' : (cur.pr[c].polar ? '0' : 'M'));
       printf("\n");
     }
 #endif
-    const TA alpha_move = (active && (dec2 > T(0))) ? TA(alpha) : TA(0);
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] += alpha_move * TA(d[i]);
+    DPLL_ITER_HOOK(it, moving, alpha);
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = yt[i];
     iters = active ? it + 1 : iters;
     const bool stage_done = converged || stalled || (!final_stage && it_stage + 1 >= opt.stage_max_iter);
     const bool advance = active && !final_stage && stage_done && !force_free;
@@ -815,20 +876,21 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     it_stage = advance ? 0 : it_stage + 1;
     best = advance ? T(3.0e38) : best;
     stall = advance ? 0 : stall;
-    if (!Lanes::wave_any(active)) break;
+    return Lanes::wave_any(active);
+  };
+  bool in_b = false;  // which of the two holds the final state (wave uniform)
+  for (int it = 0; it < opt.max_iter; it += 2) {
+    in_b = true;
+    if (!iterate(it, pa, pb)) break;
+    if (it + 1 >= opt.max_iter) break;
+    in_b = false;
+    if (!iterate(it + 1, pb, pa)) break;
   }
   DPLL_PHASE_END();
-  // forces at the final iterate, with the reference's eps
+  // forces at the final iterate, with the reference's eps: f = P_K(zs / eps) = gs / eps
   const T ieps = fast_rcp(eps);
-  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    TA jy[3];
-    cjac_apply<T, TA, NJ>(Jc[c], y, jy);
-    const T z[3] = {-T(TA(mu[c]) * jy[0] + TA(qc[c][0])) * ieps, -T(TA(mu[c]) * jy[1] + TA(qc[c][1])) * ieps,
-                    -T(jy[2] + TA(qc[c][2])) * ieps};
-    Proj<T> p;
-    lorentz_project(z, p);
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) f[c][r] = p.g[r];
-  }
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c)
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) f[c][r] = (in_b ? pb.pr[c].g[r] : pa.pr[c].g[r]) * ieps;
   return iters;
 }
 
@@ -1036,7 +1098,7 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
   pen = Lanes::group_sum(pen);
   TA y[NV];
   DPLL_CORE_STAMP(4);
-  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, force);
+  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, force, dv, opt.warm_start != 0);
   DPLL_CORE_STAMP(5);
   // invalid-solve mask (multibody_learnable_system.py:186-192)
   bool bad = false;
@@ -1173,7 +1235,7 @@ DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const Solv
     qc[c][2] = jv[2] + cg.phi * idt;
   }
   TA y[NV];
-  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, impulse);
+  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, impulse, vm, false);
   // v+ = v- + M^-1 J^T impulse = v- + y*: the primal optimum IS that velocity change (M y* = J^T f), and
   // taking it from y instead of re-solving with the projected impulse avoids amplifying the impulse's
   // rounding error by |J|^2 / (eps M).
@@ -1250,7 +1312,7 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
   }
   TA y[NV];
   T gam[KPL][3];
-  sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, gam);
+  sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, gam, vm, false);
   T yT[NV], vn[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) { yT[i] = T(y[i]); vn[i] = T(TA(vm[i]) + y[i]); }
   // ---- seed: d/d v+ plus the pull-back of d/d q+ through q+ = q (+) v+ dt ------------------------

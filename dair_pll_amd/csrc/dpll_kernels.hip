@@ -146,6 +146,65 @@ template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x
   return read_lane63(x);
 }
 
+// Chain from the batch-summed row (iota space) to the learnable parameters [theta | friction | lengths]: linear in the
+// row, with a matrix that depends on the parameters only.  One EXTRA one-wave workgroup of every gradient kernel (it
+// owns no items and runs on a SIMD the launch leaves idle) writes that matrix behind the partial rows while the other
+// workgroups solve; the finalize kernel then applies it with <= 10 multiply-adds per parameter -- the theta -> iota
+// duals are on nobody's critical path.
+template <typename S> __device__ __forceinline__ void theta_jacobian_column(int inertia_mode, const S* theta_b, int c, S (&dio)[kIota]) {
+  DualT<S> th[10], io[kIota];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) th[i] = DualT<S>(theta_b[i], i == c ? S(1) : S(0));
+  theta_to_iota<DualT<S>>(th, inertia_mode, io);
+#pragma unroll
+  for (int i = 0; i < kIota; ++i) dio[i] = io[i].d;
+}
+template <typename T, typename P, int NB>
+__device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __restrict__ theta, const P* __restrict__ friction,
+                                                   const P* __restrict__ lengths, double* __restrict__ chain) {
+  const int lane = threadIdx.x;
+  if (lane < 10 * NB) {  // lane = (body, theta component c): column c of that body's Jacobian
+    T th[10], dio[kIota];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) th[i] = T(theta[10 * (lane / 10) + i]);
+    theta_jacobian_column<T>(inertia_mode, th, lane % 10, dio);
+#pragma unroll
+    for (int i = 0; i < kIota; ++i) chain[lane * kIota + i] = double(dio[i]);
+  }
+  double* fr_fac = chain + 100 * NB;
+  double* len_sign = fr_fac + (NB + 1) * NB;
+  if (lane < (NB + 1) * NB) {  // lane = (friction entry k, body b): d (2 m0 mb / (m0 + mb)) / d friction_k, mu = |friction|
+    const int k = lane / NB, b = lane % NB;
+    const double f0 = double(friction[0]), fb = double(friction[1 + b]);
+    const double m0 = fabs(f0), mb = fabs(fb);
+    const double den = (m0 + mb) * (m0 + mb);
+    const double pk = double(friction[k]);
+    const double sign = pk > 0.0 ? 1.0 : (pk < 0.0 ? -1.0 : 0.0);
+    double fac = 0.0;
+    if (k == 0) fac += 2.0 * mb * mb / den;
+    if (k == 1 + b) fac += 2.0 * m0 * m0 / den;
+    fr_fac[lane] = fac * sign;
+  }
+  if (lane < 3 * NB) {
+    const double pl = lengths ? double(lengths[lane]) : 0.0;
+    len_sign[lane] = pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0);
+  }
+}
+// learnable parameter k = sum_{j < count} tot[tot0 + j] * chain[coef0 + j] with the row sum `tot` ([loss | iota | mu_pair | length])
+struct ChainRow { int coef0, tot0, count; };
+template <int NB> __device__ __forceinline__ ChainRow chain_row(int k) {
+  if (k < 10 * NB) return ChainRow{k * kIota, 1 + kIota * (k / 10), kIota};
+  if (k < 10 * NB + NB + 1) return ChainRow{100 * NB + (k - 10 * NB) * NB, 1 + kIota * NB, NB};
+  const int i = k - (10 * NB + NB + 1);
+  return ChainRow{100 * NB + (NB + 1) * NB + i, 1 + (kIota + 1) * NB + i, 1};
+}
+template <int NB> __device__ __forceinline__ double apply_chain(const double* tot, const double* __restrict__ chain, int k) {
+  const ChainRow cr = chain_row<NB>(k);
+  double v = 0.0;
+  for (int j = 0; j < cr.count; ++j) v += tot[cr.tot0 + j] * chain[cr.coef0 + j];
+  return v;
+}
+
 }  // namespace
 #include "dpll_mesh_kernels.hpp"
 namespace {
@@ -154,53 +213,54 @@ template <typename T, int NJ> struct Dims {
   static constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NB, G = K;
   static constexpr int IPW = kWave / G;                       // items per wave
   static constexpr int P = NB * 10 + (NB + 1) + NB * 3;       // learnable parameters [theta | friction | lengths]
-  static constexpr int PI = 1 + P;                            // partial-sum row: [loss | d/d params]
+  static constexpr int PI = 1 + P;                            // row stride of the partial sums; the output row [loss | d/d params]
+  static constexpr int PIOTA = 1 + 14 * NB;                   // a partial row: [loss | d/d iota | d/d mu_pair | d/d |length|]
+  // the chain matrix behind the rows: [d iota_b,i / d theta_b,c (NB, 10 c, 10 i) | d mu_pair,b / d friction_k (NB + 1 k, NB b) |
+  // sign(length_params) (3 NB)], doubles
+  static constexpr int CHAIN = 100 * NB + (NB + 1) * NB + 3 * NB;
 };
 
 template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
 
 
-// Wave reduction of the items' d/d(iota, mu, |length|), then the chain to (theta, friction, lengths) with one
-// parameter per lane (lane l >= 1 carries d iota / d theta_(l-1) in `diota`): the row written is in parameter space.
-template <typename T, int NJ, typename P = T, int G = Dims<T, NJ>::G>
-__device__ __forceinline__ void store_param_row(const LossGrad<T, NJ>& acc, double loss_acc,
-                                                const T (&diota)[NJ + 1][kIota], const P* __restrict__ friction,
-                                                const P* __restrict__ lengths, double* __restrict__ partials) {
+// Wave reduction of the items' d/d(iota, mu_pair, |length|): one row [loss | d/d iota (10 NB) | d/d mu_pair (NB) |
+// d/d |length| (3 NB)] of double partial sums per wave, written by lane 63 (where the DPP row reduction lands).  The
+// chain to the learnable parameters (theta, friction_params, length_params) is linear in the row, so it runs ONCE on
+// the row sum in the finalize kernel instead of in every wave's prologue (forward-mode duals of theta -> iota cost
+// ~3.5 k cycles per wave there).  Row stride D::PI (>= 1 + 14 NB).
+template <int G, typename T> __device__ __forceinline__ T wave_sum_to_lane63(T x) {
+  if (G == 1) {
+    x += dpp_mov<kQuadXor1>(x);
+    x += dpp_mov<kQuadXor2>(x);
+  }
+  if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
+  x += dpp_mov<kRowMirror>(x);
+  x += dpp_rows<kRowBcast15, 0xA>(x);
+  x += dpp_rows<kRowBcast31, 0xC>(x);
+  return x;  // the total over the groups in lane 63; other lanes hold partial sums
+}
+
+template <typename T, int NJ, int G = Dims<T, NJ>::G>
+__device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ>& acc, double loss_acc, double* __restrict__ partials) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<G>;
-  const int lane = threadIdx.x;
-  const double loss_sum = wave_sum_of_groups<G>(Lanes::group_sum(loss_acc));
-  double s_mu[D::NB], s_len[D::NB * 3];
-  double theta_bar = 0.0;
+  double row[D::PIOTA];
+  row[0] = wave_sum_to_lane63<G>(Lanes::group_sum(loss_acc));
 #pragma unroll
   for (int b = 0; b < D::NB; ++b) {
 #pragma unroll
     for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
-      theta_bar += double(wave_sum_of_groups<G>(acc.g_iota[b][i])) * double(diota[b][i]);
-    s_mu[b] = double(wave_sum_of_groups<G>(Lanes::group_sum(acc.g_mu[b])));
+      row[1 + kIota * b + i] = double(wave_sum_to_lane63<G>(acc.g_iota[b][i]));
+    row[1 + kIota * D::NB + b] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_mu[b])));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s_len[b * 3 + i] = double(wave_sum_of_groups<G>(Lanes::group_sum(acc.g_len[b][i])));
+    for (int i = 0; i < 3; ++i)
+      row[1 + (kIota + 1) * D::NB + 3 * b + i] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[b][i])));
   }
-  const int k = lane - 1;
-  double fr[D::NB + 1], ln[D::NB * 3];
+  if (threadIdx.x == kWave - 1) {
+    double* dst = partials + (long long)blockIdx.x * D::PI;
 #pragma unroll
-  for (int i = 0; i < D::NB + 1; ++i) fr[i] = double(friction[i]);
-#pragma unroll
-  for (int i = 0; i < D::NB * 3; ++i) ln[i] = lengths ? double(lengths[i]) : 0.0;
-  double val = loss_sum;
-  if (k >= 0 && k < D::NB * 10) val = theta_bar;
-  // friction and length components: evaluate all (a handful of flops) and select, no runtime indexing
-#pragma unroll
-  for (int i = 0; i < D::NB + 1; ++i) {
-    const double c = friction_grad_component(D::NB, fr, s_mu, i);
-    val = (k == D::NB * 10 + i) ? c : val;
+    for (int i = 0; i < D::PIOTA; ++i) dst[i] = row[i];
   }
-#pragma unroll
-  for (int i = 0; i < D::NB * 3; ++i) {
-    const double c = length_grad_component(ln, s_len, i);
-    val = (k == D::NB * 10 + D::NB + 1 + i) ? c : val;
-  }
-  if (lane < D::PI) partials[(long long)blockIdx.x * D::PI + lane] = val;
 }
 
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
@@ -223,9 +283,14 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
   const int slot = lane / D::G;
+  const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
+  if ((int)blockIdx.x == item_blocks) {
+    if (want_grad) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    return;
+  }
   DPLL_STAMP(0);
   // the first item's state rows are requested before the parameter math so that their memory latency hides behind it
-  const long long stride = (long long)gridDim.x * D::IPW;
+  const long long stride = (long long)item_blocks * D::IPW;
   long long base = (long long)blockIdx.x * D::IPW;
   long long item = base + slot;
   bool valid = item < batch;
@@ -233,10 +298,8 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
   T xr[D::NX], xpr[D::NX];
 #pragma unroll
   for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
-  // lane l >= 1 owns learnable parameter l - 1 of the output row and carries d iota / d theta_(l-1)
   Derived<T, NJ> dp;
-  T diota[D::NB][kIota];
-  derive_params_seeded<T, NJ>(md, theta, friction, lengths, lane - 1, dp, diota);
+  derive_params<T, NJ>(md, theta, friction, lengths, dp);
   LossGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
@@ -291,7 +354,7 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
   }
   if (!want_grad) return;
-  store_param_row<T, NJ>(acc, loss_acc, diota, friction, lengths, partials);
+  store_iota_row<T, NJ>(acc, loss_acc, partials);
   DPLL_STAMP(3);
 }
 
@@ -310,13 +373,17 @@ __global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOp
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<1>;
   const int lane = threadIdx.x;
+  const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
+  if ((int)blockIdx.x == item_blocks) {
+    if (want_grad) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    return;
+  }
   Derived<T, NJ> dp;
-  T diota[D::NB][kIota];
-  derive_params_seeded<T, NJ>(md, theta, friction, lengths, lane - 1, dp, diota);
+  derive_params<T, NJ>(md, theta, friction, lengths, dp);
   LossGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
-  const long long stride = (long long)gridDim.x * kWave;
+  const long long stride = (long long)item_blocks * kWave;
   for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
     const long long item = base + lane;
     const bool valid = item < batch;
@@ -344,27 +411,31 @@ __global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOp
     loss_acc += double(w) * double(L);
   }
   if (!want_grad) return;
-  store_param_row<T, NJ, T, 1>(acc, loss_acc, diota, friction, lengths, partials);
+  store_iota_row<T, NJ, 1>(acc, loss_acc, partials);
 }
 
 // sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype.
 // 32 row groups x 32 columns = 1024 threads; every thread first issues all of its (independent) loads,
 // so the kernel costs about one memory round trip instead of one per row.
 constexpr int kFinalizeThreads = 1024;
-constexpr int kFinalizeLoads = kMaxLossBlocks / 32;  // rows per thread at the largest grid
+static_assert(kMaxLossBlocks <= 2048, "finalize_kernel sums at most two passes of 32 rows per thread");
 
-// rows rowg, rowg + 32, ... of one column, all loads issued before the first add (fixed summation order)
+// rows rowg, rowg + 32, ... of one column, all loads issued before the first add (fixed summation order).  The loads
+// are unconditional (clamped addresses, the value masked afterwards): no branch per load, all of them in flight at once.
 template <int LOADS>
-__device__ __forceinline__ double finalize_column(const double* __restrict__ partials, int n_rows, int width, int col, int rowg) {
+__device__ __forceinline__ double finalize_column(const double* __restrict__ partials, int n_rows, int stride, int width, int col, int rowg,
+                                                  int row0 = 0) {
   double v[LOADS];
+  const int c = col < width ? col : width - 1;
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
-    const int r = rowg + 32 * i;
-    v[i] = (col < width && r < n_rows) ? partials[(long long)r * width + col] : 0.0;
+    const int r = row0 + rowg + 32 * i;
+    const int rc = r < n_rows ? r : n_rows - 1;
+    v[i] = partials[(long long)rc * stride + c];
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < LOADS; ++i) s += v[i];
+  for (int i = 0; i < LOADS; ++i) s += (col < width && row0 + rowg + 32 * i < n_rows) ? v[i] : 0.0;
   return s;
 }
 
@@ -379,20 +450,29 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
   using D = Dims<T, NJ>;
   static_assert(D::PI <= 32, "partial row must fit 32 columns");
   __shared__ double red[32][33];
+  __shared__ double tot[32];
   const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
   // uniform branch (n_rows is a kernel argument): the headline grid has 256 rows = 8 per thread
-  const double s = n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, col, rowg)
-                   : n_rows <= 1024 ? finalize_column<32>(partials, n_rows, D::PI, col, rowg)
-                                    : finalize_column<kFinalizeLoads>(partials, n_rows, D::PI, col, rowg);
+  const double s = n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
+                   : n_rows <= 1024 ? finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
+                                    : finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg) +
+                                          finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg, 1024);
+  // thread 1 + k writes learnable parameter k: the chain matrix (written behind the rows by the producing kernel's extra
+  // workgroup) applied to the row sum.  (Requesting the <= 10 coefficients per parameter together with the partial rows
+  // was measured slower: 3.9 vs 2.9 us -- 1024 threads asking for the same few lines.)
+  const int k = (int)threadIdx.x - 1;
+  const double* chain = partials + (long long)n_rows * D::PI;
   red[rowg][col] = s;
   __syncthreads();
-  T value = T(0);
-  if (threadIdx.x < D::PI) {
+  if (threadIdx.x < 32) {
     double t = 0.0;
 #pragma unroll
     for (int r = 0; r < 32; ++r) t += red[r][col];
-    value = T(t);
+    tot[threadIdx.x] = t;
   }
+  __syncthreads();
+  T value = T(0);
+  if (threadIdx.x < D::PI) value = T(k < 0 ? tot[0] : apply_chain<D::NB>(tot, chain, k));
   if constexpr (FUSED) {
     constexpr int kWordsPer = sizeof(T) / 4;
     __shared__ uint32_t words[D::PI * kWordsPer];
@@ -490,6 +570,11 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
   const int slot = lane / D::G;
+  const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
+  if ((int)blockIdx.x == item_blocks) {
+    write_chain_matrix<C, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    return;
+  }
   C theta_c[D::NB * 10], friction_c[D::NB + 1], lengths_c[D::NB * 3];
 #pragma unroll
   for (int i = 0; i < D::NB * 10; ++i) theta_c[i] = C(theta[i]);
@@ -498,11 +583,10 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
 #pragma unroll
   for (int i = 0; i < D::NB * 3; ++i) lengths_c[i] = lengths ? C(lengths[i]) : C(0);
   Derived<C, NJ> dp;
-  C diota[D::NB][kIota];
-  derive_params_seeded<C, NJ>(md, theta_c, friction_c, lengths ? lengths_c : nullptr, lane - 1, dp, diota);
+  derive_params<C, NJ>(md, theta_c, friction_c, lengths ? lengths_c : nullptr, dp);
   LossGrad<C, NJ> acc;
   zero_grad(acc);
-  const long long stride = (long long)gridDim.x * D::IPW;
+  const long long stride = (long long)item_blocks * D::IPW;
   for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
     const long long item = base + slot;
     const bool valid = item < batch;
@@ -555,7 +639,7 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
   for (int b = 0; b < D::NB; ++b)
 #pragma unroll
     for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] = Lanes::group_sum(acc.g_iota[b][i]);
-  store_param_row<C, NJ, T>(acc, 0.0, diota, friction, lengths, partials);
+  store_iota_row<C, NJ>(acc, 0.0, partials);
 }
 
 // ---- MultibodyTerms.forward for API parity (off the hot path: the loss / step kernels never form D) ----
@@ -667,9 +751,11 @@ SolverOpts default_opts(int dtype) {
   if (dtype == DPLL_F64) {
     o.max_iter = 100; o.max_ls = 50; o.tol = 1e-13; o.stall_tol = 1e-10; o.ls_tol = 0.9;
     o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.9; o.stage_max_ls = 50; o.fast_ls = 1;
+    o.warm_start = 0; o.wide = -1;
   } else {
     o.max_iter = 60; o.max_ls = 30; o.tol = 1e-6; o.stall_tol = 1e-5; o.ls_tol = 0.9;
     o.n_stages = 6; o.stage_max_iter = 3; o.stage_factor = 3.0; o.stage_tol = 0.3; o.stage_ls_tol = 0.9; o.stage_max_ls = 50; o.fast_ls = 1;
+    o.warm_start = 0; o.wide = -1;
   }
   return o;
 }
@@ -709,23 +795,24 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
   // builds vs wide, M steps/s: cube f32 16,384 pairs 524 vs 398, 32,768 level, 65,536 934 vs 1340, 262,144 1221 vs 1723;
   // at 65,536: cube f64 423 vs 684, elbow f32 293 vs 476 (0.5-1.4 KB of scratch spills and still ahead); elbow f64
   // 118 vs 85 (3.2 KB of spills): that one stays on the lane-per-contact builds
-  const char* wide_env = std::getenv("DPLL_WIDE");  // diagnostic override: 1 = always the wide build, 0 = never
-  const bool wide = wide_env ? wide_env[0] == '1' : (batch >= 65536 && !(std::is_same<T, double>::value && NJ == 1));
+  // dpll_solver_opts_t::wide overrides the choice (tests compare the builds on the same inputs)
+  const int wide_opt = m->opts[dtype].wide;
+  const bool wide = wide_opt >= 0 ? wide_opt == 1 : (batch >= 65536 && !(std::is_same<T, double>::value && NJ == 1));
   int rows = blocks;
   if (wide) {
     long long wb = (batch + kWave - 1) / kWave;
     rows = (int)(wb > kMaxLossBlocks ? kMaxLossBlocks : wb);
-    hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), dim3(rows), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+    hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad);
   } else if (blocks > kSimds)  // more waves than SIMDs: the two-waves-per-SIMD build
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, true>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
   else
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
@@ -741,7 +828,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   const int blocks = loss_blocks<T, NJ>(batch);
   const int want_grad = grad != nullptr;
   if (want_grad) {
-    if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+    if (!workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
       return fail(-3, "dpll_contactnets_loss: workspace too small%s");
   } else if (loss_total) {
     return fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
@@ -752,10 +839,12 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   if (want_grad) {
     if (ar)
       hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         rows, (T*)grad, (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
+                         rows, (T*)grad,
+                         (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
     else
       hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         rows, (T*)grad, (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                         rows, (T*)grad,
+                         (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (int rc = check_launch("finalize_kernel")) return rc;
   }
   return 0;
@@ -769,7 +858,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
                  hipStream_t stream, int reps, float* ms_loss, float* ms_finalize) {
   using D = Dims<T, NJ>;
   const int blocks = loss_blocks<T, NJ>(batch);
-  if (!grad || !workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+  if (!grad || !workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
     return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
   // two passes, two events each (an event between every pair of kernels costs several microseconds of its own):
   // `reps` loss kernels back to back, then `reps` (loss, finalize) pairs; finalize = the difference
@@ -787,7 +876,8 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
   for (int r = 0; r < reps; ++r) {
     launch_loss_only();
     hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                       rows, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                       rows, (T*)grad,
+                       (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
   }
   (void)hipEventRecord(ev[3], stream);
   int rc = check_launch("profile launches");
@@ -826,19 +916,20 @@ int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p,
                          long long workspace_bytes, hipStream_t stream, void* grad_x, long long ld_gx) {
   using D = Dims<T, NJ>;
   const int blocks = loss_blocks<T, NJ>(batch);
-  if (!workspace || workspace_bytes < (long long)blocks * D::PI * (long long)sizeof(double))
+  if (!workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
     return fail(-3, "dpll_step_backward: workspace too small%s");
   if (grad_x)
-    hipLaunchKernelGGL((step_backward_kernel<T, NJ, true>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[DPLL_F64],
+    hipLaunchKernelGGL((step_backward_kernel<T, NJ, true>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[DPLL_F64],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
                        ld_g, batch, (double*)workspace, (T*)grad_x, ld_gx, (const T*)nullptr, (T*)nullptr);
   else
-    hipLaunchKernelGGL((step_backward_kernel<T, NJ, false>), dim3(blocks), dim3(kWave), 0, stream, m->desc, m->opts[DPLL_F64],
+    hipLaunchKernelGGL((step_backward_kernel<T, NJ, false>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[DPLL_F64],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx,
                        ld_g, batch, (double*)workspace, (T*)nullptr, 0LL, (const T*)nullptr, (T*)nullptr);
   if (int rc = check_launch("step_backward_kernel")) return rc;
   hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
-                     (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                     (T*)grad, (T*)nullptr,
+                     dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
   return check_launch("finalize_kernel");
 }
 
@@ -887,7 +978,7 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   // MFMA path: Vb (icnn_bwd1) and U1 (icnn_fwd2) as operand tiles for icnn_bwd2, whole 32-row tiles
   pl.off_Vb = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
   pl.off_U1 = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
-  pl.off_rows = take(sizeof(double) * 16 * pl.loss_blocks);
+  pl.off_rows = take(sizeof(double) * (16 * pl.loss_blocks + Dims<T, 0>::CHAIN));
   pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
   pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
   pl.total = off;
@@ -975,7 +1066,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   const IcnnWeights<T> w = mesh_weights<T>(mp);
   const int want_grad = grad != nullptr;
   if (int rc = mesh_forward<T>(pl, w, ws, (const T*)xp, ld_xp, stream, want_grad != 0)) return rc;  // terms live at the NEXT state
-  hipLaunchKernelGGL((loss_kernel<T, 0, true>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+  hipLaunchKernelGGL((loss_kernel<T, 0, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
                      want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);
@@ -1010,7 +1101,7 @@ int launch_mesh_step_backward(const dpll_model* m, int dtype, const dpll_params_
   const IcnnWeights<T> w = mesh_weights<T>(mp);
   if (int rc = mesh_forward<T>(pl, w, ws, (const T*)x, ld_x, stream, true)) return rc;
 #define DPLL_LAUNCH_SB(STATE_)                                                                                             \
-  hipLaunchKernelGGL((step_backward_kernel<T, 0, STATE_, true>), dim3(pl.loss_blocks), dim3(kWave), 0, stream, m->desc,    \
+  hipLaunchKernelGGL((step_backward_kernel<T, 0, STATE_, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc,    \
                      m->opts[DPLL_F64], (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x,      \
                      (const T*)gx, ld_g, batch, (double*)(ws + pl.off_rows), (T*)grad_x, ld_gx, (const T*)(ws + pl.off_P), \
                      (T*)(ws + pl.off_RB))
@@ -1069,7 +1160,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 7; }
+int dpll_abi_version(void) { return 8; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1093,6 +1184,7 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
   if (!model || !opts || (dtype != DPLL_F32 && dtype != DPLL_F64)) return fail(-1, "dpll_model_set_solver: bad argument%s");
   if (opts->max_iter < 1 || opts->max_ls < 1 || opts->n_stages < 1 || opts->stage_max_iter < 1 || opts->stage_max_ls < 1 || !(opts->stage_factor >= 1.0))
     return fail(-1, "dpll_model_set_solver: iteration limits must be >= 1%s");
+  if (opts->wide < -1 || opts->wide > 1) return fail(-1, "dpll_model_set_solver: wide must be -1, 0 or 1%s");
   std::memcpy(&model->opts[dtype], opts, sizeof(SolverOpts));
   return 0;
 }
@@ -1119,7 +1211,8 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;
   const int64_t pi = 1 + 10 * nb + (nb + 1) + 3 * nb;
-  return blocks * pi * (int64_t)sizeof(double);
+  const int64_t chain = 100 * nb + (nb + 1) * nb + 3 * nb;  // the rows-to-parameters matrix behind the rows
+  return (blocks * pi + chain) * (int64_t)sizeof(double);
 }
 
 int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,

@@ -344,11 +344,20 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
       s *= (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0));
     }
     grad[kHead + kW * kW + c] = T(s);
-  } else if (threadIdx.x <= kHead) {  // 0: loss, 1..12: theta, friction
+  } else {
+    // head: the loss kernel's rows are in iota space [loss | d/d iota (10) | d/d mu_pair | 3 unused], the chain matrix to
+    // (theta, friction) sits behind them; threads 0..63 are one wave: every lane gathers the 12 totals, thread 1 + k
+    // chains parameter k
+    double tot[16];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) tot[i] = __shfl(s, i);
+#pragma unroll
+    for (int i = 12; i < 16; ++i) tot[i] = 0.0;
+    const int k = (int)threadIdx.x - 1;
     if (threadIdx.x == 0) {
       if (loss_total) *loss_total = T(s);
-    } else {
-      grad[threadIdx.x - 1] = T(s);
+    } else if (k < kHead) {
+      grad[k] = T(apply_chain<1>(tot, rows + (long long)n_rows * 16, k));
     }
   }
 }

@@ -66,6 +66,8 @@ typedef struct dpll_solver_opts {
   double stage_ls_tol;    /* line-search tolerance and probe cap of the non-final stages */
   int32_t stage_max_ls;
   int32_t fast_ls;        /* probes per iteration while the decrement keeps falling; 0 = always the full search */
+  int32_t warm_start;     /* loss solve starts from the observed velocity jump dv instead of 0 */
+  int32_t wide;           /* loss-kernel build: -1 = by batch size, 0 = one lane per contact, 1 = one lane per item */
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;

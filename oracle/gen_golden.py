@@ -241,6 +241,72 @@ def record_bench_batch(name: str, n_pairs: int = 4096, seed: int = 0) -> None:
     print(f'{name}: {n_pairs} of {x_all.shape[0]} pairs, loss mean {loss.mean().item():.6e}')
 
 
+def elbow_rollouts(n_traj: int = 40, steps: int = 120, seed: int = 0) -> torch.Tensor:
+    """BASELINE configs[2] inputs exactly as SURVEY 8d specifies them: ``n_traj`` initial states from the
+    reference's own ``UniformSampler(space, ELBOW_SAMPLER_RANGE, x_0=ELBOW_X_0)`` (reference
+    state_space.py:900-948, examples/contactnets_simple.py:60-67; global generator seeded with ``seed``),
+    each rolled out ``steps`` (= TRAJECTORY_LENGTHS['elbow'], :70) steps with the reference's own
+    ``System.simulate`` on the stub-built system.  Returns ``(n_traj, steps + 1, 15)``."""
+    system, _ = build_reference_system(os.path.join(ASSETS, 'contactnets_elbow.urdf'), 'reference_literal')
+    x_0 = torch.tensor([1., 0., 0., 0., 0., 0., 0.21 + .015, np.pi, 0., 0., 0., 0., 0., -.075, 0.])
+    ranges = torch.tensor([2 * np.pi, 2 * np.pi, 2 * np.pi, .03, .03, .015, np.pi, 6., 6., 6., .5, .5, .075, 6.])
+    sampler = state_space.UniformSampler(system.space, ranges, x_0=x_0)
+    torch.manual_seed(seed)
+    starts = torch.stack([sampler.get_sample() for _ in range(n_traj)])
+    with torch.no_grad():
+        traj, _ = system.simulate(starts.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
+    return traj
+
+
+def record_elbow_bench_batch(name: str = 'elbow_box_4096', n_pairs: int = 4096, seed: int = 0) -> None:
+    """BASELINE configs[2]: 4096 seeded (x, x+) pairs of 120-step elbow tosses (sliced by the reference's
+    TrajectorySliceDataset), expected per-item loss, batch mean and every parameter gradient from the reference run."""
+    elbow = os.path.join(ASSETS, 'contactnets_elbow.urdf')
+    traj = elbow_rollouts(seed=seed)
+    dataset = TrajectorySliceDataset(TrajectorySliceConfig())
+    for t in traj:
+        dataset.add_slices_from_trajectory(t)
+    x_all = torch.stack(dataset.previous_states_slices)[..., -1, :]
+    xp_all = torch.stack(dataset.future_states_slices)[..., 0, :]
+    pick = torch.randperm(x_all.shape[0], generator=torch.Generator().manual_seed(seed))[:n_pairs]
+    x, x_plus = x_all[pick].clone(), xp_all[pick].clone()
+    system, _ = build_reference_system(elbow, 'reference_literal')
+    system.zero_grad()
+    mean_loss = DrakeMultibodyLearnableExperiment.contactnets_loss(None, x.unsqueeze(-2), x_plus.unsqueeze(-2), system)
+    mean_loss.backward()
+    with torch.no_grad():
+        loss = system.contactnets_loss(x, torch.zeros(x.shape[:-1] + (0,)), x_plus)
+        rows = list(range(0, n_pairs, n_pairs // 256))
+        v_next = system.forward_dynamics(*system.space.q_v(x[rows]), torch.zeros((len(rows), 0)))
+    out = {'urdf': os.path.basename(elbow), 'dt': DT, 'inertia_mode': 'reference_literal', 'n_total_pairs': x_all.shape[0],
+           'x': x.numpy(), 'x_plus': x_plus.numpy(), 'loss': loss.numpy(), 'loss_mean': mean_loss.detach().numpy(),
+           'dynamics/rows': np.array(rows), 'dynamics/v_next': v_next.numpy()}
+    for key, value in named_values(system).items():
+        out['param/' + key] = value
+    for key, value in named_grads(system).items():
+        out['grad/' + key] = value
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print(f'{name}: {n_pairs} of {x_all.shape[0]} pairs, loss mean {float(mean_loss):.6e}, max {loss.max().item():.3e}')
+
+
+def record_slice_fixture(name: str = 'cube_trajectories_0_2') -> None:
+    """The reference's own data files assets/contactnets_cube/{0,1,2}.pt as raw arrays (data, not code) together with
+    the (x, x+) pairs the reference's TrajectorySliceDataset makes of them (dataset_management.py:43-59): pins the
+    trainer's slice rule on real trajectories."""
+    out = {}
+    for index in (0, 1, 2):
+        out[f'trajectory/{index}'] = torch.load(os.path.join(ASSETS, 'contactnets_cube', f'{index}.pt')).numpy()
+    x, xp = cube_pairs([0, 1, 2])
+    out['x'], out['x_plus'] = x.numpy(), xp.numpy()
+    dataset = TrajectorySliceDataset(TrajectorySliceConfig(t_prediction=3))
+    for index in (0, 1, 2):
+        dataset.add_slices_from_trajectory(torch.load(os.path.join(ASSETS, 'contactnets_cube', f'{index}.pt')))
+    out['window3/x_past'] = torch.stack(dataset.previous_states_slices).numpy()
+    out['window3/x_future'] = torch.stack(dataset.future_states_slices).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print(f'{name}: {x.shape[0]} pairs, {out["window3/x_past"].shape[0]} windows of 3')
+
+
 def main() -> None:
     cube = os.path.join(ASSETS, 'contactnets_cube.urdf')
     record_bench_batch('cube_box_4096')
@@ -253,7 +319,13 @@ def main() -> None:
     mx, mxp = cube_pairs([3], stride=2)
     record_case('cube_mesh_literal', os.path.join(ASSETS, 'contactnets_cube_mesh.urdf'), mx, mxp,
                 'reference_literal')
+    record_elbow_bench_batch()
+    record_slice_fixture()
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1:  # python oracle/gen_golden.py record_elbow_bench_batch record_slice_fixture ...
+        for _fn in sys.argv[1:]:
+            globals()[_fn]()
+    else:
+        main()

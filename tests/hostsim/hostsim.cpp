@@ -5,6 +5,12 @@
 #include <cstdint>
 #include <vector>
 
+// solver statistics for tools/diag/host_iters.py: bit `it` of an item's mask is set when iteration `it` did not take
+// the full Newton step (alpha != 1)
+static thread_local uint64_t g_reject_mask = 0;
+static std::vector<uint64_t> g_reject_masks;
+#define DPLL_ITER_HOOK(it, active, alpha) do { if ((active) && !((alpha) == 1) && (it) < 64) g_reject_mask |= (1ull << (it)); } while (0)
+
 #include "../../dair_pll_amd/csrc/dpll_icnn.hpp"
 
 using namespace dpll;
@@ -25,7 +31,10 @@ void loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, cons
     T f[K][3];
     int it = 0;
     const T w = T(scale) * (weights ? weights[i] : T(1));
+    g_reject_mask = 0;
     loss[i] = loss_item<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, xp + i * NX, 0, w, grad != nullptr, g, f, it);
+    if ((int64_t)g_reject_masks.size() < B) g_reject_masks.resize(B);
+    g_reject_masks[i] = g_reject_mask;
     if (iters) iters[i] = it;
     if (force)
       for (int c = 0; c < K; ++c) {
@@ -270,4 +279,9 @@ int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const 
 }
 
 int hostsim_sizeof_model_desc() { return (int)sizeof(ModelDesc); }
+int64_t hostsim_reject_masks(uint64_t* out, int64_t n) {
+  const int64_t m = n < (int64_t)g_reject_masks.size() ? n : (int64_t)g_reject_masks.size();
+  for (int64_t i = 0; i < m; ++i) out[i] = g_reject_masks[i];
+  return m;
+}
 }

@@ -55,6 +55,52 @@ def test_loss_matches_reference_run(golden, case, dtype):
         assert err < 5e-6  # what float32 with the double-accumulated cone residual actually achieves
 
 
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_benchmark_batch_elbow_4096(golden, dtype):
+    """BASELINE configs[2] at its stated size: 4096 seeded pairs of 120-step elbow tosses around ELBOW_X_0 (SURVEY 8d;
+    512 one-wave workgroups of 8 items), expected per-item loss, batch mean, parameter gradients and next velocities
+    from the reference run (oracle/gen_golden.py: record_elbow_bench_batch)."""
+    g = golden('elbow_box_4096')
+    system = build_system(g, dtype)
+    x, xp = dev(g['x'], dtype), dev(g['x_plus'], dtype)
+    loss, force, iters = system.contact_forces(x, xp)
+    err = np.abs(loss.cpu().double().numpy() - g['loss']).max()
+    assert err < TOL[dtype], err
+    assert iters.max().item() <= 60
+    total = system.contactnets_loss_and_grad(x, xp)
+    assert abs(total.item() - float(g['loss_mean'])) < (1e-12 if dtype == torch.float64 else 1e-7)
+    if dtype == torch.float64:
+        for name, param in system.named_parameters():
+            ref = g['grad/' + name]
+            assert np.abs(param.grad.cpu().numpy() - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
+    else:
+        # float32 gradients: simulated tosses rest with phi = O(1e-7), where the sign of phi -- the |phi| kink of the loss --
+        # flips with float32 input rounding; those items are left out and the rest compared with the float64 kernels
+        # (which the assertion above pins to the reference run on the whole batch)
+        ref_system = build_system(g, torch.float64)
+        q64, v64 = ref_system.space.q_v(dev(g['x_plus'], torch.float64))
+        phi = ref_system.multibody_terms(q64, v64, torch.zeros((x.shape[0], 0), device='cuda:0'))[3]
+        keep = phi.abs().min(-1).values >= 1e-6
+        assert keep.float().mean().item() > 0.5
+        ref_system.contactnets_loss_and_grad(dev(g['x'], torch.float64)[keep], dev(g['x_plus'], torch.float64)[keep])
+        system.contactnets_loss_and_grad(x[keep], xp[keep])
+        for (name, param), ref_param in zip(system.named_parameters(), ref_system.parameters()):
+            ref = ref_param.grad.cpu().numpy()
+            err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+            assert err <= 2e-3 * max(np.abs(ref).max(), 1e-6), (name, err, np.abs(ref).max())
+    k = system.spec.n_contacts
+    f = force.cpu().double().numpy()
+    assert (np.linalg.norm(f[:, k:].reshape(-1, k, 2), axis=-1) <= f[:, :k] + 1e-6).all()
+    rows = g['dynamics/rows']
+    x_next = system.step(x[rows]).detach()
+    v_err = np.abs(x_next[:, system.space.n_q:].cpu().double().numpy() - g['dynamics/v_next']).max()
+    assert v_err < TOL[dtype], v_err
+    # the one-lane-per-item build at the same size
+    system.set_solver(wide=1)
+    wide = system.contact_forces(x, xp)[0]
+    assert np.abs(wide.cpu().double().numpy() - g['loss']).max() < TOL[dtype]
+
+
 @pytest.mark.parametrize('case', BOX_CASES)
 def test_gradients_match_reference_run_f64(golden, case):
     g = golden(case)

@@ -36,7 +36,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
             t = mine.to(dtype).cuda()
             peer.all_reduce(t)
             expect = sum(e.to(dtype).double() for e in everyone)
-            assert (t.cpu().double() - expect).abs().max() <= 1e-6 * world if dtype == torch.float32 else 1e-15 * world
+            assert (t.cpu().double() - expect).abs().max() <= (1e-6 if dtype == torch.float32 else 1e-15) * world
     assert peer.healthy()
     # graph replay advances the call counter on the device
     t = torch.full((16,), float(rank + 1), device='cuda')

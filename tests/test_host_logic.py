@@ -88,14 +88,14 @@ def test_library_exports_every_declared_symbol():
     lib = _capi.library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dpll_abi_version() == 7
+    assert lib.dpll_abi_version() == _capi.ABI_VERSION
     assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
     assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
     assert lib.dpll_n_x(handle) == 15 and lib.dpll_n_contacts(handle) == 8 and lib.dpll_param_count(handle) == 29
-    assert lib.dpll_workspace_bytes(handle, 4096) == 512 * 30 * 8
+    assert lib.dpll_workspace_bytes(handle, 4096) == (512 * 30 + 200 + 6 + 6) * 8  # rows + chain matrix
     opts = _capi.SolverOpts()
     assert lib.dpll_model_get_solver(handle, _capi.F32, ctypes.byref(opts)) == 0 and opts.max_iter == 60
     opts.max_iter = 0

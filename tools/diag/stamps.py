@@ -39,7 +39,7 @@ print('mean per segment', dict(zip(names, seg.mean(0).round(0))), 'mean total', 
 print('newton ticks per iteration (slowest wave)', seg[order[-1], 2] / max(1, its[order[-1]]))
 print('launch skew: last start', t[:, 0].max() - t[:, 0].min(), 'last end', t[:, 3].max() - t[:, 0].min())
 
-pn = ['residual+proj+grad', 'hessian+reduce', 'cholesky+solve', 'decrement+ls-setup', 'line-search', 'update+stage-logic']
+pn = ['grad+hessian+reduce', 'cholesky+solve', 'decrement+tests', 'state at y+d', 'fallback search', 'update+stage-logic']
 w = order[-1]
 print('phase cycles, slowest wave (sum over its iterations):', dict(zip(pn, phases[w, :6])), 'per iteration:', dict(zip(pn, (phases[w, :6] / max(1, its[w])).round(0))))
 print('phase cycles, mean over waves per iteration:', dict(zip(pn, (phases[:, :6].sum(0) / max(1, its.sum())).round(0))))
