@@ -1,20 +1,25 @@
 """Headline benchmark: trajectory-steps/s of the ContactNets loss, forward + backward, on the
 4096-pair cube-toss batch (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f64] [--batch B] [--no-graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f64] [--batch B] [--workload cube|elbow|mesh|simulate]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
 
 One "step" = one pass of the hot path over one batch: every (x, x+) pair goes through MultibodyTerms,
 the cone solve, the loss and the analytic backward to parameter gradients (dpll_contactnets_loss =
-loss kernel + finalize kernel), plus -- for N > 1 -- the single RCCL all-reduce of [loss, gradients].
+loss kernel + finalize kernel), plus -- for N > 1 -- the single all-reduce of [loss, gradients].
 Inputs are resident in HBM before the timed region.  Batches shard over ranks (weak scaling: 4096 pairs
-per GPU); `value` is pairs processed by all ranks per second.
+per GPU); `value` is pairs processed by all ranks per second.  The timed region (exactly --steps steps
+between barrier + synchronize fences, MAX over ranks) is repeated --repeats times and the MEDIAN repeat
+is reported (all of them are listed under config.repeat_ms).
 
 The printed JSON line also carries `roofline` (algorithmic bytes of the loss kernel over its HIP-event
-duration, against the 8 TB/s HBM peak) and, on rank 0 at N = 1, `cpu_baseline` (the oracle -- a PyTorch
-CPU float64 restatement of the reference path -- timed on this host's cores on a bounded sample).
+duration, against the 8 TB/s HBM peak), on rank 0 at N = 1 `cpu_baseline` (the oracle -- a PyTorch CPU
+float64 restatement of the reference path -- timed on this host's cores on a bounded sample) and
+`configs`: the other BASELINE.json configurations measured in the same run (elbow 4096, mesh 4096, cube f64,
+65,536 pairs in f32 / f64, fused rollouts), each with its own value / kernel time / roofline.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -30,24 +35,31 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix rate: 256 CUs x 256 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32: 64 cyc/SIMD)
 VALU_F64_PEAK_TFLOPS = 78.6   # f64 vector FMA rate
-BYTES_PER_STEP = {('cube', 'f32'): 2 * 13 * 4 + 4, ('cube', 'f64'): 2 * 13 * 8 + 8,  # read x, x+; write loss
-                  ('elbow', 'f32'): 2 * 15 * 4 + 4, ('elbow', 'f64'): 2 * 15 * 8 + 8,
-                  ('mesh', 'f32'): 2 * 13 * 4 + 4, ('mesh', 'f64'): 2 * 13 * 8 + 8}
+N_X = {'cube': 13, 'elbow': 15, 'mesh': 13}
+ELEM = {'f32': 4, 'f64': 8}
+URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf'}
+FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz'}
+DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set (tests/golden/cube_box_4096.npz, '
+                'seed 0); ranks > 0 take the same pairs in a permuted order, other batch sizes resample with replacement (SURVEY 8d '
+                'config 5); URDF-initial parameters',
+        'elbow': 'fixture: 4096 seeded pairs of 40 synthetic 120-step elbow tosses around ELBOW_X_0 (SURVEY 8d config 3, '
+                 'tests/golden/elbow_box_4096.npz: reference UniformSampler + reference simulate); URDF-initial parameters',
+        'mesh': 'the cube fixture pairs; ICNN weights drawn from the reference\'s init distributions, torch.manual_seed(0) (SURVEY 8d config 4)'}
+
+
+def bytes_per_step(workload: str, dtype: str) -> int:
+    """loss fwd+bwd: read x, x+, write loss (the fused path skips the loss write but the figure is the contract's)"""
+    return (2 * N_X[workload] + 1) * ELEM[dtype]
 
 
 def load_pairs(batch: int, seed: int, workload: str = 'cube'):
-    """cube: the 4096 real cube pairs of the reference's data set committed as a fixture (inputs only
-    are used here); ranks > 0 take them in a permuted order (weak scaling: every GPU gets the same mix of easy
-    and hard pairs), other batch sizes resample them with replacement.
-    elbow: the 144 synthetic elbow-toss pairs of the elbow fixture, resampled to the batch size."""
-    name = 'elbow_box_literal.npz' if workload == 'elbow' else 'cube_box_4096.npz'
-    g = np.load(os.path.join(REPO, 'tests', 'golden', name))
+    g = np.load(os.path.join(REPO, 'tests', 'golden', FIXTURE[workload]))
     x, xp = g['x'], g['x_plus']
     if batch == x.shape[0] and seed != 0:
         pick = np.random.default_rng(seed).permutation(batch)  # other ranks: the same pairs in another order
         x, xp = x[pick], xp[pick]
     elif batch != x.shape[0]:
-        pick = np.random.default_rng(seed).integers(0, x.shape[0], size=batch)
+        pick = np.random.default_rng(seed + 1).integers(0, x.shape[0], size=batch)  # with replacement, seed 1 on rank 0
         x, xp = x[pick], xp[pick]
     return x, xp, float(g['dt'])
 
@@ -59,7 +71,7 @@ def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
     from oracle import dpll_oracle as O
     threads = torch.get_num_threads()
     sample = min(1024, x.shape[0])
-    system = O.OracleSystem(os.path.join(REPO, 'assets', workload + '.urdf'), dt).requires_grad_()
+    system = O.OracleSystem(os.path.join(REPO, 'assets', URDF[workload]), dt).requires_grad_()
     xs, xps = torch.tensor(x[:sample]), torch.tensor(xp[:sample])
 
     def one():
@@ -85,20 +97,180 @@ def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
                       ', '.join(f'{rate:.0f} steps/s with {n} threads' for rate, n, _ in results)}
 
 
+def newest_profile(pattern: str):
+    """profiles/rNN_<pattern>, newest round first"""
+    found = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]_' + pattern)), reverse=True)
+    return found[0] if found else None
+
+
+class Timer:
+    """Exactly `steps` steps between fences, `repeats` times; hipGraph replay of `per_graph` steps at a time."""
+
+    def __init__(self, step, steps: int, warmup: int, use_graph: bool, steps_per_graph: int, fence, max_over_ranks):
+        self.step, self.steps, self.fence, self.max_over_ranks = step, steps, fence, max_over_ranks
+        self.graph, self.per_graph = None, 1
+        self.capture_error = None
+        if use_graph:
+            # the largest divisor of --steps that is <= --steps-per-graph, whatever --warmup is (the warm-up replays the
+            # same graph and may run a few steps more than asked: a single-step graph pays a ~8.5 us replay gap per step)
+            self.per_graph = max(d for d in range(1, max(1, min(steps, steps_per_graph)) + 1) if steps % d == 0)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    step()
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    for _ in range(self.per_graph):
+                        step()
+                self.graph = graph
+            except Exception as error:  # noqa: BLE001 -- fall back to eager launches, say so in the output
+                self.capture_error = repr(error)
+                self.graph, self.per_graph = None, 1
+        self.run = self.graph.replay if self.graph is not None else step
+        for _ in range(-(-warmup // self.per_graph)):
+            self.run()
+
+    def agree_on_graph(self, dist, device) -> None:
+        """every rank must run the same launch sequence: if capture failed anywhere, all ranks go eager"""
+        flag = torch.tensor([1 if self.graph is not None else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0 and self.graph is not None:
+            self.graph, self.per_graph, self.run = None, 1, self.step
+
+    def measure(self, repeats: int):
+        times = []
+        for _ in range(repeats):
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(self.steps // self.per_graph):
+                self.run()
+            self.fence()
+            times.append(self.max_over_ranks(time.perf_counter() - t0))
+        return float(np.median(times)), times
+
+    @property
+    def launch(self) -> str:
+        if self.graph is not None:
+            return f'hipGraph replay, {self.per_graph} steps per graph'
+        return 'eager' + (f' (hipGraph capture failed: {self.capture_error})' if self.capture_error else '')
+
+
+def loss_roofline(system, workload, dtype, batch, x, xp):
+    """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
+    alg_bytes = bytes_per_step(workload, dtype) * batch
+    if workload == 'mesh':
+        mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
+        # the mesh pipeline is bounded by its four N x 256 x 256 f32 GEMMs (SURVEY 8d: MFMA); the dominant kernel is
+        # the slowest of them, its algorithmic work 2 * N * 256 * 256 flop with N = 4 * batch support queries
+        gemms = {k: mesh_ms[k] for k in ('icnn_fwd1', 'icnn_fwd2', 'icnn_bwd1', 'icnn_bwd2')}
+        dominant = max(gemms, key=gemms.get)
+        flops = 2.0 * (4 * batch) * 256 * 256
+        tflops = flops / (gemms[dominant] * 1e-3) / 1e12
+        peak = MFMA_F32_PEAK_TFLOPS if dtype == 'f32' else VALU_F64_PEAK_TFLOPS
+        return {'bound': 'mfma', 'achieved': tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tflops / peak,
+                'traffic': None, 'kernel': dominant, 'kernel_ms': gemms[dominant],
+                'algorithmic_flops_per_launch': flops, 'all_kernels_ms': mesh_ms,
+                'pipeline_gemm_tflops': 4 * flops / (sum(gemms.values()) * 1e-3) / 1e12,
+                'note': 'v_mfma_f32_32x32x2_f32 (exact f32); peak = dense f32 matrix rate of MI355X_MICROARCH.md'
+                        if dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
+    ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
+    achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
+    traffic = valu_frac = source = None
+    path = newest_profile('hbm_traffic.json')
+    try:  # HBM bytes per launch / VALU issue slots from the committed PMC passes, only for the configuration they measured
+        with open(path) as handle:
+            pmc = json.load(handle)
+        if (pmc['workload'], pmc['dtype'], pmc['batch']) == (workload, dtype, batch):
+            traffic, source = pmc['traffic_bytes_per_launch'], os.path.relpath(path, REPO)
+            with open(path.replace('hbm_traffic.json', 'loss_kernel_pmc.csv')) as handle:
+                counters = {row.split(',')[0]: float(row.split(',')[1]) for row in handle.read().splitlines()[1:]}
+            valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * 2.4e9 * 1024)
+    except (OSError, KeyError, ValueError, IndexError, TypeError):
+        pass
+    return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': traffic,
+            'traffic_source': f'{source} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' if traffic else None,
+            'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
+            'algorithmic_bytes_per_launch': alg_bytes, 'valu_issue_frac': valu_frac,
+            'note': 'latency/instruction bound by construction (SURVEY 8d): the batch is independent 6-7-dimensional cone '
+                    'problems with data-dependent Newton iteration counts, a few hundred KB per launch; valu_issue_frac = '
+                    'SQ_INSTS_VALU per launch (committed PMC pass) x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs)'}
+
+
+def build_system(workload, dtype_name, dt, device):
+    from dair_pll_amd import MultibodyLearnableSystem
+    torch.manual_seed(0)  # mesh workload: ICNN weights from the reference's init distributions (SURVEY 8d config 4)
+    dtype = torch.float32 if dtype_name == 'f32' else torch.float64
+    return MultibodyLearnableSystem({workload: os.path.join(REPO, 'assets', URDF[workload])}, dt, dtype=dtype, device=str(device))
+
+
+def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device, use_graph=True, steps_per_graph=50):
+    """one single-GPU configuration of the loss path: value, step time, roofline"""
+    dtype = torch.float32 if dtype_name == 'f32' else torch.float64
+    x_np, xp_np, dt = load_pairs(batch, 0, workload)
+    system = build_system(workload, dtype_name, dt, device)
+    x, xp = torch.tensor(x_np, dtype=dtype, device=device), torch.tensor(xp_np, dtype=dtype, device=device)
+    step = lambda: system.contactnets_loss_and_grad(x, xp)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    timer = Timer(step, steps, warmup, use_graph, steps_per_graph, torch.cuda.synchronize, lambda t: t)
+    elapsed, times = timer.measure(repeats)
+    roof = loss_roofline(system, workload, dtype_name, batch, x, xp)
+    return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
+            'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
+            'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
+            'roofline': {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel') if k in roof}}
+
+
+def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device):
+    """fused rollouts (dpll_simulate: the time loop inside the kernel): one step = one VelocityIntegrator.step of one
+    trajectory; algorithmic bytes per step = read x + write x+ (cube 104 B in f32)"""
+    dtype = torch.float32 if dtype_name == 'f32' else torch.float64
+    x_np, _, dt = load_pairs(batch, 0, workload)
+    system = build_system(workload, dtype_name, dt, device)
+    x0 = torch.tensor(x_np, dtype=dtype, device=device).unsqueeze(-2)
+    carry = torch.zeros((batch, 1), device=device)
+    with torch.no_grad():
+        for _ in range(2):
+            system.simulate(x0, carry, horizon)
+        times = []
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            start.record()
+            system.simulate(x0, carry, horizon)
+            end.record()
+            torch.cuda.synchronize()
+            times.append(start.elapsed_time(end))  # ms; the kernel is launched on torch's current stream
+    ms = float(np.median(times))
+    alg = 2 * N_X[workload] * ELEM[dtype_name] * batch * horizon
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {'workload': f'simulate ({workload}, {horizon} steps per launch)', 'dtype': dtype_name, 'batch': batch,
+            'value': batch * horizon / (ms * 1e-3), 'unit': 'trajectory-steps/s (forward only)', 'ms_per_step': ms / horizon,
+            'kernel_ms': ms, 'launch': 'one simulate_kernel launch per rollout',
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'kernel': 'simulate_kernel'}}
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
     parser.add_argument('--steps', type=int, default=2000)
     parser.add_argument('--warmup', type=int, default=200)
+    parser.add_argument('--repeats', type=int, default=5, help='repeats of the timed region; the median is reported')
     parser.add_argument('--dtype', choices=['f32', 'f64'], default='f32')
     parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
     parser.add_argument('--workload', choices=['cube', 'elbow', 'mesh'], default='cube',
-                        help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]')
+                        help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]; mesh = configs[3]')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     parser.add_argument('--steps-per-graph', type=int, default=50,
                         help='steps captured per hipGraph (amortises the ~10 us replay floor); the timed region '
                              'still runs exactly --steps steps, serialised on one stream')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (N = 1 only)')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
     parser.add_argument('--allreduce', choices=['auto', 'peer', 'collective'], default='auto',
                         help='gradient exchange: peer = one-shot kernel over xGMI peer memory, collective = the '
@@ -120,6 +292,7 @@ def main() -> None:
     device = torch.device('cuda', local_rank)
     distributed = world > 1
     host_staged = False
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -129,54 +302,13 @@ def main() -> None:
             dist.init_process_group(args.backend)
             host_staged = True  # gloo collectives cannot be captured (the peer-memory kernel can)
 
-    from dair_pll_amd import MultibodyLearnableSystem
     from dair_pll_amd.distributed import GradientAllReduce
 
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     x_np, xp_np, dt = load_pairs(args.batch, seed=rank, workload=args.workload)
-    torch.manual_seed(0)  # mesh workload: ICNN weights from the reference's init distributions
-    urdf_name = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf'}[args.workload]
-    system = MultibodyLearnableSystem({args.workload: os.path.join(REPO, 'assets', urdf_name)}, dt, dtype=dtype,
-                                      device=str(device))
+    system = build_system(args.workload, args.dtype, dt, device)
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
-    reducer = GradientAllReduce(system, transport=args.allreduce, fuse=not args.no_fuse) if distributed else None
-
-    def step():
-        system.contactnets_loss_and_grad(x, xp)
-        if reducer is not None:
-            reducer.all_reduce_mean()
-
-    # eager warm-up (allocates workspace / gradient buffers, builds RCCL communicators)
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-
-    use_graph = not args.no_graph and not (host_staged and reducer is not None and reducer.transport != 'peer')
-    graph = None
-    per_graph = 1
-    if use_graph:
-        per_graph = max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0 and args.warmup % d == 0) \
-            if args.warmup > 0 else max(d for d in range(1, max(1, args.steps_per_graph) + 1) if args.steps % d == 0)
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for _ in range(per_graph):
-                    step()
-        except Exception as error:  # noqa: BLE001 -- fall back to eager launches, say so in the output
-            print(f'[bench] hipGraph capture failed ({error!r}); running eagerly', file=sys.stderr)
-            graph = None
-            use_graph = False
-            per_graph = 1
-    run = graph.replay if graph is not None else step
-
-    for _ in range(args.warmup // per_graph):
-        run()
 
     def fence():
         torch.cuda.synchronize()
@@ -184,100 +316,107 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps // per_graph):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
+    def max_over_ranks(elapsed):
+        if not distributed:
+            return elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        return t.item()
 
-    mesh_ms = None
-    if args.workload == 'mesh':
-        mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
-        ms_loss, ms_fin = mesh_ms['loss_kernel'], mesh_ms['icnn_reduce']
-    else:
-        ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
+    def timed(reducer):
+        def step():
+            system.contactnets_loss_and_grad(x, xp)
+            if reducer is not None:
+                reducer.all_reduce_mean()
+        for _ in range(3):  # eager warm-up (allocates workspace / gradient buffers, builds RCCL communicators)
+            step()
+        torch.cuda.synchronize()
+        use_graph = not args.no_graph and not (host_staged and reducer is not None and reducer.transport != 'peer')
+        timer = Timer(step, args.steps, args.warmup, use_graph, args.steps_per_graph, fence, max_over_ranks)
+        if distributed:
+            timer.agree_on_graph(dist, device)
+        elapsed, times = timer.measure(args.repeats)
+        if reducer is not None:
+            reducer.check_healthy()  # raises if a peer exchange timed out: never report numbers of a broken exchange
+        return timer, elapsed, times
+
+    reducer = alt = None
+    rccl_ranks = None
+    error = None
+    try:
+        if distributed:
+            reducer = GradientAllReduce(system, transport=args.allreduce, fuse=not args.no_fuse)
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)  # an actual collective of the backend (RCCL for nccl): counts the ranks that took part
+            rccl_ranks = int(probe.item())
+        timer, elapsed, times = timed(reducer)
+        if distributed and reducer.transport == 'peer' and not host_staged:
+            # north_star names a single RCCL all-reduce: time that route in the same run too
+            other = GradientAllReduce(system, transport='collective')
+            alt_timer, alt_elapsed, _ = timed(other)
+            alt = {'collective': f'one {args.backend} all-reduce of [loss, gradients] per step', 'launch': alt_timer.launch,
+                   'ms_per_step': alt_elapsed / args.steps * 1e3, 'value': args.batch * world * args.steps / alt_elapsed}
+            system._fused_ar = reducer.peer._ar if reducer.fused else None  # back to the reported route
+    except Exception as exc:  # noqa: BLE001 -- one JSON error line, non-zero exit
+        error = repr(exc)
+    if error is not None:
+        if rank == 0:
+            print(json.dumps({'metric': 'trajectory-steps/sec (fwd+bwd), batched cube-toss contact sim', 'value': None,
+                              'n_gpus': world, 'error': error}), flush=True)
+        if distributed:
+            dist.destroy_process_group()
+        raise SystemExit(1)
+
+    roof = loss_roofline(system, args.workload, args.dtype, args.batch, x, xp)
     total = system.contactnets_loss_and_grad(x, xp)
     if reducer is not None:
         total = reducer.all_reduce_mean()[:1]
     total_loss = total.item()
 
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the configuration they measured
-        with open(os.path.join(REPO, 'profiles', 'r01_hbm_traffic.json')) as handle:
-            pmc = json.load(handle)
-        if (pmc['workload'], pmc['dtype'], pmc['batch']) == (args.workload, args.dtype, args.batch):
-            traffic = pmc['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        pass
-
-    valu_frac = None
-    try:  # VALU issue-slot occupancy from the committed SQ counter pass (same configuration only)
-        if traffic is not None:
-            with open(os.path.join(REPO, 'profiles', 'r01_loss_kernel_pmc.csv')) as handle:
-                counters = {row.split(',')[0]: float(row.split(',')[1]) for row in handle.read().splitlines()[1:]}
-            valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * 2.4e9 * 1024)
-    except (OSError, KeyError, ValueError, IndexError):
-        pass
-
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        alg_bytes = BYTES_PER_STEP[(args.workload, args.dtype)] * args.batch
-        achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
+        names = {'cube': 'contactnets_cube.urdf, 4 friction contacts', 'elbow': 'contactnets_elbow.urdf, 8 friction contacts',
+                 'mesh': 'contactnets_cube_mesh.urdf, DeepSupportConvex (ICNN 2x256) geometry incl. 67,328 network weights'}
+        collective = 'none'
+        if distributed:
+            collective = ('one-shot peer-memory all-reduce (xGMI stores + in-order sum) of [loss, gradients] per step, '
+                          + ('inside the finalize kernel of the loss launch' if reducer.fused else 'one kernel after the loss launch')
+                          ) if reducer.transport == 'peer' else f'one {args.backend} all-reduce of [loss, gradients] per step'
         line = {
             'metric': 'trajectory-steps/sec (fwd+bwd), batched cube-toss contact sim',
             'value': args.batch * world * args.steps / elapsed,
             'unit': 'trajectory-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step,
+            'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype + (' (cone residual accumulated in f64)' if args.dtype == 'f32' else ''),
-            'data': ('fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set '
-                     '(tests/golden/cube_box_4096.npz, seed 0); ranks > 0 take the same pairs in a permuted order, other batch sizes resample with replacement; URDF-initial parameters')
-            if args.workload == 'cube' else 'synthetic elbow tosses (tests/golden/elbow_box_literal.npz) resampled with replacement',
-            'config': {'workload': (f'contactnets_cube.urdf, 4 friction contacts, batch={args.batch} per GPU, '
-                                    f'fwd+bwd contactnets_loss') if args.workload == 'cube' else
-                                   (f'contactnets_elbow.urdf, 8 friction contacts, batch={args.batch} per GPU, '
-                                    f'fwd+bwd contactnets_loss (synthetic elbow tosses, resampled)') if args.workload == 'elbow' else
-                                   (f'contactnets_cube_mesh.urdf, DeepSupportConvex (ICNN 2x256) geometry, batch={args.batch} per GPU, '
-                                    f'fwd+bwd contactnets_loss incl. 67,328 network weights'), 'per_gpu_batch': args.batch,
-                       'global_batch': args.batch * world, 'launch': f'hipGraph replay, {per_graph} steps per graph' if use_graph else 'eager',
-                       'collective': ('none' if not distributed else
-                                      ('one-shot peer-memory all-reduce (xGMI stores + in-order sum) of [loss, gradients] per step, '
-                                       + ('inside the finalize kernel of the loss launch' if reducer.fused else 'one kernel after the loss launch'))
-                                      if reducer.transport == 'peer' else
-                                      f'one {args.backend} all-reduce of [loss, gradients] per step'),
-                       'mean_loss': total_loss},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' if traffic else None,
-                         'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'valu_issue_frac': valu_frac,
-                         'note': 'latency/instruction bound by construction (SURVEY 8d): 0.44 MB per launch; valu_issue_frac = '
-                                 'SQ_INSTS_VALU per launch (profiles/r01_loss_kernel_pmc.csv) x 4 cycles / (kernel time x 2.4 GHz x '
-                                 '1024 SIMDs): the launch is 256 one-wave workgroups, one wave on every fourth SIMD'},
+            'data': DATA[args.workload],
+            'config': {'workload': f'{names[args.workload]}, batch={args.batch} per GPU, fwd+bwd contactnets_loss',
+                       'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'launch': timer.launch,
+                       'timing': f'median of {args.repeats} repeats of the {args.steps}-step timed region',
+                       'repeat_ms': [t * 1e3 for t in times], 'collective': collective, 'mean_loss': total_loss},
+            'roofline': roof,
         }
-        if mesh_ms is not None:
-            # the mesh pipeline is bounded by its four N x 256 x 256 f32 GEMMs (MFMA); the dominant kernel is
-            # the slowest of them, its algorithmic work 2 * N * 256 * 256 flop with N = 4 * batch support queries
-            gemms = {k: mesh_ms[k] for k in ('icnn_fwd1', 'icnn_fwd2', 'icnn_bwd1', 'icnn_bwd2')}
-            dominant = max(gemms, key=gemms.get)
-            flops = 2.0 * (4 * args.batch) * 256 * 256
-            tflops = flops / (gemms[dominant] * 1e-3) / 1e12
-            peak = MFMA_F32_PEAK_TFLOPS if args.dtype == 'f32' else VALU_F64_PEAK_TFLOPS
-            line['roofline'] = {'bound': 'mfma', 'achieved': tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tflops / peak,
-                                'traffic': None, 'kernel': dominant, 'kernel_ms': gemms[dominant],
-                                'algorithmic_flops_per_launch': flops, 'all_kernels_ms': mesh_ms,
-                                'pipeline_gemm_tflops': 4 * flops / (sum(gemms.values()) * 1e-3) / 1e12,
-                                'note': 'v_mfma_f32_32x32x2_f32 (exact f32); peak = dense f32 matrix rate of MI355X_MICROARCH.md'
-                                        if args.dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
+        if distributed:
+            line['config']['rccl_ranks'] = rccl_ranks
+            line['config']['collective_alt'] = alt
+            line['config']['collective_alt_ms'] = alt['ms_per_step'] if alt else None
+        if world == 1 and not args.no_configs and args.workload == 'cube' and args.batch == 4096:
+            # the other BASELINE.json configurations, same process, after the headline (about a minute in total)
+            configs = []
+            for w, d, b, k in (('elbow', 'f32', 4096, 1000), ('elbow', 'f64', 4096, 500), ('mesh', 'f32', 4096, 200),
+                               ('cube', 'f64', 4096, 1000), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100)):
+                try:
+                    configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
+                except Exception as exc:  # noqa: BLE001
+                    configs.append({'workload': w, 'dtype': d, 'batch': b, 'error': repr(exc)})
+            for w, d, b, h in (('cube', 'f32', 4096, 80), ('cube', 'f32', 65536, 80), ('elbow', 'f32', 4096, 120)):
+                try:
+                    configs.append(run_simulate_config(w, d, b, h, 5, device))
+                except Exception as exc:  # noqa: BLE001
+                    configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
+            line['configs'] = configs
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload if args.workload != 'mesh' else 'cube_mesh')
+            line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()

@@ -14,7 +14,8 @@
 //     call-(s+1) data, which a peer sends only after it finished reading slot s & 1 of call s.
 // Buffers are device memory allocated UNCACHED (fine-grained) and shared through hipIpc handles, so polls and
 // remote stores are never served from a stale L2 line.  Every spin is bounded; a timeout raises an error word
-// that the host checks (dpll_ar_status) -- the caller then falls back to RCCL.
+// that the host checks (dpll_ar_status), and the words that never arrived are replaced by NaN so that the reduced row
+// cannot be mistaken for a result -- the caller then falls back to RCCL.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -24,7 +25,8 @@ namespace dpll_arx {
 
 constexpr int kMaxWorld = 16;
 constexpr int kMaxWords = 256;  // 32-bit words per call (128 doubles / 256 floats)
-constexpr unsigned long long kSpinLimit = 400000000ull;  // s_memtime ticks (~4 s at 100 MHz): then give up
+constexpr unsigned long long kSpinLimit = 5000000ull;  // s_memrealtime ticks (100 MHz): 50 ms, then give up
+constexpr uint32_t kPoison = 0x7ff80000u;              // a word that reads as NaN both as a float and as the high half of a double
 
 struct Peers {
   unsigned long long* recv[kMaxWorld];  // receive buffers of all ranks as seen from this process
@@ -62,7 +64,8 @@ __device__ __forceinline__ void exchange_words(const uint32_t* words, uint32_t (
       __builtin_amdgcn_s_sleep(1);
       g = load_granule(p);
     }
-    gathered[from][i] = (uint32_t)g;
+    // a peer that never arrived must not contribute a stale or partial value silently: the sum becomes NaN
+    gathered[from][i] = timed_out ? kPoison : (uint32_t)g;
   }
   if (timed_out) atomicExch(err, 1u);
   __syncthreads();

@@ -430,7 +430,7 @@ __device__ __forceinline__ double finalize_column(const double* __restrict__ par
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
     const int r = row0 + rowg + 32 * i;
-    const int rc = r < n_rows ? r : n_rows - 1;
+    const int rc = r < n_rows ? r : (n_rows > 0 ? n_rows - 1 : 0);  // n_rows = 0 (empty shard): reads the chain area, masked below
     v[i] = partials[(long long)rc * stride + c];
   }
   double s = 0.0;
@@ -799,6 +799,13 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
   const int wide_opt = m->opts[dtype].wide;
   const bool wide = wide_opt >= 0 ? wide_opt == 1 : (batch >= 65536 && !(std::is_same<T, double>::value && NJ == 1));
   int rows = blocks;
+  if (batch == 0) {  // an empty shard: no item workgroups, only the one that writes the chain matrix; zero partial rows
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
+    return 0;
+  }
   if (wide) {
     long long wb = (batch + kWave - 1) / kWave;
     rows = (int)(wb > kMaxLossBlocks ? kMaxLossBlocks : wb);
@@ -862,34 +869,38 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
     return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
   // two passes, two events each (an event between every pair of kernels costs several microseconds of its own):
   // `reps` loss kernels back to back, then `reps` (loss, finalize) pairs; finalize = the difference
-  hipEvent_t ev[4];
-  for (int i = 0; i < 4; ++i) (void)hipEventCreate(&ev[i]);
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ok = true;
+  for (int i = 0; i < 4; ++i) ok = ok && hipEventCreate(&ev[i]) == hipSuccess;
   int rows = blocks;
   auto launch_loss_only = [&]() {
     rows = launch_loss_kernel<T, NJ>(m, dtype, p, x, ld_x, xp, ld_xp, batch, nullptr, scale, nullptr, nullptr, nullptr, workspace, 1,
                                      stream);
   };
-  (void)hipEventRecord(ev[0], stream);
-  for (int r = 0; r < reps; ++r) launch_loss_only();
-  (void)hipEventRecord(ev[1], stream);
-  (void)hipEventRecord(ev[2], stream);
-  for (int r = 0; r < reps; ++r) {
-    launch_loss_only();
-    hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                       rows, (T*)grad,
-                       (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
-  }
-  (void)hipEventRecord(ev[3], stream);
-  int rc = check_launch("profile launches");
-  (void)hipEventSynchronize(ev[3]);
+  int rc = 0;
   float t_loss = 0.f, t_pair = 0.f;
-  (void)hipEventElapsedTime(&t_loss, ev[0], ev[1]);
-  (void)hipEventElapsedTime(&t_pair, ev[2], ev[3]);
+  if (ok) {
+    ok = hipEventRecord(ev[0], stream) == hipSuccess;
+    for (int r = 0; r < reps; ++r) launch_loss_only();
+    ok = ok && hipEventRecord(ev[1], stream) == hipSuccess && hipEventRecord(ev[2], stream) == hipSuccess;
+    for (int r = 0; r < reps; ++r) {
+      launch_loss_only();
+      hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
+                         rows, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    }
+    ok = ok && hipEventRecord(ev[3], stream) == hipSuccess;
+    rc = check_launch("profile launches");
+    ok = ok && hipEventSynchronize(ev[3]) == hipSuccess && hipEventElapsedTime(&t_loss, ev[0], ev[1]) == hipSuccess &&
+         hipEventElapsedTime(&t_pair, ev[2], ev[3]) == hipSuccess;
+  }
+  for (int i = 0; i < 4; ++i)
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+  if (rc) return rc;
+  if (!ok) return fail(-5, "dpll_profile_contactnets_loss: a HIP event call failed%s");
   const double t_fin = t_pair > t_loss ? t_pair - t_loss : 0.0;
-  for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ev[i]);
   if (ms_loss) *ms_loss = (float)(t_loss / reps);
   if (ms_finalize) *ms_finalize = (float)(t_fin / reps);
-  return rc;
+  return 0;
 }
 
 template <typename T, int NJ>
@@ -1220,8 +1231,8 @@ int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_param
                           double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
                           void* workspace, int64_t workspace_bytes, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_loss")) return rc;
-  if (batch == 0) return fail(-1, "dpll_contactnets_loss: empty batch%s");
-  if (!x || !x_plus) return fail(-1, "dpll_contactnets_loss: null state pointer%s");
+  if (batch == 0 && !grad) return fail(-1, "dpll_contactnets_loss: empty batch%s");
+  if (batch > 0 && (!x || !x_plus)) return fail(-1, "dpll_contactnets_loss: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss: row stride smaller than n_x%s");
   DPLL_DISPATCH(launch_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total,
@@ -1233,8 +1244,8 @@ int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const 
                                     double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                     dpll_ar_t* ar, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_loss_allreduce")) return rc;
-  if (batch == 0) return fail(-1, "dpll_contactnets_loss_allreduce: empty batch%s");
-  if (!x || !x_plus || !grad || !loss_total || !ar) return fail(-1, "dpll_contactnets_loss_allreduce: null argument%s");
+  // batch == 0 is a rank whose shard of a ragged tail batch is empty: it contributes a zero row and still takes part
+  if ((batch > 0 && (!x || !x_plus)) || !grad || !loss_total || !ar) return fail(-1, "dpll_contactnets_loss_allreduce: null argument%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss_allreduce: row stride smaller than n_x%s");
   if ((dpll_param_count(model) + 1) * (dtype == DPLL_F64 ? 2 : 1) > dpll_arx::kMaxWords)
@@ -1446,12 +1457,12 @@ int dpll_ar_create(int rank, int world, void* handle_out, dpll_ar_t** out) {
   }
   if (hipMemset(ar->local, 0, bytes) != hipSuccess || hipMalloc((void**)&ar->state, 2 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ar->state, 0, 2 * sizeof(uint32_t)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-    delete ar;
+    dpll_ar_destroy(ar);  // frees whatever was allocated
     return fail(-5, "dpll_ar_create: buffer setup failed%s");
   }
   hipIpcMemHandle_t handle;
   if (hipIpcGetMemHandle(&handle, ar->local) != hipSuccess) {
-    delete ar;
+    dpll_ar_destroy(ar);
     return fail(-5, "dpll_ar_create: hipIpcGetMemHandle failed (HSA_ENABLE_IPC_MODE_LEGACY=0 needed)%s");
   }
   std::memcpy(handle_out, &handle, sizeof(handle));

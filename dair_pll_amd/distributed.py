@@ -145,6 +145,13 @@ class GradientAllReduce:
         self.fused = bool(fuse and self.peer is not None and getattr(system, '_mesh', lambda: None)() is None)
         system._fused_ar = self.peer._ar if self.fused else None
 
+    def check_healthy(self) -> None:
+        """Synchronises and raises if a peer-memory exchange hit its spin limit (the affected rows were replaced by NaN,
+        never by partial sums).  Collective in effect: every rank of a timed-out exchange sees its own error word."""
+        if self.peer is not None and not self.peer.healthy():
+            raise _capi.DpllError('peer-memory all-reduce timed out (a rank did not arrive within 50 ms); '
+                                  'use GradientAllReduce(transport=\'collective\')')
+
     def all_reduce_mean(self) -> torch.Tensor:
         buf = self.system.grad_buffer()
         if self.fused and self.system._grad_reduced:

@@ -147,8 +147,12 @@ class _LossFunction(torch.autograd.Function):
     def backward(ctx, grad_output):  # pylint: disable=arguments-differ
         x, x_plus = ctx.saved_tensors
         system = ctx.system
-        _, flat_grad, _ = system._launch_loss(x, x_plus, weights=grad_output.contiguous(), scale=1.0, want_grad=True)
-        return (None, None, None) + tuple(system._split_flat(flat_grad.clone()))
+        # a buffer of its own: the shared one is what the parameters' .grad alias after a fused step, and autograd adds
+        # what is returned here ON TOP of .grad
+        own = torch.empty(1 + system._packed().numel(), dtype=system.dtype, device=x.device)
+        _, flat_grad, _ = system._launch_loss(x, x_plus, weights=grad_output.contiguous(), scale=1.0, want_grad=True,
+                                              grad_out=own)
+        return (None, None, None) + tuple(system._split_flat(flat_grad))
 
 
 class _StepFunction(torch.autograd.Function):
@@ -337,7 +341,10 @@ class MultibodyLearnableSystem(Module):
     # ---- ContactNets loss -----------------------------------------------------------------------
     def _launch_loss(self, x: Tensor, x_plus: Tensor, weights: Optional[Tensor], scale: float, want_grad: bool,
                      force: Optional[Tensor] = None, iters: Optional[Tensor] = None,
-                     loss: Optional[Tensor] = None, want_loss: bool = True, fused_ar=None):
+                     loss: Optional[Tensor] = None, want_loss: bool = True, fused_ar=None,
+                     grad_out: Optional[Tensor] = None):
+        """``grad_out``: a ``(1 + n_params,)`` buffer ``[loss total | gradient]`` to write instead of the shared one
+        (whose slices are the parameters' ``.grad`` after a fused step)."""
         lib = _capi.library()
         flat = self._packed()
         batch = x.shape[0]
@@ -346,9 +353,12 @@ class MultibodyLearnableSystem(Module):
         grad = total = workspace = None
         ws_bytes = 0
         if want_grad:
-            if self._flat_grad is None or self._flat_grad.device != x.device:
-                self._alloc_grad_buffer(flat.numel(), x.device)
-            grad, total = self._flat_grad, self._loss_total
+            if grad_out is not None:
+                total, grad = grad_out[:1], grad_out[1:]
+            else:
+                if self._flat_grad is None or self._flat_grad.device != x.device:
+                    self._alloc_grad_buffer(flat.numel(), x.device)
+                grad, total = self._flat_grad, self._loss_total
             ws_bytes = lib.dpll_workspace_bytes(self._model(), batch) if self._mesh() is None else 0
             if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != x.device:
                 self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
@@ -395,11 +405,16 @@ class MultibodyLearnableSystem(Module):
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
         denom = self.global_batch if self.global_batch > 0 else xf.shape[0] * self.grad_world
+        if denom <= 0:
+            raise _capi.DpllError('contactnets_loss_and_grad: empty batch (an empty SHARD of a data-parallel batch is fine '
+                                  'once global_batch is set)')
         self._grad_reduced = False
+        # accumulate: the old gradients may BE views of the buffer the launch overwrites -- take them out first
+        old = [None if (not accumulate or p.grad is None) else p.grad.clone() for p in self._param_list()]
         _, grad, total = self._launch_loss(xf, xpf, None, 1.0 / denom, True, want_loss=False, fused_ar=self._fused_ar)
-        for param, piece in zip(self._param_list(), self._split_flat(grad)):
-            if accumulate and param.grad is not None:
-                param.grad = param.grad + piece
+        for param, piece, before in zip(self._param_list(), self._split_flat(grad), old):
+            if before is not None:
+                param.grad = before + piece
             elif param.grad is None or param.grad.data_ptr() != piece.data_ptr():
                 param.grad = piece
         return total

@@ -107,11 +107,15 @@ class ContactNetsTrainer:
             if self.use_graph and idx.numel() == self._graph_rows():
                 losses.append(self._graph_step(x, x_plus, idx))
                 continue
+            # a ragged tail batch may leave some ranks an empty shard: they launch a zero row and still take part in
+            # the exchange (dpll_contactnets_loss accepts batch = 0 together with a gradient buffer)
             total = self.system.contactnets_loss_and_grad(x[idx], x_plus[idx])
             if self.reducer is not None:
                 self.reducer.all_reduce_mean()
             self.optimizer.step()
             losses.append(total.clone())
+        if self.reducer is not None:
+            self.reducer.check_healthy()  # once per epoch: a timed-out exchange must not train on silently
         return torch.stack(losses).mean().item()
 
     # ---- hipGraph replay of the training step ----------------------------------------------------------
@@ -142,6 +146,8 @@ class ContactNetsTrainer:
             # the state an eager warm-up changes (parameters, Adam moments and step count) is restored afterwards,
             # so that captured training is step for step the eager training
             params = [p.detach().clone() for p in self.system.parameters()]
+            saved_state = {id(p): {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
+                           for p, st in self.optimizer.state.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -153,10 +159,16 @@ class ContactNetsTrainer:
             with torch.no_grad():
                 for p, saved in zip(self.system.parameters(), params):
                     p.copy_(saved)
+                # optimizer state back to what it was before the warm-up (moments of earlier eager steps, a loaded
+                # checkpoint, or zeros when no step had been taken), IN PLACE: the graph holds these tensors' addresses
                 for k, st in self.optimizer.state.items():
                     for n, v in st.items():
                         if torch.is_tensor(v):
-                            v.zero_()  # first real step starts from zero moments / step 0
+                            before = saved_state.get(id(k), {}).get(n)
+                            if before is not None:
+                                v.copy_(before)
+                            else:
+                                v.zero_()
             self._graph, self._static = graph, (xs, xps, total)
         xs, xps, total = self._static
         torch.index_select(x, 0, idx, out=xs)

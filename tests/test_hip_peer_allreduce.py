@@ -98,6 +98,16 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     assert unfused.transport == 'peer' and not unfused.fused and system._fused_ar is None
     system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
     assert torch.equal(unfused.all_reduce_mean(), fused_result)
+    # a tail batch smaller than the world: ranks with an empty shard launch a zero row and still take part (fused exchange)
+    tail = GradientAllReduce(system, global_batch=1)
+    lo1, hi1 = shard_bounds(1, rank, world)
+    system.contactnets_loss_and_grad(x[lo1:hi1], xp[lo1:hi1])
+    tail_reduced = tail.all_reduce_mean().clone()
+    tail.check_healthy()
+    single = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, float(g['dt']), dtype=torch.float64,
+                                      device='cuda:0')
+    single.contactnets_loss_and_grad(x[:1], xp[:1])
+    assert (tail_reduced - single.grad_buffer()).abs().max() < 1e-15
     np.save(os.path.join(out_dir, f'rank{rank}.npy'), reduced.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()

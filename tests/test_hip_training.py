@@ -118,3 +118,54 @@ def test_graph_replayed_training_step_equals_eager():
     assert np.allclose(log_e.epoch_losses, log_g.epoch_losses, rtol=1e-4)
     print(f'training step: eager {t_e * 1e6:.0f} us, graph {t_g * 1e6:.0f} us')
     assert t_g < t_e
+
+
+def test_gradient_buffers_do_not_alias_across_paths():
+    """(1) accumulate=True must add the new gradient to the old one although the old `.grad` is a view of
+    the buffer the next launch overwrites; (2) an autograd backward after a fused step (no zero_grad, or
+    zero_grad(set_to_none=False)) must add its gradient once -- the kernel must not write into `.grad` itself."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    g = np.load(os.path.join(GOLDEN_DIR, 'cube_box_4096.npz'))
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, float(g['dt']), dtype=torch.float64,
+                                      device='cuda:0')
+    xa, xpa = (torch.tensor(g[k][:512], device='cuda:0') for k in ('x', 'x_plus'))
+    xb, xpb = (torch.tensor(g[k][512:1024], device='cuda:0') for k in ('x', 'x_plus'))
+    flat = lambda: torch.cat([p.grad.reshape(-1) for p in system._param_list()]).clone()
+    system.contactnets_loss_and_grad(xa, xpa)
+    ga = flat()
+    system.zero_grad()
+    system.contactnets_loss_and_grad(xb, xpb)
+    gb = flat()
+    # (1) accumulate
+    system.zero_grad()
+    system.contactnets_loss_and_grad(xa, xpa)
+    system.contactnets_loss_and_grad(xb, xpb, accumulate=True)
+    assert (flat() - (ga + gb)).abs().max() <= 1e-15 * (ga + gb).abs().max()
+    # (2) fused step, then autograd on top without clearing
+    system.zero_grad()
+    system.contactnets_loss_and_grad(xa, xpa)
+    system.contactnets_loss(xb, torch.zeros((512, 0), device='cuda:0'), xpb).mean().backward()
+    assert (flat() - (ga + gb)).abs().max() <= 1e-14 * (ga + gb).abs().max()
+    # ... and with gradients zeroed in place in between
+    system.zero_grad(set_to_none=False)
+    system.contactnets_loss(xb, torch.zeros((512, 0), device='cuda:0'), xpb).mean().backward()
+    assert (flat() - gb).abs().max() <= 1e-14 * gb.abs().max()
+
+
+def test_empty_shard_contributes_a_zero_row():
+    """A ragged tail batch smaller than the world size leaves some ranks an empty shard: with `global_batch` set the
+    call launches no item workgroups, writes zero loss / gradients and (distributed) still takes part in the exchange."""
+    from dair_pll_amd import MultibodyLearnableSystem, _capi
+    g = np.load(os.path.join(GOLDEN_DIR, 'cube_box_4096.npz'))
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, float(g['dt']), dtype=torch.float32,
+                                      device='cuda:0')
+    x = torch.tensor(g['x'][:8], dtype=torch.float32, device='cuda:0')
+    xp = torch.tensor(g['x_plus'][:8], dtype=torch.float32, device='cuda:0')
+    system.contactnets_loss_and_grad(x, xp)
+    assert system.grad_buffer().abs().max() > 0
+    system.global_batch = 3
+    total = system.contactnets_loss_and_grad(x[:0], xp[:0])
+    assert total.item() == 0.0 and torch.count_nonzero(system.grad_buffer()).item() == 0
+    system.global_batch = 0
+    with pytest.raises(_capi.DpllError):
+        system.contactnets_loss_and_grad(x[:0], xp[:0])

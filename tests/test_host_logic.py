@@ -183,3 +183,21 @@ def test_extract_mesh_of_an_analytic_support_function():
     lines = export.mesh_to_obj(vertices, faces).splitlines()
     assert sum(l.startswith('v ') for l in lines) == 8 and sum(l.startswith('vn ') for l in lines) == 12
     assert [l for l in lines if l.startswith('f ')][3].count('//4') == 3
+
+
+def test_slice_rule_on_the_reference_trajectories():
+    """dataset_management.py:43-59 on real data: the raw trajectories assets/contactnets_cube/{0,1,2}.pt (shipped as
+    arrays) sliced by trainer.slice_pairs / slice_windows equal what the reference's TrajectorySliceDataset made of them
+    (oracle/gen_golden.py: record_slice_fixture), pair for pair and in the same order."""
+    from dair_pll_amd.trainer import slice_pairs, slice_windows
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_trajectories_0_2.npz'))
+    trajectories = [torch.tensor(g[f'trajectory/{i}']) for i in range(3)]
+    assert [t.shape[0] for t in trajectories] == [int(g[f'trajectory/{i}'].shape[0]) for i in range(3)]
+    x, x_plus = slice_pairs(trajectories)
+    assert x.shape == (sum(t.shape[0] - 1 for t in trajectories), 13)
+    assert np.array_equal(x.numpy(), g['x']) and np.array_equal(x_plus.numpy(), g['x_plus'])
+    past, future = slice_windows(trajectories, 3)
+    assert np.array_equal(past.numpy(), g['window3/x_past']) and np.array_equal(future.numpy(), g['window3/x_future'])
+    # the first fixture of the parity tests was cut from the same files by the reference: same pairs
+    literal = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_literal.npz'))
+    assert np.array_equal(literal['x'], g['x']) and np.array_equal(literal['x_plus'], g['x_plus'])
