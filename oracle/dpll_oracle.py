@@ -647,6 +647,39 @@ def sap_solve(J: Tensor, q: Tensor, eps: float, tol: float = 1e-13, max_iter: in
     return force
 
 
+def sap_solve_diff(J: Tensor, q: Tensor, eps: float) -> Tensor:
+    """``sap_solve`` that is differentiable in ``J`` and ``q``: what ``sappy.SAPSolver.apply`` is to the
+    reference's ``forward_dynamics`` (multibody_learnable_system.py:293-298, not detached there; sappy's own
+    backward is third party and UNPINNED -- this is the canonical answer, the implicit-function derivative of the
+    unique optimum).
+
+    With the converged primal optimum x* (grad l(x*; J, q) = 0) and the generalised Hessian H of l at x*, both held
+    constant, one more Newton step written with autograd-visible ``J, q``,
+
+        x(J, q) = x* - H^-1 grad l(x*; J, q),        f = P_K(-(J x(J, q) + q) / eps),
+
+    has the value of the converged solution and -- because the Newton map's derivative at a fixed point is
+    -H^-1 d(grad l)/d(J, q) -- exactly the implicit-function derivative dx*/d(J, q).  The projection's derivative is
+    autograd's through ``lorentz_project`` (its generalised Jacobian region by region)."""
+    batch = J.shape[:-2]
+    m, n = J.shape[-2:]
+    k = m // 3
+    with torch.no_grad():
+        _, x_star, _ = sap_solve(J, q, eps, return_info=True)
+        z_star = (-((J @ x_star.unsqueeze(-1)).squeeze(-1) + q) / eps).reshape(batch + (k, 3))
+        dp = lorentz_project_jacobian(z_star)
+        J3 = J.reshape(batch + (k, 3, n))
+        hess = torch.eye(n, dtype=J.dtype) + (J3.transpose(-1, -2) @ dp @ J3).sum(-3) / eps
+
+    def gamma(x: Tensor) -> Tensor:
+        z = (-((J @ x.unsqueeze(-1)).squeeze(-1) + q) / eps).reshape(batch + (k, 3))
+        return lorentz_project(z)[0].reshape(batch + (m,))
+
+    grad_l = x_star - (J.transpose(-1, -2) @ gamma(x_star).unsqueeze(-1)).squeeze(-1)
+    x = x_star - torch.linalg.solve(hess, grad_l.unsqueeze(-1)).squeeze(-1)
+    return gamma(x)
+
+
 def kkt_residuals(J: Tensor, q: Tensor, eps: float, f: Tensor) -> Dict[str, Tensor]:
     """KKT certificate of the dual QP: f in K, r = (J J^T + eps I) f + q in K* = K, f . r = 0."""
     m = J.shape[-2]
@@ -843,7 +876,10 @@ class OracleSystem:
         phi_then_zero = torch.cat((phi, torch.zeros(phi.shape[:-1] + (2 * k,), dtype=q.dtype)), -1)
         v_minus = v + dt * a
         q_full = (J @ v_minus.unsqueeze(-1)).squeeze(-1) + phi_then_zero / dt
-        impulse_s = sap_solve(J_M, (q_full.unsqueeze(-2) @ P).squeeze(-2), DYNAMICS_EPS)
+        q_s = (q_full.unsqueeze(-2) @ P).squeeze(-2)
+        # not detached in the reference (:293-298): with a graph to build, the solve is differentiated implicitly
+        solve = sap_solve_diff if (torch.is_grad_enabled() and (J_M.requires_grad or q_s.requires_grad)) else sap_solve
+        impulse_s = solve(J_M, q_s, DYNAMICS_EPS)
         impulse = (impulse_s.unsqueeze(-2) @ P.t()).squeeze(-2)
         v_plus = v_minus + torch.linalg.solve(M, (J.transpose(-1, -2) @ impulse.unsqueeze(-1))).squeeze(-1)
         if return_impulse:

@@ -64,7 +64,9 @@ class RecordingSolver:
         self.calls = []
 
     def apply(self, J, q, eps):
-        f = O.sap_solve(J, q, eps)
+        # differentiable wherever the reference keeps the graph (forward_dynamics; the loss detaches the result itself)
+        diff = torch.is_grad_enabled() and (J.requires_grad or q.requires_grad)
+        f = O.sap_solve_diff(J, q, eps) if diff else O.sap_solve(J, q, eps)
         self.calls.append((J.detach().clone(), q.detach().clone(), eps, f.detach().clone()))
         return f
 
@@ -307,6 +309,40 @@ def record_slice_fixture(name: str = 'cube_trajectories_0_2') -> None:
     print(f'{name}: {x.shape[0]} pairs, {out["window3/x_past"].shape[0]} windows of 3')
 
 
+def record_dynamics_gradients(name: str = 'dynamics_gradients') -> None:
+    """gradients THROUGH the reference's own ``forward_dynamics`` / ``VelocityIntegrator.step`` /
+    ``Integrator.simulate`` (multibody_learnable_system.py:293-304, experiment.py:292-320) by torch autograd, with
+    respect to every learnable parameter and to the input state, for seeded linear functionals of the next state /
+    of a 3-step rollout.  Only the cone solve's backward is not the reference's (sappy is absent): it is the
+    implicit-function derivative of the unique optimum, ``oracle.sap_solve_diff``."""
+    out = {'dt': DT}
+    cases = (('cube', os.path.join(ASSETS, 'contactnets_cube.urdf'), 'cube_box_literal', 96),
+             ('elbow', os.path.join(ASSETS, 'contactnets_elbow.urdf'), 'elbow_box_literal', 48))
+    for key, urdf, source, count in cases:
+        g = np.load(os.path.join(GOLDEN, source + '.npz'))
+        rows = np.linspace(0, g['x'].shape[0] - 1, count).astype(int)
+        gen = torch.Generator().manual_seed(7)
+        for label, steps in (('step', 1), ('rollout3', 3)):
+            system, _ = build_reference_system(urdf, 'reference_literal')
+            x = torch.tensor(g['x'][rows]).clone().requires_grad_(True)
+            carry = torch.zeros((count, 1))
+            traj, _ = system.simulate(x.unsqueeze(-2), carry, steps)
+            w = torch.rand(traj[:, 1:].shape, generator=gen) - 0.5
+            total = (traj[:, 1:] * w).sum()
+            system.zero_grad()
+            total.backward()
+            prefix = f'{key}/{label}/'
+            out[prefix + 'x'] = x.detach().numpy()
+            out[prefix + 'w'] = w.numpy()
+            out[prefix + 'traj'] = traj.detach().numpy()
+            out[prefix + 'total'] = total.detach().numpy()
+            out[prefix + 'grad_x'] = x.grad.numpy()
+            for pname, value in named_grads(system).items():
+                out[prefix + 'grad/' + pname] = value
+            print(f'{name}: {key} {label}: total {float(total):.6e}, |grad_x| max {x.grad.abs().max().item():.3e}')
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+
+
 def main() -> None:
     cube = os.path.join(ASSETS, 'contactnets_cube.urdf')
     record_bench_batch('cube_box_4096')
@@ -321,6 +357,7 @@ def main() -> None:
                 'reference_literal')
     record_elbow_bench_batch()
     record_slice_fixture()
+    record_dynamics_gradients()
 
 
 if __name__ == '__main__':

@@ -401,3 +401,36 @@ def test_state_adjoint_float32_matches_float64(golden):
         rel = ((gx32 - gx64).abs().max(-1).values / (gx64.abs().max(-1).values + 1e-9)).numpy()
         assert np.median(rel) < 1e-4 and (rel < 5e-3).mean() > 0.9, (case, np.sort(rel)[-5:])
         assert ((gp32 - gp64).abs() <= 5e-3 * gp64.abs().max()).all(), (case, (gp32 - gp64).abs().max(), gp64.abs().max())
+
+
+@pytest.mark.parametrize('key,urdf', [('cube', 'cube.urdf'), ('elbow', 'elbow.urdf')])
+@pytest.mark.parametrize('label,steps', [('step', 1), ('rollout3', 3)])
+def test_dynamics_gradients_match_autograd_through_the_reference(golden, key, urdf, label, steps):
+    """back-propagation through `simulate` (one autograd node per step: dpll_step_backward, parameter
+    gradient + state adjoint by implicit differentiation of the cone solve) against torch autograd through the
+    reference's own forward_dynamics / VelocityIntegrator.step / Integrator.simulate (fixture dynamics_gradients,
+    oracle/gen_golden.py record_dynamics_gradients; only the solve's backward there is the oracle's implicit-function
+    derivative -- sappy's is third party and unpinned).  The state gradient is compared on the tangent space of the
+    unit quaternions (quirk Q2: along q itself oracle and kernels differ by convention, and that component never
+    reaches a parameter)."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    g = golden('dynamics_gradients')
+    system = MultibodyLearnableSystem({key: os.path.join(ASSET_DIR, urdf)}, float(g['dt']), dtype=torch.float64, device='cuda:0')
+    prefix = f'{key}/{label}/'
+    x = dev(g[prefix + 'x'], torch.float64).requires_grad_(True)
+    w = dev(g[prefix + 'w'], torch.float64)
+    traj, _ = system.simulate(x.unsqueeze(-2), torch.zeros((x.shape[0], 1), device='cuda:0'), steps)
+    assert np.abs(traj.detach().cpu().numpy() - g[prefix + 'traj']).max() < 1e-9
+    total = (traj[:, 1:] * w).sum()
+    assert abs(total.item() - float(g[prefix + 'total'])) < 1e-8 * max(1.0, abs(float(g[prefix + 'total'])))
+    total.backward()
+    for name, param in system.named_parameters():
+        ref = g[prefix + 'grad/' + name]
+        err = np.abs(param.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-8 * max(np.abs(ref).max(), 1e-3), (name, err, np.abs(ref).max())
+    ref_x = g[prefix + 'grad_x']
+    diff = x.grad.cpu().numpy() - ref_x
+    q = g[prefix + 'x'][:, :4]
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    diff[:, :4] -= (diff[:, :4] * q).sum(-1, keepdims=True) * q
+    assert np.abs(diff).max() <= 1e-8 * np.abs(ref_x).max(), (np.abs(diff).max(), np.abs(ref_x).max())

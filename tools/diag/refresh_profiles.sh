@@ -1,18 +1,28 @@
 #!/bin/bash
-# Regenerates the raw material of profiles/ on the MI355X box (run through gpurun from the repo root).
+# Regenerates the raw material of profiles/ on the MI355X box (run through gpurun from the repo root):
+#   tools/diag/refresh_profiles.sh [tag, default r02]
 # Every rocprofv3 pass is its own process; counter passes carry no trace domain.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/r01p
+TAG=${1:-r02}
+O=gpurun_out/${TAG}p
 rm -rf $O; mkdir -p $O
+B="--no-cpu-baseline --no-configs"
 python3 bench.py --steps 2000 --warmup 100 > $O/bench_f32.json 2> $O/bench_f32.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline > $O/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph --no-cpu-baseline > $O/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq1 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph --no-cpu-baseline > $O/pmc_sq1.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d $O/pmc_sq2 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph --no-cpu-baseline > $O/pmc_sq2.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mesh -o run -- python3 bench.py --workload mesh --steps 50 --warmup 50 --no-cpu-baseline > $O/stats_mesh.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 300 --warmup 20 $B > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f64 -o run -- python3 bench.py --dtype f64 --steps 300 --warmup 20 $B > $O/stats_f64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_elbow -o run -- python3 bench.py --workload elbow --steps 300 --warmup 20 $B > $O/stats_elbow.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_elbow_f64 -o run -- python3 bench.py --workload elbow --dtype f64 --steps 300 --warmup 20 $B > $O/stats_elbow_f64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b65536 -o run -- python3 bench.py --batch 65536 --steps 100 --warmup 20 $B > $O/stats_b65536.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b65536_f64 -o run -- python3 bench.py --batch 65536 --dtype f64 --steps 100 --warmup 20 $B > $O/stats_b65536_f64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mesh -o run -- python3 bench.py --workload mesh --steps 50 --warmup 50 $B > $O/stats_mesh.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sim -o run -- python3 tools/diag/sim_bench.py > $O/stats_sim.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph $B > $O/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq1 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph $B > $O/pmc_sq1.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d $O/pmc_sq2 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph $B > $O/pmc_sq2.log 2>&1
 python3 tools/diag/stamps.py > $O/stamps.txt 2>&1
 find $O -name '*.csv' -size +20M -delete
-ls -R $O | head -60
+find $O -name '*_agent_info.csv' -delete
+ls -R $O | head -80

@@ -2,10 +2,10 @@
 import csv, json, os, re, shutil, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r01p')
+SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r02p')
 DST = os.path.join(REPO, 'profiles')
-TAG = sys.argv[2] if len(sys.argv) > 2 else 'r01'
-KERNEL = 'loss_kernel<float, 0, false>'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+KERNEL = 'loss_kernel<float, 0, false'  # <T, NJ, MESH, DENSE>: the box builds
 
 
 def counter_means(path):
@@ -18,7 +18,11 @@ def counter_means(path):
 
 
 shutil.copy(os.path.join(SRC, 'stats', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_f32_kernel_stats.csv'))
-shutil.copy(os.path.join(SRC, 'stats_mesh', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_mesh_f32_kernel_stats.csv'))
+for sub, name in (('stats_mesh', 'mesh_f32'), ('stats_f64', 'f64'), ('stats_elbow', 'elbow_f32'), ('stats_elbow_f64', 'elbow_f64'),
+                  ('stats_b65536', 'f32_b65536'), ('stats_b65536_f64', 'f64_b65536'), ('stats_sim', 'simulate')):
+    src = os.path.join(SRC, sub, 'run_kernel_stats.csv')
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(DST, f'{TAG}_bench_{name}_kernel_stats.csv'))
 with open(os.path.join(SRC, 'stats', 'run_kernel_trace.csv')) as f:
     lines = f.readlines()
 with open(os.path.join(DST, f'{TAG}_bench_f32_kernel_trace_tail.csv'), 'w') as f:
@@ -40,7 +44,9 @@ for sub, name in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
         csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(keep)
 fetch_kb, n_f = traffic['FETCH_SIZE']
 write_kb, n_w = traffic['WRITE_SIZE']
-old = json.load(open(os.path.join(DST, f'{TAG}_hbm_traffic.json')))
+template = os.path.join(DST, f'{TAG}_hbm_traffic.json')
+old = json.load(open(template if os.path.exists(template) else os.path.join(DST, 'r01_hbm_traffic.json')))
+old['kernel'] = 'loss_kernel<float,0,false,false>'
 old.update({'FETCH_SIZE_KB_per_launch': round(fetch_kb, 2), 'WRITE_SIZE_KB_per_launch': round(write_kb, 2),
             'traffic_bytes_per_launch': int(round((fetch_kb + write_kb) * 1024)),
             'method': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no trace domains), means over {n_f} / {n_w} '
