@@ -13,8 +13,10 @@ from .urdf import ModelSpec, check_supported
 
 MAX_JOINTS = 2
 MAX_BODIES = 3
+MAX_GEOMS = 3
+GEOM_KINDS = {'box': 0, 'sphere': 1}
 F32, F64 = 0, 1
-ABI_VERSION = 8  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 9  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +27,8 @@ class ModelDesc(ctypes.Structure):
     """``dpll_model_desc_t``"""
     _fields_ = [('n_joints', c_int32), ('inertia_mode', c_int32), ('dt', c_double), ('gravity_z', c_double),
                 ('joint_origin', (c_double * 3) * MAX_JOINTS), ('joint_axis', (c_double * 3) * MAX_JOINTS),
-                ('geom_origin', (c_double * 3) * MAX_BODIES)]
+                ('geom_origin', (c_double * 3) * MAX_GEOMS), ('parent', c_int32 * MAX_JOINTS), ('n_geoms', c_int32),
+                ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('reserved', c_int32)]
 
 
 class SolverOpts(ctypes.Structure):
@@ -48,6 +51,8 @@ class MeshParams(ctypes.Structure):
 
 
 def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal') -> ModelDesc:
+    """``dpll_model_desc_t`` of a parsed model.  The cube / elbow topologies (a serial chain of at most one joint with
+    one box -- or one mesh -- per body) use the fast builds (``n_geoms = 0``); everything else the general build."""
     check_supported(spec)
     desc = ModelDesc()
     desc.n_joints = spec.n_joints
@@ -55,11 +60,18 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
     desc.dt = dt
     desc.gravity_z = spec.gravity_z
     for index, body in enumerate(spec.bodies):
-        for axis in range(3):
-            desc.geom_origin[index][axis] = body.geoms[0].origin[axis]
-            if index > 0:
+        if index > 0:
+            desc.parent[index - 1] = body.parent
+            for axis in range(3):
                 desc.joint_origin[index - 1][axis] = body.joint_origin[axis]
                 desc.joint_axis[index - 1][axis] = body.joint_axis[axis]
+    geoms = spec.geoms()
+    for g, (body_index, geom) in enumerate(geoms):
+        desc.geom_body[g] = body_index
+        desc.geom_kind[g] = GEOM_KINDS.get(geom.kind, 0)
+        for axis in range(3):
+            desc.geom_origin[g][axis] = geom.origin[axis]
+    desc.n_geoms = 0 if spec.is_fast() else len(geoms)
     return desc
 
 

@@ -1,0 +1,235 @@
+// dpll_common.hpp -- what the translation units of libdpll_hip.so share: launch constants, cross-lane primitives,
+// kernel dimensions, the partial-row / chain-matrix layout of the gradient reduction and the host-side handle types.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/dpll.h"
+#include "dpll_core.hpp"
+#include "dpll_allreduce.hpp"
+
+namespace {
+
+using namespace dpll;
+
+static_assert(sizeof(ModelDesc) == sizeof(dpll_model_desc_t), "ModelDesc must mirror dpll_model_desc_t");
+static_assert(sizeof(SolverOpts) == sizeof(dpll_solver_opts_t), "SolverOpts must mirror dpll_solver_opts_t");
+static_assert(kMaxJoints == DPLL_MAX_JOINTS && kMaxBodies == DPLL_MAX_BODIES && kMaxGeoms == DPLL_MAX_GEOMS, "limits");
+static_assert(kGeomBox == DPLL_GEOM_BOX && kGeomSphere == DPLL_GEOM_SPHERE, "geometry kinds");
+
+constexpr int kWave = 64;
+constexpr int kMaxLossBlocks = 2048;  // partial-sum rows; 8 one-wave workgroups per CU
+constexpr int kSimds = 1024;          // 256 CUs x 4
+
+// ---- cross-lane primitives --------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+  // old = 0 + bound_ctrl lets the backend fold the move into the consuming add (v_add_f32_dpp); every
+  // source lane of the controls used here is inside the wave, so the value of `old` never shows
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int lo = (int)(unsigned)(u & 0xffffffffull), hi = (int)(unsigned)(u >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+  return __builtin_bit_cast(double, r);
+}
+constexpr int kQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int kQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int kRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
+constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
+
+template <int G> struct GpuLanes {
+  static_assert(G == 1 || G == 4 || G == 8, "lanes per item: one per contact (4 or 8), or 1 (wide build)");
+  static constexpr int kGroup = G;
+  template <typename T> static __device__ __forceinline__ T group_sum(T x) {
+    if (G == 1) return x;
+    x += dpp_mov<kQuadXor1>(x);
+    x += dpp_mov<kQuadXor2>(x);
+    if (G == 8) x += dpp_mov<kRowHalfMirror>(x);  // both quads hold their own sum -> mirror pairs them
+    return x;
+  }
+  static __device__ __forceinline__ bool group_any(bool x) {
+    if (G == 1) return x;
+    const unsigned long long b = __ballot(x);
+    const int base = (threadIdx.x & (kWave - 1)) & ~(G - 1);
+    return ((b >> base) & ((1ull << G) - 1ull)) != 0ull;
+  }
+  static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
+};
+
+// sum over the whole wave of a value that is already uniform inside each group of G lanes, counting every
+// group once; the result is valid in every lane.  Rows of 16 lanes are closed with the mirror controls, the four
+// rows with row_bcast:15 / row_bcast:31 (the total lands in lane 63) and one v_readlane: no LDS permutes.
+constexpr int kRowBcast15 = 0x142;  // lane 15 of each row -> every lane of the next row (row_mask 0xA)
+constexpr int kRowBcast31 = 0x143;  // lane 31 -> rows 2 and 3 (row_mask 0xC)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_rows(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_rows(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  int lo = (int)(unsigned)(u & 0xffffffffull), hi = (int)(unsigned)(u >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+  return __builtin_bit_cast(double, r);  // +0.0 in the rows outside ROW_MASK
+}
+__device__ __forceinline__ float read_lane63(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ double read_lane63(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x) {
+  if (G == 1) {
+    x += dpp_mov<kQuadXor1>(x);
+    x += dpp_mov<kQuadXor2>(x);
+  }
+  if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
+  x += dpp_mov<kRowMirror>(x);
+  x += dpp_rows<kRowBcast15, 0xA>(x);
+  x += dpp_rows<kRowBcast31, 0xC>(x);
+  return read_lane63(x);
+}
+
+// Chain from the batch-summed row (iota space) to the learnable parameters [theta | friction | lengths]: linear in the
+// row, with a matrix that depends on the parameters only.  One EXTRA one-wave workgroup of every gradient kernel (it
+// owns no items and runs on a SIMD the launch leaves idle) writes that matrix behind the partial rows while the other
+// workgroups solve; the finalize kernel then applies it with <= 10 multiply-adds per parameter -- the theta -> iota
+// duals are on nobody's critical path.
+template <typename S> __device__ __forceinline__ void theta_jacobian_column(int inertia_mode, const S* theta_b, int c, S (&dio)[kIota]) {
+  DualT<S> th[10], io[kIota];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) th[i] = DualT<S>(theta_b[i], i == c ? S(1) : S(0));
+  theta_to_iota<DualT<S>>(th, inertia_mode, io);
+#pragma unroll
+  for (int i = 0; i < kIota; ++i) dio[i] = io[i].d;
+}
+template <typename T, typename P, int NB, int NG = NB>
+__device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __restrict__ theta, const P* __restrict__ friction,
+                                                   const P* __restrict__ lengths, double* __restrict__ chain) {
+  const int lane = threadIdx.x;
+  if (lane < 10 * NB) {  // lane = (body, theta component c): column c of that body's Jacobian
+    T th[10], dio[kIota];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) th[i] = T(theta[10 * (lane / 10) + i]);
+    theta_jacobian_column<T>(inertia_mode, th, lane % 10, dio);
+#pragma unroll
+    for (int i = 0; i < kIota; ++i) chain[lane * kIota + i] = double(dio[i]);
+  }
+  double* fr_fac = chain + 100 * NB;
+  double* len_sign = fr_fac + (NG + 1) * NG;
+  if (lane < (NG + 1) * NG) {  // lane = (friction entry k, geometry b): d (2 m0 mb / (m0 + mb)) / d friction_k, mu = |friction|
+    const int k = lane / NG, b = lane % NG;
+    const double f0 = double(friction[0]), fb = double(friction[1 + b]);
+    const double m0 = fabs(f0), mb = fabs(fb);
+    const double den = (m0 + mb) * (m0 + mb);
+    const double pk = double(friction[k]);
+    const double sign = pk > 0.0 ? 1.0 : (pk < 0.0 ? -1.0 : 0.0);
+    double fac = 0.0;
+    if (k == 0) fac += 2.0 * mb * mb / den;
+    if (k == 1 + b) fac += 2.0 * m0 * m0 / den;
+    fr_fac[lane] = fac * sign;
+  }
+  if (lane < 3 * NG) {
+    const double pl = lengths ? double(lengths[lane]) : 0.0;
+    len_sign[lane] = pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0);
+  }
+}
+// learnable parameter k = sum_{j < count} tot[tot0 + j] * chain[coef0 + j] with the row sum `tot` ([loss | iota | mu_pair | length])
+struct ChainRow { int coef0, tot0, count; };
+template <int NB, int NG = NB> __device__ __forceinline__ ChainRow chain_row(int k) {
+  if (k < 10 * NB) return ChainRow{k * kIota, 1 + kIota * (k / 10), kIota};
+  if (k < 10 * NB + NG + 1) return ChainRow{100 * NB + (k - 10 * NB) * NG, 1 + kIota * NB, NG};
+  const int i = k - (10 * NB + NG + 1);
+  return ChainRow{100 * NB + (NG + 1) * NG + i, 1 + kIota * NB + NG + i, 1};
+}
+template <int NB, int NG = NB> __device__ __forceinline__ double apply_chain(const double* tot, const double* __restrict__ chain, int k) {
+  const ChainRow cr = chain_row<NB, NG>(k);
+  double v = 0.0;
+  for (int j = 0; j < cr.count; ++j) v += tot[cr.tot0 + j] * chain[cr.coef0 + j];
+  return v;
+}
+
+
+// NG = collision geometries (the two fast builds: one per body; the general build: always kMaxGeoms slots)
+template <typename T, int NJ, int NG_ = NJ + 1> struct Dims {
+  static constexpr int NB = NJ + 1, NG = NG_, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NG, G = K;
+  static constexpr int IPW = kWave / G;                       // items per wave (lane-per-contact builds: G = 4 or 8)
+  static constexpr int P = NB * 10 + (NG + 1) + NG * 3;       // learnable parameters [theta | friction | lengths]
+  static constexpr int PI = 1 + P;                            // row stride of the partial sums; the output row [loss | d/d params]
+  static constexpr int PIOTA = 1 + 10 * NB + 4 * NG;          // a partial row: [loss | d/d iota | d/d mu_pair | d/d |length|]
+  // the chain matrix behind the rows: [d iota_b,i / d theta_b,c (NB, 10 c, 10 i) | d mu_pair,g / d friction_k (NG + 1 k, NG g) |
+  // sign(length_params) (3 NG)], doubles
+  static constexpr int CHAIN = 100 * NB + (NG + 1) * NG + 3 * NG;
+};
+
+template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
+
+
+// Wave reduction of the items' d/d(iota, mu_pair, |length|): one row [loss | d/d iota (10 NB) | d/d mu_pair (NB) |
+// d/d |length| (3 NB)] of double partial sums per wave, written by lane 63 (where the DPP row reduction lands).  The
+// chain to the learnable parameters (theta, friction_params, length_params) is linear in the row, so it runs ONCE on
+// the row sum in the finalize kernel instead of in every wave's prologue (forward-mode duals of theta -> iota cost
+// ~3.5 k cycles per wave there).  Row stride D::PI (>= 1 + 14 NB).
+template <int G, typename T> __device__ __forceinline__ T wave_sum_to_lane63(T x) {
+  if (G == 1) {
+    x += dpp_mov<kQuadXor1>(x);
+    x += dpp_mov<kQuadXor2>(x);
+  }
+  if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
+  x += dpp_mov<kRowMirror>(x);
+  x += dpp_rows<kRowBcast15, 0xA>(x);
+  x += dpp_rows<kRowBcast31, 0xC>(x);
+  return x;  // the total over the groups in lane 63; other lanes hold partial sums
+}
+
+template <typename T, int NJ, int G = Dims<T, NJ>::G, int NG = NJ + 1>
+__device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG>& acc, double loss_acc, double* __restrict__ partials) {
+  using D = Dims<T, NJ, NG>;
+  using Lanes = GpuLanes<G>;
+  double row[D::PIOTA];
+  row[0] = wave_sum_to_lane63<G>(Lanes::group_sum(loss_acc));
+#pragma unroll
+  for (int b = 0; b < D::NB; ++b)
+#pragma unroll
+    for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
+      row[1 + kIota * b + i] = double(wave_sum_to_lane63<G>(acc.g_iota[b][i]));
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    row[1 + kIota * D::NB + g] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_mu[g])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      row[1 + kIota * D::NB + NG + 3 * g + i] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[g][i])));
+  }
+  if (threadIdx.x == kWave - 1) {
+    double* dst = partials + (long long)blockIdx.x * D::PI;
+#pragma unroll
+    for (int i = 0; i < D::PIOTA; ++i) dst[i] = row[i];
+  }
+}
+
+
+}  // namespace
+
+struct dpll_ar {
+  int rank, world;
+  void* local;             // this rank's receive buffer (uncached device memory)
+  uint32_t* state;         // [0] call counter, [1] error word (device)
+  dpll_arx::Peers peers;
+  void* opened[dpll_arx::kMaxWorld];
+};
+
+struct dpll_model {
+  dpll::ModelDesc desc;
+  dpll::SolverOpts opts[2];
+};
+
+// error reporting shared by the translation units (defined in dpll_kernels.hip)
+int dpll_fail(int code, const char* fmt, const char* detail = "");
+int dpll_check_launch(const char* what);

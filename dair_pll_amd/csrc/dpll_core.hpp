@@ -56,8 +56,10 @@
 
 namespace dpll {
 
-constexpr int kMaxJoints = 2;   // revolute joints in a serial chain hanging off the floating base
+constexpr int kMaxJoints = 2;   // revolute joints of the tree hanging off the floating base
 constexpr int kMaxBodies = kMaxJoints + 1;
+constexpr int kMaxGeoms = 3;    // convex collision geometries of a model (each against the ground half-space)
+constexpr int kGeomBox = 0, kGeomSphere = 1;
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
 
@@ -69,7 +71,20 @@ struct ModelDesc {
   double gravity_z;
   double joint_origin[kMaxJoints][3];  // joint j+1 frame origin in the parent body frame
   double joint_axis[kMaxJoints][3];    // unit axis, same in parent and child frames
-  double geom_origin[kMaxBodies][3];   // one convex geometry per body: its origin in the body frame
+  double geom_origin[kMaxGeoms][3];    // geometry g: its origin in the frame of its body
+  // General models only (n_geoms > 0; MultibodyTerms handles any tree and any number of geometries,
+  // multibody_terms.py:328-382, drake_utils.py:309-335).  The two fast builds (cube, elbow) leave these zero and mean: a
+  // serial chain, one box per body, geometry g on body g.
+  int32_t parent[kMaxJoints];          // parent body of body j + 1 (< j + 1)
+  int32_t n_geoms;
+  int32_t geom_body[kMaxGeoms];
+  int32_t geom_kind[kMaxGeoms];        // kGeomBox | kGeomSphere
+  int32_t reserved;
+  static constexpr bool kGeneral = false;
+};
+// same layout; selects the tree / geometry-table code paths at compile time
+struct GeneralDesc : ModelDesc {
+  static constexpr bool kGeneral = true;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -260,18 +275,62 @@ template <typename T, int NJ> struct Kin {
   T pj[NB][3];      // joint origin in the parent frame (index >= 1)
   T ax[NB][3];      // joint axis in body coordinates (index >= 1)
   T axw[NB][3];     // joint axis in the world (index >= 1)
+  int par[NB];      // parent body (serial chain: j - 1, known at compile time; general models: from the description)
+  bool anc[NB][NB]; // anc[b][j]: joint j (the joint of body j >= 1) lies between the base and body b
 };
 
-template <typename T, int NJ> DPLL_HD void kinematics(const ModelDesc& md, const T* q, Kin<T, NJ>& k) {
+// arr[idx] for idx < upto, without run-time indexing (register arrays): the selects fold when idx is a constant
+template <typename T, int N> DPLL_HD void pick3(const T (&arr)[N][3], int idx, int upto, T (&out)[3]) {
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) out[i] = arr[0][i];
+  DPLL_UNROLL for (int c = 1; c < N; ++c)
+    if (c < upto) {
+      const bool pick = (idx == c);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) out[i] = pick ? arr[c][i] : out[i];
+    }
+}
+template <typename T, int N> DPLL_HD void pick33(const T (&arr)[N][3][3], int idx, int upto, T (&out)[3][3]) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) out[r][i] = arr[0][r][i];
+  DPLL_UNROLL for (int c = 1; c < N; ++c)
+    if (c < upto) {
+      const bool pick = (idx == c);
+      DPLL_UNROLL for (int r = 0; r < 3; ++r)
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) out[r][i] = pick ? arr[c][r][i] : out[r][i];
+    }
+}
+// does joint jj move body b (b may differ from lane to lane)?
+template <typename T, int NJ> DPLL_HD bool joint_moves(const Kin<T, NJ>& k, int jj, int b) {
+  bool yes = false;
+  DPLL_UNROLL for (int bb = 1; bb <= NJ; ++bb)
+    if (bb >= jj) yes = yes || (b == bb && k.anc[bb][jj]);
+  return yes;
+}
+
+template <typename T, int NJ, class MD> DPLL_HD void kinematics(const MD& md, const T* q, Kin<T, NJ>& k) {
   quat_to_rot(q, k.R[0]);
   DPLL_UNROLL for (int i = 0; i < 3; ++i) k.o[0][i] = q[4 + i];
+  k.par[0] = 0;
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b)
+    DPLL_UNROLL for (int j = 0; j <= NJ; ++j) k.anc[b][j] = false;
   DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+    int p = j - 1;
+    if constexpr (MD::kGeneral) p = md.parent[j - 1];
+    k.par[j] = p;
+    k.anc[j][j] = true;
+    DPLL_UNROLL for (int a = 1; a < j; ++a) {  // the parent's ancestors are mine
+      bool up = false;
+      DPLL_UNROLL for (int c = 1; c < j; ++c) up = up || (p == c && k.anc[c][a]);
+      k.anc[j][a] = up;
+    }
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { k.pj[j][i] = T(md.joint_origin[j - 1][i]); k.ax[j][i] = T(md.joint_axis[j - 1][i]); }
     axis_rot(k.ax[j], q[7 + j - 1], k.Rpc[j]);
-    mat3_mul(k.R[j - 1], k.Rpc[j], k.R[j]);
+    T Rp[3][3], op[3];
+    pick33(k.R, p, j, Rp);
+    pick3(k.o, p, j, op);
+    mat3_mul(Rp, k.Rpc[j], k.R[j]);
     T t[3];
-    mat3_vec(k.R[j - 1], k.pj[j], t);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) k.o[j][i] = k.o[j - 1][i] + t[i];
+    mat3_vec(Rp, k.pj[j], t);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) k.o[j][i] = op[i] + t[i];
     mat3_vec(k.R[j], k.ax[j], k.axw[j]);
   }
 }
@@ -284,11 +343,13 @@ DPLL_HD void body_twists(const Kin<T, NJ>& k, const T* y, T (&Yw)[NJ + 1][3], T 
   DPLL_UNROLL for (int i = 0; i < 3; ++i) Yw[0][i] = y[i];
   mat3t_vec(k.R[0], vl, Yu[0]);
   DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
-    T wxp[3], t[3];
-    cross(Yw[j - 1], k.pj[j], wxp);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = Yu[j - 1][i] + wxp[i];
+    T pw[3], pu[3], wxp[3], t[3];
+    pick3(Yw, k.par[j], j, pw);
+    pick3(Yu, k.par[j], j, pu);
+    cross(pw, k.pj[j], wxp);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = pu[i] + wxp[i];
     mat3t_vec(k.Rpc[j], t, Yu[j]);
-    mat3t_vec(k.Rpc[j], Yw[j - 1], t);
+    mat3t_vec(k.Rpc[j], pw, t);
     DPLL_UNROLL for (int i = 0; i < 3; ++i) Yw[j][i] = t[i] + k.ax[j][i] * y[6 + j - 1];
   }
 }
@@ -307,17 +368,22 @@ DPLL_HD void mass_matrix(const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], T 
     const T zero[3] = {T(0), T(0), T(0)};
     inertia_apply(comp[j], k.ax[j], zero, n, f);
     M[6 + j - 1][6 + j - 1] = dot3(k.ax[j], n);
+    DPLL_UNROLL for (int a = 1; a < j; ++a) { M[6 + a - 1][6 + j - 1] = T(0); M[6 + j - 1][6 + a - 1] = T(0); }
+    int cur = j;  // the wrench is expressed in the frame of body `cur`; walk up through the ancestors only
     DPLL_UNROLL for (int a = j; a >= 1; --a) {
-      // transform the wrench from body a to its parent a-1
+      const bool on = (a == cur);
+      // transform the wrench from body a to its parent
       T rn[3], rf[3], pxf[3];
       mat3_vec(k.Rpc[a], n, rn);
       mat3_vec(k.Rpc[a], f, rf);
       cross(k.pj[a], rf, pxf);
-      DPLL_UNROLL for (int i = 0; i < 3; ++i) { n[i] = rn[i] + pxf[i]; f[i] = rf[i]; }
-      if (a - 1 >= 1) {
-        const T val = dot3(k.ax[a - 1], n);
-        M[6 + a - 2][6 + j - 1] = val;
-        M[6 + j - 1][6 + a - 2] = val;
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) { n[i] = on ? rn[i] + pxf[i] : n[i]; f[i] = on ? rf[i] : f[i]; }
+      cur = on ? k.par[a] : cur;
+      DPLL_UNROLL for (int c = 1; c < a; ++c) {
+        const bool hit = on && (cur == c);
+        const T val = dot3(k.ax[c], n);
+        M[6 + c - 1][6 + j - 1] = hit ? val : M[6 + c - 1][6 + j - 1];
+        M[6 + j - 1][6 + c - 1] = hit ? val : M[6 + j - 1][6 + c - 1];
       }
     }
     T wf[3];
@@ -346,10 +412,11 @@ DPLL_HD void mass_matrix(const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], T 
         const T delta = (r == c) ? T(1) : T(0);
         Ip[r][c] = RIRt[r][c] - m * (d[r] * d[c] - dd * delta) - (hc[r] * d[c] + d[r] * hc[c] - T(2) * dh * delta);
       }
-    comp[j - 1][0] += m;
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) comp[j - 1][1 + i] += hc[i] + m * d[i];
-    comp[j - 1][4] += Ip[0][0]; comp[j - 1][5] += Ip[1][1]; comp[j - 1][6] += Ip[2][2];
-    comp[j - 1][7] += Ip[0][1]; comp[j - 1][8] += Ip[0][2]; comp[j - 1][9] += Ip[1][2];
+    const T add[kIota] = {m, hc[0] + m * d[0], hc[1] + m * d[1], hc[2] + m * d[2], Ip[0][0], Ip[1][1], Ip[2][2], Ip[0][1], Ip[0][2], Ip[1][2]};
+    DPLL_UNROLL for (int c = 0; c < j; ++c) {
+      const bool mine = (k.par[j] == c);
+      DPLL_UNROLL for (int i = 0; i < kIota; ++i) comp[c][i] += mine ? add[i] : T(0);
+    }
   }
   // base block [[I_o, S(h) R^T],[R S(h)^T, m 1]]
   const T(&c0)[kIota] = comp[0];
@@ -368,8 +435,8 @@ DPLL_HD void mass_matrix(const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], T 
 // Non-contact generalized force F(q, v) = gamma^T(-C + tau_g) (multibody_terms.py:142-146, n_u = 0)
 // by recursive Newton-Euler at zero generalized acceleration.  Also returns the body twists V and
 // the bias-minus-gravity spatial accelerations AG = A_b - G_b needed by the backward pass.
-template <typename T, int NJ>
-DPLL_HD void bias_forces(const ModelDesc& md, const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], const T* v,
+template <typename T, int NJ, class MD>
+DPLL_HD void bias_forces(const MD& md, const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], const T* v,
                          T (&F)[6 + NJ], T (&Vw)[NJ + 1][3], T (&Vu)[NJ + 1][3], T (&AGw)[NJ + 1][3],
                          T (&AGu)[NJ + 1][3]) {
   constexpr int NB = NJ + 1;
@@ -381,11 +448,13 @@ DPLL_HD void bias_forces(const ModelDesc& md, const Kin<T, NJ>& k, const T (&iot
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { Aw[0][i] = T(0); Au[0][i] = -wxu[i]; }
   }
   DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
-    T wxp[3], t[3], r1[3], r2[3];
-    cross(Aw[j - 1], k.pj[j], wxp);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = Au[j - 1][i] + wxp[i];
+    T pw[3], pu[3], wxp[3], t[3], r1[3], r2[3];
+    pick3(Aw, k.par[j], j, pw);
+    pick3(Au, k.par[j], j, pu);
+    cross(pw, k.pj[j], wxp);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = pu[i] + wxp[i];
     mat3t_vec(k.Rpc[j], t, r2);
-    mat3t_vec(k.Rpc[j], Aw[j - 1], r1);
+    mat3t_vec(k.Rpc[j], pw, r1);
     const T rate = v[6 + j - 1];
     T sr[3], c1[3], c2[3];
     DPLL_UNROLL for (int i = 0; i < 3; ++i) sr[i] = k.ax[j][i] * rate;
@@ -415,7 +484,10 @@ DPLL_HD void bias_forces(const ModelDesc& md, const Kin<T, NJ>& k, const T (&iot
     mat3_vec(k.Rpc[j], Wn[j], rn);
     mat3_vec(k.Rpc[j], Wf[j], rf);
     cross(k.pj[j], rf, pxf);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) { Wn[j - 1][i] += rn[i] + pxf[i]; Wf[j - 1][i] += rf[i]; }
+    DPLL_UNROLL for (int c = 0; c < j; ++c) {
+      const bool mine = (k.par[j] == c);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) { Wn[c][i] += mine ? rn[i] + pxf[i] : T(0); Wf[c][i] += mine ? rf[i] : T(0); }
+    }
   }
   T wf[3];
   mat3_vec(k.R[0], Wf[0], wf);
@@ -518,7 +590,8 @@ DPLL_HD void contact_jacobian(const Kin<T, NJ>& k, int b, const T (&pt)[3], CJac
     T dj[3], x[3];
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dj[i] = pt[i] - k.o[jj][i];
     cross(k.axw[jj], dj, x);
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) J.j[jj - 1][r] = (jj <= b) ? x[r] : T(0);
+    const bool moves = joint_moves(k, jj, b);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) J.j[jj - 1][r] = moves ? x[r] : T(0);
   }
 }
 // Jp y and Jp^T a
@@ -542,8 +615,10 @@ template <typename T, int NJ> DPLL_HD void cjac_apply_t_add(const CJac<T, NJ>& J
 template <typename T, int NJ> DPLL_HD void world_omega(const Kin<T, NJ>& k, int b, const T* y, T (&w)[3]) {
   const T yb[3] = {y[0], y[1], y[2]};
   mat3_vec(k.R[0], yb, w);
-  DPLL_UNROLL for (int j = 1; j <= NJ; ++j)
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) w[i] += (j <= b) ? k.axw[j][i] * y[6 + j - 1] : T(0);
+  DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
+    const bool moves = joint_moves(k, j, b);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) w[i] += moves ? k.axw[j][i] * y[6 + j - 1] : T(0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -897,41 +972,26 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
 // ---------------------------------------------------------------------------------------------
 // learnable parameters as the item code sees them
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NJ> struct Derived {
+// NG = number of collision geometries (the two fast builds: one per body)
+template <typename T, int NJ, int NG = NJ + 1> struct Derived {
   static constexpr int NB = NJ + 1;
   T iota[NB][kIota];
-  T mu[NB];       // pair coefficient ground-vs-geometry b: 2 mu_0 mu_b / (mu_0 + mu_b), mu = |friction_params| (multibody_terms.py:321-324, :471)
-  T habs[NB][3];  // |length_params| (geometry.py:393-403)
+  T mu[NG];       // pair coefficient ground-vs-geometry g: 2 mu_0 mu_g / (mu_0 + mu_g), mu = |friction_params| (multibody_terms.py:321-324, :471)
+  T habs[NG][3];  // |length_params| of a box (geometry.py:393-403); [0] = |length_param|, the radius of a sphere (:415-456)
 };
 
-template <typename T, int NJ>
-DPLL_HD void derive_params(const ModelDesc& md, const T* theta, const T* friction, const T* lengths, Derived<T, NJ>& dp) {
+template <typename T, int NJ, int NG, class MD>
+DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, const T* lengths, Derived<T, NJ, NG>& dp) {
   const T mu0 = tabs(friction[0]);
   DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
     T th[10];
     DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = theta[10 * b + i];
     theta_to_iota<T>(th, md.inertia_mode, dp.iota[b]);
-    const T mub = tabs(friction[1 + b]);
-    dp.mu[b] = T(2) * mu0 * mub / (mu0 + mub);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = lengths ? tabs(lengths[3 * b + i]) : T(0);
   }
-}
-
-// Same, plus the derivative of every iota_b along ONE theta component `seed` (index into the flattened
-// (n_bodies, 10) theta, negative = none): the loss kernel gives each lane a different seed so that a wave
-// holds the whole Jacobian d iota / d theta and can chain its batch-reduced d/d iota to d/d theta itself.
-template <typename T, int NJ>
-DPLL_HD void derive_params_seeded(const ModelDesc& md, const T* theta, const T* friction, const T* lengths, int seed,
-                                  Derived<T, NJ>& dp, T (&diota)[NJ + 1][kIota]) {
-  const T mu0 = tabs(friction[0]);
-  DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
-    DualT<T> th[10], io[kIota];
-    DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = DualT<T>(theta[10 * b + i], (seed == 10 * b + i) ? T(1) : T(0));
-    theta_to_iota<DualT<T>>(th, md.inertia_mode, io);
-    DPLL_UNROLL for (int i = 0; i < kIota; ++i) { dp.iota[b][i] = io[i].v; diota[b][i] = io[i].d; }
-    const T mub = tabs(friction[1 + b]);
-    dp.mu[b] = T(2) * mu0 * mub / (mu0 + mub);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[b][i] = lengths ? tabs(lengths[3 * b + i]) : T(0);
+  DPLL_UNROLL for (int g = 0; g < NG; ++g) {
+    const T mug = tabs(friction[1 + g]);
+    dp.mu[g] = T(2) * mu0 * mug / (mu0 + mug);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[g][i] = lengths ? tabs(lengths[3 * g + i]) : T(0);
   }
 }
 
@@ -951,13 +1011,17 @@ template <typename T, typename TA, int NJ> DPLL_HD void convert_kin(const Kin<TA
       DPLL_UNROLL for (int c = 0; c < 3; ++c) { k.R[b][r][c] = T(a.R[b][r][c]); k.Rpc[b][r][c] = T(a.Rpc[b][r][c]); }
       k.o[b][r] = T(a.o[b][r]); k.pj[b][r] = T(a.pj[b][r]); k.ax[b][r] = T(a.ax[b][r]); k.axw[b][r] = T(a.axw[b][r]);
     }
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
+    k.par[b] = a.par[b];
+    DPLL_UNROLL for (int j = 0; j <= NJ; ++j) k.anc[b][j] = a.anc[b][j];
+  }
 }
 
 // Kinematics run in the accumulation type TA (double in the float kernels): the signed distance
 // phi = o_z + (R r)_z is a cancellation of O(0.1) terms down to O(1e-4) that the dynamics then divides by dt,
 // and evaluating it in float perturbs the next velocity by up to 2e-4 in weakly constrained directions.
-template <typename T, typename TA, int NJ>
-DPLL_HD void compute_terms(const ModelDesc& md, const Derived<T, NJ>& dp, const T* q, const T* v, Terms<T, NJ>& t,
+template <typename T, typename TA, int NJ, int NG, class MD>
+DPLL_HD void compute_terms(const MD& md, const Derived<T, NJ, NG>& dp, const T* q, const T* v, Terms<T, NJ>& t,
                            Kin<TA, NJ>& kinA) {
   constexpr int NV = 6 + NJ;
   TA qA[7 + NJ];
@@ -971,35 +1035,60 @@ DPLL_HD void compute_terms(const ModelDesc& md, const Derived<T, NJ>& dp, const 
   chol_solve<T, NV>(t.LM, t.invdM, F, t.a);
 }
 
-// One contact of this lane: geometry index g (= body index), slot 0..3.
+// One contact of this lane: geometry g = contact / 4 (the fast builds: geometry g sits on body g), slot 0..3.
 template <typename T, int NJ> struct ContactGeom {
   int body;
-  T sgn[3];      // corner sign pattern
+  int geom;
+  T sgn[3];      // box: corner sign pattern = d witness_i / d |length_i|; sphere: zero
+  T drad[3];     // sphere: d witness / d radius (the support direction); box: zero
   T phi;
   T mu;
   T R[3][3];     // rotation of the contact's body
   CJac<T, NJ> J; // world-frame point Jacobian
 };
 
+constexpr double kMaskedPhi = 1e3;  // signed distance of a contact slot that does not exist: no force, no gradient
+
 // `witness` (mesh geometry, DeepSupportConvex): the support point of this contact in the geometry frame, already
-// evaluated by the ICNN kernels (geometry.py:309-325); nullptr = box corner chosen here.
-template <typename T, typename TA, int NJ>
-DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, const Kin<T, NJ>& kin,
+// evaluated by the ICNN kernels (geometry.py:309-325); nullptr = box corner / sphere point chosen here.
+template <typename T, typename TA, int NJ, int NG, class MD>
+DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
                              const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ>& cg,
                              const T* witness = nullptr) {
   constexpr int NB = NJ + 1;
-  const int b = contact / kQuery;
+  const int g = contact / kQuery;
   const int slot = contact % kQuery;
-  cg.body = b;
-  // select this contact's body data (b is lane dependent on the GPU)
-  T o[3], habs[3], gorg[3];
-  TA Rz[3], oz = kinA.o[0][2];  // third row of the body rotation and origin height, in TA, for phi
+  // geometry data by g (g differs from lane to lane in the lane-per-contact builds)
+  T habs[3], gorg[3];
   T mu = dp.mu[0];
+  int b = 0, kind = kGeomBox;
+  bool masked = false;
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) { habs[r] = dp.habs[0][r]; gorg[r] = T(md.geom_origin[0][r]); }
+  if constexpr (MD::kGeneral) { b = md.geom_body[0]; kind = md.geom_kind[0]; masked = md.n_geoms < 1; }
+  DPLL_UNROLL for (int gg = 1; gg < NG; ++gg) {
+    const bool pick = (g == gg);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      habs[r] = pick ? dp.habs[gg][r] : habs[r];
+      gorg[r] = pick ? T(md.geom_origin[gg][r]) : gorg[r];
+    }
+    mu = pick ? dp.mu[gg] : mu;
+    if constexpr (MD::kGeneral) {
+      b = pick ? md.geom_body[gg] : b;
+      kind = pick ? md.geom_kind[gg] : kind;
+      masked = pick ? (md.n_geoms < gg + 1) : masked;
+    } else {
+      b = pick ? gg : b;
+    }
+  }
+  cg.body = b;
+  cg.geom = g;
+  cg.mu = mu;
+  // body data by b
+  T o[3];
+  TA Rz[3], oz = kinA.o[0][2];  // third row of the body rotation and origin height, in TA, for phi
   DPLL_UNROLL for (int r = 0; r < 3; ++r) {
     DPLL_UNROLL for (int c = 0; c < 3; ++c) cg.R[r][c] = kin.R[0][r][c];
     o[r] = kin.o[0][r];
-    habs[r] = dp.habs[0][r];
-    gorg[r] = T(md.geom_origin[0][r]);
     Rz[r] = kinA.R[0][2][r];
   }
   DPLL_UNROLL for (int j = 1; j < NB; ++j) {
@@ -1007,22 +1096,29 @@ DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, cons
     DPLL_UNROLL for (int r = 0; r < 3; ++r) {
       DPLL_UNROLL for (int c = 0; c < 3; ++c) cg.R[r][c] = pick ? kin.R[j][r][c] : cg.R[r][c];
       o[r] = pick ? kin.o[j][r] : o[r];
-      habs[r] = pick ? dp.habs[j][r] : habs[r];
-      gorg[r] = pick ? T(md.geom_origin[j][r]) : gorg[r];
       Rz[r] = pick ? kinA.R[j][2][r] : Rz[r];
     }
     oz = pick ? kinA.o[j][2] : oz;
-    mu = pick ? dp.mu[j] : mu;
   }
-  cg.mu = mu;
   // support direction in the body frame: -(row 2 of R_AB) (geometry.py:560-564)
   const T d[3] = {-cg.R[2][0], -cg.R[2][1], -cg.R[2][2]};
   T wit[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) cg.drad[i] = T(0);
   if (witness) {
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { cg.sgn[i] = T(0); wit[i] = witness[i]; }
   } else {
     box_corner_signs(d, habs, slot, cg.sgn);
     DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = cg.sgn[i] * habs[i];
+    if constexpr (MD::kGeneral) {
+      // Sphere.support_points (geometry.py:440-452): ONE witness, direction * radius; slots 1..3 do not exist
+      const bool sphere = (kind == kGeomSphere);
+      masked = masked || (sphere && slot != 0);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+        wit[i] = sphere ? d[i] * habs[0] : wit[i];
+        cg.drad[i] = sphere ? d[i] : T(0);
+        cg.sgn[i] = sphere ? T(0) : cg.sgn[i];
+      }
+    }
   }
   T r_b[3], rho[3], pt[3];
   DPLL_UNROLL for (int i = 0; i < 3; ++i) r_b[i] = gorg[i] + wit[i];
@@ -1030,7 +1126,7 @@ DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, cons
   DPLL_UNROLL for (int i = 0; i < 3; ++i) pt[i] = o[i] + rho[i];
   TA phiA = oz;
   DPLL_UNROLL for (int i = 0; i < 3; ++i) phiA += Rz[i] * (TA(gorg[i]) + TA(wit[i]));
-  cg.phi = T(phiA);
+  cg.phi = masked ? T(kMaskedPhi) : T(phiA);
   contact_jacobian<T, NJ>(kin, b, pt, cg.J);
 }
 
@@ -1041,18 +1137,30 @@ DPLL_HD void compute_contact(const ModelDesc& md, const Derived<T, NJ>& dp, cons
 //   g_mu[b]        d/d (pair friction) -- this lane's contacts only (sum over lanes = item total)
 //   g_len[b][3]    d/d |length_params| -- this lane's contacts only
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NJ> struct LossGrad {
+template <typename T, int NJ, int NG = NJ + 1> struct LossGrad {
   static constexpr int NB = NJ + 1;
   T g_iota[NB][kIota];
-  T g_mu[NB];
-  T g_len[NB][3];
+  T g_mu[NG];
+  T g_len[NG][3];
 };
 
-template <typename T, int NJ> DPLL_HD void zero_grad(LossGrad<T, NJ>& g) {
-  DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
+template <typename T, int NJ, int NG> DPLL_HD void zero_grad(LossGrad<T, NJ, NG>& g) {
+  DPLL_UNROLL for (int b = 0; b <= NJ; ++b)
     DPLL_UNROLL for (int i = 0; i < kIota; ++i) g.g_iota[b][i] = T(0);
-    g.g_mu[b] = T(0);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) g.g_len[b][i] = T(0);
+  DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) {
+    g.g_mu[gg] = T(0);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) g.g_len[gg][i] = T(0);
+  }
+}
+
+// this contact's share of d/d(mu_pair, geometry lengths): gmu and the witness adjoint r_bar
+template <typename T, int NJ, int NG>
+DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ>& cg, T gmu, const T (&rbar)[3], LossGrad<T, NJ, NG>& grad) {
+  const T grad_r = cg.drad[0] * rbar[0] + cg.drad[1] * rbar[1] + cg.drad[2] * rbar[2];
+  DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) {
+    const bool mine = (cg.geom == gg);
+    grad.g_mu[gg] += mine ? gmu : T(0);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][i] += mine ? cg.sgn[i] * rbar[i] + (i == 0 ? grad_r : T(0)) : T(0);
   }
 }
 
@@ -1060,9 +1168,9 @@ constexpr double kLossEps = 1e-3;       // multibody_learnable_system.py:130
 constexpr double kDynamicsEps = 1e-4;   // multibody_learnable_system.py:283, 298
 constexpr double kInvalidForce = 1e3;   // multibody_learnable_system.py:187
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x, const T* xp,
-                    int first_contact, T weight, bool want_grad, LossGrad<T, NJ>& grad, T (&force)[KPL][3],
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x, const T* xp,
+                    int first_contact, T weight, bool want_grad, LossGrad<T, NJ, NG>& grad, T (&force)[KPL][3],
                     int& iters, const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kLossEps);
@@ -1180,11 +1288,8 @@ DPLL_HD T loss_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverO
     if (rbar_out) {
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = wt * rbar[i];
     }
-    DPLL_UNROLL for (int b = 0; b < NB; ++b) {
-      const bool mine = (cg[c].body == b);
-      grad.g_mu[b] += mine ? wt * gmu : T(0);
-      DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[b][i] += mine ? wt * cg[c].sgn[i] * rbar[i] : T(0);
-    }
+    const T wrbar[3] = {wt * rbar[0], wt * rbar[1], wt * rbar[2]};
+    add_geometry_grad(cg[c], wt * gmu, wrbar, grad);
   }
   return loss;
 }
@@ -1207,8 +1312,8 @@ template <typename T> DPLL_HD void quat_exp_mul(const T* q, const T (&r)[3], T* 
   out[3] = q[0] * e[3] + e[0] * q[3] + (q[1] * e[2] - q[2] * e[1]);
 }
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD void step_item(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+DPLL_HD void step_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x,
                        int first_contact, T* x_next, T (&impulse)[KPL][3], int& iters,
                        const T (*witness)[3] = nullptr) {
   constexpr int NV = 6 + NJ, NQ = 7 + NJ;
@@ -1276,14 +1381,14 @@ template <typename T> DPLL_HD void quat_exp_mul_adjoint(const T* q, const T (&r)
   DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar[i] = -T(0.5) * sfac * r[i] * e0bar + sfac * evbar[i] + dsfac * rdot * r[i];
 }
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, const T* x, int first_contact,
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
                                 const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3] = nullptr);
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, const SolverOpts& opt, const T* x,
-                                int first_contact, const T* xbar_next, LossGrad<T, NJ>& grad,
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x,
+                                int first_contact, const T* xbar_next, LossGrad<T, NJ, NG>& grad,
                                 const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr,
                                 T (*xbar)[13 + 2 * NJ] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
@@ -1396,11 +1501,7 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
     if (rbar_out) {
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = rbar[i];
     }
-    DPLL_UNROLL for (int b = 0; b < NB; ++b) {
-      const bool mine = (cg[c].body == b);
-      grad.g_mu[b] += mine ? gmu : T(0);
-      DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[b][i] += mine ? cg[c].sgn[i] * rbar[i] : T(0);
-    }
+    add_geometry_grad(cg[c], gmu, rbar, grad);
   }
   T abar[NV], bvec[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) abar[i] = dt * (sv[i] - Lanes::group_sum(jtk[i]));
@@ -1435,17 +1536,18 @@ DPLL_HD void step_item_backward(const ModelDesc& md, const Derived<T, NJ>& dp, c
 // the accumulation type.  The witness is piecewise constant in q in both geometries: a box corner, or the support
 // point of a LeakyReLU network (piecewise linear support function => piecewise constant gradient), passed in.
 // ---------------------------------------------------------------------------------------------
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD void step_state_adjoint(const ModelDesc& md, const Derived<T, NJ>& dp, const T* x, int first_contact,
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
                                 const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3]) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = NQ + NV;
   using S = DualT<TA>;
-  Derived<S, NJ> dps;
-  DPLL_UNROLL for (int b = 0; b < NB; ++b) {
+  Derived<S, NJ, NG> dps;
+  DPLL_UNROLL for (int b = 0; b < NB; ++b)
     DPLL_UNROLL for (int i = 0; i < kIota; ++i) dps.iota[b][i] = S(TA(dp.iota[b][i]));
-    dps.mu[b] = S(TA(dp.mu[b]));
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dps.habs[b][i] = S(TA(dp.habs[b][i]));
+  DPLL_UNROLL for (int g = 0; g < NG; ++g) {
+    dps.mu[g] = S(TA(dp.mu[g]));
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dps.habs[g][i] = S(TA(dp.habs[g][i]));
   }
   const S dt = S(TA(md.dt)), idt = S(TA(1) / TA(md.dt)), mieps = S(TA(-1) / TA(kDynamicsEps));
   for (int k = 0; k < NX; ++k) {  // deliberately not unrolled: one copy of the dual forward pass

@@ -59,209 +59,10 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
 #include "dpll_core.hpp"
 #include "dpll_allreduce.hpp"
 
-namespace {
-
-using namespace dpll;
-
-static_assert(sizeof(ModelDesc) == sizeof(dpll_model_desc_t), "ModelDesc must mirror dpll_model_desc_t");
-static_assert(sizeof(SolverOpts) == sizeof(dpll_solver_opts_t), "SolverOpts must mirror dpll_solver_opts_t");
-static_assert(kMaxJoints == DPLL_MAX_JOINTS && kMaxBodies == DPLL_MAX_BODIES, "limits");
-
-constexpr int kWave = 64;
-constexpr int kMaxLossBlocks = 2048;  // partial-sum rows; 8 one-wave workgroups per CU
-constexpr int kSimds = 1024;          // 256 CUs x 4
-
-// ---- cross-lane primitives --------------------------------------------------------------------
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
-  // old = 0 + bound_ctrl lets the backend fold the move into the consuming add (v_add_f32_dpp); every
-  // source lane of the controls used here is inside the wave, so the value of `old` never shows
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  int lo = (int)(unsigned)(u & 0xffffffffull), hi = (int)(unsigned)(u >> 32);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
-  return __builtin_bit_cast(double, r);
-}
-constexpr int kQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
-constexpr int kQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
-constexpr int kRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
-constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
-
-template <int G> struct GpuLanes {
-  static_assert(G == 1 || G == 4 || G == 8, "lanes per item: one per contact (4 or 8), or 1 (wide build)");
-  static constexpr int kGroup = G;
-  template <typename T> static __device__ __forceinline__ T group_sum(T x) {
-    if (G == 1) return x;
-    x += dpp_mov<kQuadXor1>(x);
-    x += dpp_mov<kQuadXor2>(x);
-    if (G == 8) x += dpp_mov<kRowHalfMirror>(x);  // both quads hold their own sum -> mirror pairs them
-    return x;
-  }
-  static __device__ __forceinline__ bool group_any(bool x) {
-    if (G == 1) return x;
-    const unsigned long long b = __ballot(x);
-    const int base = (threadIdx.x & (kWave - 1)) & ~(G - 1);
-    return ((b >> base) & ((1ull << G) - 1ull)) != 0ull;
-  }
-  static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
-};
-
-// sum over the whole wave of a value that is already uniform inside each group of G lanes, counting every
-// group once; the result is valid in every lane.  Rows of 16 lanes are closed with the mirror controls, the four
-// rows with row_bcast:15 / row_bcast:31 (the total lands in lane 63) and one v_readlane: no LDS permutes.
-constexpr int kRowBcast15 = 0x142;  // lane 15 of each row -> every lane of the next row (row_mask 0xA)
-constexpr int kRowBcast31 = 0x143;  // lane 31 -> rows 2 and 3 (row_mask 0xC)
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_rows(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_rows(double x) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  int lo = (int)(unsigned)(u & 0xffffffffull), hi = (int)(unsigned)(u >> 32);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
-  const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
-  return __builtin_bit_cast(double, r);  // +0.0 in the rows outside ROW_MASK
-}
-__device__ __forceinline__ float read_lane63(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
-}
-__device__ __forceinline__ double read_lane63(double x) {
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 63);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
-}
-template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x) {
-  if (G == 1) {
-    x += dpp_mov<kQuadXor1>(x);
-    x += dpp_mov<kQuadXor2>(x);
-  }
-  if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
-  x += dpp_mov<kRowMirror>(x);
-  x += dpp_rows<kRowBcast15, 0xA>(x);
-  x += dpp_rows<kRowBcast31, 0xC>(x);
-  return read_lane63(x);
-}
-
-// Chain from the batch-summed row (iota space) to the learnable parameters [theta | friction | lengths]: linear in the
-// row, with a matrix that depends on the parameters only.  One EXTRA one-wave workgroup of every gradient kernel (it
-// owns no items and runs on a SIMD the launch leaves idle) writes that matrix behind the partial rows while the other
-// workgroups solve; the finalize kernel then applies it with <= 10 multiply-adds per parameter -- the theta -> iota
-// duals are on nobody's critical path.
-template <typename S> __device__ __forceinline__ void theta_jacobian_column(int inertia_mode, const S* theta_b, int c, S (&dio)[kIota]) {
-  DualT<S> th[10], io[kIota];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) th[i] = DualT<S>(theta_b[i], i == c ? S(1) : S(0));
-  theta_to_iota<DualT<S>>(th, inertia_mode, io);
-#pragma unroll
-  for (int i = 0; i < kIota; ++i) dio[i] = io[i].d;
-}
-template <typename T, typename P, int NB>
-__device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __restrict__ theta, const P* __restrict__ friction,
-                                                   const P* __restrict__ lengths, double* __restrict__ chain) {
-  const int lane = threadIdx.x;
-  if (lane < 10 * NB) {  // lane = (body, theta component c): column c of that body's Jacobian
-    T th[10], dio[kIota];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) th[i] = T(theta[10 * (lane / 10) + i]);
-    theta_jacobian_column<T>(inertia_mode, th, lane % 10, dio);
-#pragma unroll
-    for (int i = 0; i < kIota; ++i) chain[lane * kIota + i] = double(dio[i]);
-  }
-  double* fr_fac = chain + 100 * NB;
-  double* len_sign = fr_fac + (NB + 1) * NB;
-  if (lane < (NB + 1) * NB) {  // lane = (friction entry k, body b): d (2 m0 mb / (m0 + mb)) / d friction_k, mu = |friction|
-    const int k = lane / NB, b = lane % NB;
-    const double f0 = double(friction[0]), fb = double(friction[1 + b]);
-    const double m0 = fabs(f0), mb = fabs(fb);
-    const double den = (m0 + mb) * (m0 + mb);
-    const double pk = double(friction[k]);
-    const double sign = pk > 0.0 ? 1.0 : (pk < 0.0 ? -1.0 : 0.0);
-    double fac = 0.0;
-    if (k == 0) fac += 2.0 * mb * mb / den;
-    if (k == 1 + b) fac += 2.0 * m0 * m0 / den;
-    fr_fac[lane] = fac * sign;
-  }
-  if (lane < 3 * NB) {
-    const double pl = lengths ? double(lengths[lane]) : 0.0;
-    len_sign[lane] = pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0);
-  }
-}
-// learnable parameter k = sum_{j < count} tot[tot0 + j] * chain[coef0 + j] with the row sum `tot` ([loss | iota | mu_pair | length])
-struct ChainRow { int coef0, tot0, count; };
-template <int NB> __device__ __forceinline__ ChainRow chain_row(int k) {
-  if (k < 10 * NB) return ChainRow{k * kIota, 1 + kIota * (k / 10), kIota};
-  if (k < 10 * NB + NB + 1) return ChainRow{100 * NB + (k - 10 * NB) * NB, 1 + kIota * NB, NB};
-  const int i = k - (10 * NB + NB + 1);
-  return ChainRow{100 * NB + (NB + 1) * NB + i, 1 + (kIota + 1) * NB + i, 1};
-}
-template <int NB> __device__ __forceinline__ double apply_chain(const double* tot, const double* __restrict__ chain, int k) {
-  const ChainRow cr = chain_row<NB>(k);
-  double v = 0.0;
-  for (int j = 0; j < cr.count; ++j) v += tot[cr.tot0 + j] * chain[cr.coef0 + j];
-  return v;
-}
-
-}  // namespace
+#include "dpll_common.hpp"
+#include "dpll_general.hpp"
 #include "dpll_mesh_kernels.hpp"
 namespace {
-
-template <typename T, int NJ> struct Dims {
-  static constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NB, G = K;
-  static constexpr int IPW = kWave / G;                       // items per wave
-  static constexpr int P = NB * 10 + (NB + 1) + NB * 3;       // learnable parameters [theta | friction | lengths]
-  static constexpr int PI = 1 + P;                            // row stride of the partial sums; the output row [loss | d/d params]
-  static constexpr int PIOTA = 1 + 14 * NB;                   // a partial row: [loss | d/d iota | d/d mu_pair | d/d |length|]
-  // the chain matrix behind the rows: [d iota_b,i / d theta_b,c (NB, 10 c, 10 i) | d mu_pair,b / d friction_k (NB + 1 k, NB b) |
-  // sign(length_params) (3 NB)], doubles
-  static constexpr int CHAIN = 100 * NB + (NB + 1) * NB + 3 * NB;
-};
-
-template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
-
-
-// Wave reduction of the items' d/d(iota, mu_pair, |length|): one row [loss | d/d iota (10 NB) | d/d mu_pair (NB) |
-// d/d |length| (3 NB)] of double partial sums per wave, written by lane 63 (where the DPP row reduction lands).  The
-// chain to the learnable parameters (theta, friction_params, length_params) is linear in the row, so it runs ONCE on
-// the row sum in the finalize kernel instead of in every wave's prologue (forward-mode duals of theta -> iota cost
-// ~3.5 k cycles per wave there).  Row stride D::PI (>= 1 + 14 NB).
-template <int G, typename T> __device__ __forceinline__ T wave_sum_to_lane63(T x) {
-  if (G == 1) {
-    x += dpp_mov<kQuadXor1>(x);
-    x += dpp_mov<kQuadXor2>(x);
-  }
-  if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
-  x += dpp_mov<kRowMirror>(x);
-  x += dpp_rows<kRowBcast15, 0xA>(x);
-  x += dpp_rows<kRowBcast31, 0xC>(x);
-  return x;  // the total over the groups in lane 63; other lanes hold partial sums
-}
-
-template <typename T, int NJ, int G = Dims<T, NJ>::G>
-__device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ>& acc, double loss_acc, double* __restrict__ partials) {
-  using D = Dims<T, NJ>;
-  using Lanes = GpuLanes<G>;
-  double row[D::PIOTA];
-  row[0] = wave_sum_to_lane63<G>(Lanes::group_sum(loss_acc));
-#pragma unroll
-  for (int b = 0; b < D::NB; ++b) {
-#pragma unroll
-    for (int i = 0; i < kIota; ++i)  // g_iota is replicated inside the group: no group_sum
-      row[1 + kIota * b + i] = double(wave_sum_to_lane63<G>(acc.g_iota[b][i]));
-    row[1 + kIota * D::NB + b] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_mu[b])));
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      row[1 + (kIota + 1) * D::NB + 3 * b + i] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[b][i])));
-  }
-  if (threadIdx.x == kWave - 1) {
-    double* dst = partials + (long long)blockIdx.x * D::PI;
-#pragma unroll
-    for (int i = 0; i < D::PIOTA; ++i) dst[i] = row[i];
-  }
-}
 
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
 // MESH: the contact's support point is read from `witness` (ICNN kernels) and its adjoint written to `rbar_out`;
@@ -770,18 +571,8 @@ template <typename T, int NJ> int loss_blocks(long long batch) {
 
 }  // namespace
 
-struct dpll_ar {
-  int rank, world;
-  void* local;             // this rank's receive buffer (uncached device memory)
-  uint32_t* state;         // [0] call counter, [1] error word (device)
-  dpll_arx::Peers peers;
-  void* opened[dpll_arx::kMaxWorld];
-};
-
-struct dpll_model {
-  ModelDesc desc;
-  SolverOpts opts[2];
-};
+int dpll_fail(int code, const char* fmt, const char* detail) { return fail(code, fmt, detail); }
+int dpll_check_launch(const char* what) { return check_launch(what); }
 
 namespace {
 
@@ -1136,7 +927,7 @@ int launch_mesh_support(const dpll_mesh_params_t* mp, const void* x, long long l
 }
 
 int check_mesh(const dpll_model* m, const dpll_mesh_params_t* mp, const char* who) {
-  if (m->desc.n_joints != 0) return fail(-2, "%s: mesh geometry is implemented for single-body systems", who);
+  if (m->desc.n_joints != 0 || m->desc.n_geoms > 0) return fail(-2, "%s: mesh geometry is implemented for single-body systems", who);
   if (!mp || !mp->hidden_weight || !mp->input_weight0 || !mp->input_weight1 || !mp->output_weight || !mp->perturbations)
     return fail(-1, "%s: null mesh parameter pointer", who);
   return 0;
@@ -1171,12 +962,22 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 8; }
+int dpll_abi_version(void) { return 9; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
-  if (desc->n_joints < 0 || desc->n_joints > 1)
-    return fail(-2, "dpll_model_create: this build supports 0 or 1 revolute joints%s");
+  const bool general = desc->n_geoms > 0;
+  if (desc->n_joints < 0 || desc->n_joints > (general ? DPLL_MAX_JOINTS : 1))
+    return fail(-2, "dpll_model_create: the specialised builds take 0 or 1 revolute joints, the general build (n_geoms > 0) up to 2%s");
+  if (general) {
+    if (desc->n_geoms > DPLL_MAX_GEOMS) return fail(-2, "dpll_model_create: at most 3 collision geometries%s");
+    for (int j = 0; j < desc->n_joints; ++j)
+      if (desc->parent[j] < 0 || desc->parent[j] > j) return fail(-1, "dpll_model_create: parent[j] must be a body listed before body j + 1%s");
+    for (int g = 0; g < desc->n_geoms; ++g) {
+      if (desc->geom_body[g] < 0 || desc->geom_body[g] > desc->n_joints) return fail(-1, "dpll_model_create: geom_body out of range%s");
+      if (desc->geom_kind[g] != DPLL_GEOM_BOX && desc->geom_kind[g] != DPLL_GEOM_SPHERE) return fail(-1, "dpll_model_create: unknown geometry kind%s");
+    }
+  }
   if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");
   if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL)
     return fail(-1, "dpll_model_create: unknown inertia_mode%s");
@@ -1207,15 +1008,20 @@ int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts
 }
 
 int dpll_n_x(const dpll_model_t* model) { return model ? 13 + 2 * model->desc.n_joints : -1; }
-int dpll_n_contacts(const dpll_model_t* model) { return model ? kQuery * (model->desc.n_joints + 1) : -1; }
+int dpll_n_contacts(const dpll_model_t* model) {
+  if (!model) return -1;
+  return kQuery * (model->desc.n_geoms > 0 ? DPLL_MAX_GEOMS : model->desc.n_joints + 1);  // contact SLOTS of the build
+}
 int dpll_param_count(const dpll_model_t* model) {
   if (!model) return -1;
+  if (model->desc.n_geoms > 0) return dpll_general::param_count(model);
   const int nb = model->desc.n_joints + 1;
   return 10 * nb + (nb + 1) + 3 * nb;
 }
 
 int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (!model || batch < 0) return -1;
+  if (model->desc.n_geoms > 0) return dpll_general::workspace_bytes(model, batch);
   const int nb = model->desc.n_joints + 1;
   int64_t ipw = kWave / (kQuery * nb);
   int64_t blocks = (batch + ipw - 1) / ipw;
@@ -1235,6 +1041,9 @@ int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_param
   if (batch > 0 && (!x || !x_plus)) return fail(-1, "dpll_contactnets_loss: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss: row stride smaller than n_x%s");
+  if (model->desc.n_geoms > 0)
+    return dpll_general::loss(model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total, force,
+                              iters, workspace, workspace_bytes, (hipStream_t)stream);
   DPLL_DISPATCH(launch_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total,
                 force, iters, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1244,6 +1053,8 @@ int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const 
                                     double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                     dpll_ar_t* ar, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_loss_allreduce")) return rc;
+  if (model->desc.n_geoms > 0)
+    return fail(-2, "dpll_contactnets_loss_allreduce: the general build exchanges gradients with dpll_ar_allreduce after dpll_contactnets_loss%s");
   // batch == 0 is a rank whose shard of a ragged tail batch is empty: it contributes a zero row and still takes part
   if ((batch > 0 && (!x || !x_plus)) || !grad || !loss_total || !ar) return fail(-1, "dpll_contactnets_loss_allreduce: null argument%s");
   const int nx = dpll_n_x(model);
@@ -1260,6 +1071,7 @@ int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dp
                                   float* ms_loss_kernel, float* ms_finalize_kernel) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_profile_contactnets_loss")) return rc;
   if (batch == 0 || !x || !x_plus || reps < 1 || reps > 100000) return fail(-1, "dpll_profile_contactnets_loss: bad argument%s");
+  if (model->desc.n_geoms > 0) return fail(-2, "dpll_profile_contactnets_loss: specialised builds only%s");
   DPLL_DISPATCH(profile_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, scale, grad, workspace,
                 workspace_bytes, (hipStream_t)stream, reps, ms_loss_kernel, ms_finalize_kernel);
 }
@@ -1271,6 +1083,8 @@ int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params,
   if (!x || !x_next) return fail(-1, "dpll_step: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_next < nx) return fail(-1, "dpll_step: row stride smaller than n_x%s");
+  if (model->desc.n_geoms > 0)
+    return dpll_general::simulate(model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters, (hipStream_t)stream);
   DPLL_DISPATCH(launch_simulate, model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters,
                 (hipStream_t)stream);
 }
@@ -1282,6 +1096,9 @@ int dpll_step_backward(const dpll_model_t* model, int dtype, const dpll_params_t
   if (batch == 0 || !x || !grad_x_next || !grad) return fail(-1, "dpll_step_backward: bad argument%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_g < nx || (grad_x && ld_gx < nx)) return fail(-1, "dpll_step_backward: row stride smaller than n_x%s");
+  if (model->desc.n_geoms > 0)
+    return dpll_general::step_backward(model, dtype, params, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx, workspace,
+                                       workspace_bytes, (hipStream_t)stream);
   DPLL_DISPATCH(launch_step_backward, model, dtype, params, x, ld_x, grad_x_next, ld_g, batch, grad, workspace,
                 workspace_bytes, (hipStream_t)stream, grad_x, ld_gx);
 }
@@ -1294,6 +1111,9 @@ int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* par
   if (!x0 || !traj) return fail(-1, "dpll_simulate: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx) return fail(-1, "dpll_simulate: row stride smaller than n_x%s");
+  if (model->desc.n_geoms > 0)
+    return dpll_general::simulate(model, dtype, params, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, 1, nullptr,
+                                  (hipStream_t)stream);
   DPLL_DISPATCH(launch_simulate, model, dtype, params, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, 1,
                 nullptr, (hipStream_t)stream);
 }
@@ -1430,6 +1250,8 @@ int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params
   if (batch == 0) return 0;
   if (!x) return fail(-1, "dpll_terms: null state pointer%s");
   if (ld_x < dpll_n_x(model)) return fail(-1, "dpll_terms: row stride smaller than n_x%s");
+  if (model->desc.n_geoms > 0)
+    return dpll_general::terms(model, dtype, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);
   DPLL_DISPATCH(launch_terms, model, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);
 }
 

@@ -142,7 +142,8 @@ class GradientAllReduce:
         self.transport = 'peer' if self.peer is not None else 'collective'
         # fuse: with the peer transport the exchange runs inside the finalize kernel of the loss launch
         # (dpll_contactnets_loss_allreduce); all_reduce_mean() then has nothing left to launch
-        self.fused = bool(fuse and self.peer is not None and getattr(system, '_mesh', lambda: None)() is None)
+        self.fused = bool(fuse and self.peer is not None and getattr(system, '_mesh', lambda: None)() is None and
+                          system.spec.is_fast())  # the general build reduces with a kernel of its own after the launch
         system._fused_ar = self.peer._ar if self.fused else None
 
     def check_healthy(self) -> None:

@@ -83,31 +83,35 @@ def _set_shape(geometry_element: ET.Element, tag: str, attributes: Dict[str, str
     shape.attrib = dict(attributes)
 
 
-def fill_link(link: ET.Element, pi_cm: Sequence[float], shape: Tuple[str, Dict[str, str]], mu: float) -> None:
+def fill_link(link: ET.Element, pi_cm: Sequence[float], shapes: List[Tuple[Tuple[str, Dict[str, str]], float]]) -> None:
     """Writes one body's learned values into its ``<link>`` (``urdf_utils.py:255-314``): mass, centre of
-    mass (``pi_cm[1:4] / m``), central inertia, the collision AND visual shape, ``drake:mu_static``."""
+    mass (``pi_cm[1:4] / m``), central inertia, and for every ``(shape, mu)`` of ``shapes`` the link's next
+    ``<collision>`` shape with its ``drake:mu_static``; the first shape is also the ``<visual>`` one."""
     zero3 = {'xyz': '0. 0. 0.', 'rpy': '0. 0. 0.'}
     inertial = _find_or_add(link, 'inertial', {})
     _find_or_add(inertial, 'mass', {'value': '0.'}).set('value', repr(float(pi_cm[0])))
     _find_or_add(inertial, 'origin', zero3).set('xyz', ' '.join(repr(float(c) / float(pi_cm[0])) for c in pi_cm[1:4]))
     _find_or_add(inertial, 'inertia', {}).attrib = {k: repr(float(v)) for k, v in zip(INERTIA_ATTRIBUTES, pi_cm[4:])}
-    collision = _find_or_add(link, 'collision', {})
-    visual = _find_or_add(link, 'visual', {})
-    for holder in (collision, visual):
-        _set_shape(_find_or_add(holder, 'geometry', {}), shape[0], shape[1])
-    properties = _find_or_add(collision, _PROX, {})
-    _find_or_add(properties, _MU, {'value': '0.'}).set('value', repr(float(mu)))
+    collisions = link.findall('collision')
+    while len(collisions) < len(shapes):
+        collisions.append(ET.SubElement(link, 'collision', {}))
+    for position, ((shape, mu), collision) in enumerate(zip(shapes, collisions)):
+        holders = (collision, _find_or_add(link, 'visual', {})) if position == 0 else (collision,)
+        for holder in holders:
+            _set_shape(_find_or_add(holder, 'geometry', {}), shape[0], shape[1])
+        properties = _find_or_add(collision, _PROX, {})
+        _find_or_add(properties, _MU, {'value': '0.'}).set('value', repr(float(mu)))
 
 
-def render_urdf(source_path: str, bodies: List[Tuple[str, Sequence[float], Tuple[str, Dict[str, str]], float]]) -> str:
-    """The source URDF with every listed ``(link name, pi_cm, shape, mu)`` written into it, as text
+def render_urdf(source_path: str, bodies: List[Tuple[str, Sequence[float], List[Tuple[Tuple[str, Dict[str, str]], float]]]]) -> str:
+    """The source URDF with every listed ``(link name, pi_cm, [(shape, mu), ...])`` written into it, as text
     (``urdf_utils.py:317-384``); links not listed (no inertia: the world) are left alone."""
     tree = ET.parse(source_path)
-    by_name = {name: (pi_cm, shape, mu) for name, pi_cm, shape, mu in bodies}
+    by_name = {name: (pi_cm, shapes) for name, pi_cm, shapes in bodies}
     for element in tree.iter():
         if element.tag == 'link' and element.get('name') in by_name:
-            pi_cm, shape, mu = by_name[element.get('name')]
-            fill_link(element, pi_cm, shape, mu)
+            pi_cm, shapes = by_name[element.get('name')]
+            fill_link(element, pi_cm, shapes)
     ET.register_namespace('drake', DRAKE_URL)
     return '<?xml version="1.0"?>\n' + ET.tostring(tree.getroot(), encoding='utf-8').decode('utf-8')
 

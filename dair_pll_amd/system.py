@@ -39,6 +39,20 @@ class Plane(Module):
     """Ground half-space z <= 0 (``dair_pll/geometry.py:94-129``); no parameters."""
 
 
+class Sphere(Module):
+    """``dair_pll/geometry.py:415-456``: ``length_param`` is the radius, a scalar (its absolute value is used); ONE
+    witness point per sphere.  (The reference's constructor cannot be called -- ``assert radius.numel == 1`` compares a
+    bound method with 1, ``:431`` -- so no reference object of this class exists outside a ``__new__`` bypass; the
+    arithmetic below it is what is reproduced.)"""
+
+    def __init__(self, radius: Tensor) -> None:
+        super().__init__()
+        self.length_param = Parameter(radius.reshape(()).clone(), requires_grad=True)
+
+    def get_radius(self) -> Tensor:
+        return torch.abs(self.length_param)
+
+
 class Box(Module):
     """``dair_pll/geometry.py:367-412``: ``length_params`` are the half lengths, shape ``(1, 3)``."""
 
@@ -120,10 +134,11 @@ class MultibodyTerms(Module):
         as_t = lambda a: torch.tensor(np.asarray(a), dtype=dtype, device=device)
         self.lagrangian_terms = LagrangianTerms(as_t(theta))
         geometries: List[Module] = [Plane()]
-        for body in spec.bodies:
-            geom = body.geoms[0]
+        for _, geom in spec.geoms():  # body order, as friction_params (multibody_terms.py:314-317)
             if geom.kind == 'box':
                 geometries.append(Box(as_t(geom.half_lengths)))
+            elif geom.kind == 'sphere':
+                geometries.append(Sphere(as_t(geom.radius)))
             else:
                 geometries.append(DeepSupportConvex(torch.tensor(geom.vertices), dtype, device))
         self.contact_terms = ContactTerms(as_t(spec.friction_init()), geometries)
@@ -212,16 +227,36 @@ class MultibodyLearnableSystem(Module):
         self._grad_reduced = False  # the last contactnets_loss_and_grad already summed [loss | gradients] over the ranks
 
     # ---- parameters ---------------------------------------------------------------------------
-    def _param_list(self) -> List[Parameter]:
+    def _geom_slots(self) -> int:
+        """geometry slots of the build that serves this model: one per body (specialised builds) or always 3 (general)"""
+        return self.spec.n_joints + 1 if self.spec.is_fast() else _capi.MAX_GEOMS
+
+    def _layout(self):
+        """``[(parameter, offset in the flat buffer)]`` and the buffer's length.  Layout of ``dpll_param_count``:
+        ``[theta (n_bodies, 10) | friction (1 + slots) | lengths (slots, 3)]`` (a sphere's radius sits in column 0 of
+        its row; slots the model does not use are padding), then -- mesh systems, which have no lengths block -- the
+        network weights."""
         terms = self.multibody_terms
-        shape: List[Parameter] = []
-        for geometry in terms.contact_terms.geometries:
+        n_b, slots = self.spec.n_joints + 1, self._geom_slots()
+        out = [(terms.lagrangian_terms.inertial_parameters, 0), (terms.contact_terms.friction_params, 10 * n_b)]
+        lengths0 = 10 * n_b + 1 + slots
+        end = lengths0
+        for g, geometry in enumerate(list(terms.contact_terms.geometries)[1:]):
             if isinstance(geometry, Box):
-                shape.append(geometry.length_params)
+                out.append((geometry.length_params, lengths0 + 3 * g))
+                end = lengths0 + 3 * slots
+            elif isinstance(geometry, Sphere):
+                out.append((geometry.length_param, lengths0 + 3 * g))
+                end = lengths0 + 3 * slots
             elif isinstance(geometry, DeepSupportConvex):
                 net = geometry.network
-                shape += [net.hidden_weights[0], net.input_weights[0], net.input_weights[1], net.output_weight]
-        return [terms.lagrangian_terms.inertial_parameters, terms.contact_terms.friction_params] + shape
+                for p in (net.hidden_weights[0], net.input_weights[0], net.input_weights[1], net.output_weight):
+                    out.append((p, end))
+                    end += p.numel()
+        return out, end
+
+    def _param_list(self) -> List[Parameter]:
+        return [p for p, _ in self._layout()[0]]
 
     def _mesh(self) -> Optional['DeepSupportConvex']:
         for geometry in self.multibody_terms.contact_terms.geometries:
@@ -250,25 +285,25 @@ class MultibodyLearnableSystem(Module):
         return sum(p.numel() for p in self._param_list())
 
     def _packed(self) -> Tensor:
-        """All learnable parameters as views of ONE flat device buffer ``[theta | friction |
-        lengths]`` (the layout ``dpll_param_count`` documents), so a kernel call needs no gather
-        and an optimizer's in-place update is seen by the next call."""
-        params = self._param_list()
+        """All learnable parameters as views of ONE flat device buffer (:meth:`_layout`), so a kernel call needs no
+        gather and an optimizer's in-place update is seen by the next call."""
+        layout, total = self._layout()
         flat = self._flat
-        ok = flat is not None and flat.dtype == params[0].dtype and flat.device == params[0].device
-        offset = 0
+        first = layout[0][0]
+        ok = flat is not None and flat.numel() == total and flat.dtype == first.dtype and flat.device == first.device
         if ok:
-            for p in params:
+            for p, offset in layout:
                 if p.data_ptr() != flat.data_ptr() + offset * flat.element_size() or not p.is_contiguous():
                     ok = False
                     break
-                offset += p.numel()
         if not ok:
-            flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
-            offset = 0
-            for p in params:
+            flat = torch.zeros(total, dtype=first.dtype, device=first.device)
+            n_b, slots = self.spec.n_joints + 1, self._geom_slots()
+            flat[10 * n_b:10 * n_b + 1 + slots] = 1.0  # friction of geometry slots the model does not use
+            for p, offset in layout:
+                flat[offset:offset + p.numel()] = p.detach().reshape(-1)
+            for p, offset in layout:
                 p.data = flat[offset:offset + p.numel()].view(p.shape)
-                offset += p.numel()
             self._flat = flat
             self._flat_grad = self._grad_buf = self._loss_total = None
         return flat
@@ -287,11 +322,7 @@ class MultibodyLearnableSystem(Module):
         return self._grad_buf
 
     def _split_flat(self, flat: Tensor) -> List[Tensor]:
-        out, offset = [], 0
-        for p in self._param_list():
-            out.append(flat[offset:offset + p.numel()].view(p.shape))
-            offset += p.numel()
-        return out
+        return [flat[offset:offset + p.numel()].view(p.shape) for p, offset in self._layout()[0]]
 
     # ---- native handle ------------------------------------------------------------------------
     def _model(self) -> ctypes.c_void_p:
@@ -330,9 +361,9 @@ class MultibodyLearnableSystem(Module):
         return tensor if tensor.stride(-1) == 1 and tensor.stride(0) >= width else tensor.contiguous()
 
     def _params_struct(self, flat: Tensor) -> _capi.Params:
-        n_b = self.spec.n_joints + 1
+        n_b, slots = self.spec.n_joints + 1, self._geom_slots()
         base, size = flat.data_ptr(), flat.element_size()
-        return _capi.Params(base, base + 10 * n_b * size, base + (10 * n_b + n_b + 1) * size)
+        return _capi.Params(base, base + 10 * n_b * size, base + (10 * n_b + slots + 1) * size)
 
     @staticmethod
     def _stream() -> int:
@@ -477,10 +508,20 @@ class MultibodyLearnableSystem(Module):
         batch_shape = x.shape[:-1]
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
-        force = torch.empty((xf.shape[0], 3 * self.spec.n_contacts), dtype=self.dtype, device=xf.device)
+        force = torch.empty((xf.shape[0], 3 * 4 * self._geom_slots()), dtype=self.dtype, device=xf.device)
         iters = torch.empty(xf.shape[0], dtype=torch.int32, device=xf.device)
         loss, _, _ = self._launch_loss(xf, xpf, None, 1.0, False, force=force, iters=iters)
+        force = force[:, self._contact_rows(force.device)]  # the kernels' contact slots -> the model's contacts
         return loss.reshape(batch_shape), force.reshape(batch_shape + (-1,)), iters.reshape(batch_shape)
+
+    def _contact_rows(self, device) -> Tensor:
+        """rows of the kernels' ``[normals (K) | (t_x, t_y) per contact (2 K)]`` slot layout that belong to the model's
+        contacts (a sphere uses one of its geometry's four slots, unused geometry slots none), in the reference's
+        order (multibody_terms.py:415-426)"""
+        slots = self.spec.contact_slots()
+        k_slots = 4 * self._geom_slots()
+        rows = slots + [k_slots + 2 * s + t for s in slots for t in (0, 1)]
+        return torch.tensor(rows, dtype=torch.long, device=device)
 
     # ---- dynamics -------------------------------------------------------------------------------
     def _step(self, x: Tensor) -> Tensor:
@@ -604,11 +645,17 @@ class MultibodyLearnableSystem(Module):
                 out[f'{body.name}_com_{axis}'] = float(value)
             for name, value in zip(('I_xx', 'I_yy', 'I_zz', 'I_xy', 'I_xz', 'I_yz'), pi_cm[4:]):
                 out[f'{body.name}_{name}'] = float(value)
-            geometry = self.multibody_terms.contact_terms.geometries[index + 1]
-            if isinstance(geometry, Box):
-                for axis, value in zip('xyz', geometry.get_half_lengths().detach().cpu().reshape(-1)):
-                    out[f'{body.name}_len_{axis}'] = 2 * float(value)
-            out[f'{body.name}_mu'] = float(friction[index + 1])
+            mine = [g for g, (b, _) in enumerate(self.spec.geoms()) if b == index]
+            for count, g in enumerate(mine):
+                # one geometry per body is all the reference's key scheme distinguishes; further ones get a suffix
+                prefix = body.name if count == 0 else f'{body.name}_g{count}'
+                geometry = self.multibody_terms.contact_terms.geometries[g + 1]
+                if isinstance(geometry, Box):
+                    for axis, value in zip('xyz', geometry.get_half_lengths().detach().cpu().reshape(-1)):
+                        out[f'{prefix}_len_{axis}'] = 2 * float(value)
+                elif isinstance(geometry, Sphere):
+                    out[f'{prefix}_radius'] = float(geometry.get_radius())
+                out[f'{prefix}_mu'] = float(friction[g + 1])
         return out
 
     def _pi_cm(self) -> np.ndarray:
@@ -621,8 +668,9 @@ class MultibodyLearnableSystem(Module):
         shape (``multibody_terms.py:561-563`` with ``deep_support_function.py:93-123``)."""
         from . import export
         meshes = {}
-        for index, body in enumerate(self.spec.bodies):
-            geometry = self.multibody_terms.contact_terms.geometries[index + 1]
+        for g, (index, _) in enumerate(self.spec.geoms()):
+            body = self.spec.bodies[index]
+            geometry = self.multibody_terms.contact_terms.geometries[g + 1]
             if isinstance(geometry, DeepSupportConvex):
                 def support(directions: np.ndarray) -> np.ndarray:
                     # the HIP kernels evaluate the network (dpll_mesh_support_points): a state whose rotation takes
@@ -666,14 +714,21 @@ class MultibodyLearnableSystem(Module):
         meshes = self.extract_meshes()
         bodies = []
         for index, body in enumerate(self.spec.bodies):
-            geometry = self.multibody_terms.contact_terms.geometries[index + 1]
-            if isinstance(geometry, Box):
-                half = geometry.get_half_lengths().detach().double().cpu().numpy().reshape(-1)
-                shape = ('box', {'size': ' '.join(repr(2.0 * float(h)) for h in half)})
-            else:
-                export.save_string(os.path.join(self.output_urdfs_dir, export.MESH_FILE), export.mesh_to_obj(*meshes[body.name]))
-                shape = ('mesh', {'filename': export.MESH_FILE})
-            bodies.append((body.name, pi_cm[index], shape, float(friction[index + 1])))
+            shapes = []  # this link's <collision> elements in order
+            for g, (b, _) in enumerate(self.spec.geoms()):
+                if b != index:
+                    continue
+                geometry = self.multibody_terms.contact_terms.geometries[g + 1]
+                if isinstance(geometry, Box):
+                    half = geometry.get_half_lengths().detach().double().cpu().numpy().reshape(-1)
+                    shape = ('box', {'size': ' '.join(repr(2.0 * float(h)) for h in half)})
+                elif isinstance(geometry, Sphere):
+                    shape = ('sphere', {'radius': repr(float(geometry.get_radius()))})
+                else:
+                    export.save_string(os.path.join(self.output_urdfs_dir, export.MESH_FILE), export.mesh_to_obj(*meshes[body.name]))
+                    shape = ('mesh', {'filename': export.MESH_FILE})
+                shapes.append((shape, float(friction[g + 1])))
+            bodies.append((body.name, pi_cm[index], shapes))
         new_urdfs = {}
         for name, source in self.urdfs.items():
             target = os.path.join(self.output_urdfs_dir, os.path.basename(source))
@@ -687,7 +742,7 @@ class MultibodyLearnableSystem(Module):
         batch_shape = q.shape[:-1]
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
         flat = self._packed()
-        n, n_v, k = x.shape[0], self.space.n_v, self.spec.n_contacts
+        n, n_v, k = x.shape[0], self.space.n_v, 4 * self._geom_slots()
         new = lambda *shape: torch.empty((n,) + shape, dtype=self.dtype, device=x.device)
         delassus, mass, jac, phi, acc = new(3 * k, 3 * k), new(n_v, n_v), new(3 * k, n_v), new(k), new(n_v)
         params = self._params_struct(flat)
@@ -700,5 +755,10 @@ class MultibodyLearnableSystem(Module):
         else:
             _capi.check(lib.dpll_terms(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0), n,
                                        _ptr(delassus), _ptr(mass), _ptr(jac), _ptr(phi), _ptr(acc), self._stream()))
+        if k != self.spec.n_contacts:  # keep the model's contacts of the kernels' slots
+            rows = self._contact_rows(x.device)
+            delassus = delassus[:, rows][:, :, rows]
+            jac = jac[:, rows]
+            phi = phi[:, torch.tensor(self.spec.contact_slots(), dtype=torch.long, device=x.device)]
         shape = lambda t: t.reshape(batch_shape + t.shape[1:])
         return shape(delassus), shape(mass), shape(jac), shape(phi), shape(acc)

@@ -4,10 +4,12 @@ The reference obtains the same facts from Drake's parser and symbolic plant
 (``dair_pll/drake_utils.py:248-335``, ``dair_pll/multibody_terms.py:161-207, 355-376``): per body
 mass / centre of mass / central inertia, the joint tree, collision geometry with
 ``drake:mu_static``, and a ground half-space with friction 1.0 added to every plant
-(``drake_utils.py:280-288``).  The kernels support one floating-base serial chain of revolute
-joints with one box collision geometry per body, all of it touching only the ground (the elbow's
-links are collision filtered, ``assets/contactnets_elbow.urdf``), which covers the cube and elbow
-systems of the reference's ContactNets example.
+(``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to two revolute
+joints with up to three box / sphere collision geometries on any of its bodies (or one mesh on a
+single body), all of it touching only the ground (the elbow's links are collision filtered,
+``assets/contactnets_elbow.urdf``).  The cube and elbow systems of the reference's ContactNets example
+-- a serial chain with exactly one box per body -- run on builds specialised for them
+(:meth:`ModelSpec.is_fast`).
 """
 from __future__ import annotations
 
@@ -20,14 +22,16 @@ from typing import List, Optional
 GROUND_MU = 1.0  # dair_pll/drake_utils.py:280-288
 GRAVITY_Z = -9.81  # Drake's default UniformGravityField
 MAX_JOINTS = 2  # dpll_core.hpp kMaxJoints
+MAX_GEOMS = 3  # dpll_core.hpp kMaxGeoms
 
 
 @dataclass
 class GeomSpec:
-    kind: str  # 'box' | 'mesh'
+    kind: str  # 'box' | 'sphere' | 'mesh'
     origin: List[float]
     mu: float
     half_lengths: Optional[List[float]] = None
+    radius: Optional[float] = None
     mesh_file: Optional[str] = None
     vertices: Optional[List[List[float]]] = None
 
@@ -63,9 +67,27 @@ class ModelSpec:
     def n_v(self) -> int:
         return 6 + self.n_joints
 
+    def geoms(self):
+        """``[(body index, GeomSpec)]`` in body order: the order of ``friction_params[1:]`` and of the contact blocks"""
+        return [(index, geom) for index, body in enumerate(self.bodies) for geom in body.geoms]
+
     @property
     def n_contacts(self) -> int:
-        return 4 * sum(len(b.geoms) for b in self.bodies)
+        """witness points per geometry: 4 for a box / mesh (geometry.py:47-48, 490), 1 for a sphere (:440-452)"""
+        return sum(1 if geom.kind == 'sphere' else 4 for _, geom in self.geoms())
+
+    def contact_slots(self) -> List[int]:
+        """indices of the real contacts among the kernels' 4 slots per geometry (a sphere uses slot 0 only)"""
+        out = []
+        for g, (_, geom) in enumerate(self.geoms()):
+            out += [4 * g] if geom.kind == 'sphere' else [4 * g + s for s in range(4)]
+        return out
+
+    def is_fast(self) -> bool:
+        """the cube / elbow topology the specialised builds are written for: a serial chain of at most one joint with
+        exactly one box (or mesh) per body"""
+        return (self.n_joints <= 1 and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
+                and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0))
 
     def friction_init(self) -> List[float]:
         """``friction_params`` initial value: ground first, then every geometry in body order
@@ -126,12 +148,14 @@ def parse_urdf(path: str) -> ModelSpec:
             if geometry.find('box') is not None:
                 size = _vec(geometry.find('box').get('size'))
                 body.geoms.append(GeomSpec('box', xyz, mu, half_lengths=[0.5 * s for s in size]))
+            elif geometry.find('sphere') is not None:
+                body.geoms.append(GeomSpec('sphere', xyz, mu, radius=float(geometry.find('sphere').get('radius'))))
             elif geometry.find('mesh') is not None:
                 filename = geometry.find('mesh').get('filename')
                 mesh_path = os.path.join(os.path.dirname(os.path.abspath(path)), filename)
                 body.geoms.append(GeomSpec('mesh', xyz, mu, mesh_file=filename, vertices=_obj_vertices(mesh_path)))
             else:
-                raise NotImplementedError('only <box> and <mesh> collision geometry is supported')
+                raise NotImplementedError('only <box>, <sphere> and <mesh> collision geometry is supported')
         by_name[body.name] = body
         order.append(body.name)
     joints = []
@@ -167,10 +191,11 @@ def check_supported(spec: ModelSpec) -> None:
     """What the HIP kernels are written for; anything else fails loudly at construction."""
     if spec.n_joints > MAX_JOINTS:
         raise NotImplementedError(f'at most {MAX_JOINTS} joints')
+    geoms = spec.geoms()
+    if not 1 <= len(geoms) <= MAX_GEOMS:
+        raise NotImplementedError(f'between 1 and {MAX_GEOMS} collision geometries')
     for index, body in enumerate(spec.bodies):
-        if index > 0 and body.parent != index - 1:
-            raise NotImplementedError('only serial chains (each link hangs off the previous one)')
-        if len(body.geoms) != 1:
-            raise NotImplementedError('exactly one collision geometry per body')
-        if body.geoms[0].kind == 'mesh' and spec.n_joints != 0:
-            raise NotImplementedError('mesh (DeepSupportConvex) geometry is implemented for single-body systems')
+        if index > 0 and not 0 <= body.parent < index:
+            raise NotImplementedError('links must be listed after their parent')
+    if any(geom.kind == 'mesh' for _, geom in geoms) and (spec.n_joints != 0 or len(geoms) != 1):
+        raise NotImplementedError('mesh (DeepSupportConvex) geometry is implemented for single-body systems with one geometry')

@@ -22,8 +22,9 @@
  * State layout (dair_pll/state_space.py:412-424):  x = [quat wxyz, p_world(3), joint angles |
  * omega_body(3), v_world(3), joint rates], n_x = 13 + 2 n_joints.
  * Parameter layout: theta (n_bodies, 10) log-Cholesky inertial parameters (inertia.py:206-234);
- * friction (1 + n_bodies,) with the ground first (multibody_terms.py:314-317, drake_utils.py:280-288);
- * lengths (n_bodies, 3) box half lengths (geometry.py:367-403).
+ * friction (1 + n_geoms,) with the ground first (multibody_terms.py:314-317, drake_utils.py:280-288);
+ * lengths (n_geoms, 3) box half lengths (geometry.py:367-403), a sphere's radius in [g][0] (geometry.py:415-456);
+ * n_geoms = n_bodies for the fast builds.
  */
 #ifndef DPLL_H_
 #define DPLL_H_
@@ -36,11 +37,16 @@ extern "C" {
 
 #define DPLL_MAX_JOINTS 2
 #define DPLL_MAX_BODIES 3
+#define DPLL_MAX_GEOMS 3
 
 enum dpll_dtype { DPLL_F32 = 0, DPLL_F64 = 1 };
 enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1 };
+enum dpll_geom_kind { DPLL_GEOM_BOX = 0, DPLL_GEOM_SPHERE = 1 };
 
-/* One floating-base serial chain of revolute joints, one box geometry per body, ground half-space at z = 0. */
+/* One floating-base tree of revolute joints with convex collision geometries against the ground half-space at z = 0:
+ * what Drake extracts from the URDF for MultibodyTerms (multibody_terms.py:328-382, drake_utils.py:248-335).
+ * n_geoms = 0 selects the two fast builds (a serial chain with one box per body, geometry g on body g: the cube and
+ * elbow systems); n_geoms > 0 the general build: any parent tree, 1..DPLL_MAX_GEOMS boxes / spheres on any bodies. */
 typedef struct dpll_model_desc {
   int32_t n_joints;
   int32_t inertia_mode;
@@ -48,7 +54,12 @@ typedef struct dpll_model_desc {
   double gravity_z;
   double joint_origin[DPLL_MAX_JOINTS][3]; /* joint j+1: origin in the parent body frame */
   double joint_axis[DPLL_MAX_JOINTS][3];   /* unit axis */
-  double geom_origin[DPLL_MAX_BODIES][3];  /* collision geometry origin in its body frame */
+  double geom_origin[DPLL_MAX_GEOMS][3];   /* collision geometry origin in the frame of its body */
+  int32_t parent[DPLL_MAX_JOINTS];         /* general build: parent body of body j + 1 */
+  int32_t n_geoms;                         /* 0: fast builds */
+  int32_t geom_body[DPLL_MAX_GEOMS];
+  int32_t geom_kind[DPLL_MAX_GEOMS];       /* dpll_geom_kind */
+  int32_t reserved;
 } dpll_model_desc_t;
 
 typedef struct dpll_solver_opts {

@@ -111,6 +111,8 @@ def parse_urdf(path: str) -> Dict:
             if geometry.find('box') is not None:
                 size = _floats(geometry.find('box').get('size'), 3)
                 geom.update(kind='box', half=[0.5 * s for s in size])
+            elif geometry.find('sphere') is not None:
+                geom.update(kind='sphere', radius=float(geometry.find('sphere').get('radius')))
             elif geometry.find('mesh') is not None:
                 filename = geometry.find('mesh').get('filename')
                 mesh_path = os.path.join(os.path.dirname(os.path.abspath(path)), filename)
@@ -724,7 +726,8 @@ class OracleSystem:
         self.n_q = 7 + self.n_joints
         self.n_v = 6 + self.n_joints
         self.n_x = self.n_q + self.n_v
-        self.n_contacts = N_QUERY * (len(self.geoms) - 1)
+        # witness points per geometry: 4 (box: geometry.py:490; mesh: :47-48), 1 for a sphere (:440-452)
+        self.n_contacts = sum(1 if g['kind'] == 'sphere' else N_QUERY for g in self.geoms[1:])
         pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
                               for b in self.spec['bodies']], dtype=torch.float64)
         # theta_0 = pi_o_to_theta(drake inertia), reference multibody_terms.py:186-188
@@ -736,6 +739,8 @@ class OracleSystem:
                 self.geom_params.append(None)
             elif geom['kind'] == 'box':
                 self.geom_params.append({'length_params': torch.tensor([geom['half']], dtype=dtype)})
+            elif geom['kind'] == 'sphere':
+                self.geom_params.append({'length_param': torch.tensor(geom['radius'], dtype=dtype)})
             else:
                 if mesh_params is not None and index in mesh_params:
                     self.geom_params.append({k: v.to(dtype) for k, v in mesh_params[index].items()})
@@ -754,7 +759,7 @@ class OracleSystem:
                 if key == 'perturbations':
                     continue
                 prefix = f'multibody_terms.contact_terms.geometries.{index}.'
-                out[prefix + (key if key == 'length_params' else 'network.' + key)] = value
+                out[prefix + (key if key in ('length_params', 'length_param') else 'network.' + key)] = value
         return out
 
     def requires_grad_(self, flag: bool = True) -> 'OracleSystem':
@@ -783,6 +788,8 @@ class OracleSystem:
         params = self.geom_params[geom_index]
         if 'length_params' in params:
             return topk_support(directions, box_vertices(params['length_params']))
+        if 'length_param' in params:  # Sphere.support_points, reference geometry.py:440-452: ONE witness point
+            return (directions * torch.abs(params['length_param'])).unsqueeze(-2)
         weights = {k: v for k, v in params.items() if k != 'perturbations'}
         return mesh_support(weights, params['perturbations'], directions)
 

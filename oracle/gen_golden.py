@@ -45,7 +45,7 @@ from dair_pll import state_space  # noqa: E402
 from dair_pll.data_config import TrajectorySliceConfig  # noqa: E402
 from dair_pll.dataset_management import TrajectorySliceDataset  # noqa: E402
 from dair_pll.drake_experiment import DrakeMultibodyLearnableExperiment  # noqa: E402
-from dair_pll.geometry import Box, DeepSupportConvex, Plane  # noqa: E402
+from dair_pll.geometry import Box, DeepSupportConvex, Plane, Sphere  # noqa: E402
 from dair_pll.inertia import InertialParameterConverter  # noqa: E402
 from dair_pll.integrator import VelocityIntegrator  # noqa: E402
 from dair_pll.multibody_learnable_system import MultibodyLearnableSystem  # noqa: E402
@@ -96,6 +96,13 @@ def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0):
             modules.append(Plane())
         elif geom['kind'] == 'box':
             modules.append(Box(torch.tensor(geom['half']), 4))
+        elif geom['kind'] == 'sphere':
+            # Sphere.__init__ cannot run (geometry.py:431 asserts `radius.numel == 1`, a bound method compared with 1):
+            # built like the Drake-dependent classes, by __new__ + the attribute its methods use
+            sphere = Sphere.__new__(Sphere)
+            nn.Module.__init__(sphere)
+            sphere.length_param = Parameter(torch.tensor(geom['radius']), requires_grad=True)
+            modules.append(sphere)
         else:
             torch.manual_seed(mesh_seed)
             modules.append(DeepSupportConvex(torch.tensor(geom['vertices'])))
@@ -343,6 +350,31 @@ def record_dynamics_gradients(name: str = 'dynamics_gradients') -> None:
     np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
 
 
+def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+    """models beyond the cube / elbow topologies -- three-link serial chain, branching tree, several
+    geometries on one body, spheres (this repository's own URDFs under assets/) -- through the reference's own
+    MultibodyTerms / contactnets_loss / forward_dynamics / simulate, exactly as `record_case` does for the reference's
+    assets.  Inputs: seeded tosses (random attitude, 5-12 cm above the ground, spinning) rolled out by the reference's
+    simulate on the stub-built system, every `keep_every`-th pair kept."""
+    for name in ('chain3', 'vee', 'ballcube', 'mace'):
+        urdf = os.path.join(REPO, 'assets', name + '.urdf')
+        system, spec = build_reference_system(urdf, 'reference_literal')
+        n_j = spec['n_joints']
+        gen = torch.Generator().manual_seed(seed)
+        quat = torch.randn((n_traj, 4), generator=gen)
+        quat = quat / quat.norm(dim=-1, keepdim=True)
+        pos = torch.cat((0.05 * torch.randn((n_traj, 2), generator=gen), 0.05 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
+        joints = 1.5 * torch.randn((n_traj, n_j), generator=gen)
+        vel = torch.cat((4.0 * torch.randn((n_traj, 3), generator=gen), 0.4 * torch.randn((n_traj, 3), generator=gen),
+                         3.0 * torch.randn((n_traj, n_j), generator=gen)), -1)
+        x_0 = torch.cat((quat, pos, joints, vel), -1)
+        with torch.no_grad():
+            traj, _ = system.simulate(x_0.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
+        x = traj[:, :-1][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+        x_plus = traj[:, 1:][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+        record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3)
+
+
 def main() -> None:
     cube = os.path.join(ASSETS, 'contactnets_cube.urdf')
     record_bench_batch('cube_box_4096')
@@ -358,6 +390,7 @@ def main() -> None:
     record_elbow_bench_batch()
     record_slice_fixture()
     record_dynamics_gradients()
+    record_general_cases()
 
 
 if __name__ == '__main__':

@@ -17,16 +17,16 @@ using namespace dpll;
 
 namespace {
 
-template <typename T, typename TA, int NJ>
-void loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
+template <typename T, typename TA, int NJ, int NG = NJ + 1, class MD = ModelDesc>
+void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
                 const T* x, const T* xp, int64_t B, const T* weights, double scale, T* loss, double* grad, T* force,
                 int32_t* iters) {
-  constexpr int NB = NJ + 1, K = kQuery * NB, NX = 13 + 2 * NJ;
-  Derived<T, NJ> dp;
+  constexpr int NB = NJ + 1, K = kQuery * NG, NX = 13 + 2 * NJ;
+  Derived<T, NJ, NG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  double g_iota[NB][kIota] = {}, g_mu[NB] = {}, g_len[NB][3] = {};
+  double g_iota[NB][kIota] = {}, g_mu[NG] = {}, g_len[NG][3] = {};
   for (int64_t i = 0; i < B; ++i) {
-    LossGrad<T, NJ> g;
+    LossGrad<T, NJ, NG> g;
     zero_grad(g);
     T f[K][3];
     int it = 0;
@@ -43,28 +43,29 @@ void loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, cons
         force[i * 3 * K + K + 2 * c] = f[c][0];
         force[i * 3 * K + K + 2 * c + 1] = f[c][1];
       }
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NB; ++b)
       for (int k = 0; k < kIota; ++k) g_iota[b][k] += double(g.g_iota[b][k]);
+    for (int b = 0; b < NG; ++b) {
       g_mu[b] += double(g.g_mu[b]);
       for (int k = 0; k < 3; ++k) g_len[b][k] += double(g.g_len[b][k]);
     }
   }
   if (!grad) return;
-  double th[NB * 10], fr[NB + 1], ln[NB * 3];
+  double th[NB * 10], fr[NG + 1], ln[NG * 3];
   for (int i = 0; i < NB * 10; ++i) th[i] = double(theta[i]);
-  for (int i = 0; i < NB + 1; ++i) fr[i] = double(friction[i]);
-  for (int i = 0; i < NB * 3; ++i) ln[i] = double(lengths[i]);
+  for (int i = 0; i < NG + 1; ++i) fr[i] = double(friction[i]);
+  for (int i = 0; i < NG * 3; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
-  for (int k = 0; k < NB + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NB, fr, g_mu, k);
-  for (int k = 0; k < NB * 3; ++k) grad[NB * 10 + NB + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
+  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k);
+  for (int k = 0; k < NG * 3; ++k) grad[NB * 10 + NG + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
 }
 
-template <typename T, typename TA, int NJ>
-void step_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
+template <typename T, typename TA, int NJ, int NG = NJ + 1, class MD = ModelDesc>
+void step_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
                 const T* x, int64_t B, T* x_next, int32_t* iters) {
-  constexpr int NB = NJ + 1, K = kQuery * NB, NX = 13 + 2 * NJ;
-  Derived<T, NJ> dp;
+  constexpr int K = kQuery * NG, NX = 13 + 2 * NJ;
+  Derived<T, NJ, NG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
   for (int64_t i = 0; i < B; ++i) {
     T imp[K][3];
@@ -175,34 +176,45 @@ void mesh_loss_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta,
 }
 
 
-template <typename T, typename TA, int NJ>
-void step_backward_batch(const ModelDesc& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
+template <typename T, typename TA, int NJ, int NG = NJ + 1, class MD = ModelDesc>
+void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
                          const T* x, const T* xbar_next, int64_t B, double* grad, T* xbar) {
-  constexpr int NB = NJ + 1, K = kQuery * NB, NX = 13 + 2 * NJ;
-  Derived<T, NJ> dp;
+  constexpr int NB = NJ + 1, K = kQuery * NG, NX = 13 + 2 * NJ;
+  Derived<T, NJ, NG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  double g_iota[NB][kIota] = {}, g_mu[NB] = {}, g_len[NB][3] = {};
+  double g_iota[NB][kIota] = {}, g_mu[NG] = {}, g_len[NG][3] = {};
   for (int64_t i = 0; i < B; ++i) {
-    LossGrad<T, NJ> g;
+    LossGrad<T, NJ, NG> g;
     zero_grad(g);
     T xb[NX] = {};
     step_item_backward<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, xbar_next + i * NX, g, nullptr, nullptr,
                                               xbar ? &xb : nullptr);
     if (xbar) for (int k = 0; k < NX; ++k) xbar[i * NX + k] = xb[k];
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NB; ++b)
       for (int k = 0; k < kIota; ++k) g_iota[b][k] += double(g.g_iota[b][k]);
+    for (int b = 0; b < NG; ++b) {
       g_mu[b] += double(g.g_mu[b]);
       for (int k = 0; k < 3; ++k) g_len[b][k] += double(g.g_len[b][k]);
     }
   }
-  double th[NB * 10], fr[NB + 1], ln[NB * 3];
+  double th[NB * 10], fr[NG + 1], ln[NG * 3];
   for (int i = 0; i < NB * 10; ++i) th[i] = double(theta[i]);
-  for (int i = 0; i < NB + 1; ++i) fr[i] = double(friction[i]);
-  for (int i = 0; i < NB * 3; ++i) ln[i] = double(lengths[i]);
+  for (int i = 0; i < NG + 1; ++i) fr[i] = double(friction[i]);
+  for (int i = 0; i < NG * 3; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
-  for (int k = 0; k < NB + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NB, fr, g_mu, k);
-  for (int k = 0; k < NB * 3; ++k) grad[NB * 10 + NB + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
+  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k);
+  for (int k = 0; k < NG * 3; ++k) grad[NB * 10 + NG + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
+}
+
+// general models (tree topology, geometry table): always three geometry slots, the unused ones masked
+template <typename T, typename TA, class F0, class F1, class F2> int general_dispatch(const ModelDesc* md, F0 f0, F1 f1, F2 f2) {
+  const GeneralDesc& gd = *static_cast<const GeneralDesc*>(md);
+  if (md->n_joints == 0) f0(gd);
+  else if (md->n_joints == 1) f1(gd);
+  else if (md->n_joints == 2) f2(gd);
+  else return -1;
+  return 0;
 }
 
 }  // namespace
@@ -212,6 +224,11 @@ extern "C" {
 int hostsim_loss_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
                      const double* lengths, const double* x, const double* xp, int64_t B, const double* weights,
                      double scale, double* loss, double* grad, double* force, int32_t* iters) {
+  if (md->n_geoms > 0)
+    return general_dispatch<double, double>(
+        md, [&](const GeneralDesc& g) { loss_batch<double, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<double, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<double, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
   if (md->n_joints == 0) loss_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
   else if (md->n_joints == 1) loss_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
   else return -1;
@@ -222,6 +239,11 @@ int hostsim_loss_f64(const ModelDesc* md, const SolverOpts* opt, const double* t
 int hostsim_loss_f32(const ModelDesc* md, const SolverOpts* opt, const float* theta, const float* friction,
                      const float* lengths, const float* x, const float* xp, int64_t B, const float* weights,
                      double scale, float* loss, double* grad, float* force, int32_t* iters, int mixed) {
+  if (md->n_geoms > 0)
+    return general_dispatch<float, double>(
+        md, [&](const GeneralDesc& g) { loss_batch<float, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<float, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<float, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
   if (md->n_joints == 0) {
     if (mixed) loss_batch<float, double, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
     else loss_batch<float, float, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
@@ -234,6 +256,11 @@ int hostsim_loss_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
 
 int hostsim_step_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
                      const double* lengths, const double* x, int64_t B, double* x_next, int32_t* iters) {
+  if (md->n_geoms > 0)
+    return general_dispatch<double, double>(
+        md, [&](const GeneralDesc& g) { step_batch<double, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<double, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<double, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
   if (md->n_joints == 0) step_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
   else if (md->n_joints == 1) step_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
   else return -1;
@@ -242,6 +269,11 @@ int hostsim_step_f64(const ModelDesc* md, const SolverOpts* opt, const double* t
 
 int hostsim_step_f32(const ModelDesc* md, const SolverOpts* opt, const float* theta, const float* friction,
                      const float* lengths, const float* x, int64_t B, float* x_next, int32_t* iters, int mixed) {
+  if (md->n_geoms > 0)
+    return general_dispatch<float, double>(
+        md, [&](const GeneralDesc& g) { step_batch<float, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<float, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<float, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
   if (md->n_joints == 0) {
     if (mixed) step_batch<float, double, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
     else step_batch<float, float, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
@@ -272,6 +304,11 @@ int hostsim_mesh_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
 int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
                               const double* lengths, const double* x, const double* xbar_next, int64_t B, double* grad,
                               double* xbar) {
+  if (md->n_geoms > 0)
+    return general_dispatch<double, double>(
+        md, [&](const GeneralDesc& g) { step_backward_batch<double, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
+        [&](const GeneralDesc& g) { step_backward_batch<double, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
+        [&](const GeneralDesc& g) { step_backward_batch<double, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); });
   if (md->n_joints == 0) step_backward_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else if (md->n_joints == 1) step_backward_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else return -1;

@@ -1,0 +1,203 @@
+"""Models beyond the cube / elbow topologies: a three-link serial chain, a branching tree, several
+geometries on one body, spheres -- the GENERAL build (csrc/dpll_general.hip, GeneralDesc branches of csrc/dpll_core.hpp).
+
+Fixtures `{chain3, vee, ballcube, mace}_literal.npz` were recorded by running the reference's own MultibodyTerms /
+contactnets_loss / forward_dynamics / simulate on these URDFs (oracle/gen_golden.py record_general_cases).  CPU tests:
+the oracle and the host build of the per-item math against them; GPU tests (`-m gpu`): the kernels through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import hostsim
+from conftest import ASSET_DIR
+from dair_pll_amd._capi import make_desc
+from dair_pll_amd.urdf import parse_urdf
+from oracle import dpll_oracle as O
+
+MODELS = ['chain3', 'vee', 'ballcube', 'mace']
+P = 'multibody_terms.'
+
+
+def oracle_from(g, name) -> O.OracleSystem:
+    system = O.OracleSystem(os.path.join(ASSET_DIR, name + '.urdf'), float(g['dt']))
+    system.theta = torch.tensor(g['param/' + P + 'lagrangian_terms.inertial_parameters'])
+    system.friction = torch.tensor(g['param/' + P + 'contact_terms.friction_params'])
+    for index, params in enumerate(system.geom_params):
+        for key in list((params or {}).keys()):
+            params[key] = torch.tensor(g['param/' + P + f'contact_terms.geometries.{index}.{key}'])
+    return system
+
+
+def reference_gradient(g, spec):
+    """the reference run's gradients in the kernels' flat layout [theta | friction (1 + 3 slots) | lengths (3 slots, 3)]"""
+    n_b = spec.n_joints + 1
+    out = np.zeros(10 * n_b + 4 + 9)
+    out[:10 * n_b] = g['grad/' + P + 'lagrangian_terms.inertial_parameters'].ravel()
+    friction = g['grad/' + P + 'contact_terms.friction_params']
+    out[10 * n_b:10 * n_b + len(friction)] = friction
+    for index, (_, geom) in enumerate(spec.geoms()):
+        key = 'length_params' if geom.kind == 'box' else 'length_param'
+        value = g['grad/' + P + f'contact_terms.geometries.{index + 1}.{key}'].ravel()
+        out[10 * n_b + 4 + 3 * index:10 * n_b + 4 + 3 * index + len(value)] = value
+    return out
+
+
+def canonical(spec, phi, J=None, D=None):
+    """contacts of one geometry sorted by signed distance (the reference's top-k order is unspecified, quirk Q3)"""
+    k = phi.shape[-1]
+    order = np.zeros(phi.shape, dtype=np.int64)
+    start = 0
+    for _, geom in spec.geoms():
+        n = 1 if geom.kind == 'sphere' else 4
+        order[:, start:start + n] = start + np.argsort(phi[:, start:start + n], axis=-1, kind='stable')
+        start += n
+    rows = np.arange(phi.shape[0])[:, None]
+    idx = np.concatenate((order, k + 2 * np.repeat(order, 2, -1) + np.tile([0, 1], k)), -1)
+    out = [phi[rows, order]]
+    if J is not None:
+        out.append(J[rows, idx])
+    if D is not None:
+        out.append(D[rows[:, :, None], idx[:, :, None], idx[:, None, :]])
+    return out
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_oracle_reproduces_the_reference_run(golden, name):
+    g = golden(name + '_literal')
+    system = oracle_from(g, name).requires_grad_()
+    spec = parse_urdf(os.path.join(ASSET_DIR, name + '.urdf'))
+    x, xp = torch.tensor(g['x']), torch.tensor(g['x_plus'])
+    loss = system.contactnets_loss(x, xp)
+    assert (loss.detach() - torch.tensor(g['loss'])).abs().max() < 1e-12
+    loss.mean().backward()
+    for key, value in system.named_parameters().items():
+        ref = g['grad/' + key]
+        assert np.abs(value.grad.numpy() - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), key
+    with torch.no_grad():
+        q, v = system.q_v(xp)
+        D, M, J, phi, a = system.multibody_terms(q, v)
+        assert (M - torch.tensor(g['terms/M'])).abs().max() < 1e-12 and (a - torch.tensor(g['terms/a'])).abs().max() < 1e-9
+        mine = canonical(spec, phi.numpy(), J.numpy(), D.numpy())
+        ref = canonical(spec, g['terms/phi'], g['terms/J'], g['terms/D'])
+        for m, r in zip(mine, ref):
+            assert np.abs(m - r).max() < 1e-9
+        assert (system.step(x) - torch.tensor(g['dynamics/x_next'])).abs().max() < 1e-9
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_host_build_of_the_kernel_math(golden, name):
+    """csrc/dpll_core.hpp compiled for the host with GeneralDesc (tree + geometry table branches): loss, every
+    gradient, next state against the reference run; float32 with the double-accumulated residual within 1e-4."""
+    g = golden(name + '_literal')
+    spec = parse_urdf(os.path.join(ASSET_DIR, name + '.urdf'))
+    desc = make_desc(spec, float(g['dt']))
+    theta, friction, lengths = hostsim.general_params(spec)
+    out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'])
+    assert np.abs(out['loss'] - g['loss']).max() < 1e-12
+    ref = reference_gradient(g, spec)
+    assert np.abs(out['grad'] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    x_next, iters = hostsim.step(desc, theta, friction, lengths, g['x'])
+    assert np.abs(x_next - g['dynamics/x_next']).max() < 1e-10 and iters.max() < 100
+    out32 = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float32)
+    assert np.abs(out32['loss'] - g['loss']).max() < 2e-5
+    x_next32, _ = hostsim.step(desc, theta, friction, lengths, g['x'], dtype=np.float32)
+    assert np.abs(x_next32 - g['dynamics/x_next']).max() < 1e-4
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------
+def gpu_system(g, name, dtype):
+    from dair_pll_amd import MultibodyLearnableSystem
+    system = MultibodyLearnableSystem({name: os.path.join(ASSET_DIR, name + '.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+    system.load_state_dict({key: torch.tensor(g['param/' + key]) for key, _ in system.named_parameters()})
+    return system
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', MODELS)
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_gpu_loss_gradients_dynamics(golden, name, dtype):
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, dtype)
+    assert not system.spec.is_fast()
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    u = torch.zeros(x.shape[:-1] + (0,), device='cuda:0')
+    f64 = dtype == torch.float64
+    loss = system.contactnets_loss(x, u, xp)
+    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4)
+    loss.mean().backward()
+    for key, param in system.named_parameters():
+        ref = g['grad/' + key]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= (1e-9 if f64 else 5e-3) * max(np.abs(ref).max(), 1.0 if f64 else 1e-3), (key, err, np.abs(ref).max())
+    system.zero_grad()
+    total = system.contactnets_loss_and_grad(x, xp)
+    assert abs(total.item() - float(g['loss_mean'])) < (1e-12 if f64 else 1e-6)
+    if f64:
+        for key, param in system.named_parameters():
+            ref = g['grad/' + key]
+            assert np.abs(param.grad.cpu().numpy() - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), key
+    # forces: one row per real contact, feasible
+    _, force, iters = system.contact_forces(x, xp)
+    k = system.spec.n_contacts
+    assert force.shape == (x.shape[0], 3 * k) and iters.max().item() < 100
+    f = force.cpu().double().numpy()
+    assert (np.linalg.norm(f[:, k:].reshape(-1, k, 2), axis=-1) <= f[:, :k] + 1e-6).all()
+    # dynamics
+    tol = 1e-10 if f64 else 1e-4
+    q, v = system.space.q_v(x)
+    v_next = system.forward_dynamics(q, v, u)
+    assert np.abs(v_next.detach().cpu().double().numpy() - g['dynamics/v_next']).max() < tol
+    assert np.abs(system.step(x).detach().cpu().double().numpy() - g['dynamics/x_next']).max() < tol
+    rows, steps = g['simulate/rows'], int(g['simulate/steps'])
+    traj, _ = system.simulate(x[rows].unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), steps)
+    assert np.abs(traj.detach().cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', MODELS)
+def test_gpu_terms(golden, name):
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, torch.float64)
+    xp = torch.tensor(g['x_plus'], device='cuda:0')
+    q, v = system.space.q_v(xp)
+    D, M, J, phi, a = system.multibody_terms(q, v, torch.zeros(xp.shape[:-1] + (0,), device='cuda:0'))
+    k = system.spec.n_contacts
+    assert phi.shape == (xp.shape[0], k) and J.shape == (xp.shape[0], 3 * k, system.space.n_v) and D.shape[-2:] == (3 * k, 3 * k)
+    assert np.abs(M.cpu().numpy() - g['terms/M']).max() < 1e-12 and np.abs(a.cpu().numpy() - g['terms/a']).max() < 1e-9
+    mine = canonical(system.spec, phi.cpu().numpy(), J.cpu().numpy(), D.cpu().numpy())
+    ref = canonical(system.spec, g['terms/phi'], g['terms/J'], g['terms/D'])
+    for m, r in zip(mine, ref):
+        assert np.abs(m - r).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', MODELS)
+def test_gpu_step_backward_against_oracle_autograd(golden, name):
+    """parameter gradient and state adjoint of a 2-step rollout: dpll_step_backward of the general build against torch
+    autograd through the oracle (differentiable cone solve); state gradients on the unit-quaternion tangent space (Q2)"""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, torch.float64)
+    rows = np.linspace(0, g['x'].shape[0] - 1, 24).astype(int)
+    x_np = g['x'][rows]
+    gen = torch.Generator().manual_seed(5)
+    w = torch.rand((len(rows), 2, x_np.shape[1]), generator=gen, dtype=torch.float64) - 0.5
+    oracle = oracle_from(g, name).requires_grad_()
+    x_ref = torch.tensor(x_np).requires_grad_(True)
+    traj_ref = oracle.simulate(x_ref, 2)
+    (traj_ref[:, 1:] * w).sum().backward()
+    x = torch.tensor(x_np, device='cuda:0').requires_grad_(True)
+    traj, _ = system.simulate(x.unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), 2)
+    assert (traj.detach().cpu() - traj_ref.detach()).abs().max() < 1e-9
+    (traj[:, 1:] * w.cuda()).sum().backward()
+    ref_named = oracle.named_parameters()
+    for key, param in system.named_parameters():
+        ref = ref_named[key].grad.numpy()
+        err = np.abs(param.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-7 * max(np.abs(ref).max(), 1e-3), (key, err, np.abs(ref).max())
+    diff = (x.grad.cpu() - x_ref.grad).numpy()
+    q = x_np[:, :4] / np.linalg.norm(x_np[:, :4], axis=-1, keepdims=True)
+    diff[:, :4] -= (diff[:, :4] * q).sum(-1, keepdims=True) * q
+    assert np.abs(diff).max() <= 1e-7 * x_ref.grad.abs().max().item()

@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9) + 4 * (2 + 1 + 3 + 3 + 1)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
@@ -201,3 +201,38 @@ def test_slice_rule_on_the_reference_trajectories():
     # the first fixture of the parity tests was cut from the same files by the reference: same pairs
     literal = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_literal.npz'))
     assert np.array_equal(literal['x'], g['x']) and np.array_equal(literal['x_plus'], g['x_plus'])
+
+
+def test_general_models_are_described_for_the_general_build():
+    """trees, several geometries per body, spheres: parsed like the reference's Drake front end would see them
+    (multibody_terms.py:328-382, drake_utils.py:309-335) and handed to the general build (n_geoms > 0)"""
+    lib = _capi.library()
+    expect = {'chain3': (2, [0, 1], [0, 1, 2], [0, 0, 0], 12), 'vee': (2, [0, 0], [0, 1, 2], [0, 0, 0], 12),
+              'ballcube': (0, [], [0, 0, 0], [0, 1, 1], 6), 'mace': (1, [0], [0, 1, 1], [0, 1, 0], 9)}
+    for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
+        spec = parse_urdf(os.path.join(ASSET_DIR, name + '.urdf'))
+        assert not spec.is_fast() and spec.n_joints == n_joints and spec.n_contacts == n_contacts
+        desc = _capi.make_desc(spec, 0.0068)
+        assert desc.n_geoms == 3 and list(desc.parent)[:n_joints] == parents
+        assert list(desc.geom_body) == geom_body and list(desc.geom_kind) == kinds
+        handle = ctypes.c_void_p()
+        assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
+        assert lib.dpll_n_x(handle) == 13 + 2 * n_joints and lib.dpll_n_contacts(handle) == 12
+        assert lib.dpll_param_count(handle) == 10 * (n_joints + 1) + 4 + 9
+        system = MultibodyLearnableSystem({name: os.path.join(ASSET_DIR, name + '.urdf')}, 0.0068, device='cpu')
+        flat = system._packed()
+        assert flat.numel() == lib.dpll_param_count(handle)
+        names = [n for n, _ in system.named_parameters()]
+        assert names[0].endswith('inertial_parameters') and names[1].endswith('friction_params')
+        assert system.multibody_terms.contact_terms.friction_params.shape == (1 + 3,)
+        for g, kind in enumerate(kinds):
+            geometry = system.multibody_terms.contact_terms.geometries[g + 1]
+            param = geometry.length_param if kind == 1 else geometry.length_params
+            assert param.data_ptr() == flat.data_ptr() + (10 * (n_joints + 1) + 4 + 3 * g) * flat.element_size()
+        lib.dpll_model_destroy(handle)
+    # the cube and the elbow stay on the specialised builds
+    assert _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068).n_geoms == 0
+    bad = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'vee.urdf')), 0.0068)
+    bad.parent[1] = 2
+    handle = ctypes.c_void_p()
+    assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(handle)) != 0
