@@ -255,6 +255,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
   const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
   // uniform branch (n_rows is a kernel argument): the headline grid has 256 rows = 8 per thread
   const double s = n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
+                   : n_rows <= 512 ? finalize_column<16>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
                    : n_rows <= 1024 ? finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
                                     : finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg) +
                                           finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg, 1024);
