@@ -753,7 +753,7 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
 struct MeshPlan {
   long long N;
   int loss_blocks, gemm_blocks, b1_blocks, n_slabs;
-  size_t off_A, off_AT, off_a, off_P, off_RB, off_M1, off_U0, off_Vb, off_U1, off_rows, off_b1, off_slabs, total;
+  size_t off_A, off_AT, off_Af, off_ATf, off_a, off_P, off_RB, off_M1, off_U0, off_Vb, off_U1, off_rows, off_b1, off_slabs, total;
   long long n_tiles;
 };
 
@@ -772,6 +772,8 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   pl.off_A = take(sizeof(T) * kW * kW);
   pl.off_AT = take(sizeof(T) * kW * kW);
+  pl.off_Af = take(kMfma ? sizeof(T) * kW * kW : 0);   // the same two matrices in the MFMA kernels' fragment order
+  pl.off_ATf = take(kMfma ? sizeof(T) * kW * kW : 0);
   pl.off_a = take(sizeof(T) * kW);
   pl.off_P = take(sizeof(T) * 3 * pl.N);
   pl.off_RB = take(sizeof(T) * 3 * pl.N);
@@ -807,14 +809,16 @@ template <typename T>
 int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, hipStream_t stream,
                  bool for_backward = false) {
   T* A = (T*)(ws + pl.off_A); T* AT = (T*)(ws + pl.off_AT); T* a = (T*)(ws + pl.off_a);
-  hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a);
+  constexpr bool kMfmaPath = std::is_same<T, float>::value;
+  hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
+                     kMfmaPath ? (T*)(ws + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(ws + pl.off_ATf) : (T*)nullptr);
   mesh_mark(stream);
   if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)A,
-                       (uint32_t*)(ws + pl.off_M1));
+    hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w,
+                       (const float*)(ws + pl.off_Af), (uint32_t*)(ws + pl.off_M1));
     mesh_mark(stream);
-    hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w, (const float*)AT,
-                       (const float*)a, (const uint32_t*)(ws + pl.off_M1), (float*)(ws + pl.off_U0),
+    hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w,
+                       (const float*)(ws + pl.off_ATf), (const float*)a, (const uint32_t*)(ws + pl.off_M1), (float*)(ws + pl.off_U0),
                        (float*)(ws + pl.off_P), for_backward ? (float*)(ws + pl.off_U1) : (float*)nullptr);
   } else {
     hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
@@ -834,7 +838,7 @@ int mesh_backward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T
                   void* loss_total, hipStream_t stream) {
   if constexpr (std::is_same<T, float>::value) {
     hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)state, ld, pl.N, w,
-                       (const float*)(ws + pl.off_A), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
+                       (const float*)(ws + pl.off_Af), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
                        (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1),
                        (float*)(ws + pl.off_Vb));
     mesh_mark(stream);

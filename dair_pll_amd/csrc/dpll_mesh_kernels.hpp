@@ -44,15 +44,28 @@ template <typename T> struct MeshBuffers {
 
 __device__ __forceinline__ float mask_factor(uint32_t word, int bit) { return ((word >> bit) & 1u) ? 1.0f : float(kIcnnSlope); }
 
+// position of B-operand element (k, j) of a 256 x 256 matrix in the "fragment order" the MFMA row-tile kernels load
+// their weight block in: wave j / 32 of a block keeps, per lane (half = k & 1, column j & 31), the 128 values k / 2 = 0..127;
+// four consecutive ones (one float4) of all 64 lanes are 1 KB contiguous, so a wave fetches its 32 KB with 32 coalesced
+// dwordx4 loads instead of 128 dword loads (two rounds of the 64-deep load queue: ~2 us of the kernels' fixed cost)
+__device__ __forceinline__ int frag_index(int k, int j) {
+  const int kk = k >> 1, lane = (k & 1) * 32 + (j & 31);
+  return (((j >> 5) * 32 + (kk >> 2)) * 64 + lane) * 4 + (kk & 3);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void icnn_prep_kernel(IcnnWeights<T> w, T* __restrict__ A, T* __restrict__ AT,
-                                                        T* __restrict__ a) {
+                                                        T* __restrict__ a, T* __restrict__ Af, T* __restrict__ ATf) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx < kW * kW) {
     const int k = idx / kW, j = idx % kW;
     const T v = tabs(w.Wh[idx]);
     A[idx] = v;
     AT[j * kW + k] = v;
+    if (Af) {  // float path: the same two matrices in fragment order
+      Af[frag_index(k, j)] = v;
+      ATf[frag_index(j, k)] = v;
+    }
   }
   if (idx < kW) a[idx] = tabs(w.wout[idx]);
 }
@@ -430,6 +443,17 @@ __device__ __forceinline__ void load_queries32(const float* __restrict__ x, long
   }
 }
 
+// this lane's 128 weights of its wave's 256 x 32 column block, from a matrix in fragment order (frag_index)
+__device__ __forceinline__ void load_weight_fragment(const float* __restrict__ F, int wv, int lane, float (&bfrag)[kW / 2]) {
+  const f32x4* f = (const f32x4*)F + (wv * 32) * 64 + lane;
+#pragma unroll
+  for (int q = 0; q < kW / 8; ++q) {
+    const f32x4 v = f[q * 64];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bfrag[4 * q + e] = v[e];
+  }
+}
+
 // C(32 x 32 of this wave) = Xs(32 x 256, LDS in the xop layout) * Wfrag(256 x 32, registers)
 __device__ __forceinline__ f32x16 mfma_tile(const float* __restrict__ Xs, const float (&bfrag)[kW / 2], int l31, int half) {
   f32x16 acc;
@@ -453,8 +477,7 @@ __global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
   float bfrag[kW / 2];
-#pragma unroll
-  for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = A[(2 * kk + half) * kW + col];
+  load_weight_fragment(A, wv, lane, bfrag);  // A: |Wh| in fragment order
   const float wd1[3] = {w.Wd1[col], w.Wd1[kW + col], w.Wd1[2 * kW + col]};
   const long long tiles = (N + kMfmaRows - 1) / kMfmaRows;
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -496,8 +519,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
   float bfrag[kW / 2];
-#pragma unroll
-  for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = AT[(2 * kk + half) * kW + col];
+  load_weight_fragment(AT, wv, lane, bfrag);  // AT: |Wh|^T in fragment order
   const float wd0[3] = {w.Wd0[col], w.Wd0[kW + col], w.Wd0[2 * kW + col]};
   // input weights of both layers by column for the support-point product below: [c] = (Wd1[0..2][c], 0 | Wd0[0..2][c], 0);
   // read back as two float4 per column (the 96 global loads per thread and tile they replace kept the vector-memory
@@ -567,8 +589,7 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int col = 32 * wv + l31;
   float bfrag[kW / 2];
-#pragma unroll
-  for (int kk = 0; kk < kW / 2; ++kk) bfrag[kk] = A[(2 * kk + half) * kW + col];
+  load_weight_fragment(A, wv, lane, bfrag);  // A: |Wh| in fragment order
   const float wd1[3] = {w.Wd1[col], w.Wd1[kW + col], w.Wd1[2 * kW + col]};
   const float acol = a[col];
   double abar = 0.0, g1[3] = {0.0, 0.0, 0.0}, g0[3] = {0.0, 0.0, 0.0};
