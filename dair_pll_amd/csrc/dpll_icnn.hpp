@@ -24,7 +24,12 @@ template <typename T> struct IcnnWeights {
   const T* Wd1;   // (3, 256)   input_weights.1
   const T* wout;  // (256,)     output_weight
   const T* pert;  // (4, 3)     perturbations, row 0 is zero (geometry.py:306-307)
+  // support points / their adjoints of query n = 4 item + s sit at element (n / 4) * point_stride + 3 s of the arrays the
+  // kernels are given: 12 when this geometry is the item's only one, 3 * (contacts per item) when it is one of several
+  // (the arrays are then offset by 12 * geometry index)
+  int point_stride = 12;
 };
+DPLL_HD long long icnn_point_index(long long n, int point_stride) { return (n >> 2) * point_stride + (n & 3) * 3; }
 
 // un-normalised rotation row 2 from the quaternion (same polynomial as quat_to_rot) -> query direction
 template <typename T> DPLL_HD void icnn_query(const T* quat, const T* pert3, T (&q)[3]) {

@@ -749,18 +749,26 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
 }
 
 
-// ---- mesh (DeepSupportConvex) path: one floating body, N = 4 * batch support queries ----------------
+// ---- mesh (DeepSupportConvex) path: every body of a specialised build carries its own network; N = 4 * batch support
+// queries per network and launch ------------------------------------------------------------------------------------
 struct MeshPlan {
-  long long N;
-  int loss_blocks, gemm_blocks, b1_blocks, n_slabs;
-  size_t off_A, off_AT, off_Af, off_ATf, off_a, off_P, off_RB, off_M1, off_U0, off_Vb, off_U1, off_rows, off_b1, off_slabs, total;
-  long long n_tiles;
+  long long N, n_tiles;
+  int n_nets, loss_blocks, gemm_blocks, b1_blocks, n_slabs, row_stride;
+  // one block of buffers per network (offsets relative to the block): the backward of a network needs its own forward
+  size_t off_A, off_AT, off_Af, off_ATf, off_a, off_M1, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
+  // shared: support points / their adjoints of all networks (batch, 4 n_nets, 3), the loss kernel's rows + chain matrix,
+  // the bodies' world quaternions (batch, n_nets, 4; only for n_nets > 1)
+  size_t off_P, off_RB, off_rows, off_bq, off_nets, total;
+  char* net(char* ws, int g) const { return ws + off_nets + (size_t)g * net_bytes; }
 };
 
-template <typename T> MeshPlan mesh_plan(long long batch) {
+template <typename T, int NJ> MeshPlan mesh_plan(long long batch) {
+  using D = Dims<T, NJ>;
   MeshPlan pl;
   pl.N = 4 * batch;
-  pl.loss_blocks = loss_blocks<T, 0>(batch);
+  pl.n_nets = D::NB;
+  pl.row_stride = D::PI;
+  pl.loss_blocks = loss_blocks<T, NJ>(batch);
   constexpr bool kMfma = std::is_same<T, float>::value;  // float: MFMA kernels on 32-row tiles
   const long long tiles = (pl.N + (kMfma ? kMfmaRows : kTileRows) - 1) / (kMfma ? kMfmaRows : kTileRows);
   const long long cap = kMfma ? 256 : 2048;  // MFMA blocks keep their 256 x 32 weight block in registers: one per CU
@@ -768,6 +776,7 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   pl.b1_blocks = (int)(tiles < 256 ? tiles : 256);
   long long slabs = pl.N / (kMfma ? 256 : 1024);
   pl.n_slabs = (int)(slabs < 1 ? 1 : (slabs > 64 ? 64 : slabs));
+  pl.n_tiles = tiles;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   pl.off_A = take(sizeof(T) * kW * kW);
@@ -775,19 +784,47 @@ template <typename T> MeshPlan mesh_plan(long long batch) {
   pl.off_Af = take(kMfma ? sizeof(T) * kW * kW : 0);   // the same two matrices in the MFMA kernels' fragment order
   pl.off_ATf = take(kMfma ? sizeof(T) * kW * kW : 0);
   pl.off_a = take(sizeof(T) * kW);
-  pl.off_P = take(sizeof(T) * 3 * pl.N);
-  pl.off_RB = take(sizeof(T) * 3 * pl.N);
   pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
   pl.off_U0 = take(sizeof(T) * kW * pl.N);
-  pl.n_tiles = tiles;
   // MFMA path: Vb (icnn_bwd1) and U1 (icnn_fwd2) as operand tiles for icnn_bwd2, whole 32-row tiles
   pl.off_Vb = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
   pl.off_U1 = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
-  pl.off_rows = take(sizeof(double) * (16 * pl.loss_blocks + Dims<T, 0>::CHAIN));
   pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
   pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
-  pl.total = off;
+  pl.net_bytes = off;
+  off = 0;
+  pl.off_P = take(sizeof(T) * 3 * pl.N * pl.n_nets);
+  pl.off_RB = take(sizeof(T) * 3 * pl.N * pl.n_nets);
+  pl.off_rows = take(sizeof(double) * ((size_t)D::PI * pl.loss_blocks + D::CHAIN));
+  pl.off_bq = take(pl.n_nets > 1 ? sizeof(T) * 4 * pl.n_nets * batch : 0);
+  pl.off_nets = off;
+  pl.total = off + pl.net_bytes * pl.n_nets;
   return pl;
+}
+
+// world <- body quaternions of every body of a serial chain: q_b = q_(b-1) (x) [cos(angle / 2), axis sin(angle / 2)]; the ICNN
+// kernels take a body's support direction from "its" quaternion exactly as they do for a single body (the rotation of the
+// product is the product of the rotations, also for the un-normalised base quaternion of quirk Q2)
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void mesh_body_quat_kernel(ModelDesc md, const T* __restrict__ x, long long ld, long long batch,
+                                                             T* __restrict__ bq) {
+  const long long it = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (it >= batch) return;
+  T q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { q[i] = x[it * ld + i]; bq[(it * (NJ + 1)) * 4 + i] = q[i]; }
+#pragma unroll
+  for (int j = 1; j <= NJ; ++j) {
+    T sn, cs;
+    tsincos(x[it * ld + 7 + j - 1] * T(0.5), sn, cs);
+    const T r[4] = {cs, T(md.joint_axis[j - 1][0]) * sn, T(md.joint_axis[j - 1][1]) * sn, T(md.joint_axis[j - 1][2]) * sn};
+    const T o[4] = {q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3],
+                    q[0] * r[1] + r[0] * q[1] + (q[2] * r[3] - q[3] * r[2]),
+                    q[0] * r[2] + r[0] * q[2] + (q[3] * r[1] - q[1] * r[3]),
+                    q[0] * r[3] + r[0] * q[3] + (q[1] * r[2] - q[2] * r[1])};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q[i] = o[i]; bq[(it * (NJ + 1) + j) * 4 + i] = o[i]; }
+  }
 }
 
 // measuring aid of dpll_profile_contactnets_loss_mesh: when set, an event is recorded on the launch stream after each
@@ -799,116 +836,162 @@ inline void mesh_mark(hipStream_t stream) {
   if (t_mesh_marks && t_mesh_mark < kMeshKernels) (void)hipEventRecord(t_mesh_marks[t_mesh_mark++], stream);
 }
 
-template <typename T> IcnnWeights<T> mesh_weights(const dpll_mesh_params_t* mp) {
-  return IcnnWeights<T>{(const T*)mp->hidden_weight, (const T*)mp->input_weight0, (const T*)mp->input_weight1,
-                        (const T*)mp->output_weight, (const T*)mp->perturbations};
+// network g of a model with n_nets bodies: its points sit at (item, 4 g + s) of the shared (batch, 4 n_nets, 3) arrays
+template <typename T> IcnnWeights<T> mesh_weights(const dpll_mesh_params_t* mp, int g, int n_nets) {
+  IcnnWeights<T> w{(const T*)mp[g].hidden_weight, (const T*)mp[g].input_weight0, (const T*)mp[g].input_weight1,
+                   (const T*)mp[g].output_weight, (const T*)mp[g].perturbations};
+  w.point_stride = 12 * n_nets;
+  return w;
 }
 
-// forward half: prep + the two forward GEMMs -> P (and M1, U0 for the backward half)
+// where network g's kernels read "their" quaternion: the state itself for a single body, else the body-quaternion buffer
+template <typename T> struct QuatSource { const T* ptr; long long ld; };
+template <typename T, int NJ>
+QuatSource<T> quat_source(const MeshPlan& pl, char* ws, const T* state, long long ld, int g) {
+  if (NJ == 0) return QuatSource<T>{state, ld};
+  return QuatSource<T>{(const T*)(ws + pl.off_bq) + 4 * g, 4LL * (NJ + 1)};
+}
+
+template <typename T, int NJ>
+int mesh_body_quats(const dpll_model* m, const MeshPlan& pl, char* ws, const T* state, long long ld, long long batch, hipStream_t stream) {
+  if (NJ == 0) return 0;
+  hipLaunchKernelGGL((mesh_body_quat_kernel<T, NJ>), dim3((int)((batch + 255) / 256)), dim3(256), 0, stream, m->desc, state, ld, batch,
+                     (T*)(ws + pl.off_bq));
+  return check_launch("mesh_body_quat_kernel");
+}
+
+// forward half of network g: prep + the two forward GEMMs -> its support points (and M1, U0 for the backward half)
 template <typename T>
-int mesh_forward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, hipStream_t stream,
+int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, hipStream_t stream,
                  bool for_backward = false) {
-  T* A = (T*)(ws + pl.off_A); T* AT = (T*)(ws + pl.off_AT); T* a = (T*)(ws + pl.off_a);
+  char* nb = pl.net(ws, g);
+  T* A = (T*)(nb + pl.off_A); T* AT = (T*)(nb + pl.off_AT); T* a = (T*)(nb + pl.off_a);
+  T* P = (T*)(ws + pl.off_P) + 12 * g;
   constexpr bool kMfmaPath = std::is_same<T, float>::value;
   hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
-                     kMfmaPath ? (T*)(ws + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(ws + pl.off_ATf) : (T*)nullptr);
+                     kMfmaPath ? (T*)(nb + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + pl.off_ATf) : (T*)nullptr);
   mesh_mark(stream);
   if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w,
-                       (const float*)(ws + pl.off_Af), (uint32_t*)(ws + pl.off_M1));
+    hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
+                       (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1));
     mesh_mark(stream);
-    hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, state, ld, pl.N, w,
-                       (const float*)(ws + pl.off_ATf), (const float*)a, (const uint32_t*)(ws + pl.off_M1), (float*)(ws + pl.off_U0),
-                       (float*)(ws + pl.off_P), for_backward ? (float*)(ws + pl.off_U1) : (float*)nullptr);
+    hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
+                       (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
+                       (float*)P, for_backward ? (float*)(nb + pl.off_U1) : (float*)nullptr);
   } else {
-    hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)A,
-                       (uint32_t*)(ws + pl.off_M1));
+    hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, q.ptr, q.ld, pl.N, w, (const T*)A,
+                       (uint32_t*)(nb + pl.off_M1));
     mesh_mark(stream);
-    hipLaunchKernelGGL((icnn_fwd2_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, state, ld, pl.N, w, (const T*)AT,
-                       (const T*)a, (const uint32_t*)(ws + pl.off_M1), (T*)(ws + pl.off_U0), (T*)(ws + pl.off_P));
+    hipLaunchKernelGGL((icnn_fwd2_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, q.ptr, q.ld, pl.N, w, (const T*)AT,
+                       (const T*)a, (const uint32_t*)(nb + pl.off_M1), (T*)(nb + pl.off_U0), P);
   }
   mesh_mark(stream);
   return check_launch("icnn forward");
 }
 
-// backward half shared by the loss and by the step backward: r_bar (ws.RB) and the row partials (ws.rows) are in
-// place, `state` is the state the support points were evaluated at
-template <typename T>
-int mesh_backward(const MeshPlan& pl, const IcnnWeights<T>& w, char* ws, const T* state, long long ld, void* grad,
-                  void* loss_total, hipStream_t stream) {
+// backward half of network g, shared by the loss and by the step backward: r_bar (ws.RB) and the row partials (ws.rows)
+// are in place; grad_w = this network's slice of the gradient, grad_head / loss_total only with the first network
+template <typename T, int NB>
+int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, T* grad_w, T* grad_head,
+                  T* loss_total, hipStream_t stream) {
+  char* nb = pl.net(ws, g);
+  const T* RB = (const T*)(ws + pl.off_RB) + 12 * g;
   if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)state, ld, pl.N, w,
-                       (const float*)(ws + pl.off_Af), (const float*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
-                       (const float*)(ws + pl.off_U0), (const float*)(ws + pl.off_RB), (double*)(ws + pl.off_b1),
-                       (float*)(ws + pl.off_Vb));
+    hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
+                       (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
+                       (const float*)(nb + pl.off_U0), (const float*)RB, (double*)(nb + pl.off_b1),
+                       (float*)(nb + pl.off_Vb));
     mesh_mark(stream);
     hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
-                       (const float*)(ws + pl.off_Vb), (const float*)(ws + pl.off_U1), (float*)(ws + pl.off_slabs));
+                       (const float*)(nb + pl.off_Vb), (const float*)(nb + pl.off_U1), (float*)(nb + pl.off_slabs));
   } else {
-    hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)state, ld, pl.N, w,
-                       (const T*)(ws + pl.off_A), (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1),
-                       (const T*)(ws + pl.off_U0), (const T*)(ws + pl.off_RB), (double*)(ws + pl.off_b1));
+    hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)q.ptr, q.ld, pl.N, w,
+                       (const T*)(nb + pl.off_A), (const T*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
+                       (const T*)(nb + pl.off_U0), RB, (double*)(nb + pl.off_b1));
     mesh_mark(stream);
-    hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)state, ld, pl.N, w,
-                       (const T*)(ws + pl.off_a), (const uint32_t*)(ws + pl.off_M1), (const T*)(ws + pl.off_RB),
-                       (T*)(ws + pl.off_slabs));
+    hipLaunchKernelGGL((icnn_bwd2_kernel<T>), dim3(16, pl.n_slabs), dim3(256), 0, stream, (const T*)q.ptr, q.ld, pl.N, w,
+                       (const T*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1), RB, (T*)(nb + pl.off_slabs));
   }
   mesh_mark(stream);
-  hipLaunchKernelGGL((icnn_reduce_kernel<T>), dim3(kRedBlocks), dim3(256), 0, stream, w,
-                     (const double*)(ws + pl.off_rows), pl.loss_blocks, (const double*)(ws + pl.off_b1), pl.b1_blocks,
-                     (const T*)(ws + pl.off_slabs), pl.n_slabs, (T*)grad, (T*)loss_total);
+  hipLaunchKernelGGL((icnn_reduce_kernel<T, NB>), dim3(kRedBlocks), dim3(256), 0, stream, w,
+                     (const double*)(ws + pl.off_rows), pl.loss_blocks, pl.row_stride, (const double*)(nb + pl.off_b1), pl.b1_blocks,
+                     (const T*)(nb + pl.off_slabs), pl.n_slabs, grad_w, grad_head, loss_total);
   mesh_mark(stream);
   return check_launch("icnn backward");
 }
 
-template <typename T>
+constexpr int kNetParams = kW * kW + 7 * kW;  // [Wh | Wd0 | Wd1 | wout] of one network
+
+template <typename T, int NJ>
+int mesh_backward_all(const MeshPlan& pl, const dpll_mesh_params_t* mp, char* ws, const T* state, long long ld, void* grad,
+                      void* loss_total, hipStream_t stream) {
+  constexpr int NB = NJ + 1, kHead = 10 * NB + 1 + NB;
+  for (int g = 0; g < NB; ++g)
+    if (int rc = mesh_backward<T, NB>(pl, g, mesh_weights<T>(mp, g, NB), ws, quat_source<T, NJ>(pl, ws, state, ld, g),
+                                      (T*)grad + kHead + (size_t)g * kNetParams, g == 0 ? (T*)grad : (T*)nullptr,
+                                      g == 0 ? (T*)loss_total : (T*)nullptr, stream))
+      return rc;
+  return 0;
+}
+
+template <typename T, int NJ>
+int mesh_forward_all(const dpll_model* m, const MeshPlan& pl, const dpll_mesh_params_t* mp, char* ws, const T* state,
+                     long long ld, long long batch, hipStream_t stream, bool for_backward) {
+  constexpr int NB = NJ + 1;
+  if (int rc = mesh_body_quats<T, NJ>(m, pl, ws, state, ld, batch, stream)) return rc;
+  for (int g = 0; g < NB; ++g)
+    if (int rc = mesh_forward<T>(pl, g, mesh_weights<T>(mp, g, NB), ws, quat_source<T, NJ>(pl, ws, state, ld, g), stream, for_backward))
+      return rc;
+  return 0;
+}
+
+template <typename T, int NJ>
 int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
                      long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
                      void* loss, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
                      long long workspace_bytes, hipStream_t stream) {
-  const MeshPlan pl = mesh_plan<T>(batch);
+  const MeshPlan pl = mesh_plan<T, NJ>(batch);
   if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_contactnets_loss_mesh: workspace too small%s");
   if (!grad && loss_total) return fail(-3, "dpll_contactnets_loss_mesh: loss_total requires grad%s");
   char* ws = (char*)workspace;
-  const IcnnWeights<T> w = mesh_weights<T>(mp);
   const int want_grad = grad != nullptr;
-  if (int rc = mesh_forward<T>(pl, w, ws, (const T*)xp, ld_xp, stream, want_grad != 0)) return rc;  // terms live at the NEXT state
-  hipLaunchKernelGGL((loss_kernel<T, 0, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+  // terms live at the NEXT state
+  if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, (const T*)xp, ld_xp, batch, stream, want_grad != 0)) return rc;
+  hipLaunchKernelGGL((loss_kernel<T, NJ, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
                      want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);
   mesh_mark(stream);
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
-  return mesh_backward<T>(pl, w, ws, (const T*)xp, ld_xp, grad, loss_total, stream);
+  return mesh_backward_all<T, NJ>(pl, mp, ws, (const T*)xp, ld_xp, grad, loss_total, stream);
 }
 
-template <typename T>
+template <typename T, int NJ>
 int launch_mesh_step(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
                      long long ld_x, long long batch, void* x_next, long long ld_next, void* workspace,
                      long long workspace_bytes, hipStream_t stream) {
-  const MeshPlan pl = mesh_plan<T>(batch);
+  const MeshPlan pl = mesh_plan<T, NJ>(batch);
   if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_step_mesh: workspace too small%s");
   char* ws = (char*)workspace;
-  if (int rc = mesh_forward<T>(pl, mesh_weights<T>(mp), ws, (const T*)x, ld_x, stream)) return rc;
+  if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, (const T*)x, ld_x, batch, stream, false)) return rc;
   dpll_params_t q = *p;
   q.lengths = nullptr;
-  return launch_simulate<T, 0>(m, dtype, &q, x, ld_x, batch, 1, x_next, ld_next, 0, 0, nullptr, stream, ws + pl.off_P);
+  return launch_simulate<T, NJ>(m, dtype, &q, x, ld_x, batch, 1, x_next, ld_next, 0, 0, nullptr, stream, ws + pl.off_P);
 }
 
 // backward of dpll_step_mesh: support points at x, step backward (emits r_bar and the theta / friction row partials),
 // then the ICNN backward kernels as for the loss
-template <typename T>
+template <typename T, int NJ>
 int launch_mesh_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp,
                               const void* x, long long ld_x, const void* gx, long long ld_g, long long batch, void* grad,
                               void* grad_x, long long ld_gx, void* workspace, long long workspace_bytes, hipStream_t stream) {
-  const MeshPlan pl = mesh_plan<T>(batch);
+  const MeshPlan pl = mesh_plan<T, NJ>(batch);
   if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_step_backward_mesh: workspace too small%s");
   char* ws = (char*)workspace;
-  const IcnnWeights<T> w = mesh_weights<T>(mp);
-  if (int rc = mesh_forward<T>(pl, w, ws, (const T*)x, ld_x, stream, true)) return rc;
+  if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, (const T*)x, ld_x, batch, stream, true)) return rc;
 #define DPLL_LAUNCH_SB(STATE_)                                                                                             \
-  hipLaunchKernelGGL((step_backward_kernel<T, 0, STATE_, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc,    \
+  hipLaunchKernelGGL((step_backward_kernel<T, NJ, STATE_, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc,   \
                      m->opts[DPLL_F64], (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x,      \
                      (const T*)gx, ld_g, batch, (double*)(ws + pl.off_rows), (T*)grad_x, ld_gx, (const T*)(ws + pl.off_P), \
                      (T*)(ws + pl.off_RB))
@@ -916,27 +999,53 @@ int launch_mesh_step_backward(const dpll_model* m, int dtype, const dpll_params_
   else DPLL_LAUNCH_SB(false);
 #undef DPLL_LAUNCH_SB
   if (int rc = check_launch("step_backward_kernel (mesh)")) return rc;
-  return mesh_backward<T>(pl, w, ws, (const T*)x, ld_x, grad, nullptr, stream);
+  return mesh_backward_all<T, NJ>(pl, mp, ws, (const T*)x, ld_x, grad, nullptr, stream);
 }
 
-template <typename T>
-int launch_mesh_support(const dpll_mesh_params_t* mp, const void* x, long long ld_x, long long batch, void* points,
+template <typename T, int NJ>
+int launch_mesh_support(const dpll_model* m, const dpll_mesh_params_t* mp, const void* x, long long ld_x, long long batch, void* points,
                         void* workspace, long long workspace_bytes, hipStream_t stream) {
-  const MeshPlan pl = mesh_plan<T>(batch);
+  const MeshPlan pl = mesh_plan<T, NJ>(batch);
   if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_mesh_support_points: workspace too small%s");
   char* ws = (char*)workspace;
-  if (int rc = mesh_forward<T>(pl, mesh_weights<T>(mp), ws, (const T*)x, ld_x, stream)) return rc;
-  if (hipMemcpyAsync(points, ws + pl.off_P, sizeof(T) * 3 * pl.N, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+  if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, (const T*)x, ld_x, batch, stream, false)) return rc;
+  if (hipMemcpyAsync(points, ws + pl.off_P, sizeof(T) * 3 * pl.N * pl.n_nets, hipMemcpyDeviceToDevice, stream) != hipSuccess)
     return fail(-5, "dpll_mesh_support_points: copy failed%s");
   return 0;
 }
 
+template <typename T, int NJ>
+int launch_mesh_terms(const dpll_model* m, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x, long long ld_x,
+                      long long batch, void* Dm, void* M, void* J, void* phi, void* a, void* workspace, long long workspace_bytes,
+                      hipStream_t stream) {
+  const MeshPlan pl = mesh_plan<T, NJ>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_terms_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, (const T*)x, ld_x, batch, stream, false)) return rc;
+  dpll_params_t q = *p;
+  q.lengths = nullptr;
+  return launch_terms<T, NJ>(m, &q, x, ld_x, batch, Dm, M, J, phi, a, stream, ws + pl.off_P);
+}
+
+// `mp`: one dpll_mesh_params_t per body (n_joints + 1 of them)
 int check_mesh(const dpll_model* m, const dpll_mesh_params_t* mp, const char* who) {
-  if (m->desc.n_joints != 0 || m->desc.n_geoms > 0) return fail(-2, "%s: mesh geometry is implemented for single-body systems", who);
-  if (!mp || !mp->hidden_weight || !mp->input_weight0 || !mp->input_weight1 || !mp->output_weight || !mp->perturbations)
-    return fail(-1, "%s: null mesh parameter pointer", who);
+  if (m->desc.n_geoms > 0 || m->desc.n_joints > 1) return fail(-2, "%s: mesh geometry is implemented for the specialised builds (0 or 1 joints, one mesh per body)", who);
+  if (!mp) return fail(-1, "%s: null mesh parameter pointer", who);
+  for (int g = 0; g <= m->desc.n_joints; ++g)
+    if (!mp[g].hidden_weight || !mp[g].input_weight0 || !mp[g].input_weight1 || !mp[g].output_weight || !mp[g].perturbations)
+      return fail(-1, "%s: null mesh parameter pointer", who);
   return 0;
 }
+
+#define DPLL_MESH_DISPATCH(FN, ...)                                                          \
+  do {                                                                                       \
+    const int nj = model->desc.n_joints;                                                     \
+    if (dtype == DPLL_F32 && nj == 0) return FN<float, 0>(__VA_ARGS__);                      \
+    if (dtype == DPLL_F32 && nj == 1) return FN<float, 1>(__VA_ARGS__);                      \
+    if (dtype == DPLL_F64 && nj == 0) return FN<double, 0>(__VA_ARGS__);                     \
+    if (dtype == DPLL_F64 && nj == 1) return FN<double, 1>(__VA_ARGS__);                     \
+    return fail(-2, "%s: mesh kernels are built for 0 or 1 joints", #FN);                    \
+  } while (0)
 
 int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long long batch, const char* who) {
   if (!m) return fail(-1, "%s: null model", who);
@@ -1123,28 +1232,39 @@ int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* par
                 nullptr, (hipStream_t)stream);
 }
 
-int dpll_mesh_param_count(const dpll_model_t* model) { return model ? 12 + kW * kW + 7 * kW : -1; }
+int dpll_mesh_param_count(const dpll_model_t* model) {
+  if (!model) return -1;
+  const int nb = model->desc.n_joints + 1;
+  return 10 * nb + 1 + nb + nb * kNetParams;  // [theta | friction | one network per body]
+}
 
 int64_t dpll_mesh_workspace_bytes(const dpll_model_t* model, int64_t batch, int dtype) {
-  if (!model || batch < 1) return -1;
-  return (int64_t)(dtype == DPLL_F64 ? mesh_plan<double>(batch).total : mesh_plan<float>(batch).total);
+  if (!model || batch < 1 || model->desc.n_joints > 1 || model->desc.n_geoms > 0) return -1;
+  if (model->desc.n_joints == 0) return (int64_t)(dtype == DPLL_F64 ? mesh_plan<double, 0>(batch).total : mesh_plan<float, 0>(batch).total);
+  return (int64_t)(dtype == DPLL_F64 ? mesh_plan<double, 1>(batch).total : mesh_plan<float, 1>(batch).total);
 }
+
+namespace {
+int check_mesh_call(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                    const char* who) {
+  if (!model) return fail(-1, "%s: null model", who);
+  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "%s: bad dtype", who);
+  if (params && (!params->theta || !params->friction)) return fail(-1, "%s: null parameter pointer", who);
+  return check_mesh(model, mesh, who);
+}
+}  // namespace
 
 int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,
                                const dpll_mesh_params_t* mesh, const void* x, int64_t ld_x, const void* x_plus,
                                int64_t ld_xp, int64_t batch, const void* weights, double scale, void* loss, void* grad,
                                void* loss_total, void* force, int32_t* iters, void* workspace, int64_t workspace_bytes,
                                void* stream) {
-  if (!model) return fail(-1, "dpll_contactnets_loss_mesh: null model%s");
-  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_contactnets_loss_mesh: bad dtype%s");
-  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_contactnets_loss_mesh: null parameter pointer%s");
-  if (int rc = check_mesh(model, mesh, "dpll_contactnets_loss_mesh")) return rc;
-  if (batch < 1 || !x || !x_plus || ld_x < 13 || ld_xp < 13) return fail(-1, "dpll_contactnets_loss_mesh: bad state arguments%s");
-  if (dtype == DPLL_F32)
-    return launch_mesh_loss<float>(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
-                                   loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
-  return launch_mesh_loss<double>(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
-                                  loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+  if (!params) return fail(-1, "dpll_contactnets_loss_mesh: null parameter pointer%s");
+  if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_contactnets_loss_mesh")) return rc;
+  const int nx = dpll_n_x(model);
+  if (batch < 1 || !x || !x_plus || ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss_mesh: bad state arguments%s");
+  DPLL_MESH_DISPATCH(launch_mesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
+                     loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,
@@ -1152,13 +1272,15 @@ int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, con
                                        int64_t ld_xp, int64_t batch, double scale, void* grad, void* workspace,
                                        int64_t workspace_bytes, void* stream, int32_t reps, float* ms_kernels) {
   if (!grad || !ms_kernels || reps < 1 || reps > 10000) return fail(-1, "dpll_profile_contactnets_loss_mesh: bad argument%s");
+  if (!model || model->desc.n_joints != 0) return fail(-2, "dpll_profile_contactnets_loss_mesh: single-body systems (one network: seven kernels)%s");
   const int per = kMeshKernels + 1;
   hipEvent_t* ev = new (std::nothrow) hipEvent_t[(size_t)per * reps];
   if (!ev) return fail(-4, "dpll_profile_contactnets_loss_mesh: out of memory%s");
-  for (int i = 0; i < per * reps; ++i) (void)hipEventCreate(&ev[i]);
-  int rc = 0;
+  bool ok = true;
+  for (int i = 0; i < per * reps; ++i) ok = (hipEventCreate(&ev[i]) == hipSuccess) && ok;
+  int rc = ok ? 0 : fail(-5, "dpll_profile_contactnets_loss_mesh: hipEventCreate failed%s");
   for (int r = 0; r < reps && rc == 0; ++r) {
-    (void)hipEventRecord(ev[per * r], (hipStream_t)stream);
+    ok = hipEventRecord(ev[per * r], (hipStream_t)stream) == hipSuccess && ok;
     t_mesh_marks = ev + per * r + 1;
     t_mesh_mark = 0;
     rc = dpll_contactnets_loss_mesh(model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, nullptr, scale, nullptr, grad,
@@ -1167,16 +1289,17 @@ int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, con
   }
   t_mesh_marks = nullptr;
   if (rc == 0) {
-    (void)hipEventSynchronize(ev[per * reps - 1]);
+    ok = hipEventSynchronize(ev[per * reps - 1]) == hipSuccess && ok;
     for (int k = 0; k < kMeshKernels; ++k) {
       double total = 0.0;
       for (int r = 0; r < reps; ++r) {
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev[per * r + k], ev[per * r + k + 1]);
+        ok = hipEventElapsedTime(&ms, ev[per * r + k], ev[per * r + k + 1]) == hipSuccess && ok;
         total += ms;
       }
       ms_kernels[k] = (float)(total / reps);
     }
+    if (!ok) rc = fail(-5, "dpll_profile_contactnets_loss_mesh: a HIP event call failed%s");
   } else {
     (void)hipStreamSynchronize((hipStream_t)stream);
   }
@@ -1188,65 +1311,43 @@ int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, con
 int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                    const void* x, int64_t ld_x, int64_t batch, void* x_next, int64_t ld_next, void* workspace,
                    int64_t workspace_bytes, void* stream) {
-  if (!model) return fail(-1, "dpll_step_mesh: null model%s");
-  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_step_mesh: bad dtype%s");
-  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_step_mesh: null parameter pointer%s");
-  if (int rc = check_mesh(model, mesh, "dpll_step_mesh")) return rc;
-  if (batch < 1 || !x || !x_next || ld_x < 13 || ld_next < 13) return fail(-1, "dpll_step_mesh: bad state arguments%s");
-  if (dtype == DPLL_F32)
-    return launch_mesh_step<float>(model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
-                                   (hipStream_t)stream);
-  return launch_mesh_step<double>(model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
-                                  (hipStream_t)stream);
+  if (!params) return fail(-1, "dpll_step_mesh: null parameter pointer%s");
+  if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_step_mesh")) return rc;
+  const int nx = dpll_n_x(model);
+  if (batch < 1 || !x || !x_next || ld_x < nx || ld_next < nx) return fail(-1, "dpll_step_mesh: bad state arguments%s");
+  DPLL_MESH_DISPATCH(launch_mesh_step, model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
+                     (hipStream_t)stream);
 }
 
 int dpll_step_backward_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                             const void* x, int64_t ld_x, const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad,
                             void* grad_x, int64_t ld_gx, void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!model) return fail(-1, "dpll_step_backward_mesh: null model%s");
-  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_step_backward_mesh: bad dtype%s");
-  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_step_backward_mesh: null parameter pointer%s");
-  if (int rc = check_mesh(model, mesh, "dpll_step_backward_mesh")) return rc;
-  if (batch < 1 || !x || !grad_x_next || !grad || ld_x < 13 || ld_g < 13 || (grad_x && ld_gx < 13))
+  if (!params) return fail(-1, "dpll_step_backward_mesh: null parameter pointer%s");
+  if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_step_backward_mesh")) return rc;
+  const int nx = dpll_n_x(model);
+  if (batch < 1 || !x || !grad_x_next || !grad || ld_x < nx || ld_g < nx || (grad_x && ld_gx < nx))
     return fail(-1, "dpll_step_backward_mesh: bad arguments%s");
-  if (dtype == DPLL_F32)
-    return launch_mesh_step_backward<float>(model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
-                                            workspace, workspace_bytes, (hipStream_t)stream);
-  return launch_mesh_step_backward<double>(model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
-                                           workspace, workspace_bytes, (hipStream_t)stream);
+  DPLL_MESH_DISPATCH(launch_mesh_step_backward, model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
+                     workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_mesh_params_t* mesh, const void* x,
                              int64_t ld_x, int64_t batch, void* points, void* workspace, int64_t workspace_bytes,
                              void* stream) {
-  if (!model) return fail(-1, "dpll_mesh_support_points: null model%s");
-  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_mesh_support_points: bad dtype%s");
-  if (int rc = check_mesh(model, mesh, "dpll_mesh_support_points")) return rc;
-  if (batch < 1 || !x || !points || ld_x < 4) return fail(-1, "dpll_mesh_support_points: bad arguments%s");
-  if (dtype == DPLL_F32) return launch_mesh_support<float>(mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
-  return launch_mesh_support<double>(mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
+  if (int rc = check_mesh_call(model, dtype, nullptr, mesh, "dpll_mesh_support_points")) return rc;
+  if (batch < 1 || !x || !points || ld_x < (model->desc.n_joints == 0 ? 4 : dpll_n_x(model)))
+    return fail(-1, "dpll_mesh_support_points: bad arguments%s");
+  DPLL_MESH_DISPATCH(launch_mesh_support, model, mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int dpll_terms_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                     const void* x, int64_t ld_x, int64_t batch, void* delassus, void* M, void* J, void* phi, void* a,
                     void* workspace, int64_t workspace_bytes, void* stream) {
-  if (!model) return fail(-1, "dpll_terms_mesh: null model%s");
-  if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "dpll_terms_mesh: bad dtype%s");
-  if (!params || !params->theta || !params->friction) return fail(-1, "dpll_terms_mesh: null parameter pointer%s");
-  if (int rc = check_mesh(model, mesh, "dpll_terms_mesh")) return rc;
-  if (batch < 1 || !x || ld_x < 13) return fail(-1, "dpll_terms_mesh: bad state arguments%s");
-  dpll_params_t q = *params;
-  q.lengths = nullptr;
-  if (dtype == DPLL_F32) {
-    const MeshPlan pl = mesh_plan<float>(batch);
-    if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_terms_mesh: workspace too small%s");
-    if (int rc = mesh_forward<float>(pl, mesh_weights<float>(mesh), (char*)workspace, (const float*)x, ld_x, (hipStream_t)stream)) return rc;
-    return launch_terms<float, 0>(model, &q, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream, (char*)workspace + pl.off_P);
-  }
-  const MeshPlan pl = mesh_plan<double>(batch);
-  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_terms_mesh: workspace too small%s");
-  if (int rc = mesh_forward<double>(pl, mesh_weights<double>(mesh), (char*)workspace, (const double*)x, ld_x, (hipStream_t)stream)) return rc;
-  return launch_terms<double, 0>(model, &q, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream, (char*)workspace + pl.off_P);
+  if (!params) return fail(-1, "dpll_terms_mesh: null parameter pointer%s");
+  if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_terms_mesh")) return rc;
+  if (batch < 1 || !x || ld_x < dpll_n_x(model)) return fail(-1, "dpll_terms_mesh: bad state arguments%s");
+  DPLL_MESH_DISPATCH(launch_mesh_terms, model, params, mesh, x, ld_x, batch, delassus, M, J, phi, a, workspace, workspace_bytes,
+                     (hipStream_t)stream);
 }
 
 int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x, int64_t ld_x,

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void icnn_fwd2_kernel(const T* __restrict__ x,
     __syncthreads();
     if (threadIdx.x < kTileRows * 3) {
       const int r = threadIdx.x / 3, i = threadIdx.x % 3;
-      if (n0 + r < N) P[(n0 + r) * 3 + i] = (Pp[0][r][i] + Pp[1][r][i]) + (Pp[2][r][i] + Pp[3][r][i]);
+      if (n0 + r < N) P[icnn_point_index(n0 + r, w.point_stride) + i] = (Pp[0][r][i] + Pp[1][r][i]) + (Pp[2][r][i] + Pp[3][r][i]);
     }
   }
 }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void icnn_bwd1_kernel(const T* __restrict__ x,
     load_queries<T>(x, ld, w.pert, n0, N, Qs);
     if (threadIdx.x < kTileRows * 3) {
       const int r = threadIdx.x / 3, i = threadIdx.x % 3;
-      Rs[r][i] = (n0 + r < N) ? RB[(n0 + r) * 3 + i] : T(0);
+      Rs[r][i] = (n0 + r < N) ? RB[icnn_point_index(n0 + r, w.point_stride) + i] : T(0);
     }
     __syncthreads();
 #pragma unroll
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void icnn_bwd2_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < 4; ++i) quat[i] = x[(n >> 2) * ld + i];
         icnn_query<T>(quat, w.pert + 3 * (n & 3), qd);
-        const T r0 = RB[n * 3], r1 = RB[n * 3 + 1], r2 = RB[n * 3 + 2];
+        const long long pn = icnn_point_index(n, w.point_stride);
+        const T r0 = RB[pn], r1 = RB[pn + 1], r2 = RB[pn + 2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int k = k0 + 4 * g + t;
@@ -319,12 +320,18 @@ __device__ __forceinline__ void reduce_strided4(const S* __restrict__ base, long
   }
 }
 
-template <typename T>
+// NB bodies, each with its own network: one launch per network.  `grad_w` = where this network's weight gradients go
+// ([Wh | Wd0 | Wd1 | wout], 67,328 entries); `grad_head` (first network's launch only, else nullptr) = the head of the
+// gradient, [theta (10 NB) | friction (1 + NB)], chained from the loss kernel's iota-space rows (row stride
+// `row_stride`, the chain matrix behind the rows).
+template <typename T, int NB>
 __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, const double* __restrict__ rows,
-                                                          int n_rows, const double* __restrict__ b1, int b1_blocks,
+                                                          int n_rows, int row_stride, const double* __restrict__ b1, int b1_blocks,
                                                           const T* __restrict__ slabs, int n_slabs,
-                                                          T* __restrict__ grad, T* __restrict__ loss_total) {
-  constexpr int kHead = 12;
+                                                          T* __restrict__ grad_w, T* __restrict__ grad_head, T* __restrict__ loss_total) {
+  constexpr int kHead = 10 * NB + 1 + NB;     // theta, friction
+  constexpr int kCols = 1 + 10 * NB + 4 * NB; // columns of a row: [loss | iota | mu_pair | lengths (unused)]
+  static_assert(kCols <= 32 && kHead < 64, "head must fit the wave that chains it");
   __shared__ double red[kRedGroups][kRedOut + 1];
   const int cg = threadIdx.x & 15, sg = threadIdx.x >> 4;
   const int b = blockIdx.x;
@@ -336,8 +343,11 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
     const int c0 = (b - kRedWhBlocks) * kRedOut;
     const int col0 = c0 < 3 * kW ? 4 * kW + c0 : (c0 < 6 * kW ? kW + (c0 - 3 * kW) : c0 - 6 * kW);
     reduce_strided4<double>(b1 + col0 + 4 * cg, (long long)kB1Cols, b1_blocks, sg, acc);
-  } else if (cg < 4) {  // head: 16 columns of the loss kernel's rows = 4 column groups
-    reduce_strided4<double>(rows + 4 * cg, 16, n_rows, sg, acc);
+  } else if (grad_head && cg < 8) {  // head: up to 32 columns of the loss kernel's rows = 8 column groups (scalar loads: odd strides)
+    for (int r = sg; r < n_rows; r += kRedGroups)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * cg + i < kCols) acc[i] += rows[(long long)r * row_stride + 4 * cg + i];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) red[sg][4 * cg + i] = acc[i];
@@ -349,28 +359,25 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
   if (b < kRedWhBlocks) {
     const long long idx = (long long)b * kRedOut + threadIdx.x;
     const T raw = w.Wh[idx];
-    grad[kHead + idx] = T(s * (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0)));
+    grad_w[idx] = T(s * (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0)));
   } else if (b < kRedWhBlocks + kRedB1Blocks) {
     const int c = (b - kRedWhBlocks) * kRedOut + threadIdx.x;
     if (c >= 6 * kW) {
       const T raw = w.wout[c - 6 * kW];
       s *= (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0));
     }
-    grad[kHead + kW * kW + c] = T(s);
-  } else {
-    // head: the loss kernel's rows are in iota space [loss | d/d iota (10) | d/d mu_pair | 3 unused], the chain matrix to
-    // (theta, friction) sits behind them; threads 0..63 are one wave: every lane gathers the 12 totals, thread 1 + k
-    // chains parameter k
-    double tot[16];
+    grad_w[kW * kW + c] = T(s);
+  } else if (grad_head) {
+    // head: the rows are in iota space, the chain matrix to (theta, friction) sits behind them; threads 0..63 are one
+    // wave: every lane gathers the column totals, thread 1 + k chains parameter k
+    double tot[32];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) tot[i] = __shfl(s, i);
-#pragma unroll
-    for (int i = 12; i < 16; ++i) tot[i] = 0.0;
+    for (int i = 0; i < 32; ++i) tot[i] = i < kCols ? __shfl(s, i) : 0.0;
     const int k = (int)threadIdx.x - 1;
     if (threadIdx.x == 0) {
       if (loss_total) *loss_total = T(s);
     } else if (k < kHead) {
-      grad[k] = T(apply_chain<1>(tot, rows + (long long)n_rows * 16, k));
+      grad_head[k] = T(apply_chain<NB, NB>(tot, rows + (long long)n_rows * row_stride, k));
     }
   }
 }
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
         v += dpp_mov<kQuadXor2>(v);
         v += dpp_mov<kRowHalfMirror>(v);
         v += dpp_mov<kRowMirror>(v);
-        if (part == 0 && n0 + row < N) P[(n0 + row) * 3 + i] = v;
+        if (part == 0 && n0 + row < N) P[icnn_point_index(n0 + row, w.point_stride) + i] = v;
       }
     }
   }
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
     load_queries32(x, ld, w.pert, n0, N, Qs);
     if (threadIdx.x >= 64 && threadIdx.x < 64 + kMfmaRows * 3) {
       const int t = threadIdx.x - 64, r = t / 3, i = t % 3;
-      Rs[r][i] = (n0 + r < N) ? RB[(n0 + r) * 3 + i] : 0.f;
+      Rs[r][i] = (n0 + r < N) ? RB[icnn_point_index(n0 + r, w.point_stride) + i] : 0.f;
     }
     __syncthreads();
     {  // Vb tile

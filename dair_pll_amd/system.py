@@ -264,16 +264,27 @@ class MultibodyLearnableSystem(Module):
                 return geometry
         return None
 
-    def _mesh_struct(self, flat: Tensor) -> _capi.MeshParams:
+    def _meshes(self) -> List['DeepSupportConvex']:
+        return [g for g in self.multibody_terms.contact_terms.geometries if isinstance(g, DeepSupportConvex)]
+
+    def _mesh_struct(self, flat: Tensor):
+        """``dpll_mesh_params_t[n_bodies]``: one network per body, its weights at ``head + g * 67,328`` of the flat buffer"""
         base, size, width = flat.data_ptr(), flat.element_size(), ICNN_WIDTH
-        off = 12
-        mesh = self._mesh()
-        pert = mesh.perturbations
-        if pert.dtype != flat.dtype or pert.device != flat.device:
-            mesh.perturbations = pert = pert.to(device=flat.device, dtype=flat.dtype)
-        return _capi.MeshParams(base + off * size, base + (off + width * width) * size,
-                                base + (off + width * width + 3 * width) * size,
-                                base + (off + width * width + 6 * width) * size, pert.contiguous().data_ptr())
+        n_b = self.spec.n_joints + 1
+        per_net = width * width + 7 * width
+        meshes = self._meshes()
+        array = (_capi.MeshParams * len(meshes))()
+        self._pert_keepalive = []
+        for g, mesh in enumerate(meshes):
+            off = 10 * n_b + 1 + n_b + g * per_net
+            pert = mesh.perturbations
+            if pert.dtype != flat.dtype or pert.device != flat.device or not pert.is_contiguous():
+                mesh.perturbations = pert = pert.to(device=flat.device, dtype=flat.dtype).contiguous()
+            self._pert_keepalive.append(pert)
+            array[g] = _capi.MeshParams(base + off * size, base + (off + width * width) * size,
+                                        base + (off + width * width + 3 * width) * size,
+                                        base + (off + width * width + 6 * width) * size, pert.data_ptr())
+        return array
 
     def _mesh_workspace(self, batch: int, device) -> Tensor:
         need = _capi.library().dpll_mesh_workspace_bytes(self._model(), batch, _DTYPES[self.dtype])
@@ -399,7 +410,7 @@ class MultibodyLearnableSystem(Module):
             workspace = self._mesh_workspace(batch, x.device)
             mesh = self._mesh_struct(flat)
             _capi.check(lib.dpll_contactnets_loss_mesh(
-                self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(x), x.stride(0),
+                self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh, _ptr(x), x.stride(0),
                 _ptr(x_plus), x_plus.stride(0), batch, _ptr(weights), float(scale), _ptr(loss), _ptr(grad), _ptr(total),
                 _ptr(force), _ptr(iters), _ptr(workspace), workspace.numel(), self._stream()))
             return loss, grad, total
@@ -452,7 +463,7 @@ class MultibodyLearnableSystem(Module):
 
     def support_points(self, x: Tensor) -> Tensor:
         """``DeepSupportConvex.get_vertices`` for the ground-contact direction of every state:
-        ``(*, n_x) -> (*, 4, 3)`` support points in the body frame (mesh systems only)."""
+        ``(*, n_x) -> (*, 4 n_bodies, 3)`` support points in the frames of their bodies (mesh systems only)."""
         if self._mesh() is None:
             raise TypeError('support_points needs a mesh (DeepSupportConvex) geometry')
         lib = _capi.library()
@@ -461,11 +472,12 @@ class MultibodyLearnableSystem(Module):
         flat = self._packed()
         workspace = self._mesh_workspace(xf.shape[0], xf.device)
         mesh = self._mesh_struct(flat)
-        points = torch.empty((xf.shape[0], 4, 3), dtype=self.dtype, device=xf.device)
-        _capi.check(lib.dpll_mesh_support_points(self._model(), _DTYPES[self.dtype], ctypes.byref(mesh), _ptr(xf),
+        k = 4 * len(self._meshes())
+        points = torch.empty((xf.shape[0], k, 3), dtype=self.dtype, device=xf.device)
+        _capi.check(lib.dpll_mesh_support_points(self._model(), _DTYPES[self.dtype], mesh, _ptr(xf),
                                                  xf.stride(0), xf.shape[0], _ptr(points), _ptr(workspace),
                                                  workspace.numel(), self._stream()))
-        return points.reshape(batch_shape + (4, 3))
+        return points.reshape(batch_shape + (k, 3))
 
     def profile_loss_kernels(self, x: Tensor, x_plus: Tensor, reps: int = 100) -> Tuple[float, float]:
         """Average duration in ms of (loss kernel, finalize kernel) measured with HIP events on the
@@ -497,7 +509,7 @@ class MultibodyLearnableSystem(Module):
         workspace = self._mesh_workspace(xf.shape[0], xf.device)
         out = (ctypes.c_float * len(self.MESH_KERNELS))()
         _capi.check(lib.dpll_profile_contactnets_loss_mesh(
-            self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(xf), xf.stride(0), _ptr(xpf),
+            self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh, _ptr(xf), xf.stride(0), _ptr(xpf),
             xpf.stride(0), xf.shape[0], 1.0 / xf.shape[0], _ptr(self._flat_grad), _ptr(workspace), workspace.numel(),
             self._stream(), reps, out))
         return dict(zip(self.MESH_KERNELS, (float(v) for v in out)))
@@ -532,7 +544,7 @@ class MultibodyLearnableSystem(Module):
         if self._mesh() is not None:
             workspace = self._mesh_workspace(x.shape[0], x.device)
             mesh = self._mesh_struct(flat)
-            _capi.check(lib.dpll_step_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh),
+            _capi.check(lib.dpll_step_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh,
                                            _ptr(x), x.stride(0), x.shape[0], _ptr(x_next), x_next.stride(0),
                                            _ptr(workspace), workspace.numel(), self._stream()))
             return x_next
@@ -552,7 +564,7 @@ class MultibodyLearnableSystem(Module):
             workspace = self._mesh_workspace(x.shape[0], x.device)
             mesh = self._mesh_struct(flat)
             _capi.check(lib.dpll_step_backward_mesh(
-                self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh), _ptr(x), x.stride(0), _ptr(gx),
+                self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh, _ptr(x), x.stride(0), _ptr(gx),
                 gx.stride(0), x.shape[0], _ptr(grad), _ptr(grad_x), ld_gx, _ptr(workspace), workspace.numel(), self._stream()))
             return grad, grad_x
         ws_bytes = lib.dpll_workspace_bytes(self._model(), x.shape[0])
@@ -685,9 +697,9 @@ class MultibodyLearnableSystem(Module):
                     quat = quat / quat.norm(dim=-1, keepdim=True)
                     x = torch.zeros((d.shape[0], self.space.n_x), dtype=torch.float64)
                     x[:, :4] = quat
-                    with torch.no_grad():
+                    with torch.no_grad():  # joint angles zero: every body has the base's rotation
                         points = self.support_points(x.to(device=param.device, dtype=param.dtype))
-                    return points[:, 0, :].double().cpu().numpy()
+                    return points[:, 4 * g, :].double().cpu().numpy()
                 meshes[body.name] = export.extract_mesh(support)
         return meshes
 
@@ -725,8 +737,11 @@ class MultibodyLearnableSystem(Module):
                 elif isinstance(geometry, Sphere):
                     shape = ('sphere', {'radius': repr(float(geometry.get_radius()))})
                 else:
-                    export.save_string(os.path.join(self.output_urdfs_dir, export.MESH_FILE), export.mesh_to_obj(*meshes[body.name]))
-                    shape = ('mesh', {'filename': export.MESH_FILE})
+                    # the reference writes every learned shape to 'test.obj' (urdf_utils.py:244-252): with one mesh per
+                    # body of a multi-body system that would overwrite, so those get a file per body
+                    obj_name = export.MESH_FILE if len(meshes) == 1 else f'{body.name}.obj'
+                    export.save_string(os.path.join(self.output_urdfs_dir, obj_name), export.mesh_to_obj(*meshes[body.name]))
+                    shape = ('mesh', {'filename': obj_name})
                 shapes.append((shape, float(friction[g + 1])))
             bodies.append((body.name, pi_cm[index], shapes))
         new_urdfs = {}
@@ -749,7 +764,7 @@ class MultibodyLearnableSystem(Module):
         if self._mesh() is not None:
             workspace = self._mesh_workspace(n, x.device)
             mesh = self._mesh_struct(flat)
-            _capi.check(lib.dpll_terms_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), ctypes.byref(mesh),
+            _capi.check(lib.dpll_terms_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh,
                                             _ptr(x), x.stride(0), n, _ptr(delassus), _ptr(mass), _ptr(jac), _ptr(phi),
                                             _ptr(acc), _ptr(workspace), workspace.numel(), self._stream()))
         else:

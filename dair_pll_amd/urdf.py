@@ -197,5 +197,7 @@ def check_supported(spec: ModelSpec) -> None:
     for index, body in enumerate(spec.bodies):
         if index > 0 and not 0 <= body.parent < index:
             raise NotImplementedError('links must be listed after their parent')
-    if any(geom.kind == 'mesh' for _, geom in geoms) and (spec.n_joints != 0 or len(geoms) != 1):
-        raise NotImplementedError('mesh (DeepSupportConvex) geometry is implemented for single-body systems with one geometry')
+    if any(geom.kind == 'mesh' for _, geom in geoms):
+        if not (spec.is_fast() and all(geom.kind == 'mesh' for _, geom in geoms)):
+            raise NotImplementedError('mesh (DeepSupportConvex) geometry: a serial chain of at most one joint with exactly '
+                                      'one mesh on every body (contactnets_cube_mesh.urdf, contactnets_elbow_mesh.urdf)')

@@ -153,11 +153,14 @@ int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* par
                   int64_t batch, int64_t steps, void* traj, void* stream);
 
 /* ---- mesh geometry: DeepSupportConvex / HomogeneousICNN (geometry.py:255-325, deep_support_function.py:125-266),
- * depth 2, width 256, one floating body.  Raw (signed) parameters, caller owned:
+ * depth 2, width 256, ONE NETWORK PER BODY of a cube / elbow model (contactnets_cube_mesh.urdf,
+ * contactnets_elbow_mesh.urdf): every `mesh` argument below points to an array of n_bodies dpll_mesh_params_t, in body
+ * order.  Raw (signed) parameters, caller owned:
  *   hidden_weight (256, 256)  network.hidden_weights.0     input_weight0 / input_weight1 (3, 256)  network.input_weights.{0,1}
  *   output_weight (256,)      network.output_weight        perturbations (4, 3) fixed buffer, row 0 zero
- * Gradient layout of the mesh entry points: [theta(10) | friction(2) | hidden_weight | input_weight0 | input_weight1 |
- * output_weight] = dpll_mesh_param_count() numbers.  The box `lengths` pointer of dpll_params_t is ignored. */
+ * Gradient layout of the mesh entry points: [theta(10 n_bodies) | friction(1 + n_bodies) | then per body: hidden_weight |
+ * input_weight0 | input_weight1 | output_weight] = dpll_mesh_param_count() numbers.  The box `lengths` pointer of
+ * dpll_params_t is ignored. */
 typedef struct dpll_mesh_params {
   const void* hidden_weight;
   const void* input_weight0;
@@ -177,7 +180,7 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
                                void* stream);
 
 /* dpll_step_backward with the network shape: grad has the layout of dpll_contactnets_loss_mesh's
- * ([theta | friction | hidden | input0 | input1 | output weights], dpll_mesh_param_count entries); the support point is
+ * ([theta | friction | per body: hidden | input0 | input1 | output weights], dpll_mesh_param_count entries); the support point is
  * piecewise constant in the state (LeakyReLU network), so grad_x needs no network Jacobian. */
 int dpll_step_backward_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                             const void* x, int64_t ld_x, const void* grad_x_next, int64_t ld_g, int64_t batch, void* grad,
@@ -201,7 +204,8 @@ int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* pa
                    const void* x, int64_t ld_x, int64_t batch, void* x_next, int64_t ld_next, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
-/* DeepSupportConvex.get_vertices for the ground-contact direction of every state: points (batch, 4, 3), body frame. */
+/* DeepSupportConvex.get_vertices for the ground-contact direction of every state and body: points (batch, 4 n_bodies, 3),
+ * each body's four in its own frame. */
 int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_mesh_params_t* mesh, const void* x,
                              int64_t ld_x, int64_t batch, void* points, void* workspace, int64_t workspace_bytes,
                              void* stream);

@@ -104,7 +104,8 @@ def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0):
             sphere.length_param = Parameter(torch.tensor(geom['radius']), requires_grad=True)
             modules.append(sphere)
         else:
-            torch.manual_seed(mesh_seed)
+            # one seed per network: mesh_seed for the first (the cube), mesh_seed + 1 for the elbow's second link, ...
+            torch.manual_seed(mesh_seed + sum(isinstance(m, DeepSupportConvex) for m in modules))
             modules.append(DeepSupportConvex(torch.tensor(geom['vertices'])))
     ct.geometries = ModuleList(modules)
     ct.friction_params = Parameter(torch.tensor([g['mu'] for g in geoms]), requires_grad=True)
@@ -375,6 +376,14 @@ def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, 
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3)
 
 
+def record_elbow_mesh() -> None:
+    """contactnets_elbow_mesh.urdf: a DeepSupportConvex on each link (two independent networks), on every 4th of the
+    synthetic elbow pairs."""
+    ex, exp_ = elbow_pairs()
+    record_case('elbow_mesh_literal', os.path.join(ASSETS, 'contactnets_elbow_mesh.urdf'), ex[::4].clone(),
+                exp_[::4].clone(), 'reference_literal', sim_steps=3)
+
+
 def main() -> None:
     cube = os.path.join(ASSETS, 'contactnets_cube.urdf')
     record_bench_batch('cube_box_4096')
@@ -391,6 +400,7 @@ def main() -> None:
     record_slice_fixture()
     record_dynamics_gradients()
     record_general_cases()
+    record_elbow_mesh()
 
 
 if __name__ == '__main__':

@@ -10,43 +10,53 @@ from conftest import ASSET_DIR
 from oracle import dpll_oracle as O
 
 pytestmark = pytest.mark.gpu
-NET = 'multibody_terms.contact_terms.geometries.1.'
+GEOM = 'multibody_terms.contact_terms.geometries.'
+NET = GEOM + '1.'
+URDF = {'contactnets_cube_mesh.urdf': 'cube_mesh.urdf', 'contactnets_elbow_mesh.urdf': 'elbow_mesh.urdf'}
+CASES = ['cube_mesh_literal', 'elbow_mesh_literal']
 
 
 def build(g, dtype):
     from dair_pll_amd import MultibodyLearnableSystem
-    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube_mesh.urdf')}, float(g['dt']), dtype=dtype,
+    system = MultibodyLearnableSystem({'model': os.path.join(ASSET_DIR, URDF[str(g['urdf'])])}, float(g['dt']), dtype=dtype,
                                       device='cuda:0')
     system.load_state_dict({name: torch.tensor(g['param/' + name]) for name, _ in system.named_parameters()})
-    system.multibody_terms.contact_terms.geometries[1].perturbations = torch.tensor(
-        g['param/' + NET + 'perturbations'], dtype=dtype, device='cuda:0')
+    for index, geometry in enumerate(system.multibody_terms.contact_terms.geometries):
+        if index > 0:  # the fixed perturbation directions are a buffer drawn at construction (geometry.py:382-385)
+            geometry.perturbations = torch.tensor(g[f'param/{GEOM}{index}.perturbations'], dtype=dtype, device='cuda:0')
     return system
 
 
 def oracle_for(g):
-    mesh = {'perturbations': torch.tensor(g['param/' + NET + 'perturbations'])}
-    for key in ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight'):
-        mesh[key] = torch.tensor(g['param/' + NET + 'network.' + key])
-    system = O.OracleSystem(os.path.join(ASSET_DIR, 'cube_mesh.urdf'), float(g['dt']), mesh_params={1: mesh})
+    n_nets = sum(1 for key in g.files if key.endswith('.perturbations'))
+    meshes = {}
+    for index in range(1, n_nets + 1):
+        meshes[index] = {'perturbations': torch.tensor(g[f'param/{GEOM}{index}.perturbations'])}
+        for key in ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight'):
+            meshes[index][key] = torch.tensor(g[f'param/{GEOM}{index}.network.{key}'])
+    system = O.OracleSystem(os.path.join(ASSET_DIR, URDF[str(g['urdf'])]), float(g['dt']), mesh_params=meshes)
     system.theta = torch.tensor(g['param/multibody_terms.lagrangian_terms.inertial_parameters'])
     system.friction = torch.tensor(g['param/multibody_terms.contact_terms.friction_params'])
     return system
 
 
+@pytest.mark.parametrize('case', CASES)
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
-def test_mesh_loss_gradients_dynamics(golden, dtype):
-    g = golden('cube_mesh_literal')
+def test_mesh_loss_gradients_dynamics(golden, dtype, case):
+    g = golden(case)
     system = build(g, dtype)
     x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
     xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
     f64 = dtype == torch.float64
-    # support points vs the oracle's DeepSupportConvex restatement (order-free: sort rows)
+    # support points vs the oracle's DeepSupportConvex restatement (order-free: sort rows), one network per body
     oracle = oracle_for(g)
-    directions = -O.quat_to_rot(torch.tensor(g['x_plus'][:, :4]))[:, 2, :]
-    ref_pts = oracle.support_points(1, directions).numpy()
+    R_WC = O.geometry_kinematics(oracle.spec, oracle.q_v(torch.tensor(g['x_plus']))[0])[0]
     pts = system.support_points(xp).cpu().double().numpy()
     key = lambda a: np.sort(a.reshape(a.shape[0], -1), axis=-1)
-    assert np.abs(key(pts) - key(ref_pts)).max() < (1e-12 if f64 else 2e-6)
+    for index in range(1, R_WC.shape[-3]):
+        ref_pts = oracle.support_points(index, -R_WC[:, index, 2, :]).numpy()
+        mine = pts[:, 4 * (index - 1):4 * index]
+        assert np.abs(key(mine) - key(ref_pts)).max() < (1e-12 if f64 else 2e-6), index
     # loss: autograd.Function path
     loss = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp)
     assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4)
@@ -120,16 +130,17 @@ def test_learned_shape_export(golden, tmp_path):
     for axis, lo, hi in zip('xyz', vertices.min(axis=0), vertices.max(axis=0)):
         assert scalars[f'body_diameter_{axis}'] == pytest.approx(hi - lo) and scalars[f'body_center_{axis}'] == pytest.approx((hi + lo) / 2)
     new = system.generate_updated_urdfs()
-    spec = parse_urdf(new['cube'])
+    spec = parse_urdf(new['model'])
     assert spec.bodies[0].geoms[0].kind == 'mesh' and spec.bodies[0].geoms[0].mesh_file == 'test.obj'
     assert np.allclose(np.array(spec.bodies[0].geoms[0].vertices), vertices, atol=0, rtol=1e-15)
 
 
-def test_mesh_terms_match_reference_run(golden):
+@pytest.mark.parametrize('case', CASES)
+def test_mesh_terms_match_reference_run(golden, case):
     """MultibodyTerms.forward (D, M, J, phi, a) with the learned shape; the reference's top-k leaves the order of
     the four witness points unspecified, so contacts are put in a canonical order first (as for the boxes)."""
     from test_hip_parity import _canonical
-    g = golden('cube_mesh_literal')
+    g = golden(case)
     system = build(g, torch.float64)
     xp = torch.tensor(g['x_plus'], dtype=torch.float64, device='cuda:0')
     q, v = system.space.q_v(xp)
@@ -145,11 +156,12 @@ def test_mesh_terms_match_reference_run(golden):
     assert np.abs(Dm[good] - Dr[good]).max() < 1e-8 * max(1.0, np.abs(Dr).max())
 
 
-def test_mesh_step_gradients_match_finite_differences(golden):
+@pytest.mark.parametrize('case', CASES)
+def test_mesh_step_gradients_match_finite_differences(golden, case):
     """dpll_step_backward_mesh: d(sum w . x_next)/d(theta, friction, network weights) and /dx for the learned-shape
     body against central differences of dpll_step_mesh, float64 (the support point is piecewise constant in the
     state and piecewise linear in every weight tensor, so differences are exact away from mask flips)."""
-    g = golden('cube_mesh_literal')
+    g = golden(case)
     system = build(g, torch.float64)
     x = torch.tensor(g['x'][::2], dtype=torch.float64, device='cuda:0').clone().requires_grad_(True)
     w = torch.randn(x.shape, generator=torch.Generator().manual_seed(3), dtype=torch.float64).to(x.device)
@@ -190,11 +202,12 @@ def test_mesh_step_gradients_match_finite_differences(golden):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in system.parameters())
 
 
+@pytest.mark.parametrize('case', CASES)
 @pytest.mark.parametrize('batch', [1, 5, 33])
-def test_mesh_ragged_batches(golden, batch):
+def test_mesh_ragged_batches(golden, batch, case):
     """Batches that do not fill a 32-row query tile or a slab: per-item losses equal those of the full fixture
     batch, and the gradient of their mean equals the weighted full-batch gradient (float32 MFMA path and float64)."""
-    g = golden('cube_mesh_literal')
+    g = golden(case)
     for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
         system = build(g, dtype)
         x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
@@ -213,3 +226,31 @@ def test_mesh_ragged_batches(golden, batch):
         for a, (name, p) in zip(g_part, system.named_parameters()):
             scale = max(p.grad.abs().max().item(), 1e-12)
             assert (a - p.grad).abs().max().item() <= (1e-9 if dtype == torch.float64 else 5e-3) * scale, (name, batch, dtype)
+
+
+def test_two_learned_shapes_export(golden, tmp_path):
+    """contactnets_elbow_mesh: a network per link -> a mesh per body in scalars_and_meshes, each the hull of its own
+    network's support points, and an OBJ file per body beside the updated URDF."""
+    from dair_pll_amd import export
+    from dair_pll_amd.urdf import parse_urdf
+    g = golden('elbow_mesh_literal')
+    system = build(g, torch.float64)
+    system.output_urdfs_dir = str(tmp_path)
+    scalars, meshes = system.scalars_and_meshes()
+    assert sorted(meshes) == ['elbow_1', 'elbow_2']
+    directions = torch.tensor(export.surface_directions())
+    for index, body in ((1, 'elbow_1'), (2, 'elbow_2')):
+        weights = {key: torch.tensor(g[f'param/{GEOM}{index}.network.{key}']) for key in
+                   ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight')}
+        expect = O.icnn_support_point(weights, directions).numpy()
+        vertices, faces = meshes[body]
+        dist = np.abs(vertices[:, None, :] - expect[None, :, :]).max(axis=2)
+        assert dist.min(axis=1).max() < 1e-12 and dist.min(axis=0).max() < 1e-12
+        assert not export.outward_normals(vertices, faces)[1].any()
+        assert scalars[f'{body}_diameter_x'] == pytest.approx(vertices[:, 0].max() - vertices[:, 0].min())
+    spec = parse_urdf(system.generate_updated_urdfs()['model'])
+    files = [body.geoms[0].mesh_file for body in spec.bodies]
+    assert files == ['elbow_1.obj', 'elbow_2.obj']
+    for body, name in zip(spec.bodies, ('elbow_1', 'elbow_2')):
+        assert np.allclose(np.array(body.geoms[0].vertices), meshes[name][0], atol=0, rtol=1e-15)
+        assert body.geoms[0].origin == ([0.0, 0.0, 0.0] if name == 'elbow_1' else [0.035, 0.0, 0.0])

@@ -12,9 +12,10 @@ from oracle import dpll_oracle as O
 
 torch.set_default_dtype(torch.float64)
 
-CASES = ['cube_box_literal', 'cube_box_physical', 'cube_box_config1', 'elbow_box_literal', 'cube_mesh_literal']
+CASES = ['cube_box_literal', 'cube_box_physical', 'cube_box_config1', 'elbow_box_literal', 'cube_mesh_literal',
+         'elbow_mesh_literal']
 URDF = {'contactnets_cube.urdf': 'cube.urdf', 'contactnets_elbow.urdf': 'elbow.urdf',
-        'contactnets_cube_mesh.urdf': 'cube_mesh.urdf'}
+        'contactnets_cube_mesh.urdf': 'cube_mesh.urdf', 'contactnets_elbow_mesh.urdf': 'elbow_mesh.urdf'}
 PREFIX = 'multibody_terms.contact_terms.geometries.'
 
 

@@ -182,7 +182,8 @@ def test_theta_round_trip():
 
 @pytest.mark.reference
 @pytest.mark.parametrize('ours,theirs', [('cube.urdf', 'contactnets_cube.urdf'), ('elbow.urdf', 'contactnets_elbow.urdf'),
-                                         ('cube_mesh.urdf', 'contactnets_cube_mesh.urdf')])
+                                         ('cube_mesh.urdf', 'contactnets_cube_mesh.urdf'),
+                                         ('elbow_mesh.urdf', 'contactnets_elbow_mesh.urdf')])
 def test_repo_assets_describe_the_reference_models(ours, theirs):
     mine = O.parse_urdf(os.path.join(ASSET_DIR, ours))
     ref = O.parse_urdf(os.path.join(REFERENCE_DIR, 'assets', theirs))
