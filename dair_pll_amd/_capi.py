@@ -14,9 +14,10 @@ from .urdf import ModelSpec, check_supported
 MAX_JOINTS = 2
 MAX_BODIES = 3
 MAX_GEOMS = 3
-GEOM_KINDS = {'box': 0, 'sphere': 1}
+GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
+GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 9  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 10  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -28,7 +29,7 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [('n_joints', c_int32), ('inertia_mode', c_int32), ('dt', c_double), ('gravity_z', c_double),
                 ('joint_origin', (c_double * 3) * MAX_JOINTS), ('joint_axis', (c_double * 3) * MAX_JOINTS),
                 ('geom_origin', (c_double * 3) * MAX_GEOMS), ('parent', c_int32 * MAX_JOINTS), ('n_geoms', c_int32),
-                ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('reserved', c_int32)]
+                ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('geom_nverts', c_int32 * MAX_GEOMS)]
 
 
 class SolverOpts(ctypes.Structure):
@@ -69,6 +70,7 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
     for g, (body_index, geom) in enumerate(geoms):
         desc.geom_body[g] = body_index
         desc.geom_kind[g] = GEOM_KINDS.get(geom.kind, 0)
+        desc.geom_nverts[g] = len(geom.vertices) if geom.kind == 'polygon' else 0
         for axis in range(3):
             desc.geom_origin[g][axis] = geom.origin[axis]
     desc.n_geoms = 0 if spec.is_fast() else len(geoms)

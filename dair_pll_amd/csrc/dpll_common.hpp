@@ -110,9 +110,12 @@ template <typename S> __device__ __forceinline__ void theta_jacobian_column(int 
 #pragma unroll
   for (int i = 0; i < kIota; ++i) dio[i] = io[i].d;
 }
-template <typename T, typename P, int NB, int NG = NB>
+// GP = numbers per geometry in the `lengths` block (3: a box; the general build: 3 kMaxPolyVerts); geom_kind (general build
+// only): a polygon's vertices are signed parameters (chain factor 1), lengths and radii enter through their absolute value
+template <typename T, typename P, int NB, int NG = NB, int GP = 3>
 __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __restrict__ theta, const P* __restrict__ friction,
-                                                   const P* __restrict__ lengths, double* __restrict__ chain) {
+                                                   const P* __restrict__ lengths, double* __restrict__ chain,
+                                                   const int32_t* geom_kind = nullptr) {
   const int lane = threadIdx.x;
   if (lane < 10 * NB) {  // lane = (body, theta component c): column c of that body's Jacobian
     T th[10], dio[kIota];
@@ -136,21 +139,22 @@ __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __
     if (k == 1 + b) fac += 2.0 * m0 * m0 / den;
     fr_fac[lane] = fac * sign;
   }
-  if (lane < 3 * NG) {
-    const double pl = lengths ? double(lengths[lane]) : 0.0;
-    len_sign[lane] = pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0);
+  for (int e = lane; e < GP * NG; e += kWave) {
+    const double pl = lengths ? double(lengths[e]) : 0.0;
+    const bool polygon = geom_kind && geom_kind[e / GP] == kGeomPolygon;
+    len_sign[e] = polygon ? 1.0 : (pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0));
   }
 }
 // learnable parameter k = sum_{j < count} tot[tot0 + j] * chain[coef0 + j] with the row sum `tot` ([loss | iota | mu_pair | length])
 struct ChainRow { int coef0, tot0, count; };
-template <int NB, int NG = NB> __device__ __forceinline__ ChainRow chain_row(int k) {
+template <int NB, int NG = NB, int GP = 3> __device__ __forceinline__ ChainRow chain_row(int k) {
   if (k < 10 * NB) return ChainRow{k * kIota, 1 + kIota * (k / 10), kIota};
   if (k < 10 * NB + NG + 1) return ChainRow{100 * NB + (k - 10 * NB) * NG, 1 + kIota * NB, NG};
   const int i = k - (10 * NB + NG + 1);
   return ChainRow{100 * NB + (NG + 1) * NG + i, 1 + kIota * NB + NG + i, 1};
 }
-template <int NB, int NG = NB> __device__ __forceinline__ double apply_chain(const double* tot, const double* __restrict__ chain, int k) {
-  const ChainRow cr = chain_row<NB, NG>(k);
+template <int NB, int NG = NB, int GP = 3> __device__ __forceinline__ double apply_chain(const double* tot, const double* __restrict__ chain, int k) {
+  const ChainRow cr = chain_row<NB, NG, GP>(k);
   double v = 0.0;
   for (int j = 0; j < cr.count; ++j) v += tot[cr.tot0 + j] * chain[cr.coef0 + j];
   return v;
@@ -158,15 +162,15 @@ template <int NB, int NG = NB> __device__ __forceinline__ double apply_chain(con
 
 
 // NG = collision geometries (the two fast builds: one per body; the general build: always kMaxGeoms slots)
-template <typename T, int NJ, int NG_ = NJ + 1> struct Dims {
-  static constexpr int NB = NJ + 1, NG = NG_, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NG, G = K;
+template <typename T, int NJ, int NG_ = NJ + 1, int GP_ = 3> struct Dims {
+  static constexpr int NB = NJ + 1, NG = NG_, GP = GP_, NV = 6 + NJ, NQ = 7 + NJ, NX = 13 + 2 * NJ, K = kQuery * NG, G = K;
   static constexpr int IPW = kWave / G;                       // items per wave (lane-per-contact builds: G = 4 or 8)
-  static constexpr int P = NB * 10 + (NG + 1) + NG * 3;       // learnable parameters [theta | friction | lengths]
+  static constexpr int P = NB * 10 + (NG + 1) + NG * GP;      // learnable parameters [theta | friction | lengths]
   static constexpr int PI = 1 + P;                            // row stride of the partial sums; the output row [loss | d/d params]
-  static constexpr int PIOTA = 1 + 10 * NB + 4 * NG;          // a partial row: [loss | d/d iota | d/d mu_pair | d/d |length|]
+  static constexpr int PIOTA = 1 + 10 * NB + (1 + GP) * NG;   // a partial row: [loss | d/d iota | d/d mu_pair | d/d |length|]
   // the chain matrix behind the rows: [d iota_b,i / d theta_b,c (NB, 10 c, 10 i) | d mu_pair,g / d friction_k (NG + 1 k, NG g) |
-  // sign(length_params) (3 NG)], doubles
-  static constexpr int CHAIN = 100 * NB + (NG + 1) * NG + 3 * NG;
+  // sign(length_params) (GP NG)], doubles
+  static constexpr int CHAIN = 100 * NB + (NG + 1) * NG + GP * NG;
 };
 
 template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double
@@ -189,10 +193,35 @@ template <int G, typename T> __device__ __forceinline__ T wave_sum_to_lane63(T x
   return x;  // the total over the groups in lane 63; other lanes hold partial sums
 }
 
-template <typename T, int NJ, int G = Dims<T, NJ>::G, int NG = NJ + 1>
-__device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG>& acc, double loss_acc, double* __restrict__ partials) {
-  using D = Dims<T, NJ, NG>;
+template <typename T, int NJ, int G = Dims<T, NJ>::G, int NG = NJ + 1, int GP = 3>
+__device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG, GP>& acc, double loss_acc, double* __restrict__ partials) {
+  using D = Dims<T, NJ, NG, GP>;
   using Lanes = GpuLanes<G>;
+  double* dst = partials + (long long)blockIdx.x * D::PI;
+  const bool writer = threadIdx.x == kWave - 1;
+  if constexpr (GP > 3) {
+    // wide rows (the general build): element by element, nothing kept live
+    const double l = wave_sum_to_lane63<G>(Lanes::group_sum(loss_acc));
+    if (writer) dst[0] = l;
+#pragma unroll
+    for (int b = 0; b < D::NB; ++b)
+#pragma unroll
+      for (int i = 0; i < kIota; ++i) {
+        const double v = double(wave_sum_to_lane63<G>(acc.g_iota[b][i]));
+        if (writer) dst[1 + kIota * b + i] = v;
+      }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const double m = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_mu[g])));
+      if (writer) dst[1 + kIota * D::NB + g] = m;
+#pragma unroll
+      for (int i = 0; i < GP; ++i) {
+        const double v = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[g][i])));
+        if (writer) dst[1 + kIota * D::NB + NG + GP * g + i] = v;
+      }
+    }
+    return;
+  }
   double row[D::PIOTA];
   row[0] = wave_sum_to_lane63<G>(Lanes::group_sum(loss_acc));
 #pragma unroll
@@ -204,11 +233,10 @@ __device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG>& acc, d
   for (int g = 0; g < NG; ++g) {
     row[1 + kIota * D::NB + g] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_mu[g])));
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      row[1 + kIota * D::NB + NG + 3 * g + i] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[g][i])));
+    for (int i = 0; i < GP; ++i)
+      row[1 + kIota * D::NB + NG + GP * g + i] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[g][i])));
   }
-  if (threadIdx.x == kWave - 1) {
-    double* dst = partials + (long long)blockIdx.x * D::PI;
+  if (writer) {
 #pragma unroll
     for (int i = 0; i < D::PIOTA; ++i) dst[i] = row[i];
   }

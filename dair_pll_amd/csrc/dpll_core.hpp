@@ -46,6 +46,7 @@
 #define DPLL_PHASE(slot) do {} while (0)
 #define DPLL_PHASE_END() do {} while (0)
 #define DPLL_PHASE_COUNT(slot) do {} while (0)
+#define DPLL_PHASE_EVENT(slot, happened) do {} while (0)
 #endif
 #ifndef DPLL_CORE_STAMP
 #define DPLL_CORE_STAMP(slot) do {} while (0)
@@ -59,7 +60,8 @@ namespace dpll {
 constexpr int kMaxJoints = 2;   // revolute joints of the tree hanging off the floating base
 constexpr int kMaxBodies = kMaxJoints + 1;
 constexpr int kMaxGeoms = 3;    // convex collision geometries of a model (each against the ground half-space)
-constexpr int kGeomBox = 0, kGeomSphere = 1;
+constexpr int kGeomBox = 0, kGeomSphere = 1, kGeomPolygon = 2;
+constexpr int kMaxPolyVerts = 8;  // vertices of a Polygon (geometry.py:220-252); the general build only
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
 
@@ -78,13 +80,16 @@ struct ModelDesc {
   int32_t parent[kMaxJoints];          // parent body of body j + 1 (< j + 1)
   int32_t n_geoms;
   int32_t geom_body[kMaxGeoms];
-  int32_t geom_kind[kMaxGeoms];        // kGeomBox | kGeomSphere
-  int32_t reserved;
+  int32_t geom_kind[kMaxGeoms];        // kGeomBox | kGeomSphere | kGeomPolygon
+  int32_t geom_nverts[kMaxGeoms];      // Polygon: number of vertices, 4 .. kMaxPolyVerts
   static constexpr bool kGeneral = false;
+  static constexpr int kGeoStride = 3;  // numbers per geometry in the `lengths` parameter block: a box's length_params
 };
 // same layout; selects the tree / geometry-table code paths at compile time
 struct GeneralDesc : ModelDesc {
   static constexpr bool kGeneral = true;
+  // box: length_params (3) | sphere: length_param (1) | polygon: vertices (n_verts, 3) row-major; the rest padding
+  static constexpr int kGeoStride = 3 * kMaxPolyVerts;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -865,7 +870,8 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     // when l is still descending at 1 (the capped search would stop at its lower bracket, alpha = 1)
     const bool reject = moving && !(tabs(first1) <= slope_tol) && (first1 > T(0) || ls_cap > 1);
     DPLL_PHASE(3);
-    if (Lanes::wave_any(reject)) {
+    const bool fell_back = Lanes::wave_any(reject);
+    if (fell_back) {
       DPLL_PHASE_COUNT(6);
       // l'(alpha) = y.Md + alpha d.Md - sum_c gamma_c(alpha) . (J_c d); from H d = -grad:
       //   d.Md = dec2 - (1/eps) sum_c (J_c d)^T dP_c (J_c d),      l''(alpha) = d.Md + (1/eps) sum_c (J_c d)^T dP_c(alpha) (J_c d)
@@ -933,6 +939,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
       sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
     }
     DPLL_PHASE(4);
+    DPLL_PHASE_EVENT(7, fell_back);
 #if defined(DPLL_TRACE) && !defined(__HIP_DEVICE_COMPILE__)
     if (active) {
       printf("  it %2d stage %d eps %.2e dec2 %.3e scale %.3e alpha %.4f conv %d stall %d regions", it, stage, double(eps_c), double(dec2), double(scale), double(alpha), int(converged), stall);
@@ -978,6 +985,7 @@ template <typename T, int NJ, int NG = NJ + 1> struct Derived {
   T iota[NB][kIota];
   T mu[NG];       // pair coefficient ground-vs-geometry g: 2 mu_0 mu_g / (mu_0 + mu_g), mu = |friction_params| (multibody_terms.py:321-324, :471)
   T habs[NG][3];  // |length_params| of a box (geometry.py:393-403); [0] = |length_param|, the radius of a sphere (:415-456)
+  const T* geo;   // the raw geometry parameter blocks (stride MD::kGeoStride): a Polygon's vertices are read from here
 };
 
 template <typename T, int NJ, int NG, class MD>
@@ -991,8 +999,9 @@ DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, cons
   DPLL_UNROLL for (int g = 0; g < NG; ++g) {
     const T mug = tabs(friction[1 + g]);
     dp.mu[g] = T(2) * mu0 * mug / (mu0 + mug);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[g][i] = lengths ? tabs(lengths[3 * g + i]) : T(0);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[g][i] = lengths ? tabs(lengths[MD::kGeoStride * g + i]) : T(0);
   }
+  dp.geo = lengths;
 }
 
 // per-item terms shared by the loss and the dynamics
@@ -1041,6 +1050,7 @@ template <typename T, int NJ> struct ContactGeom {
   int geom;
   T sgn[3];      // box: corner sign pattern = d witness_i / d |length_i|; sphere: zero
   T drad[3];     // sphere: d witness / d radius (the support direction); box: zero
+  int vidx;      // polygon: index of the vertex this contact picked (d witness / d vertices[vidx] = 1); otherwise -1
   T phi;
   T mu;
   T R[3][3];     // rotation of the contact's body
@@ -1104,6 +1114,7 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
   const T d[3] = {-cg.R[2][0], -cg.R[2][1], -cg.R[2][2]};
   T wit[3];
   DPLL_UNROLL for (int i = 0; i < 3; ++i) cg.drad[i] = T(0);
+  cg.vidx = -1;
   if (witness) {
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { cg.sgn[i] = T(0); wit[i] = witness[i]; }
   } else {
@@ -1117,6 +1128,26 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
         wit[i] = sphere ? d[i] * habs[0] : wit[i];
         cg.drad[i] = sphere ? d[i] : T(0);
         cg.sgn[i] = sphere ? T(0) : cg.sgn[i];
+      }
+      // Polygon (geometry.py:220-252 through SparseVertexConvexCollisionGeometry.support_points, :162-202): the
+      // n_query = 4 vertices with the largest d . vertex, in no particular order (quirk Q3).  Slot s takes the vertex
+      // of rank s (ties by index); the witness is that vertex itself, so its adjoint goes to the vertex unchanged.
+      if (kind == kGeomPolygon) {
+        T vert[kMaxPolyVerts][3], dots[kMaxPolyVerts];
+        const int nv = md.geom_nverts[g < kMaxGeoms ? g : 0];
+        DPLL_UNROLL for (int u = 0; u < kMaxPolyVerts; ++u) {
+          DPLL_UNROLL for (int i = 0; i < 3; ++i) vert[u][i] = dp.geo[MD::kGeoStride * g + 3 * u + i];
+          dots[u] = u < nv ? d[0] * vert[u][0] + d[1] * vert[u][1] + d[2] * vert[u][2] : T(-3.0e38);
+        }
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) { wit[i] = T(0); cg.sgn[i] = T(0); }
+        DPLL_UNROLL for (int u = 0; u < kMaxPolyVerts; ++u) {
+          int rank = 0;
+          DPLL_UNROLL for (int o2 = 0; o2 < kMaxPolyVerts; ++o2)
+            rank += (o2 != u && (o2 < u ? dots[o2] >= dots[u] : dots[o2] > dots[u])) ? 1 : 0;  // ties: lower index first
+          const bool mine = (rank == slot);
+          cg.vidx = mine ? u : cg.vidx;
+          DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = mine ? vert[u][i] : wit[i];
+        }
       }
     }
   }
@@ -1137,30 +1168,36 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
 //   g_mu[b]        d/d (pair friction) -- this lane's contacts only (sum over lanes = item total)
 //   g_len[b][3]    d/d |length_params| -- this lane's contacts only
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NJ, int NG = NJ + 1> struct LossGrad {
+// GP = numbers per geometry in g_len: 3 (a box's |length_params|; a sphere uses [0]) or, in the general build, the
+// geometry block stride 3 kMaxPolyVerts (a polygon's vertices)
+template <typename T, int NJ, int NG = NJ + 1, int GP = 3> struct LossGrad {
   static constexpr int NB = NJ + 1;
   T g_iota[NB][kIota];
   T g_mu[NG];
-  T g_len[NG][3];
+  T g_len[NG][GP];
 };
 
-template <typename T, int NJ, int NG> DPLL_HD void zero_grad(LossGrad<T, NJ, NG>& g) {
+template <typename T, int NJ, int NG, int GP> DPLL_HD void zero_grad(LossGrad<T, NJ, NG, GP>& g) {
   DPLL_UNROLL for (int b = 0; b <= NJ; ++b)
     DPLL_UNROLL for (int i = 0; i < kIota; ++i) g.g_iota[b][i] = T(0);
   DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) {
     g.g_mu[gg] = T(0);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) g.g_len[gg][i] = T(0);
+    DPLL_UNROLL for (int i = 0; i < GP; ++i) g.g_len[gg][i] = T(0);
   }
 }
 
 // this contact's share of d/d(mu_pair, geometry lengths): gmu and the witness adjoint r_bar
-template <typename T, int NJ, int NG>
-DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ>& cg, T gmu, const T (&rbar)[3], LossGrad<T, NJ, NG>& grad) {
+template <typename T, int NJ, int NG, int GP>
+DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ>& cg, T gmu, const T (&rbar)[3], LossGrad<T, NJ, NG, GP>& grad) {
   const T grad_r = cg.drad[0] * rbar[0] + cg.drad[1] * rbar[1] + cg.drad[2] * rbar[2];
   DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) {
     const bool mine = (cg.geom == gg);
     grad.g_mu[gg] += mine ? gmu : T(0);
     DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][i] += mine ? cg.sgn[i] * rbar[i] + (i == 0 ? grad_r : T(0)) : T(0);
+    if constexpr (GP >= 3 * kMaxPolyVerts) {  // (a polygon has sgn = drad = 0: the line above adds nothing for it)
+      DPLL_UNROLL for (int u = 0; u < kMaxPolyVerts; ++u)
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][3 * u + i] += (mine && cg.vidx == u) ? rbar[i] : T(0);
+    }
   }
 }
 
@@ -1168,9 +1205,9 @@ constexpr double kLossEps = 1e-3;       // multibody_learnable_system.py:130
 constexpr double kDynamicsEps = 1e-4;   // multibody_learnable_system.py:283, 298
 constexpr double kInvalidForce = 1e3;   // multibody_learnable_system.py:187
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD, int GP>
 DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x, const T* xp,
-                    int first_contact, T weight, bool want_grad, LossGrad<T, NJ, NG>& grad, T (&force)[KPL][3],
+                    int first_contact, T weight, bool want_grad, LossGrad<T, NJ, NG, GP>& grad, T (&force)[KPL][3],
                     int& iters, const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kLossEps);
@@ -1386,9 +1423,9 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
                                 const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3] = nullptr);
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
+template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD, int GP>
 DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x,
-                                int first_contact, const T* xbar_next, LossGrad<T, NJ, NG>& grad,
+                                int first_contact, const T* xbar_next, LossGrad<T, NJ, NG, GP>& grad,
                                 const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr,
                                 T (*xbar)[13 + 2 * NJ] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
@@ -1548,6 +1585,14 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
   DPLL_UNROLL for (int g = 0; g < NG; ++g) {
     dps.mu[g] = S(TA(dp.mu[g]));
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dps.habs[g][i] = S(TA(dp.habs[g][i]));
+  }
+  dps.geo = nullptr;
+  S geo_s[MD::kGeneral ? NG * MD::kGeoStride : 1];  // a polygon's vertices as constants of the dual passes
+  if constexpr (MD::kGeneral) {
+    if (dp.geo) {
+      DPLL_UNROLL for (int i = 0; i < NG * MD::kGeoStride; ++i) geo_s[i] = S(TA(dp.geo[i]));
+      dps.geo = geo_s;
+    }
   }
   const S dt = S(TA(md.dt)), idt = S(TA(1) / TA(md.dt)), mieps = S(TA(-1) / TA(kDynamicsEps));
   for (int k = 0; k < NX; ++k) {  // deliberately not unrolled: one copy of the dual forward pass

@@ -1,5 +1,5 @@
 // dpll_general.hip -- the GENERAL build of the contact-dynamics kernels: any floating-base tree of up to kMaxJoints
-// revolute joints with up to kMaxGeoms box / sphere collision geometries on any of its bodies, against the ground.
+// revolute joints with up to kMaxGeoms box / sphere / polygon collision geometries on any of its bodies, against the ground.
 //
 // What the reference handles generically in Python -- MultibodyTerms for any number of bodies and geometries
 // (multibody_terms.py:328-382, 428-521), the state space inferred from the tree (drake_utils.py:309-335), Sphere next
@@ -21,7 +21,9 @@ namespace {
 using namespace dpll;
 
 constexpr int kNG = kMaxGeoms;
-template <typename T, int NJ> using GD = Dims<T, NJ, kNG>;
+constexpr int kGP = GeneralDesc::kGeoStride;  // numbers per geometry parameter block
+template <typename T, int NJ> using GD = Dims<T, NJ, kNG, kGP>;
+template <typename T, int NJ> using GenGrad = LossGrad<T, NJ, kNG, kGP>;
 using Lanes1 = GpuLanes<1>;
 
 template <typename T, int NJ>
@@ -36,12 +38,12 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
     if (want_grad)
-      write_chain_matrix<T, T, D::NB, kNG>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+      write_chain_matrix<T, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, md.geom_kind);
     return;
   }
   Derived<T, NJ, kNG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  LossGrad<T, NJ, kNG> acc;
+  GenGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
   const long long stride = (long long)item_blocks * kWave;
@@ -72,28 +74,28 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
     loss_acc += double(w) * double(L);
   }
   if (!want_grad) return;
-  store_iota_row<T, NJ, 1, kNG>(acc, loss_acc, partials);
+  store_iota_row<T, NJ, 1, kNG, kGP>(acc, loss_acc, partials);
 }
 
-// fixed-order sum of the partial rows + the chain to the parameters; 4 row groups x 64 columns
+// fixed-order sum of the partial rows + the chain to the parameters; 2 row groups x 128 columns
 template <typename T, int NJ>
 __global__ __launch_bounds__(256) void gen_finalize_kernel(const double* __restrict__ partials, int n_rows, T* __restrict__ grad,
                                                            T* __restrict__ loss_total) {
   using D = GD<T, NJ>;
-  static_assert(D::PI <= 64, "row must fit 64 columns");
-  __shared__ double red[4][64];
-  __shared__ double tot[64];
-  const int col = threadIdx.x & 63, rowg = threadIdx.x >> 6;
+  static_assert(D::PI <= 128, "row must fit 128 columns");
+  __shared__ double red[2][128];
+  __shared__ double tot[128];
+  const int col = threadIdx.x & 127, rowg = threadIdx.x >> 7;
   double s = 0.0;
   if (col < D::PIOTA)
-    for (int r = rowg; r < n_rows; r += 4) s += partials[(long long)r * D::PI + col];
+    for (int r = rowg; r < n_rows; r += 2) s += partials[(long long)r * D::PI + col];
   red[rowg][col] = s;
   __syncthreads();
-  if (threadIdx.x < 64) tot[col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+  if (threadIdx.x < 128) tot[col] = red[0][col] + red[1][col];
   __syncthreads();
   if (threadIdx.x < D::PI) {
     const int k = (int)threadIdx.x - 1;
-    const double v = k < 0 ? tot[0] : apply_chain<D::NB, kNG>(tot, partials + (long long)n_rows * D::PI, k);
+    const double v = k < 0 ? tot[0] : apply_chain<D::NB, kNG, kGP>(tot, partials + (long long)n_rows * D::PI, k);
     if (k < 0) {
       if (loss_total) *loss_total = T(v);
     } else {
@@ -159,19 +161,19 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
   const int lane = threadIdx.x;
   const int item_blocks = (int)gridDim.x - 1;
   if ((int)blockIdx.x == item_blocks) {
-    write_chain_matrix<C, T, D::NB, kNG>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    write_chain_matrix<C, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, md.geom_kind);
     return;
   }
-  C theta_c[D::NB * 10], friction_c[kNG + 1], lengths_c[kNG * 3];
+  C theta_c[D::NB * 10], friction_c[kNG + 1], lengths_c[kNG * kGP];
 #pragma unroll
   for (int i = 0; i < D::NB * 10; ++i) theta_c[i] = C(theta[i]);
 #pragma unroll
   for (int i = 0; i < kNG + 1; ++i) friction_c[i] = C(friction[i]);
 #pragma unroll
-  for (int i = 0; i < kNG * 3; ++i) lengths_c[i] = C(lengths[i]);
+  for (int i = 0; i < kNG * kGP; ++i) lengths_c[i] = C(lengths[i]);
   Derived<C, NJ, kNG> dp;
   derive_params<C, NJ>(md, theta_c, friction_c, lengths_c, dp);
-  LossGrad<C, NJ, kNG> acc;
+  GenGrad<C, NJ> acc;
   zero_grad(acc);
   const long long stride = (long long)item_blocks * kWave;
   for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
     C xr[D::NX], gr[D::NX], xb[D::NX];
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = C(x[it * ld_x + i]); gr[i] = valid ? C(gx[it * ld_g + i]) : C(0); xb[i] = C(0); }
-    LossGrad<C, NJ, kNG> g;
+    GenGrad<C, NJ> g;
     zero_grad(g);
     step_item_backward<C, C, NJ, D::K, Lanes1>(md, dp, opt, xr, 0, gr, g, nullptr, nullptr, &xb);
     if (xbar_out && valid) {
@@ -196,10 +198,10 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
     for (int gg = 0; gg < kNG; ++gg) {
       acc.g_mu[gg] += g.g_mu[gg];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) acc.g_len[gg][i] += g.g_len[gg][i];
+      for (int i = 0; i < kGP; ++i) acc.g_len[gg][i] += g.g_len[gg][i];
     }
   }
-  store_iota_row<C, NJ, 1, kNG>(acc, 0.0, partials);
+  store_iota_row<C, NJ, 1, kNG, kGP>(acc, 0.0, partials);
 }
 
 // MultibodyTerms.forward (multibody_terms.py:584-609) over all kMaxGeoms x 4 contact slots; the host keeps the real ones
@@ -350,11 +352,11 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
 
 namespace dpll_general {
 
-int param_count(const dpll_model* m) { return 10 * (m->desc.n_joints + 1) + (kNG + 1) + 3 * kNG; }
+int param_count(const dpll_model* m) { return 10 * (m->desc.n_joints + 1) + (kNG + 1) + kGP * kNG; }
 
 long long workspace_bytes(const dpll_model* m, long long batch) {
   const long long nb = m->desc.n_joints + 1;
-  const long long pi = 1 + 10 * nb + (kNG + 1) + 3 * kNG, chain = 100 * nb + (kNG + 1) * kNG + 3 * kNG;
+  const long long pi = 1 + 10 * nb + (kNG + 1) + kGP * kNG, chain = 100 * nb + (kNG + 1) * kNG + kGP * kNG;
   return ((long long)row_blocks(batch) * pi + chain) * (long long)sizeof(double);
 }
 

@@ -47,9 +47,19 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
   __builtin_amdgcn_sched_barrier(0);
   return t_;
 }
-#define DPLL_PHASE_BEGIN() unsigned long long ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = dpll_clock_()
-#define DPLL_PHASE(slot) do { const unsigned long long t_ = dpll_clock_(); ph_acc_[slot] += t_ - ph_last_; ph_last_ = t_; } while (0)
+#define DPLL_PHASE_BEGIN() unsigned long long ph_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_dur_ = 0; unsigned long long ph_last_ = dpll_clock_()
+#define DPLL_PHASE(slot) do { const unsigned long long t_ = dpll_clock_(); ph_dur_ = t_ - ph_last_; ph_acc_[slot] += ph_dur_; ph_last_ = t_; } while (0)
 #define DPLL_PHASE_COUNT(slot) do { ph_acc_[slot] += 1; } while (0)
+// one fallback-search event of this wave: slot 7 = count | duration of the first event << 8 | shortest event << 32
+#define DPLL_PHASE_EVENT(slot, happened)                                                                   \
+  do {                                                                                                     \
+    if (happened) {                                                                                        \
+      const unsigned long long d_ = ph_dur_ & 0xffffffull, n_ = ph_acc_[7] & 0xffull;                      \
+      const unsigned long long f_ = n_ ? ((ph_acc_[7] >> 8) & 0xffffffull) : d_;                           \
+      const unsigned long long m0_ = (ph_acc_[7] >> 32) & 0xffffffull, m_ = (n_ && m0_ < d_) ? m0_ : d_;   \
+      ph_acc_[7] = (n_ + 1) | (f_ << 8) | (m_ << 32);                                                      \
+    }                                                                                                      \
+  } while (0)
 #define DPLL_PHASE_END()                                                                                   \
   do {                                                                                                     \
     if (threadIdx.x == 0 && blockIdx.x < 1024)                                                             \
@@ -1076,7 +1086,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 9; }
+int dpll_abi_version(void) { return 10; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1089,7 +1099,11 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       if (desc->parent[j] < 0 || desc->parent[j] > j) return fail(-1, "dpll_model_create: parent[j] must be a body listed before body j + 1%s");
     for (int g = 0; g < desc->n_geoms; ++g) {
       if (desc->geom_body[g] < 0 || desc->geom_body[g] > desc->n_joints) return fail(-1, "dpll_model_create: geom_body out of range%s");
-      if (desc->geom_kind[g] != DPLL_GEOM_BOX && desc->geom_kind[g] != DPLL_GEOM_SPHERE) return fail(-1, "dpll_model_create: unknown geometry kind%s");
+      if (desc->geom_kind[g] != DPLL_GEOM_BOX && desc->geom_kind[g] != DPLL_GEOM_SPHERE && desc->geom_kind[g] != DPLL_GEOM_POLYGON)
+        return fail(-1, "dpll_model_create: unknown geometry kind%s");
+      // (top-4 of the vertex set, geometry.py:196: fewer than 4 vertices cannot answer a support query)
+      if (desc->geom_kind[g] == DPLL_GEOM_POLYGON && (desc->geom_nverts[g] < 4 || desc->geom_nverts[g] > DPLL_MAX_POLYGON_VERTICES))
+        return fail(-2, "dpll_model_create: a polygon has 4 to 8 vertices%s");
     }
   }
   if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");

@@ -5,8 +5,8 @@ The reference obtains the same facts from Drake's parser and symbolic plant
 mass / centre of mass / central inertia, the joint tree, collision geometry with
 ``drake:mu_static``, and a ground half-space with friction 1.0 added to every plant
 (``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to two revolute
-joints with up to three box / sphere collision geometries on any of its bodies (or one mesh on a
-single body), all of it touching only the ground (the elbow's links are collision filtered,
+joints with up to three box / sphere / polygon collision geometries on any of its bodies (or a learned mesh on every
+body of a cube / elbow), all of it touching only the ground (the elbow's links are collision filtered,
 ``assets/contactnets_elbow.urdf``).  The cube and elbow systems of the reference's ContactNets example
 -- a serial chain with exactly one box per body -- run on builds specialised for them
 (:meth:`ModelSpec.is_fast`).
@@ -23,11 +23,12 @@ GROUND_MU = 1.0  # dair_pll/drake_utils.py:280-288
 GRAVITY_Z = -9.81  # Drake's default UniformGravityField
 MAX_JOINTS = 2  # dpll_core.hpp kMaxJoints
 MAX_GEOMS = 3  # dpll_core.hpp kMaxGeoms
+MAX_POLYGON_VERTICES = 8  # dpll_core.hpp kMaxPolyVerts
 
 
 @dataclass
 class GeomSpec:
-    kind: str  # 'box' | 'sphere' | 'mesh'
+    kind: str  # 'box' | 'sphere' | 'mesh' (DeepSupportConvex) | 'polygon' (the mesh's vertex set, geometry.py:220-252)
     origin: List[float]
     mu: float
     half_lengths: Optional[List[float]] = None
@@ -73,7 +74,7 @@ class ModelSpec:
 
     @property
     def n_contacts(self) -> int:
-        """witness points per geometry: 4 for a box / mesh (geometry.py:47-48, 490), 1 for a sphere (:440-452)"""
+        """witness points per geometry: 4 for a box / mesh / polygon (geometry.py:47-51, 490), 1 for a sphere (:440-452)"""
         return sum(1 if geom.kind == 'sphere' else 4 for _, geom in self.geoms())
 
     def contact_slots(self) -> List[int]:
@@ -119,7 +120,13 @@ def _obj_vertices(path: str) -> List[List[float]]:
     return out
 
 
-def parse_urdf(path: str) -> ModelSpec:
+def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpec:
+    """``mesh_representation``: what a ``<mesh>`` collision element becomes -- ``'deep_support'``, the reference's
+    choice (``PydrakeToCollisionGeometryFactory.convert_mesh``, geometry.py:497-504: a ``DeepSupportConvex`` initialised from
+    the OBJ's bounding box), or ``'polygon'``: a ``Polygon`` over the OBJ's vertices (geometry.py:220-252; the reference
+    has the class but no front end builds one)."""
+    if mesh_representation not in ('deep_support', 'polygon'):
+        raise ValueError("mesh_representation must be 'deep_support' or 'polygon'")
     root = ET.parse(path).getroot()
     by_name = {}
     order = []
@@ -153,7 +160,8 @@ def parse_urdf(path: str) -> ModelSpec:
             elif geometry.find('mesh') is not None:
                 filename = geometry.find('mesh').get('filename')
                 mesh_path = os.path.join(os.path.dirname(os.path.abspath(path)), filename)
-                body.geoms.append(GeomSpec('mesh', xyz, mu, mesh_file=filename, vertices=_obj_vertices(mesh_path)))
+                kind = 'mesh' if mesh_representation == 'deep_support' else 'polygon'
+                body.geoms.append(GeomSpec(kind, xyz, mu, mesh_file=filename, vertices=_obj_vertices(mesh_path)))
             else:
                 raise NotImplementedError('only <box>, <sphere> and <mesh> collision geometry is supported')
         by_name[body.name] = body
@@ -197,6 +205,9 @@ def check_supported(spec: ModelSpec) -> None:
     for index, body in enumerate(spec.bodies):
         if index > 0 and not 0 <= body.parent < index:
             raise NotImplementedError('links must be listed after their parent')
+    for _, geom in geoms:
+        if geom.kind == 'polygon' and not 4 <= len(geom.vertices) <= MAX_POLYGON_VERTICES:
+            raise NotImplementedError(f'a polygon has 4 to {MAX_POLYGON_VERTICES} vertices (support queries return 4 of them)')
     if any(geom.kind == 'mesh' for _, geom in geoms):
         if not (spec.is_fast() and all(geom.kind == 'mesh' for _, geom in geoms)):
             raise NotImplementedError('mesh (DeepSupportConvex) geometry: a serial chain of at most one joint with exactly '

@@ -41,12 +41,16 @@ extern "C" {
 
 enum dpll_dtype { DPLL_F32 = 0, DPLL_F64 = 1 };
 enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1 };
-enum dpll_geom_kind { DPLL_GEOM_BOX = 0, DPLL_GEOM_SPHERE = 1 };
+#define DPLL_MAX_POLYGON_VERTICES 8
+#define DPLL_GEOM_BLOCK (3 * DPLL_MAX_POLYGON_VERTICES) /* numbers per geometry in the general build's `lengths` block */
+
+enum dpll_geom_kind { DPLL_GEOM_BOX = 0, DPLL_GEOM_SPHERE = 1, DPLL_GEOM_POLYGON = 2 };
 
 /* One floating-base tree of revolute joints with convex collision geometries against the ground half-space at z = 0:
  * what Drake extracts from the URDF for MultibodyTerms (multibody_terms.py:328-382, drake_utils.py:248-335).
  * n_geoms = 0 selects the two fast builds (a serial chain with one box per body, geometry g on body g: the cube and
- * elbow systems); n_geoms > 0 the general build: any parent tree, 1..DPLL_MAX_GEOMS boxes / spheres on any bodies. */
+ * elbow systems); n_geoms > 0 the general build: any parent tree, 1..DPLL_MAX_GEOMS boxes / spheres / polygons (vertex
+ * sets, geometry.py:220-252) on any bodies. */
 typedef struct dpll_model_desc {
   int32_t n_joints;
   int32_t inertia_mode;
@@ -59,7 +63,7 @@ typedef struct dpll_model_desc {
   int32_t n_geoms;                         /* 0: fast builds */
   int32_t geom_body[DPLL_MAX_GEOMS];
   int32_t geom_kind[DPLL_MAX_GEOMS];       /* dpll_geom_kind */
-  int32_t reserved;
+  int32_t geom_nverts[DPLL_MAX_GEOMS];     /* DPLL_GEOM_POLYGON: vertices, 4 .. DPLL_MAX_POLYGON_VERTICES */
 } dpll_model_desc_t;
 
 typedef struct dpll_solver_opts {
@@ -86,8 +90,10 @@ typedef struct dpll_model dpll_model_t;
 /* Learnable parameters of one call: device pointers, caller owned, never written. */
 typedef struct dpll_params {
   const void* theta;    /* (n_bodies, 10) */
-  const void* friction; /* (1 + n_bodies,) */
-  const void* lengths;  /* (n_bodies, 3) */
+  const void* friction; /* fast builds (1 + n_bodies,); general build (1 + DPLL_MAX_GEOMS,), unused entries any non-zero number */
+  const void* lengths;  /* fast builds (n_bodies, 3): length_params of the boxes.  General build (DPLL_MAX_GEOMS, DPLL_GEOM_BLOCK),
+                           geometry g's block: box length_params (3) | sphere length_param (1) | polygon vertices
+                           (geom_nverts, 3) row-major; the rest of a block is padding (its gradient comes back zero) */
 } dpll_params_t;
 
 const char* dpll_last_error(void);
@@ -101,7 +107,8 @@ int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts
 
 int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
 int dpll_n_contacts(const dpll_model_t* model);   /* 4 n_bodies */
-int dpll_param_count(const dpll_model_t* model);  /* 10 n_b + (1 + n_b) + 3 n_b: layout [theta | friction | lengths] */
+int dpll_param_count(const dpll_model_t* model);  /* layout [theta | friction | lengths] as in dpll_params_t: fast builds
+                                                     10 n_b + (1 + n_b) + 3 n_b, general build 10 n_b + 4 + 3 DPLL_GEOM_BLOCK */
 
 /* bytes of scratch dpll_contactnets_loss needs for a batch of `batch` items (gradient partial sums) */
 int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch);

@@ -72,12 +72,13 @@ def _load_obj_vertices(path: str) -> List[List[float]]:
     return verts
 
 
-def parse_urdf(path: str) -> Dict:
+def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     """Parses one floating-base serial chain with revolute joints and box / mesh collision
     geometry.  Mirrors what the reference obtains from Drake: bodies with (m, com, I_cm)
     (multibody_terms.py:161-207), one joint per non-root link, collision boxes
     (geometry.py:486-490) or meshes (geometry.py:499-504), mu_static per geometry
-    (drake_utils.py:192-197)."""
+    (drake_utils.py:192-197).  mesh_representation='polygon': a mesh element becomes a Polygon over
+    the OBJ's vertices (geometry.py:220-252) instead of a DeepSupportConvex."""
     root = ET.parse(path).getroot()
     links = {}
     order = []
@@ -116,7 +117,8 @@ def parse_urdf(path: str) -> Dict:
             elif geometry.find('mesh') is not None:
                 filename = geometry.find('mesh').get('filename')
                 mesh_path = os.path.join(os.path.dirname(os.path.abspath(path)), filename)
-                geom.update(kind='mesh', file=filename, vertices=_load_obj_vertices(mesh_path))
+                geom.update(kind='mesh' if mesh_representation == 'deep_support' else 'polygon', file=filename,
+                            vertices=_load_obj_vertices(mesh_path))
             else:
                 raise TypeError('unsupported collision geometry')
             body['geoms'].append(geom)
@@ -716,8 +718,9 @@ class OracleSystem:
     weights for meshes."""
 
     def __init__(self, urdf: str, dt: float, inertia_mode: str = 'reference_literal',
-                 dtype=torch.float64, mesh_seed: int = 0, mesh_params: Optional[Dict] = None):
-        self.spec = parse_urdf(urdf)
+                 dtype=torch.float64, mesh_seed: int = 0, mesh_params: Optional[Dict] = None,
+                 mesh_representation: str = 'deep_support'):
+        self.spec = parse_urdf(urdf, mesh_representation)
         self.dt = dt
         self.dtype = dtype
         self.inertia_mode = inertia_mode
@@ -741,6 +744,8 @@ class OracleSystem:
                 self.geom_params.append({'length_params': torch.tensor([geom['half']], dtype=dtype)})
             elif geom['kind'] == 'sphere':
                 self.geom_params.append({'length_param': torch.tensor(geom['radius'], dtype=dtype)})
+            elif geom['kind'] == 'polygon':
+                self.geom_params.append({'vertices': torch.tensor(geom['vertices'], dtype=dtype)})
             else:
                 if mesh_params is not None and index in mesh_params:
                     self.geom_params.append({k: v.to(dtype) for k, v in mesh_params[index].items()})
@@ -759,7 +764,7 @@ class OracleSystem:
                 if key == 'perturbations':
                     continue
                 prefix = f'multibody_terms.contact_terms.geometries.{index}.'
-                out[prefix + (key if key in ('length_params', 'length_param') else 'network.' + key)] = value
+                out[prefix + (key if key in ('length_params', 'length_param', 'vertices') else 'network.' + key)] = value
         return out
 
     def requires_grad_(self, flag: bool = True) -> 'OracleSystem':
@@ -790,6 +795,8 @@ class OracleSystem:
             return topk_support(directions, box_vertices(params['length_params']))
         if 'length_param' in params:  # Sphere.support_points, reference geometry.py:440-452: ONE witness point
             return (directions * torch.abs(params['length_param'])).unsqueeze(-2)
+        if 'vertices' in params:  # Polygon.get_vertices (:241-243): the static vertex set, signed parameters
+            return topk_support(directions, params['vertices'])
         weights = {k: v for k, v in params.items() if k != 'perturbations'}
         return mesh_support(weights, params['perturbations'], directions)
 

@@ -45,7 +45,7 @@ from dair_pll import state_space  # noqa: E402
 from dair_pll.data_config import TrajectorySliceConfig  # noqa: E402
 from dair_pll.dataset_management import TrajectorySliceDataset  # noqa: E402
 from dair_pll.drake_experiment import DrakeMultibodyLearnableExperiment  # noqa: E402
-from dair_pll.geometry import Box, DeepSupportConvex, Plane, Sphere  # noqa: E402
+from dair_pll.geometry import Box, DeepSupportConvex, Plane, Polygon, Sphere  # noqa: E402
 from dair_pll.inertia import InertialParameterConverter  # noqa: E402
 from dair_pll.integrator import VelocityIntegrator  # noqa: E402
 from dair_pll.multibody_learnable_system import MultibodyLearnableSystem  # noqa: E402
@@ -71,9 +71,9 @@ class RecordingSolver:
         return f
 
 
-def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0):
+def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0, mesh_representation: str = 'deep_support'):
     """The reference's MultibodyLearnableSystem with Drake-dependent construction bypassed."""
-    spec = O.parse_urdf(urdf)
+    spec = O.parse_urdf(urdf, mesh_representation)
     geoms = O.geometry_table(spec)
     n_joints = spec['n_joints']
 
@@ -103,6 +103,8 @@ def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0):
             nn.Module.__init__(sphere)
             sphere.length_param = Parameter(torch.tensor(geom['radius']), requires_grad=True)
             modules.append(sphere)
+        elif geom['kind'] == 'polygon':
+            modules.append(Polygon(torch.tensor(geom['vertices'])))  # geometry.py:220-252, n_query = 4
         else:
             # one seed per network: mesh_seed for the first (the cube), mesh_seed + 1 for the elbow's second link, ...
             torch.manual_seed(mesh_seed + sum(isinstance(m, DeepSupportConvex) for m in modules))
@@ -142,8 +144,10 @@ def named_values(system) -> dict:
 
 
 def record_case(name: str, urdf: str, x: torch.Tensor, x_plus: torch.Tensor, inertia_mode: str,
-                sim_steps: int = 4, sim_rows=None) -> None:
-    system, _ = build_reference_system(urdf, inertia_mode)
+                sim_steps: int = 4, sim_rows=None, mesh_representation: str = 'deep_support', prepare=None) -> None:
+    system, _ = build_reference_system(urdf, inertia_mode, mesh_representation=mesh_representation)
+    if prepare is not None:  # e.g. move the parameters off their URDF values before anything is recorded
+        prepare(system)
     out = {'urdf': os.path.basename(urdf), 'dt': DT, 'inertia_mode': inertia_mode,
            'x': x.numpy(), 'x_plus': x_plus.numpy()}
     for key, value in named_values(system).items():
@@ -351,29 +355,56 @@ def record_dynamics_gradients(name: str = 'dynamics_gradients') -> None:
     np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
 
 
+def general_tosses(urdf: str, n_traj: int, steps: int, keep_every: int, seed: int, mesh_representation: str = 'deep_support',
+                   prepare=None):
+    """(x, x_plus) pairs of seeded tosses (random attitude, 5-12 cm above the ground, spinning) rolled out by the
+    reference's simulate on the stub-built system, every `keep_every`-th pair kept."""
+    system, spec = build_reference_system(urdf, 'reference_literal', mesh_representation=mesh_representation)
+    if prepare is not None:
+        prepare(system)
+    n_j = spec['n_joints']
+    gen = torch.Generator().manual_seed(seed)
+    quat = torch.randn((n_traj, 4), generator=gen)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    pos = torch.cat((0.05 * torch.randn((n_traj, 2), generator=gen), 0.05 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
+    joints = 1.5 * torch.randn((n_traj, n_j), generator=gen)
+    vel = torch.cat((4.0 * torch.randn((n_traj, 3), generator=gen), 0.4 * torch.randn((n_traj, 3), generator=gen),
+                     3.0 * torch.randn((n_traj, n_j), generator=gen)), -1)
+    x_0 = torch.cat((quat, pos, joints, vel), -1)
+    with torch.no_grad():
+        traj, _ = system.simulate(x_0.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
+    x = traj[:, :-1][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+    x_plus = traj[:, 1:][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+    return x, x_plus
+
+
 def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
     """models beyond the cube / elbow topologies -- three-link serial chain, branching tree, several
     geometries on one body, spheres (this repository's own URDFs under assets/) -- through the reference's own
     MultibodyTerms / contactnets_loss / forward_dynamics / simulate, exactly as `record_case` does for the reference's
-    assets.  Inputs: seeded tosses (random attitude, 5-12 cm above the ground, spinning) rolled out by the reference's
-    simulate on the stub-built system, every `keep_every`-th pair kept."""
+    assets.  Inputs: `general_tosses`."""
     for name in ('chain3', 'vee', 'ballcube', 'mace'):
         urdf = os.path.join(REPO, 'assets', name + '.urdf')
-        system, spec = build_reference_system(urdf, 'reference_literal')
-        n_j = spec['n_joints']
-        gen = torch.Generator().manual_seed(seed)
-        quat = torch.randn((n_traj, 4), generator=gen)
-        quat = quat / quat.norm(dim=-1, keepdim=True)
-        pos = torch.cat((0.05 * torch.randn((n_traj, 2), generator=gen), 0.05 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
-        joints = 1.5 * torch.randn((n_traj, n_j), generator=gen)
-        vel = torch.cat((4.0 * torch.randn((n_traj, 3), generator=gen), 0.4 * torch.randn((n_traj, 3), generator=gen),
-                         3.0 * torch.randn((n_traj, n_j), generator=gen)), -1)
-        x_0 = torch.cat((quat, pos, joints, vel), -1)
-        with torch.no_grad():
-            traj, _ = system.simulate(x_0.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
-        x = traj[:, :-1][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
-        x_plus = traj[:, 1:][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+        x, x_plus = general_tosses(urdf, n_traj, steps, keep_every, seed)
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3)
+
+
+def record_polygon_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+    """SURVEY 8f-4, Polygon (geometry.py:220-252: a learnable vertex set, support query = the 4 vertices furthest along
+    the direction) through the reference's own classes: the cube with its mesh read as the 8-vertex polygon (the
+    vertices moved off the symmetric corners by seeded millimetre noise, so no two are tied), and a 6-vertex wedge with
+    a hinged box flap."""
+    def jitter(system):
+        gen = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for geometry in system.multibody_terms.contact_terms.geometries:
+                if isinstance(geometry, Polygon):
+                    geometry.vertices.add_(0.003 * torch.randn(geometry.vertices.shape, generator=gen))
+    for name, urdf in (('polycube', os.path.join(ASSETS, 'contactnets_cube_mesh.urdf')),
+                       ('wedge', os.path.join(REPO, 'assets', 'wedge.urdf'))):
+        x, x_plus = general_tosses(urdf, n_traj, steps, keep_every, seed, 'polygon', jitter)
+        record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3, mesh_representation='polygon',
+                    prepare=jitter)
 
 
 def record_elbow_mesh() -> None:
@@ -401,6 +432,7 @@ def main() -> None:
     record_dynamics_gradients()
     record_general_cases()
     record_elbow_mesh()
+    record_polygon_cases()
 
 
 if __name__ == '__main__':

@@ -51,19 +51,31 @@ def n_geom_slots(desc: ModelDesc) -> int:
     return 3 if desc.n_geoms > 0 else desc.n_joints + 1
 
 
+def geo_stride(desc: ModelDesc) -> int:
+    """numbers per geometry in the `lengths` block: 3 (fast builds) or 24 (general build: room for a polygon's 8 vertices)"""
+    return 24 if desc.n_geoms > 0 else 3
+
+
 def general_params(spec):
-    """(theta, friction, lengths) at their URDF values in the kernels' layout: friction (1 + slots,), lengths (slots, 3)
-    with a sphere's radius in column 0; unused slots of the general build are padded (friction 1, lengths 0)."""
-    from dair_pll_amd._capi import make_desc
+    """(theta, friction, lengths) at their URDF values in the kernels' layout: friction (1 + slots,), lengths (slots, stride)
+    -- a box's half lengths, a sphere's radius in column 0, a polygon's vertices row-major; unused slots of the general build
+    are padded (friction 1, lengths 0)."""
     from dair_pll_amd.inertia import pi_cm_to_theta
-    slots = 3 if not spec.is_fast() else spec.n_joints + 1
+    fast = spec.is_fast()
+    slots, stride = (spec.n_joints + 1, 3) if fast else (3, 24)
     theta = np.stack([pi_cm_to_theta(np.array([b.mass] + [b.mass * c for c in b.com] + list(b.inertia_cm))) for b in spec.bodies])
     friction = np.ones(1 + slots)
-    lengths = np.zeros((slots, 3))
+    lengths = np.zeros((slots, stride))
     friction[0] = spec.ground_mu
     for g, (_, geom) in enumerate(spec.geoms()):
         friction[1 + g] = geom.mu
-        lengths[g] = geom.half_lengths if geom.kind == 'box' else [geom.radius, 0.0, 0.0]
+        if geom.kind == 'box':
+            lengths[g, :3] = geom.half_lengths
+        elif geom.kind == 'sphere':
+            lengths[g, 0] = geom.radius
+        else:
+            flat = np.asarray(geom.vertices, dtype=np.float64).reshape(-1)
+            lengths[g, :flat.size] = flat
     return theta, friction, lengths
 
 
@@ -80,11 +92,11 @@ def loss(desc: ModelDesc, theta, friction, lengths, x, x_plus, dtype=np.float64,
     k = 4 * n_g
     arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=dtype))
     theta, friction, lengths, x, x_plus = map(arr, (theta, friction, lengths, x, x_plus))
-    assert friction.size == 1 + n_g and lengths.size == 3 * n_g
+    assert friction.size == 1 + n_g and lengths.size == geo_stride(desc) * n_g
     batch = x.shape[0]
     scale = 1.0 / batch if scale is None else scale
     out_loss = np.zeros(batch, dtype=dtype)
-    grad = np.zeros(10 * n_b + 1 + 4 * n_g, dtype=np.float64) if want_grad else None
+    grad = np.zeros(10 * n_b + 1 + (1 + geo_stride(desc)) * n_g, dtype=np.float64) if want_grad else None
     force = np.zeros((batch, 3 * k), dtype=dtype)
     iters = np.zeros(batch, dtype=np.int32)
     weights = arr(weights) if weights is not None else None
@@ -141,7 +153,7 @@ def step_backward(desc: ModelDesc, theta, friction, lengths, x, xbar_next, opts=
     arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     theta, friction, lengths, x, xbar_next = map(arr, (theta, friction, lengths, x, xbar_next))
     n_b = desc.n_joints + 1
-    grad = np.zeros(10 * n_b + 1 + 4 * n_geom_slots(desc), dtype=np.float64)
+    grad = np.zeros(10 * n_b + 1 + (1 + geo_stride(desc)) * n_geom_slots(desc), dtype=np.float64)
     opts = opts or default_opts(np.float64)
     xbar = np.zeros_like(x) if want_state else None
     status = lib().hostsim_step_backward_f64(ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction),

@@ -24,9 +24,10 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
   constexpr int NB = NJ + 1, K = kQuery * NG, NX = 13 + 2 * NJ;
   Derived<T, NJ, NG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  double g_iota[NB][kIota] = {}, g_mu[NG] = {}, g_len[NG][3] = {};
+  constexpr int GP = MD::kGeoStride;
+  double g_iota[NB][kIota] = {}, g_mu[NG] = {}, g_len[NG][GP] = {};
   for (int64_t i = 0; i < B; ++i) {
-    LossGrad<T, NJ, NG> g;
+    LossGrad<T, NJ, NG, GP> g;
     zero_grad(g);
     T f[K][3];
     int it = 0;
@@ -47,18 +48,21 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
       for (int k = 0; k < kIota; ++k) g_iota[b][k] += double(g.g_iota[b][k]);
     for (int b = 0; b < NG; ++b) {
       g_mu[b] += double(g.g_mu[b]);
-      for (int k = 0; k < 3; ++k) g_len[b][k] += double(g.g_len[b][k]);
+      for (int k = 0; k < GP; ++k) g_len[b][k] += double(g.g_len[b][k]);
     }
   }
   if (!grad) return;
-  double th[NB * 10], fr[NG + 1], ln[NG * 3];
+  double th[NB * 10], fr[NG + 1], ln[NG * GP];
   for (int i = 0; i < NB * 10; ++i) th[i] = double(theta[i]);
   for (int i = 0; i < NG + 1; ++i) fr[i] = double(friction[i]);
-  for (int i = 0; i < NG * 3; ++i) ln[i] = double(lengths[i]);
+  for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
   for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k);
-  for (int k = 0; k < NG * 3; ++k) grad[NB * 10 + NG + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
+  for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
+    const bool polygon = MD::kGeneral && md.geom_kind[k / GP] == kGeomPolygon;
+    grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
+  }
 }
 
 template <typename T, typename TA, int NJ, int NG = NJ + 1, class MD = ModelDesc>
@@ -182,9 +186,10 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
   constexpr int NB = NJ + 1, K = kQuery * NG, NX = 13 + 2 * NJ;
   Derived<T, NJ, NG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  double g_iota[NB][kIota] = {}, g_mu[NG] = {}, g_len[NG][3] = {};
+  constexpr int GP = MD::kGeoStride;
+  double g_iota[NB][kIota] = {}, g_mu[NG] = {}, g_len[NG][GP] = {};
   for (int64_t i = 0; i < B; ++i) {
-    LossGrad<T, NJ, NG> g;
+    LossGrad<T, NJ, NG, GP> g;
     zero_grad(g);
     T xb[NX] = {};
     step_item_backward<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, xbar_next + i * NX, g, nullptr, nullptr,
@@ -194,17 +199,20 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
       for (int k = 0; k < kIota; ++k) g_iota[b][k] += double(g.g_iota[b][k]);
     for (int b = 0; b < NG; ++b) {
       g_mu[b] += double(g.g_mu[b]);
-      for (int k = 0; k < 3; ++k) g_len[b][k] += double(g.g_len[b][k]);
+      for (int k = 0; k < GP; ++k) g_len[b][k] += double(g.g_len[b][k]);
     }
   }
-  double th[NB * 10], fr[NG + 1], ln[NG * 3];
+  double th[NB * 10], fr[NG + 1], ln[NG * GP];
   for (int i = 0; i < NB * 10; ++i) th[i] = double(theta[i]);
   for (int i = 0; i < NG + 1; ++i) fr[i] = double(friction[i]);
-  for (int i = 0; i < NG * 3; ++i) ln[i] = double(lengths[i]);
+  for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
   for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k);
-  for (int k = 0; k < NG * 3; ++k) grad[NB * 10 + NG + 1 + k] = length_grad_component(ln, &g_len[0][0], k);
+  for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
+    const bool polygon = MD::kGeneral && md.geom_kind[k / GP] == kGeomPolygon;
+    grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
+  }
 }
 
 // general models (tree topology, geometry table): always three geometry slots, the unused ones masked

@@ -1,8 +1,10 @@
 """Models beyond the cube / elbow topologies: a three-link serial chain, a branching tree, several
-geometries on one body, spheres -- the GENERAL build (csrc/dpll_general.hip, GeneralDesc branches of csrc/dpll_core.hpp).
+geometries on one body, spheres, polygons (learnable vertex sets) -- the GENERAL build (csrc/dpll_general.hip,
+GeneralDesc branches of csrc/dpll_core.hpp).
 
-Fixtures `{chain3, vee, ballcube, mace}_literal.npz` were recorded by running the reference's own MultibodyTerms /
-contactnets_loss / forward_dynamics / simulate on these URDFs (oracle/gen_golden.py record_general_cases).  CPU tests:
+Fixtures `{chain3, vee, ballcube, mace, polycube, wedge}_literal.npz` were recorded by running the reference's own
+MultibodyTerms / contactnets_loss / forward_dynamics / simulate (and its Sphere / Polygon classes) on these URDFs
+(oracle/gen_golden.py record_general_cases, record_polygon_cases).  CPU tests:
 the oracle and the host build of the per-item math against them; GPU tests (`-m gpu`): the kernels through the C ABI."""
 import os
 
@@ -16,12 +18,26 @@ from dair_pll_amd._capi import make_desc
 from dair_pll_amd.urdf import parse_urdf
 from oracle import dpll_oracle as O
 
-MODELS = ['chain3', 'vee', 'ballcube', 'mace']
+MODELS = ['chain3', 'vee', 'ballcube', 'mace', 'polycube', 'wedge']
+# model -> (URDF under assets/, what a <mesh> element is read as)
+SOURCES = {'polycube': ('cube_mesh.urdf', 'polygon'), 'wedge': ('wedge.urdf', 'polygon')}
 P = 'multibody_terms.'
+STRIDE = 24  # numbers per geometry in the general build's lengths block (DPLL_GEOM_BLOCK)
+
+
+def source(name):
+    urdf, representation = SOURCES.get(name, (name + '.urdf', 'deep_support'))
+    return os.path.join(ASSET_DIR, urdf), representation
+
+
+def spec_of(name):
+    urdf, representation = source(name)
+    return parse_urdf(urdf, representation)
 
 
 def oracle_from(g, name) -> O.OracleSystem:
-    system = O.OracleSystem(os.path.join(ASSET_DIR, name + '.urdf'), float(g['dt']))
+    urdf, representation = source(name)
+    system = O.OracleSystem(urdf, float(g['dt']), mesh_representation=representation)
     system.theta = torch.tensor(g['param/' + P + 'lagrangian_terms.inertial_parameters'])
     system.friction = torch.tensor(g['param/' + P + 'contact_terms.friction_params'])
     for index, params in enumerate(system.geom_params):
@@ -31,17 +47,30 @@ def oracle_from(g, name) -> O.OracleSystem:
 
 
 def reference_gradient(g, spec):
-    """the reference run's gradients in the kernels' flat layout [theta | friction (1 + 3 slots) | lengths (3 slots, 3)]"""
+    """the reference run's gradients in the kernels' flat layout [theta | friction (1 + 3 slots) | lengths (3 slots, 24)]"""
     n_b = spec.n_joints + 1
-    out = np.zeros(10 * n_b + 4 + 9)
+    out = np.zeros(10 * n_b + 4 + 3 * STRIDE)
     out[:10 * n_b] = g['grad/' + P + 'lagrangian_terms.inertial_parameters'].ravel()
     friction = g['grad/' + P + 'contact_terms.friction_params']
     out[10 * n_b:10 * n_b + len(friction)] = friction
     for index, (_, geom) in enumerate(spec.geoms()):
-        key = 'length_params' if geom.kind == 'box' else 'length_param'
+        key = {'box': 'length_params', 'sphere': 'length_param', 'polygon': 'vertices'}[geom.kind]
         value = g['grad/' + P + f'contact_terms.geometries.{index + 1}.{key}'].ravel()
-        out[10 * n_b + 4 + 3 * index:10 * n_b + 4 + 3 * index + len(value)] = value
+        out[10 * n_b + 4 + STRIDE * index:10 * n_b + 4 + STRIDE * index + len(value)] = value
     return out
+
+
+def fixture_params(g, spec):
+    """(theta, friction, lengths) of the fixture in the kernels' layout (hostsim.general_params with the recorded values)"""
+    theta, friction, lengths = hostsim.general_params(spec)
+    theta = g['param/' + P + 'lagrangian_terms.inertial_parameters'].copy()
+    recorded = g['param/' + P + 'contact_terms.friction_params']
+    friction[:len(recorded)] = recorded
+    for index, (_, geom) in enumerate(spec.geoms()):
+        key = {'box': 'length_params', 'sphere': 'length_param', 'polygon': 'vertices'}[geom.kind]
+        value = g['param/' + P + f'contact_terms.geometries.{index + 1}.{key}'].ravel()
+        lengths[index, :len(value)] = value
+    return theta, friction, lengths
 
 
 def canonical(spec, phi, J=None, D=None):
@@ -67,7 +96,7 @@ def canonical(spec, phi, J=None, D=None):
 def test_oracle_reproduces_the_reference_run(golden, name):
     g = golden(name + '_literal')
     system = oracle_from(g, name).requires_grad_()
-    spec = parse_urdf(os.path.join(ASSET_DIR, name + '.urdf'))
+    spec = spec_of(name)
     x, xp = torch.tensor(g['x']), torch.tensor(g['x_plus'])
     loss = system.contactnets_loss(x, xp)
     assert (loss.detach() - torch.tensor(g['loss'])).abs().max() < 1e-12
@@ -91,9 +120,9 @@ def test_host_build_of_the_kernel_math(golden, name):
     """csrc/dpll_core.hpp compiled for the host with GeneralDesc (tree + geometry table branches): loss, every
     gradient, next state against the reference run; float32 with the double-accumulated residual within 1e-4."""
     g = golden(name + '_literal')
-    spec = parse_urdf(os.path.join(ASSET_DIR, name + '.urdf'))
+    spec = spec_of(name)
     desc = make_desc(spec, float(g['dt']))
-    theta, friction, lengths = hostsim.general_params(spec)
+    theta, friction, lengths = fixture_params(g, spec)
     out = hostsim.loss(desc, theta, friction, lengths, g['x'], g['x_plus'])
     assert np.abs(out['loss'] - g['loss']).max() < 1e-12
     ref = reference_gradient(g, spec)
@@ -109,7 +138,8 @@ def test_host_build_of_the_kernel_math(golden, name):
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 def gpu_system(g, name, dtype):
     from dair_pll_amd import MultibodyLearnableSystem
-    system = MultibodyLearnableSystem({name: os.path.join(ASSET_DIR, name + '.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+    urdf, representation = source(name)
+    system = MultibodyLearnableSystem({name: urdf}, float(g['dt']), dtype=dtype, device='cuda:0', mesh_representation=representation)
     system.load_state_dict({key: torch.tensor(g['param/' + key]) for key, _ in system.named_parameters()})
     return system
 

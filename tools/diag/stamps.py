@@ -44,3 +44,9 @@ w = order[-1]
 print('phase cycles, slowest wave (sum over its iterations):', dict(zip(pn, phases[w, :6])), 'per iteration:', dict(zip(pn, (phases[w, :6] / max(1, its[w])).round(0))))
 print('phase cycles, mean over waves per iteration:', dict(zip(pn, (phases[:, :6].sum(0) / max(1, its.sum())).round(0))))
 print('line-search probes per iteration: slowest wave', phases[w, 6] / max(1, its[w]), 'mean', phases[:, 6].sum() / max(1, its.sum()))
+ev = out[1024:1024 + NR, 7].astype(np.int64)
+n_ev, first, shortest = ev & 0xff, (ev >> 8) & 0xffffff, (ev >> 32) & 0xffffff
+has = n_ev > 0
+print('fallback events per wave: mean', n_ev.mean(), 'max', n_ev.max(), '| cycles of the first event: mean', first[has].mean().round(0),
+      '| shortest event of a wave (waves with >= 3 events): mean', shortest[n_ev >= 3].mean().round(0) if (n_ev >= 3).any() else None,
+      '| fallback cycles per event (all waves)', phases[:, 4].sum() / max(1, n_ev.sum()))
