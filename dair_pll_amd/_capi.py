@@ -14,10 +14,12 @@ from .urdf import ModelSpec, check_supported
 MAX_JOINTS = 2
 MAX_BODIES = 3
 MAX_GEOMS = 3
+MAX_PAIRS = 1
+GEN_SLOTS = MAX_GEOMS + MAX_PAIRS  # geometry slots of the general build (DPLL_GEN_SLOTS)
 GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 10  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 11  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +31,8 @@ class ModelDesc(ctypes.Structure):
     _fields_ = [('n_joints', c_int32), ('inertia_mode', c_int32), ('dt', c_double), ('gravity_z', c_double),
                 ('joint_origin', (c_double * 3) * MAX_JOINTS), ('joint_axis', (c_double * 3) * MAX_JOINTS),
                 ('geom_origin', (c_double * 3) * MAX_GEOMS), ('parent', c_int32 * MAX_JOINTS), ('n_geoms', c_int32),
-                ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('geom_nverts', c_int32 * MAX_GEOMS)]
+                ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('geom_nverts', c_int32 * MAX_GEOMS), ('n_pairs', c_int32),
+                ('pair_a', c_int32 * MAX_PAIRS), ('pair_b', c_int32 * MAX_PAIRS), ('reserved', c_int32)]
 
 
 class SolverOpts(ctypes.Structure):
@@ -74,6 +77,9 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
         for axis in range(3):
             desc.geom_origin[g][axis] = geom.origin[axis]
     desc.n_geoms = 0 if spec.is_fast() else len(geoms)
+    for p, (a, b) in enumerate(spec.pairs):
+        desc.pair_a[p], desc.pair_b[p] = a, b
+    desc.n_pairs = len(spec.pairs)
     return desc
 
 

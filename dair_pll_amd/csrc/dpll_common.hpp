@@ -110,12 +110,13 @@ template <typename S> __device__ __forceinline__ void theta_jacobian_column(int 
 #pragma unroll
   for (int i = 0; i < kIota; ++i) dio[i] = io[i].d;
 }
-// GP = numbers per geometry in the `lengths` block (3: a box; the general build: 3 kMaxPolyVerts); geom_kind (general build
-// only): a polygon's vertices are signed parameters (chain factor 1), lengths and radii enter through their absolute value
+// GP = numbers per geometry in the `lengths` block (3: a box; the general build: 3 kMaxPolyVerts); gd (general build
+// only): a polygon's vertices are signed parameters (chain factor 1), lengths and radii enter through their absolute value;
+// the slots behind the geometries hold the pair coefficient of a body-body candidate's two geometries
 template <typename T, typename P, int NB, int NG = NB, int GP = 3>
 __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __restrict__ theta, const P* __restrict__ friction,
                                                    const P* __restrict__ lengths, double* __restrict__ chain,
-                                                   const int32_t* geom_kind = nullptr) {
+                                                   const ModelDesc* gd = nullptr) {
   const int lane = threadIdx.x;
   if (lane < 10 * NB) {  // lane = (body, theta component c): column c of that body's Jacobian
     T th[10], dio[kIota];
@@ -129,19 +130,26 @@ __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __
   double* len_sign = fr_fac + (NG + 1) * NG;
   if (lane < (NG + 1) * NG) {  // lane = (friction entry k, geometry b): d (2 m0 mb / (m0 + mb)) / d friction_k, mu = |friction|
     const int k = lane / NG, b = lane % NG;
-    const double f0 = double(friction[0]), fb = double(friction[1 + b]);
-    const double m0 = fabs(f0), mb = fabs(fb);
+    // slot b combines friction entries ia and ib: the ground (0) with geometry b, or the two geometries of a pair
+    int ia = 0, ib = 1 + b;
+    if (gd && b >= kMaxGeoms) {
+      const int p = b - kMaxGeoms;
+      const bool on = p < gd->n_pairs;
+      ia = 1 + (on ? gd->pair_a[p < kMaxPairs ? p : 0] : 0);
+      ib = 1 + (on ? gd->pair_b[p < kMaxPairs ? p : 0] : 0);
+    }
+    const double m0 = fabs(double(friction[ia])), mb = fabs(double(friction[ib]));
     const double den = (m0 + mb) * (m0 + mb);
     const double pk = double(friction[k]);
     const double sign = pk > 0.0 ? 1.0 : (pk < 0.0 ? -1.0 : 0.0);
     double fac = 0.0;
-    if (k == 0) fac += 2.0 * mb * mb / den;
-    if (k == 1 + b) fac += 2.0 * m0 * m0 / den;
+    if (k == ia) fac += 2.0 * mb * mb / den;
+    if (k == ib) fac += 2.0 * m0 * m0 / den;
     fr_fac[lane] = fac * sign;
   }
   for (int e = lane; e < GP * NG; e += kWave) {
     const double pl = lengths ? double(lengths[e]) : 0.0;
-    const bool polygon = geom_kind && geom_kind[e / GP] == kGeomPolygon;
+    const bool polygon = gd && e / GP < kMaxGeoms && gd->geom_kind[e / GP] == kGeomPolygon;
     len_sign[e] = polygon ? 1.0 : (pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0));
   }
 }

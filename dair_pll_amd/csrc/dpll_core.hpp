@@ -62,6 +62,8 @@ constexpr int kMaxBodies = kMaxJoints + 1;
 constexpr int kMaxGeoms = 3;    // convex collision geometries of a model (each against the ground half-space)
 constexpr int kGeomBox = 0, kGeomSphere = 1, kGeomPolygon = 2;
 constexpr int kMaxPolyVerts = 8;  // vertices of a Polygon (geometry.py:220-252); the general build only
+constexpr int kMaxPairs = 1;      // body-body collision candidates (geometry.py:585-643); the general build only
+constexpr int kGenSlots = kMaxGeoms + kMaxPairs;  // geometry slots of the general build: a pair sits behind the geometries
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
 
@@ -82,6 +84,12 @@ struct ModelDesc {
   int32_t geom_body[kMaxGeoms];
   int32_t geom_kind[kMaxGeoms];        // kGeomBox | kGeomSphere | kGeomPolygon
   int32_t geom_nverts[kMaxGeoms];      // Polygon: number of vertices, 4 .. kMaxPolyVerts
+  // body-body collision candidates (ContactTerms.collision_candidates beyond the ground pairs, multibody_terms.py:286-297):
+  // geometry pair_a[p] against geometry pair_b[p], ordered as the reference orders a pair (geometry.py:46, 66-74)
+  int32_t n_pairs;
+  int32_t pair_a[kMaxPairs];
+  int32_t pair_b[kMaxPairs];
+  int32_t reserved;
   static constexpr bool kGeneral = false;
   static constexpr int kGeoStride = 3;  // numbers per geometry in the `lengths` parameter block: a box's length_params
 };
@@ -576,9 +584,14 @@ template <typename T> DPLL_HD void box_corner_signs(const T (&d)[3], const T (&h
 // j_i = a_i x (pt - o_i) for the joints between the base and body b (0 otherwise)
 // (multibody_terms.py:385-399 with tensor_utils.py:257-302, restated in closed form).  Only A and the joint
 // columns are stored: the identity block costs nothing.
-template <typename T, int NJ> struct CJac {
+// DENSE (the general build): all 3 x n_v entries -- a body-body contact is the difference of two point Jacobians rotated
+// into its contact frame (multibody_terms.py:497-513), which has no identity block.
+template <typename T, int NJ, bool DENSE = false> struct CJac {
   T A[3][3];
   T j[NJ > 0 ? NJ : 1][3];
+};
+template <typename T, int NJ> struct CJac<T, NJ, true> {
+  T m[3][6 + NJ];
 };
 
 template <typename T, int NJ>
@@ -614,6 +627,71 @@ template <typename T, int NJ> DPLL_HD void cjac_apply_t_add(const CJac<T, NJ>& J
     out[3 + c] += a[c];
   }
   DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) out[6 + jj] += J.j[jj][0] * a[0] + J.j[jj][1] * a[1] + J.j[jj][2] * a[2];
+}
+
+template <typename T, typename TY, int NJ> DPLL_HD void cjac_apply(const CJac<T, NJ, true>& J, const TY* y, TY (&out)[3]) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    TY s = TY(0);
+    DPLL_UNROLL for (int c = 0; c < 6 + NJ; ++c) s += TY(J.m[r][c]) * y[c];
+    out[r] = s;
+  }
+}
+template <typename T, int NJ> DPLL_HD void cjac_apply_t_add(const CJac<T, NJ, true>& J, const T (&a)[3], T* out) {
+  DPLL_UNROLL for (int c = 0; c < 6 + NJ; ++c) out[c] += J.m[0][c] * a[0] + J.m[1][c] * a[1] + J.m[2][c] * a[2];
+}
+// dense = sign * F [A | 1 | j] (+ what is there already when `add`); F rows = contact-frame axes in the world
+template <typename T, int NJ>
+DPLL_HD void cjac_dense(const CJac<T, NJ, false>& P, const T (&F)[3][3], T sign, bool add, CJac<T, NJ, true>& J) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+      const T a = sign * (F[r][0] * P.A[0][c] + F[r][1] * P.A[1][c] + F[r][2] * P.A[2][c]);
+      J.m[r][c] = add ? J.m[r][c] + a : a;
+      J.m[r][3 + c] = add ? J.m[r][3 + c] + sign * F[r][c] : sign * F[r][c];
+    }
+    DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) {
+      const T a = sign * (F[r][0] * P.j[jj][0] + F[r][1] * P.j[jj][1] + F[r][2] * P.j[jj][2]);
+      J.m[r][6 + jj] = add ? J.m[r][6 + jj] + a : a;
+    }
+  }
+}
+// column i of the Jacobian (the terms kernels write J out)
+template <typename T, int NJ> DPLL_HD void cjac_column(const CJac<T, NJ, false>& J, int i, T (&col)[3]) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    col[r] = i < 3 ? J.A[r][i] : (i < 6 ? (r == i - 3 ? T(1) : T(0)) : J.j[(i >= 6 && i - 6 < NJ) ? i - 6 : 0][r]);
+}
+template <typename T, int NJ> DPLL_HD void cjac_column(const CJac<T, NJ, true>& J, int i, T (&col)[3]) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) col[r] = J.m[r][i];
+}
+// H (lower triangle) += J^T C J for one contact, C symmetric 3 x 3
+template <typename T, int NJ>
+DPLL_HD void hessian_add(const CJac<T, NJ, false>& J, const T (&C)[3][3], T (&H)[6 + NJ][6 + NJ]) {
+  T CA[3][3];
+  mat3_mul(C, J.A, CA);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+    DPLL_UNROLL for (int j = 0; j <= i; ++j) {
+      H[i][j] += J.A[0][i] * CA[0][j] + J.A[1][i] * CA[1][j] + J.A[2][i] * CA[2][j];
+      H[3 + i][3 + j] += C[i][j];
+    }
+    DPLL_UNROLL for (int j = 0; j < 3; ++j) H[3 + i][j] += CA[i][j];
+  }
+  DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) {
+    T u[3];
+    mat3_vec(C, J.j[jj], u);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+      H[6 + jj][i] += J.A[0][i] * u[0] + J.A[1][i] * u[1] + J.A[2][i] * u[2];
+      H[6 + jj][3 + i] += u[i];
+    }
+    DPLL_UNROLL for (int kk = 0; kk <= jj; ++kk) H[6 + jj][6 + kk] += dot3(J.j[kk], u);
+  }
+}
+template <typename T, int NJ>
+DPLL_HD void hessian_add(const CJac<T, NJ, true>& J, const T (&C)[3][3], T (&H)[6 + NJ][6 + NJ]) {
+  constexpr int NV = 6 + NJ;
+  T CJ[3][NV];
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int c = 0; c < NV; ++c) CJ[r][c] = C[r][0] * J.m[0][c] + C[r][1] * J.m[1][c] + C[r][2] * J.m[2][c];
+  DPLL_UNROLL for (int i = 0; i < NV; ++i)
+    DPLL_UNROLL for (int j = 0; j <= i; ++j) H[i][j] += J.m[0][i] * CJ[0][j] + J.m[1][i] * CJ[1][j] + J.m[2][i] * CJ[2][j];
 }
 
 // world angular velocity of body b under generalized velocity y
@@ -741,14 +819,18 @@ template <typename T, int NV, int KPL> struct SapPoint {
   T zs[KPL][3];
   Proj<T> pr[KPL];  // pr.g = gs
   T yT[NV], My[NV];
-  T jtg[NV];        // sum_c J_c^T D_mu gs_c, summed over the lane group; [5] = sum of the normal components
+  T jtg[NV];        // sum_c J_c^T D_mu gs_c, summed over the lane group; [5] = sum of the normal components (identity block)
+  T nsum;           // sum of the normal components of gs (= jtg[5] when every Jacobian has the identity block)
 };
+template <class JT> struct JacIsDense { static constexpr bool value = false; };
+template <typename T, int NJ> struct JacIsDense<CJac<T, NJ, true>> { static constexpr bool value = true; };
 
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD void sap_evaluate(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL], const T (&mu)[KPL],
+template <typename T, typename TA, int NJ, int KPL, class Lanes, class JT>
+DPLL_HD void sap_evaluate(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const T (&mu)[KPL],
                           const T (&qc)[KPL][3], const TA (&y)[6 + NJ], SapPoint<T, 6 + NJ, KPL>& p) {
   constexpr int NV = 6 + NJ;
   DPLL_UNROLL for (int i = 0; i < NV; ++i) { p.yT[i] = T(y[i]); p.jtg[i] = T(0); }
+  T ns = T(0);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     TA jy[3];
     cjac_apply<T, TA, NJ>(Jc[c], y, jy);
@@ -758,9 +840,12 @@ DPLL_HD void sap_evaluate(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[
     lorentz_project(p.zs[c], p.pr[c]);
     const T a[3] = {mu[c] * p.pr[c].g[0], mu[c] * p.pr[c].g[1], p.pr[c].g[2]};
     cjac_apply_t_add<T, NJ>(Jc[c], a, p.jtg);
+    ns += p.pr[c].g[2];
   }
   symv<T, NV>(M, p.yT, p.My);
   DPLL_UNROLL for (int i = 0; i < NV; ++i) p.jtg[i] = Lanes::group_sum(p.jtg[i]);
+  if constexpr (JacIsDense<JT>::value) p.nsum = Lanes::group_sum(ns);
+  else p.nsum = p.jtg[5];
 }
 
 // One iteration: Newton direction d from the state at y, then the state at y + d is evaluated -- it is both the line
@@ -768,8 +853,8 @@ DPLL_HD void sap_evaluate(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[
 // the benchmark batch), the next iteration's starting state, so an accepted iteration costs one evaluation, one
 // Hessian and one Cholesky and nothing else.  Only when some item of the wave rejects alpha = 1 does the wave run the
 // derivative-based safeguarded search (re-projections of zs - alpha J d) and evaluate the state again at y + alpha d.
-template <typename T, typename TA, int NJ, int KPL, class Lanes>
-DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL], const T (&mu)[KPL],
+template <typename T, typename TA, int NJ, int KPL, class Lanes, class JT>
+DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const T (&mu)[KPL],
                        const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3],
                        const T (&y0)[6 + NJ], bool use_y0) {
   constexpr int NV = 6 + NJ;
@@ -802,7 +887,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
     T grad[NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i) grad[i] = cur.My[i] - ieps * cur.jtg[i];
     // the sum of the normal forces is zero exactly when every contact sits in the polar region
-    const bool any_force = cur.jtg[5] > T(0);
+    const bool any_force = cur.nsum > T(0);
     // Hessian H = M + sum_c [A 1 j]^T C [A 1 j],  C = D_mu dP D_mu / eps
     T H[NV][NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
@@ -812,24 +897,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ> (&Jc)[KPL
       proj_jacobian(cur.pr[c], dP);
       const T m1 = mu[c] * ieps, m2 = mu[c] * m1;
       const T C[3][3] = {{dP[0] * m2, dP[3] * m2, dP[4] * m1}, {dP[3] * m2, dP[1] * m2, dP[5] * m1}, {dP[4] * m1, dP[5] * m1, dP[2] * ieps}};
-      T CA[3][3];
-      mat3_mul(C, Jc[c].A, CA);
-      DPLL_UNROLL for (int i = 0; i < 3; ++i) {
-        DPLL_UNROLL for (int j = 0; j <= i; ++j) {
-          H[i][j] += Jc[c].A[0][i] * CA[0][j] + Jc[c].A[1][i] * CA[1][j] + Jc[c].A[2][i] * CA[2][j];
-          H[3 + i][3 + j] += C[i][j];
-        }
-        DPLL_UNROLL for (int j = 0; j < 3; ++j) H[3 + i][j] += CA[i][j];
-      }
-      DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) {
-        T u[3];
-        mat3_vec(C, Jc[c].j[jj], u);
-        DPLL_UNROLL for (int i = 0; i < 3; ++i) {
-          H[6 + jj][i] += Jc[c].A[0][i] * u[0] + Jc[c].A[1][i] * u[1] + Jc[c].A[2][i] * u[2];
-          H[6 + jj][3 + i] += u[i];
-        }
-        DPLL_UNROLL for (int kk = 0; kk <= jj; ++kk) H[6 + jj][6 + kk] += dot3(Jc[c].j[kk], u);
-      }
+      hessian_add<T, NJ>(Jc[c], C, H);
     }
     DPLL_UNROLL for (int i = 0; i < NV; ++i)
       DPLL_UNROLL for (int j = 0; j <= i; ++j) {
@@ -1002,6 +1070,16 @@ DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, cons
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[g][i] = lengths ? tabs(lengths[MD::kGeoStride * g + i]) : T(0);
   }
   dp.geo = lengths;
+  if constexpr (MD::kGeneral) {
+    // the slots behind the geometries: pair coefficient of the two geometries of a body-body candidate
+    DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) {
+      if (kMaxGeoms + p < NG) {
+        const bool on = p < md.n_pairs;
+        const T ma = tabs(friction[1 + (on ? md.pair_a[p] : 0)]), mb = tabs(friction[1 + (on ? md.pair_b[p] : 0)]);
+        dp.mu[kMaxGeoms + p < NG ? kMaxGeoms + p : 0] = T(2) * ma * mb / (ma + mb);
+      }
+    }
+  }
 }
 
 // per-item terms shared by the loss and the dynamics
@@ -1045,29 +1123,308 @@ DPLL_HD void compute_terms(const MD& md, const Derived<T, NJ, NG>& dp, const T* 
 }
 
 // One contact of this lane: geometry g = contact / 4 (the fast builds: geometry g sits on body g), slot 0..3.
-template <typename T, int NJ> struct ContactGeom {
+// GEN (the general build) adds what a body-body contact needs: the other member of the pair and the contact frame.
+template <typename T, int NJ, bool GEN> struct ContactPair {};
+template <typename T, int NJ> struct ContactPair<T, NJ, true> {
+  bool pair;       // body-body contact: geometry A (fields below) against geometry B (the fields of ContactGeom)
+  int gpar;        // geometry whose parameters the witness of ContactGeom belongs to (a ground contact: = geom)
+  int body_a, gpar_a;
+  T sgn_a[3], drad_a[3];
+  int vidx_a;
+  T Ra[3][3];
+  T F[3][3];       // rows: the contact frame's axes (t_x, t_y, n) in the world; the identity for a ground contact
+  T dir[3];        // the pair's direction in the frame of A (unit, from A to B): piecewise constant in the state
+};
+template <typename T, int NJ, bool GEN = false> struct ContactGeom : ContactPair<T, NJ, GEN> {
   int body;
-  int geom;
+  int geom;      // geometry slot: whose pair friction coefficient mu is
   T sgn[3];      // box: corner sign pattern = d witness_i / d |length_i|; sphere: zero
   T drad[3];     // sphere: d witness / d radius (the support direction); box: zero
   int vidx;      // polygon: index of the vertex this contact picked (d witness / d vertices[vidx] = 1); otherwise -1
   T phi;
   T mu;
   T R[3][3];     // rotation of the contact's body
-  CJac<T, NJ> J; // world-frame point Jacobian
+  CJac<T, NJ, GEN> J;  // contact-frame Jacobian (fast builds: world-frame point Jacobian, the ground's frame is the world's)
 };
 
 constexpr double kMaskedPhi = 1e3;  // signed distance of a contact slot that does not exist: no force, no gradient
+constexpr double kPairTie = 1e-12;   // support values (metres) closer than this are a tie
+
+// ---------------------------------------------------------------------------------------------
+// Body-body contact (general build).  The reference (GeometryCollider.collide_mesh_mesh, geometry.py:585-643) asks
+// fcl for ONE direction per pair -- the difference of the nearest points when the shapes are apart, a contact normal
+// when they overlap -- treats it as piecewise constant, and evaluates everything else from the shapes' support
+// functions: witness points p_Ac = s_A(d), p_Bc = s_B(-d), phi = (p_Bc - p_Ac) . d, contact frame
+// rotation_matrix_from_one_vector(d, 2).  fcl's role is taken by an exact search: the unit d maximising the
+// separation  sep(d) = min_b d . b - max_a d . a  of the two vertex sets (apart: the nearest-points direction;
+// overlapping: the direction of minimum penetration), found among the directions the closest features of two convex
+// polytopes can define -- vertex-vertex differences, vertex-edge perpendiculars, normals of vertex triples of either
+// set, cross products of vertex pairs of both (every unit d is a lower bound of the maximum, so candidates that are not
+// real features cost time, never correctness).  A sphere is its centre with the radius as a margin (the margin shifts
+// sep by a constant: same maximiser).
+// ---------------------------------------------------------------------------------------------
+template <typename S> struct PairBest {
+  S sep;
+  S d[3];
+};
+template <typename S>
+DPLL_HD void pair_try(const S (&n)[3], const S (*a)[3], int na, const S (*b)[3], int nb, PairBest<S>& best) {
+  const S n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+  if (!(n2 > S(0))) return;
+  S amax = S(-3.0e38), amin = S(3.0e38), bmax = S(-3.0e38), bmin = S(3.0e38);
+  for (int i = 0; i < na; ++i) {
+    const S t = n[0] * a[i][0] + n[1] * a[i][1] + n[2] * a[i][2];
+    amax = tmax(amax, t);
+    amin = tmin(amin, t);
+  }
+  for (int j = 0; j < nb; ++j) {
+    const S t = n[0] * b[j][0] + n[1] * b[j][1] + n[2] * b[j][2];
+    bmax = tmax(bmax, t);
+    bmin = tmin(bmin, t);
+  }
+  const S inv = S(1) / tsqrt(n2);
+  const S sp = (bmin - amax) * inv, sm = (amin - bmax) * inv;
+  if (sp > best.sep) {
+    best.sep = sp;
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = n[i] * inv;
+  }
+  if (sm > best.sep) {
+    best.sep = sm;
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = -n[i] * inv;
+  }
+}
+// vertex sets a (na) and b (nb) in one frame -> unit d from A towards B; runtime loops (the sets live in memory)
+template <typename S>
+DPLL_HD void pair_direction(const S (*a)[3], int na, const S (*b)[3], int nb, S (&d)[3]) {
+  PairBest<S> best;
+  best.sep = S(-3.0e38);
+  best.d[0] = S(0); best.d[1] = S(0); best.d[2] = S(1);
+  // vertex - vertex
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j) {
+      const S n[3] = {b[j][0] - a[i][0], b[j][1] - a[i][1], b[j][2] - a[i][2]};
+      pair_try(n, a, na, b, nb, best);
+    }
+  // vertex of one set - edge of the other: the part of the difference perpendicular to the edge
+  for (int pass = 0; pass < 2; ++pass) {
+    const S (*p)[3] = pass == 0 ? a : b;
+    const S (*e)[3] = pass == 0 ? b : a;
+    const int np = pass == 0 ? na : nb, ne = pass == 0 ? nb : na;
+    for (int i = 0; i < np; ++i)
+      for (int k = 0; k < ne; ++k)
+        for (int l = k + 1; l < ne; ++l) {
+          const S ed[3] = {e[l][0] - e[k][0], e[l][1] - e[k][1], e[l][2] - e[k][2]};
+          const S w[3] = {e[k][0] - p[i][0], e[k][1] - p[i][1], e[k][2] - p[i][2]};
+          const S ee = ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2];
+          if (!(ee > S(0))) continue;
+          const S t = (w[0] * ed[0] + w[1] * ed[1] + w[2] * ed[2]) / ee;
+          const S n[3] = {w[0] - t * ed[0], w[1] - t * ed[1], w[2] - t * ed[2]};
+          pair_try(n, a, na, b, nb, best);
+        }
+  }
+  // normals of the vertex triples of either set
+  for (int pass = 0; pass < 2; ++pass) {
+    const S (*p)[3] = pass == 0 ? a : b;
+    const int np = pass == 0 ? na : nb;
+    for (int i = 0; i < np; ++i)
+      for (int j = i + 1; j < np; ++j)
+        for (int k = j + 1; k < np; ++k) {
+          const S u[3] = {p[j][0] - p[i][0], p[j][1] - p[i][1], p[j][2] - p[i][2]};
+          const S v[3] = {p[k][0] - p[i][0], p[k][1] - p[i][1], p[k][2] - p[i][2]};
+          S n[3];
+          cross(u, v, n);
+          pair_try(n, a, na, b, nb, best);
+        }
+  }
+  // edge x edge
+  for (int i = 0; i < na; ++i)
+    for (int j = i + 1; j < na; ++j) {
+      const S u[3] = {a[j][0] - a[i][0], a[j][1] - a[i][1], a[j][2] - a[i][2]};
+      for (int k = 0; k < nb; ++k)
+        for (int l = k + 1; l < nb; ++l) {
+          const S v[3] = {b[l][0] - b[k][0], b[l][1] - b[k][1], b[l][2] - b[k][2]};
+          S n[3];
+          cross(u, v, n);
+          pair_try(n, a, na, b, nb, best);
+        }
+    }
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) d[i] = best.d[i];
+}
+
+// rotation_matrix_from_one_vector(d, axis = 2) (tensor_utils.py:305-366, after Drake's MakeFromOneVector): columns
+// (b, c, a = d); `rows` receives its TRANSPOSE (row k = axis k of the contact frame, in the frame d is given in)
+template <typename S> DPLL_HD void frame_from_normal(const S (&a)[3], S (&rows)[3][3]) {
+  const S m0 = tabs(a[0]), m1 = tabs(a[1]), m2 = tabs(a[2]);
+  const int i = (m0 <= m1 && m0 <= m2) ? 0 : (m1 <= m2 ? 1 : 2);  // torch.min: the first of equal minima
+  const int j = (i + 1) % 3, k = (j + 1) % 3;
+  S ai = a[0], aj = a[1], ak = a[2];
+  ai = i == 1 ? a[1] : (i == 2 ? a[2] : a[0]);
+  aj = j == 1 ? a[1] : (j == 2 ? a[2] : a[0]);
+  ak = k == 1 ? a[1] : (k == 2 ? a[2] : a[0]);
+  const S mag = tsqrt(S(1) - ai * ai);
+  const S corr = -ai / mag;
+  S colb[3] = {S(0), S(0), S(0)}, colc[3] = {S(0), S(0), S(0)};
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    colb[r] = r == j ? -ak / mag : (r == k ? aj / mag : S(0));
+    colc[r] = r == i ? mag : (r == j ? corr * aj : corr * ak);
+  }
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) { rows[0][r] = colb[r]; rows[1][r] = colc[r]; rows[2][r] = a[r]; }
+}
+
+// vertex set of geometry g in its own frame (+ the margin a sphere's radius adds)
+template <typename S, typename T, int NJ, int NG, class MD>
+DPLL_HD void geometry_vertices(const MD& md, const Derived<T, NJ, NG>& dp, int g, S (*v)[3], int& nv, S& margin) {
+  const int kind = md.geom_kind[g];
+  margin = S(0);
+  if (kind == kGeomSphere) {
+    nv = 1;
+    v[0][0] = S(0); v[0][1] = S(0); v[0][2] = S(0);
+    margin = S(dp.habs[g][0]);
+  } else if (kind == kGeomPolygon) {
+    nv = md.geom_nverts[g];
+    for (int u = 0; u < nv; ++u)
+      for (int i = 0; i < 3; ++i) v[u][i] = S(dp.geo[MD::kGeoStride * g + 3 * u + i]);
+  } else {
+    nv = 8;  // corner order of the reference's _UNIT_BOX_VERTICES (geometry.py:39-41): x is the slowest bit
+    for (int u = 0; u < 8; ++u)
+      for (int i = 0; i < 3; ++i) v[u][i] = (((u >> (2 - i)) & 1) ? S(1) : S(-1)) * S(dp.habs[g][i]);
+  }
+}
 
 // `witness` (mesh geometry, DeepSupportConvex): the support point of this contact in the geometry frame, already
 // evaluated by the ICNN kernels (geometry.py:309-325); nullptr = box corner / sphere point chosen here.
 template <typename T, typename TA, int NJ, int NG, class MD>
+DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
+                                  const Kin<TA, NJ>& kinA, int p, int slot, ContactGeom<T, NJ, true>& cg,
+                                  const TA* dir_in) {
+  constexpr int NB = NJ + 1;
+  const bool masked = p >= md.n_pairs || slot != 0;
+  const int ga = masked ? 0 : md.pair_a[p], gb = masked ? 0 : md.pair_b[p];
+  const int ba = md.geom_body[ga], bb = md.geom_body[gb];
+  cg.pair = true;
+  cg.geom = kMaxGeoms + p;
+  cg.mu = dp.mu[(kMaxGeoms + p) < NG ? kMaxGeoms + p : 0];
+  cg.body = bb; cg.gpar = gb;
+  cg.body_a = ba; cg.gpar_a = ga;
+  cg.vidx = -1; cg.vidx_a = -1;
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { cg.sgn[i] = T(0); cg.drad[i] = T(0); cg.sgn_a[i] = T(0); cg.drad_a[i] = T(0); cg.dir[i] = T(i == 2 ? 1 : 0); }
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) { cg.R[r][c] = kin.R[0][r][c]; cg.Ra[r][c] = kin.R[0][r][c]; cg.F[r][c] = T(r == c ? 1 : 0); }
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int c = 0; c < 6 + NJ; ++c) cg.J.m[r][c] = T(0);
+  cg.phi = T(kMaskedPhi);
+  if (masked) return;
+  // geometry frames in the world (TA): rotation of the body, origin = body origin + R * geometry origin
+  TA RA[3][3], RB[3][3], oA[3], oB[3];
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) { RA[r][c] = kinA.R[0][r][c]; RB[r][c] = kinA.R[0][r][c]; }
+    oA[r] = kinA.o[0][r]; oB[r] = kinA.o[0][r];
+  }
+  DPLL_UNROLL for (int j = 1; j < NB; ++j)
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+        RA[r][c] = ba == j ? kinA.R[j][r][c] : RA[r][c];
+        RB[r][c] = bb == j ? kinA.R[j][r][c] : RB[r][c];
+      }
+      oA[r] = ba == j ? kinA.o[j][r] : oA[r];
+      oB[r] = bb == j ? kinA.o[j][r] : oB[r];
+    }
+  TA gorgA[3], gorgB[3], cA[3], cB[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { gorgA[i] = TA(md.geom_origin[ga][i]); gorgB[i] = TA(md.geom_origin[gb][i]); }
+  mat3_vec(RA, gorgA, cA);
+  mat3_vec(RB, gorgB, cB);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { cA[i] += oA[i]; cB[i] += oB[i]; }
+  TA va[kMaxPolyVerts][3], vb[kMaxPolyVerts][3], marginA, marginB;
+  int na, nb;
+  geometry_vertices<TA>(md, dp, ga, va, na, marginA);
+  geometry_vertices<TA>(md, dp, gb, vb, nb, marginB);
+  // direction, in the frame of A
+  TA dA[3];
+  if (dir_in) {
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dA[i] = dir_in[i];
+  } else {
+    // B's vertices in the frame of A: R_A^T (c_B + R_B v - c_A)
+    TA vbA[kMaxPolyVerts][3];
+    for (int u = 0; u < nb; ++u) {
+      TA w[3], rel[3];
+      mat3_vec(RB, vb[u], w);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) rel[i] = w[i] + cB[i] - cA[i];
+      mat3t_vec(RA, rel, vbA[u]);
+    }
+    pair_direction<TA>(va, na, vbA, nb, dA);
+  }
+  TA dW[3], dB[3], ndW[3];
+  mat3_vec(RA, dA, dW);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) ndW[i] = -dW[i];
+  mat3t_vec(RB, ndW, dB);  // -d in the frame of B
+  // witness points: the vertex furthest along the direction + the sphere margin along it.  When the direction is a face
+  // normal or an edge normal of the shape itself several vertices are equally far up to rounding: the lowest index of
+  // those within kPairTie wins (a support function network has no such ties: its gradient is one vertex).
+  int ia = 0, ib = 0;
+  TA besta = TA(-3.0e38), bestb = TA(-3.0e38);
+  for (int u = 0; u < na; ++u) {
+    const TA t = dA[0] * va[u][0] + dA[1] * va[u][1] + dA[2] * va[u][2];
+    if (t > besta + TA(kPairTie)) { besta = t; ia = u; }
+  }
+  for (int u = 0; u < nb; ++u) {
+    const TA t = dB[0] * vb[u][0] + dB[1] * vb[u][1] + dB[2] * vb[u][2];
+    if (t > bestb + TA(kPairTie)) { bestb = t; ib = u; }
+  }
+  TA witA[3], witB[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { witA[i] = va[ia][i] + marginA * dA[i]; witB[i] = vb[ib][i] + marginB * dB[i]; }
+  // d witness / d parameters
+  const int kindA = md.geom_kind[ga], kindB = md.geom_kind[gb];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+    cg.sgn_a[i] = kindA == kGeomBox ? (((ia >> (2 - i)) & 1) ? T(1) : T(-1)) : T(0);
+    cg.sgn[i] = kindB == kGeomBox ? (((ib >> (2 - i)) & 1) ? T(1) : T(-1)) : T(0);
+    cg.drad_a[i] = kindA == kGeomSphere ? T(dA[i]) : T(0);
+    cg.drad[i] = kindB == kGeomSphere ? T(dB[i]) : T(0);
+    cg.dir[i] = T(dA[i]);
+  }
+  cg.vidx_a = kindA == kGeomPolygon ? ia : -1;
+  cg.vidx = kindB == kGeomPolygon ? ib : -1;
+  // world points, signed distance along d
+  TA rA[3], rB[3], ptA[3], ptB[3], wA[3], wB[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { rA[i] = gorgA[i] + witA[i]; rB[i] = gorgB[i] + witB[i]; }
+  mat3_vec(RA, rA, wA);
+  mat3_vec(RB, rB, wB);
+  TA phi = TA(0);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { ptA[i] = oA[i] + wA[i]; ptB[i] = oB[i] + wB[i]; phi += dW[i] * (ptB[i] - ptA[i]); }
+  cg.phi = T(phi);
+  // contact frame: rows of R_AF^T in the frame of A, taken to the world by R_A
+  TA FA[3][3];
+  frame_from_normal<TA>(dA, FA);
+  T F[3][3];
+  DPLL_UNROLL for (int k = 0; k < 3; ++k) {
+    TA axis[3];
+    mat3_vec(RA, FA[k], axis);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { F[k][i] = T(axis[i]); cg.F[k][i] = F[k][i]; }
+  }
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) { cg.Ra[r][c] = T(RA[r][c]); cg.R[r][c] = T(RB[r][c]); }
+  // J = F (J_Bc - J_Ac)  (multibody_terms.py:503-513)
+  T pa[3], pb[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { pa[i] = T(ptA[i]); pb[i] = T(ptB[i]); }
+  CJac<T, NJ, false> JA, JB;
+  contact_jacobian<T, NJ>(kin, ba, pa, JA);
+  contact_jacobian<T, NJ>(kin, bb, pb, JB);
+  cjac_dense<T, NJ>(JB, F, T(1), false, cg.J);
+  cjac_dense<T, NJ>(JA, F, T(-1), true, cg.J);
+}
+
+template <typename T, typename TA, int NJ, int NG, class MD>
 DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
-                             const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ>& cg,
-                             const T* witness = nullptr) {
+                             const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ, MD::kGeneral>& cg,
+                             const T* witness = nullptr, const TA* pair_dir = nullptr) {
   constexpr int NB = NJ + 1;
   const int g = contact / kQuery;
   const int slot = contact % kQuery;
+  if constexpr (MD::kGeneral) {
+    if (g >= kMaxGeoms) {  // the slots behind the geometries: body-body pairs
+      compute_pair_contact<T, TA, NJ>(md, dp, kin, kinA, g - kMaxGeoms, slot, cg, pair_dir);
+      return;
+    }
+  }
   // geometry data by g (g differs from lane to lane in the lane-per-contact builds)
   T habs[3], gorg[3];
   T mu = dp.mu[0];
@@ -1075,7 +1432,7 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
   bool masked = false;
   DPLL_UNROLL for (int r = 0; r < 3; ++r) { habs[r] = dp.habs[0][r]; gorg[r] = T(md.geom_origin[0][r]); }
   if constexpr (MD::kGeneral) { b = md.geom_body[0]; kind = md.geom_kind[0]; masked = md.n_geoms < 1; }
-  DPLL_UNROLL for (int gg = 1; gg < NG; ++gg) {
+  DPLL_UNROLL for (int gg = 1; gg < (MD::kGeneral ? kMaxGeoms : NG); ++gg) {
     const bool pick = (g == gg);
     DPLL_UNROLL for (int r = 0; r < 3; ++r) {
       habs[r] = pick ? dp.habs[gg][r] : habs[r];
@@ -1158,7 +1515,52 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
   TA phiA = oz;
   DPLL_UNROLL for (int i = 0; i < 3; ++i) phiA += Rz[i] * (TA(gorg[i]) + TA(wit[i]));
   cg.phi = masked ? T(kMaskedPhi) : T(phiA);
-  contact_jacobian<T, NJ>(kin, b, pt, cg.J);
+  if constexpr (MD::kGeneral) {
+    cg.pair = false;
+    cg.gpar = g;
+    cg.body_a = 0; cg.gpar_a = 0; cg.vidx_a = -1;
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      cg.sgn_a[r] = T(0); cg.drad_a[r] = T(0); cg.dir[r] = T(0);
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) { cg.F[r][c] = T(r == c ? 1 : 0); cg.Ra[r][c] = T(r == c ? 1 : 0); }
+    }
+    CJac<T, NJ, false> P;
+    contact_jacobian<T, NJ>(kin, b, pt, P);
+    cjac_dense<T, NJ>(P, cg.F, T(1), false, cg.J);
+  } else {
+    contact_jacobian<T, NJ>(kin, b, pt, cg.J);
+  }
+}
+
+// d/d(witness points) of  a1 . (J w1) + a2 . (J w2) + phibar phi  for one contact (a1, a2: contact-frame vectors with
+// the friction coefficient folded in): the world-frame point adjoint  rho_bar = a1 x omega(w1) + a2 x omega(w2) +
+// phibar n  taken to the body frame; a body-body contact has the same with the opposite sign on the side of A.
+template <typename T, int NJ, bool GEN>
+DPLL_HD void witness_adjoint(const Kin<T, NJ>& kin, const ContactGeom<T, NJ, GEN>& cg, const T (&a1)[3], const T* w1,
+                             const T (&a2)[3], const T* w2, T phibar, T (&rbar)[3], T (&rbar_a)[3]) {
+  T aw1[3], aw2[3], nW[3] = {T(0), T(0), T(1)};
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { aw1[i] = a1[i]; aw2[i] = a2[i]; rbar_a[i] = T(0); }
+  if constexpr (GEN) {
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+      aw1[i] = a1[0] * cg.F[0][i] + a1[1] * cg.F[1][i] + a1[2] * cg.F[2][i];
+      aw2[i] = a2[0] * cg.F[0][i] + a2[1] * cg.F[1][i] + a2[2] * cg.F[2][i];
+      nW[i] = cg.F[2][i];
+    }
+  }
+  T o1[3], o2[3], c1[3], c2[3], rho[3];
+  world_omega<T, NJ>(kin, cg.body, w1, o1);
+  world_omega<T, NJ>(kin, cg.body, w2, o2);
+  cross(aw1, o1, c1);
+  cross(aw2, o2, c2);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) rho[i] = c1[i] + c2[i] + phibar * nW[i];
+  mat3t_vec(cg.R, rho, rbar);
+  if constexpr (GEN) {
+    world_omega<T, NJ>(kin, cg.body_a, w1, o1);
+    world_omega<T, NJ>(kin, cg.body_a, w2, o2);
+    cross(aw1, o1, c1);
+    cross(aw2, o2, c2);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) rho[i] = cg.pair ? -(c1[i] + c2[i] + phibar * nW[i]) : T(0);
+    mat3t_vec(cg.Ra, rho, rbar_a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1187,17 +1589,29 @@ template <typename T, int NJ, int NG, int GP> DPLL_HD void zero_grad(LossGrad<T,
 }
 
 // this contact's share of d/d(mu_pair, geometry lengths): gmu and the witness adjoint r_bar
+// one witness point's adjoint into the parameters of geometry `gpar`
 template <typename T, int NJ, int NG, int GP>
-DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ>& cg, T gmu, const T (&rbar)[3], LossGrad<T, NJ, NG, GP>& grad) {
-  const T grad_r = cg.drad[0] * rbar[0] + cg.drad[1] * rbar[1] + cg.drad[2] * rbar[2];
+DPLL_HD void add_witness_grad(int gpar, const T (&sgn)[3], const T (&drad)[3], int vidx, const T (&rbar)[3],
+                              LossGrad<T, NJ, NG, GP>& grad) {
+  const T grad_r = drad[0] * rbar[0] + drad[1] * rbar[1] + drad[2] * rbar[2];
   DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) {
-    const bool mine = (cg.geom == gg);
-    grad.g_mu[gg] += mine ? gmu : T(0);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][i] += mine ? cg.sgn[i] * rbar[i] + (i == 0 ? grad_r : T(0)) : T(0);
+    const bool mine = (gpar == gg);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][i] += mine ? sgn[i] * rbar[i] + (i == 0 ? grad_r : T(0)) : T(0);
     if constexpr (GP >= 3 * kMaxPolyVerts) {  // (a polygon has sgn = drad = 0: the line above adds nothing for it)
       DPLL_UNROLL for (int u = 0; u < kMaxPolyVerts; ++u)
-        DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][3 * u + i] += (mine && cg.vidx == u) ? rbar[i] : T(0);
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) grad.g_len[gg][3 * u + i] += (mine && vidx == u) ? rbar[i] : T(0);
     }
+  }
+}
+template <typename T, int NJ, bool GEN, int NG, int GP>
+DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ, GEN>& cg, T gmu, const T (&rbar)[3], const T (&rbar_a)[3],
+                               LossGrad<T, NJ, NG, GP>& grad) {
+  DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) grad.g_mu[gg] += (cg.geom == gg) ? gmu : T(0);
+  if constexpr (GEN) {
+    add_witness_grad<T, NJ>(cg.gpar, cg.sgn, cg.drad, cg.vidx, rbar, grad);
+    add_witness_grad<T, NJ>(cg.pair ? cg.gpar_a : -1, cg.sgn_a, cg.drad_a, cg.vidx_a, rbar_a, grad);
+  } else {
+    add_witness_grad<T, NJ>(cg.geom, cg.sgn, cg.drad, cg.vidx, rbar, grad);
   }
 }
 
@@ -1220,8 +1634,8 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
   T dv[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) dv[i] = vp[i] - (v[i] + t.a[i] * dt);
   // contacts of this lane
-  ContactGeom<T, NJ> cg[KPL];
-  CJac<T, NJ> Jc[KPL];
+  ContactGeom<T, NJ, MD::kGeneral> cg[KPL];
+  CJac<T, NJ, MD::kGeneral> Jc[KPL];
   T mu[KPL], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
   T pen = T(0);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
@@ -1314,19 +1728,14 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
     const T phibar = fn * (cg[c].phi > T(0) ? T(1) : (cg[c].phi < T(0) ? T(-1) : T(0))) - T(2) * tmax(-cg[c].phi, T(0));
     const T alpha[3] = {mu[c] * ftx, mu[c] * fty, fn};
     const T beta[3] = {mu[c] * bx, mu[c] * by, T(0)};
-    T ou[3], ov[3], c1[3], c2[3], rhobar[3], rbar[3];
-    world_omega<T, NJ>(t.kin, cg[c].body, u, ou);
-    world_omega<T, NJ>(t.kin, cg[c].body, vp, ov);
-    cross(alpha, ou, c1);
-    cross(beta, ov, c2);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) rhobar[i] = c1[i] + c2[i];
-    rhobar[2] += phibar;
-    mat3t_vec(cg[c].R, rhobar, rbar);  // r_bar = R_b^T rho_bar
+    T rbar[3], rbar_a[3];
+    witness_adjoint<T, NJ>(t.kin, cg[c], alpha, u, beta, vp, phibar, rbar, rbar_a);  // r_bar = R_b^T rho_bar
     if (rbar_out) {
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = wt * rbar[i];
     }
     const T wrbar[3] = {wt * rbar[0], wt * rbar[1], wt * rbar[2]};
-    add_geometry_grad(cg[c], wt * gmu, wrbar, grad);
+    const T wrbar_a[3] = {wt * rbar_a[0], wt * rbar_a[1], wt * rbar_a[2]};
+    add_geometry_grad(cg[c], wt * gmu, wrbar, wrbar_a, grad);
   }
   return loss;
 }
@@ -1362,11 +1771,11 @@ DPLL_HD void step_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverO
   compute_terms<T, TA, NJ>(md, dp, q, v, t, kinA);
   T vm[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];
-  CJac<T, NJ> Jc[KPL];
+  CJac<T, NJ, MD::kGeneral> Jc[KPL];
   T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    ContactGeom<T, NJ> cg;
+    ContactGeom<T, NJ, MD::kGeneral> cg;
     compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg, witness ? witness[c] : nullptr);
     Jc[c] = cg.J;
     mu[c] = cg.mu;
@@ -1421,7 +1830,8 @@ template <typename T> DPLL_HD void quat_exp_mul_adjoint(const T* q, const T (&r)
 template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
 DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
-                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3] = nullptr);
+                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3] = nullptr,
+                                const T (*pair_dir)[3] = nullptr);
 
 template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD, int GP>
 DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x,
@@ -1438,8 +1848,8 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
   compute_terms<T, TA, NJ>(md, dp, q, v, t, kinA);
   T vm[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];
-  ContactGeom<T, NJ> cg[KPL];
-  CJac<T, NJ> Jc[KPL];
+  ContactGeom<T, NJ, MD::kGeneral> cg[KPL];
+  CJac<T, NJ, MD::kGeneral> Jc[KPL];
   T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
@@ -1482,24 +1892,7 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
     const T(&dP)[6] = dPc[c];
     const T m1 = mu[c] * ieps, m2 = mu[c] * m1;
     const T C[3][3] = {{dP[0] * m2, dP[3] * m2, dP[4] * m1}, {dP[3] * m2, dP[1] * m2, dP[5] * m1}, {dP[4] * m1, dP[5] * m1, dP[2] * ieps}};
-    T CA[3][3];
-    mat3_mul(C, Jc[c].A, CA);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) {
-      DPLL_UNROLL for (int j = 0; j <= i; ++j) {
-        H[i][j] += Jc[c].A[0][i] * CA[0][j] + Jc[c].A[1][i] * CA[1][j] + Jc[c].A[2][i] * CA[2][j];
-        H[3 + i][3 + j] += C[i][j];
-      }
-      DPLL_UNROLL for (int j = 0; j < 3; ++j) H[3 + i][j] += CA[i][j];
-    }
-    DPLL_UNROLL for (int jj = 0; jj < NJ; ++jj) {
-      T u[3];
-      mat3_vec(C, Jc[c].j[jj], u);
-      DPLL_UNROLL for (int i = 0; i < 3; ++i) {
-        H[6 + jj][i] += Jc[c].A[0][i] * u[0] + Jc[c].A[1][i] * u[1] + Jc[c].A[2][i] * u[2];
-        H[6 + jj][3 + i] += u[i];
-      }
-      DPLL_UNROLL for (int kk = 0; kk <= jj; ++kk) H[6 + jj][6 + kk] += dot3(Jc[c].j[kk], u);
-    }
+    hessian_add<T, NJ>(Jc[c], C, H);
   }
   DPLL_UNROLL for (int i = 0; i < NV; ++i)
     DPLL_UNROLL for (int j = 0; j <= i; ++j) {
@@ -1509,7 +1902,19 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
   T L[NV][NV], invd[NV], lam[NV];
   cholesky<T, NV>(H, L, invd);
   chol_solve<T, NV>(L, invd, sv, lam);
-  if (xbar) step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar, witness);
+  if (xbar) {
+    // the body-body directions found above are constants of the dual passes (piecewise constant in the state)
+    T pdir[kMaxPairs][3] = {};
+    if constexpr (MD::kGeneral) {
+      DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+        const int cc = first_contact + c, pp = cc / kQuery - kMaxGeoms;
+        if (pp >= 0 && pp < kMaxPairs && cc % kQuery == 0) {
+          DPLL_UNROLL for (int i = 0; i < 3; ++i) pdir[pp][i] = cg[c].dir[i];
+        }
+      }
+    }
+    step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar, witness, pdir);
+  }
   // ---- per-contact pieces: kappa_c, friction and witness gradients; s' = s - sum_c J_c^T kappa_c ---
   T jtk[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) jtk[i] = T(0);
@@ -1527,18 +1932,13 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
     const T(&g)[3] = pr[c].g;
     const T gmu = g[0] * pl[0] + g[1] * pl[1] - kap[0] * pv[0] - kap[1] * pv[1];
     const T ag[3] = {mu[c] * g[0], mu[c] * g[1], g[2]};
-    T ol[3], ov[3], c1[3], c2[3], rhobar[3], rbar[3];
-    world_omega<T, NJ>(t.kin, cg[c].body, lam, ol);
-    world_omega<T, NJ>(t.kin, cg[c].body, vn, ov);
-    cross(ag, ol, c1);
-    cross(ak, ov, c2);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) rhobar[i] = c1[i] - c2[i];
-    rhobar[2] -= kap[2] * idt;
-    mat3t_vec(cg[c].R, rhobar, rbar);
+    const T nak[3] = {-ak[0], -ak[1], -ak[2]};
+    T rbar[3], rbar_a[3];
+    witness_adjoint<T, NJ>(t.kin, cg[c], ag, lam, nak, vn, -kap[2] * idt, rbar, rbar_a);
     if (rbar_out) {
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = rbar[i];
     }
-    add_geometry_grad(cg[c], gmu, rbar, grad);
+    add_geometry_grad(cg[c], gmu, rbar, rbar_a, grad);
   }
   T abar[NV], bvec[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) abar[i] = dt * (sv[i] - Lanes::group_sum(jtk[i]));
@@ -1576,7 +1976,8 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
 template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
 DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
-                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3]) {
+                                const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3],
+                                const T (*pair_dir)[3]) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = NQ + NV;
   using S = DualT<TA>;
   Derived<S, NJ, NG> dps;
@@ -1619,12 +2020,18 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
     // + sum_c (J_c lambda) . D_mu P_K(z_c)
     S phic = S(TA(0));
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-      ContactGeom<S, NJ> cg;
+      ContactGeom<S, NJ, MD::kGeneral> cg;
       S wit[3] = {S(TA(0)), S(TA(0)), S(TA(0))};
       if (witness) {
         DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = S(TA(witness[c][i]));
       }
-      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg, witness ? wit : nullptr);
+      S pd[3] = {S(TA(0)), S(TA(0)), S(TA(1))};
+      const int pp = (first_contact + c) / kQuery - kMaxGeoms;
+      const bool is_pair = MD::kGeneral && pair_dir && pp >= 0 && pp < kMaxPairs;
+      if (is_pair) {
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) pd[i] = S(TA(pair_dir[pp][i]));
+      }
+      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg, witness ? wit : nullptr, is_pair ? pd : nullptr);
       S jy[3], jv[3], jl[3];
       cjac_apply<S, S, NJ>(cg.J, ys, jy);
       cjac_apply<S, S, NJ>(cg.J, vm, jv);
@@ -1662,15 +2069,23 @@ DPLL_HD double theta_grad_component(int inertia_mode, const double* theta, const
   DPLL_UNROLL for (int i = 0; i < kIota; ++i) s += g_iota[i] * io[i].d;
   return s;
 }
-// friction_params gradient: entry 0 is the ground, entry 1 + b the geometry of body b
-DPLL_HD double friction_grad_component(int n_bodies, const double* friction, const double* g_mu, int k) {
-  const double m0 = fabs(friction[0]);
+// friction_params gradient: entry 0 is the ground, entry 1 + b geometry b; slot b of g_mu combines the ground with
+// geometry b or (general build, the slots behind the geometries) the two geometries of a body-body candidate
+DPLL_HD double friction_grad_component(int n_slots, const double* friction, const double* g_mu, int k,
+                                       const ModelDesc* gd = nullptr) {
   double s = 0.0;
-  for (int b = 0; b < n_bodies; ++b) {
-    const double mb = fabs(friction[1 + b]);
+  for (int b = 0; b < n_slots; ++b) {
+    int ia = 0, ib = 1 + b;
+    if (gd && b >= kMaxGeoms) {
+      const int p = b - kMaxGeoms;
+      const bool on = p < gd->n_pairs;
+      ia = 1 + (on ? gd->pair_a[p] : 0);
+      ib = 1 + (on ? gd->pair_b[p] : 0);
+    }
+    const double m0 = fabs(friction[ia]), mb = fabs(friction[ib]);
     const double den = (m0 + mb) * (m0 + mb);
-    if (k == 0) s += g_mu[b] * 2.0 * mb * mb / den;
-    if (k == 1 + b) s += g_mu[b] * 2.0 * m0 * m0 / den;
+    if (k == ia) s += g_mu[b] * 2.0 * mb * mb / den;
+    if (k == ib) s += g_mu[b] * 2.0 * m0 * m0 / den;
   }
   const double p = friction[k];
   return s * (p > 0.0 ? 1.0 : (p < 0.0 ? -1.0 : 0.0));

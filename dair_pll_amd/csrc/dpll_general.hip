@@ -20,7 +20,7 @@ namespace {
 
 using namespace dpll;
 
-constexpr int kNG = kMaxGeoms;
+constexpr int kNG = kGenSlots;  // the geometries + the slot of a body-body pair
 constexpr int kGP = GeneralDesc::kGeoStride;  // numbers per geometry parameter block
 template <typename T, int NJ> using GD = Dims<T, NJ, kNG, kGP>;
 template <typename T, int NJ> using GenGrad = LossGrad<T, NJ, kNG, kGP>;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
     if (want_grad)
-      write_chain_matrix<T, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, md.geom_kind);
+      write_chain_matrix<T, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, &md);
     return;
   }
   Derived<T, NJ, kNG> dp;
@@ -77,21 +77,18 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
   store_iota_row<T, NJ, 1, kNG, kGP>(acc, loss_acc, partials);
 }
 
-// fixed-order sum of the partial rows + the chain to the parameters; 2 row groups x 128 columns
+// fixed-order sum of the partial rows + the chain to the parameters; one thread per column
 template <typename T, int NJ>
 __global__ __launch_bounds__(256) void gen_finalize_kernel(const double* __restrict__ partials, int n_rows, T* __restrict__ grad,
                                                            T* __restrict__ loss_total) {
   using D = GD<T, NJ>;
-  static_assert(D::PI <= 128, "row must fit 128 columns");
-  __shared__ double red[2][128];
-  __shared__ double tot[128];
-  const int col = threadIdx.x & 127, rowg = threadIdx.x >> 7;
+  static_assert(D::PI <= 256, "row must fit 256 columns");
+  __shared__ double tot[256];
+  const int col = threadIdx.x;
   double s = 0.0;
   if (col < D::PIOTA)
-    for (int r = rowg; r < n_rows; r += 2) s += partials[(long long)r * D::PI + col];
-  red[rowg][col] = s;
-  __syncthreads();
-  if (threadIdx.x < 128) tot[col] = red[0][col] + red[1][col];
+    for (int r = 0; r < n_rows; ++r) s += partials[(long long)r * D::PI + col];
+  tot[col] = s;
   __syncthreads();
   if (threadIdx.x < D::PI) {
     const int k = (int)threadIdx.x - 1;
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
   const int lane = threadIdx.x;
   const int item_blocks = (int)gridDim.x - 1;
   if ((int)blockIdx.x == item_blocks) {
-    write_chain_matrix<C, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, md.geom_kind);
+    write_chain_matrix<C, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, &md);
     return;
   }
   C theta_c[D::NB * 10], friction_c[kNG + 1], lengths_c[kNG * kGP];
@@ -233,13 +230,13 @@ __global__ __launch_bounds__(kWave) void gen_terms_kernel(GeneralDesc md, const 
   // (required when Dout is requested: the Delassus rows are formed from it)
   T* Jrows = Jout + it * (3 * K) * NV;
   for (int c = 0; c < K; ++c) {
-    ContactGeom<T, NJ> cg;
+    ContactGeom<T, NJ, true> cg;
     compute_contact<T, typename Acc<T>::type, NJ>(md, dp, t.kin, kinA, c, cg);
     if (phiout) phiout[it * K + c] = cg.phi;
     const int rows[3] = {c, K + 2 * c, K + 2 * c + 1};
     for (int i = 0; i < NV; ++i) {
       T col[3];
-      for (int r = 0; r < 3; ++r) col[r] = i < 3 ? cg.J.A[r][i] : (i < 6 ? (r == i - 3 ? T(1) : T(0)) : cg.J.j[i - 6 < NJ ? i - 6 : 0][r]);
+      cjac_column<T, NJ>(cg.J, i, col);
       Jrows[rows[0] * NV + i] = col[2];
       Jrows[rows[1] * NV + i] = cg.mu * col[0];
       Jrows[rows[2] * NV + i] = cg.mu * col[1];

@@ -493,8 +493,7 @@ __global__ __launch_bounds__(kWave) void terms_kernel(ModelDesc md, const T* __r
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       T col[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) col[r] = i < 3 ? cg.J.A[r][i] : (i < 6 ? (r == i - 3 ? T(1) : T(0)) : cg.J.j[i >= 6 ? i - 6 : 0][r]);
+      cjac_column<T, NJ>(cg.J, i, col);
       mine[0][i] = col[2]; mine[1][i] = cg.mu * col[0]; mine[2][i] = cg.mu * col[1];
     }
     const int rows[3] = {cidx, K + 2 * cidx, K + 2 * cidx + 1};
@@ -1086,7 +1085,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 10; }
+int dpll_abi_version(void) { return 11; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1105,6 +1104,14 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       if (desc->geom_kind[g] == DPLL_GEOM_POLYGON && (desc->geom_nverts[g] < 4 || desc->geom_nverts[g] > DPLL_MAX_POLYGON_VERTICES))
         return fail(-2, "dpll_model_create: a polygon has 4 to 8 vertices%s");
     }
+    if (desc->n_pairs < 0 || desc->n_pairs > DPLL_MAX_PAIRS) return fail(-2, "dpll_model_create: at most 1 body-body collision candidate%s");
+    for (int p = 0; p < desc->n_pairs; ++p) {
+      const int a = desc->pair_a[p], b = desc->pair_b[p];
+      if (a < 0 || b < 0 || a >= desc->n_geoms || b >= desc->n_geoms || a == b) return fail(-1, "dpll_model_create: pair geometry out of range%s");
+      if (desc->geom_body[a] == desc->geom_body[b]) return fail(-1, "dpll_model_create: a collision candidate joins geometries of two different bodies%s");
+    }
+  } else if (desc->n_pairs != 0) {
+    return fail(-2, "dpll_model_create: body-body collision candidates need the general build (n_geoms > 0)%s");
   }
   if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");
   if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL)
@@ -1138,7 +1145,7 @@ int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts
 int dpll_n_x(const dpll_model_t* model) { return model ? 13 + 2 * model->desc.n_joints : -1; }
 int dpll_n_contacts(const dpll_model_t* model) {
   if (!model) return -1;
-  return kQuery * (model->desc.n_geoms > 0 ? DPLL_MAX_GEOMS : model->desc.n_joints + 1);  // contact SLOTS of the build
+  return kQuery * (model->desc.n_geoms > 0 ? DPLL_GEN_SLOTS : model->desc.n_joints + 1);  // contact SLOTS of the build
 }
 int dpll_param_count(const dpll_model_t* model) {
   if (!model) return -1;

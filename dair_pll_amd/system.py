@@ -249,8 +249,9 @@ class MultibodyLearnableSystem(Module):
 
     # ---- parameters ---------------------------------------------------------------------------
     def _geom_slots(self) -> int:
-        """geometry slots of the build that serves this model: one per body (specialised builds) or always 3 (general)"""
-        return self.spec.n_joints + 1 if self.spec.is_fast() else _capi.MAX_GEOMS
+        """geometry slots of the build that serves this model: one per body (specialised builds) or always ``DPLL_GEN_SLOTS``
+        (general: three geometries and, behind them, the slot of a body-body pair)"""
+        return self.spec.n_joints + 1 if self.spec.is_fast() else _capi.GEN_SLOTS
 
     def _geo_stride(self) -> int:
         """numbers per geometry in the lengths block: a box's 3 (specialised builds) or ``DPLL_GEOM_BLOCK`` (general)"""

@@ -17,13 +17,16 @@ import math
 import os
 import xml.etree.ElementTree as ET
 from dataclasses import dataclass, field
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 GROUND_MU = 1.0  # dair_pll/drake_utils.py:280-288
 GRAVITY_Z = -9.81  # Drake's default UniformGravityField
 MAX_JOINTS = 2  # dpll_core.hpp kMaxJoints
 MAX_GEOMS = 3  # dpll_core.hpp kMaxGeoms
 MAX_POLYGON_VERTICES = 8  # dpll_core.hpp kMaxPolyVerts
+MAX_PAIRS = 1  # dpll_core.hpp kMaxPairs
+# GeometryCollider orders a pair by type (geometry.py:46, 66-74; multibody_terms.py:294-297)
+TYPE_ORDER = {'polygon': 1, 'box': 2, 'sphere': 3, 'mesh': 4}
 
 
 @dataclass
@@ -55,6 +58,10 @@ class ModelSpec:
     bodies: List[BodySpec]
     ground_mu: float = GROUND_MU
     gravity_z: float = GRAVITY_Z
+    # body-body collision candidates as (geometry a, geometry b), indices into :meth:`geoms`: geometries of two bodies that
+    # no joint connects and no collision filter group excludes (what Drake's GetCollisionCandidates keeps beyond the
+    # ground pairs, drake_utils.py:178-184), the pair ordered by geometry type as the reference orders it
+    pairs: List[Tuple[int, int]] = field(default_factory=list)
 
     @property
     def n_joints(self) -> int:
@@ -74,21 +81,22 @@ class ModelSpec:
 
     @property
     def n_contacts(self) -> int:
-        """witness points per geometry: 4 for a box / mesh / polygon (geometry.py:47-51, 490), 1 for a sphere (:440-452)"""
-        return sum(1 if geom.kind == 'sphere' else 4 for _, geom in self.geoms())
+        """witness points per geometry: 4 for a box / mesh / polygon (geometry.py:47-51, 490), 1 for a sphere (:440-452);
+        one per body-body candidate (geometry.py:639-643)"""
+        return sum(1 if geom.kind == 'sphere' else 4 for _, geom in self.geoms()) + len(self.pairs)
 
     def contact_slots(self) -> List[int]:
         """indices of the real contacts among the kernels' 4 slots per geometry (a sphere uses slot 0 only)"""
         out = []
         for g, (_, geom) in enumerate(self.geoms()):
             out += [4 * g] if geom.kind == 'sphere' else [4 * g + s for s in range(4)]
-        return out
+        return out + [4 * (MAX_GEOMS + p) for p in range(len(self.pairs))]  # a pair: slot 0 behind the geometries' slots
 
     def is_fast(self) -> bool:
         """the cube / elbow topology the specialised builds are written for: a serial chain of at most one joint with
         exactly one box (or mesh) per body"""
         return (self.n_joints <= 1 and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
-                and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0))
+                and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0) and not self.pairs)
 
     def friction_init(self) -> List[float]:
         """``friction_params`` initial value: ground first, then every geometry in body order
@@ -192,7 +200,37 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
                 chain.append(child)
     if len(chain) != len(order):
         raise ValueError('disconnected links')
-    return ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain])
+    spec = ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain])
+    spec.pairs = _collision_candidates(root, spec)
+    return spec
+
+
+def _collision_candidates(root, spec: ModelSpec) -> List[Tuple[int, int]]:
+    """Geometry pairs on two different bodies that can collide: Drake filters bodies connected by a joint, and the pairs a
+    ``drake:collision_filter_group`` lists under ``drake:ignored_collision_filter_group``
+    (``assets/contactnets_elbow.urdf:74-78`` of the reference)."""
+    index = {body.name: i for i, body in enumerate(spec.bodies)}
+    groups, ignores = {}, []
+    for element in root:
+        if element.tag.endswith('collision_filter_group'):
+            name = element.get('name')
+            groups[name] = {index[m.get('link')] for m in element if m.tag.endswith('member')}
+            ignores += [(name, i.get('name')) for i in element if i.tag.endswith('ignored_collision_filter_group')]
+    excluded = set()
+    for first, second in ignores:
+        for a in groups.get(first, ()):
+            for b in groups.get(second, ()):
+                excluded.add((min(a, b), max(a, b)))
+    pairs = []
+    geoms = spec.geoms()
+    for ga, (ba, geom_a) in enumerate(geoms):
+        for gb, (bb, geom_b) in enumerate(geoms):
+            if gb <= ga or ba == bb or (min(ba, bb), max(ba, bb)) in excluded:
+                continue
+            if spec.bodies[bb].parent == ba or spec.bodies[ba].parent == bb:
+                continue
+            pairs.append((gb, ga) if TYPE_ORDER[geom_a.kind] > TYPE_ORDER[geom_b.kind] else (ga, gb))
+    return pairs
 
 
 def check_supported(spec: ModelSpec) -> None:
@@ -208,7 +246,11 @@ def check_supported(spec: ModelSpec) -> None:
     for _, geom in geoms:
         if geom.kind == 'polygon' and not 4 <= len(geom.vertices) <= MAX_POLYGON_VERTICES:
             raise NotImplementedError(f'a polygon has 4 to {MAX_POLYGON_VERTICES} vertices (support queries return 4 of them)')
+    if len(spec.pairs) > MAX_PAIRS:
+        raise NotImplementedError(f'at most {MAX_PAIRS} body-body collision candidate (exclude the others with a '
+                                  'drake:collision_filter_group)')
     if any(geom.kind == 'mesh' for _, geom in geoms):
         if not (spec.is_fast() and all(geom.kind == 'mesh' for _, geom in geoms)):
             raise NotImplementedError('mesh (DeepSupportConvex) geometry: a serial chain of at most one joint with exactly '
-                                      'one mesh on every body (contactnets_cube_mesh.urdf, contactnets_elbow_mesh.urdf)')
+                                      'one mesh on every body and no body-body candidates (contactnets_cube_mesh.urdf, '
+                                      'contactnets_elbow_mesh.urdf)')

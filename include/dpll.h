@@ -38,6 +38,8 @@ extern "C" {
 #define DPLL_MAX_JOINTS 2
 #define DPLL_MAX_BODIES 3
 #define DPLL_MAX_GEOMS 3
+#define DPLL_MAX_PAIRS 1                         /* body-body collision candidates */
+#define DPLL_GEN_SLOTS (DPLL_MAX_GEOMS + DPLL_MAX_PAIRS) /* geometry slots of the general build: a pair sits behind the geometries */
 
 enum dpll_dtype { DPLL_F32 = 0, DPLL_F64 = 1 };
 enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1 };
@@ -64,6 +66,13 @@ typedef struct dpll_model_desc {
   int32_t geom_body[DPLL_MAX_GEOMS];
   int32_t geom_kind[DPLL_MAX_GEOMS];       /* dpll_geom_kind */
   int32_t geom_nverts[DPLL_MAX_GEOMS];     /* DPLL_GEOM_POLYGON: vertices, 4 .. DPLL_MAX_POLYGON_VERTICES */
+  /* body-body collision candidates beyond the ground pairs (ContactTerms.collision_candidates, multibody_terms.py:286-297;
+   * GeometryCollider.collide_mesh_mesh, geometry.py:585-643: ONE contact per pair along a direction found by an exact
+   * search in place of fcl): geometry pair_a[p] against geometry pair_b[p], on different bodies */
+  int32_t n_pairs;
+  int32_t pair_a[DPLL_MAX_PAIRS];
+  int32_t pair_b[DPLL_MAX_PAIRS];
+  int32_t reserved;
 } dpll_model_desc_t;
 
 typedef struct dpll_solver_opts {
@@ -90,8 +99,8 @@ typedef struct dpll_model dpll_model_t;
 /* Learnable parameters of one call: device pointers, caller owned, never written. */
 typedef struct dpll_params {
   const void* theta;    /* (n_bodies, 10) */
-  const void* friction; /* fast builds (1 + n_bodies,); general build (1 + DPLL_MAX_GEOMS,), unused entries any non-zero number */
-  const void* lengths;  /* fast builds (n_bodies, 3): length_params of the boxes.  General build (DPLL_MAX_GEOMS, DPLL_GEOM_BLOCK),
+  const void* friction; /* fast builds (1 + n_bodies,); general build (1 + DPLL_GEN_SLOTS,): ground, the geometries, padding (any non-zero number) */
+  const void* lengths;  /* fast builds (n_bodies, 3): length_params of the boxes.  General build (DPLL_GEN_SLOTS, DPLL_GEOM_BLOCK),
                            geometry g's block: box length_params (3) | sphere length_param (1) | polygon vertices
                            (geom_nverts, 3) row-major; the rest of a block is padding (its gradient comes back zero) */
 } dpll_params_t;
@@ -108,7 +117,7 @@ int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts
 int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
 int dpll_n_contacts(const dpll_model_t* model);   /* 4 n_bodies */
 int dpll_param_count(const dpll_model_t* model);  /* layout [theta | friction | lengths] as in dpll_params_t: fast builds
-                                                     10 n_b + (1 + n_b) + 3 n_b, general build 10 n_b + 4 + 3 DPLL_GEOM_BLOCK */
+                                                     10 n_b + (1 + n_b) + 3 n_b, general build 10 n_b + (1 + DPLL_GEN_SLOTS) + DPLL_GEN_SLOTS DPLL_GEOM_BLOCK */
 
 /* bytes of scratch dpll_contactnets_loss needs for a batch of `batch` items (gradient partial sums) */
 int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch);

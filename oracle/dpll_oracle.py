@@ -150,8 +150,44 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
                 sorted_names.append(child)
     assert len(sorted_names) == len(order)
     bodies = [links[n] for n in sorted_names]
-    return {'name': root.get('name'), 'bodies': bodies, 'n_joints': len(bodies) - 1,
-            'ground_mu': GROUND_MU}
+    spec = {'name': root.get('name'), 'bodies': bodies, 'n_joints': len(bodies) - 1, 'ground_mu': GROUND_MU}
+    spec['pairs'] = collision_candidates(root, spec)
+    return spec
+
+
+PAIR_TIE = 1e-12  # metres: support values closer than this are a tie (witness vertex of a body-body contact)
+_TYPE_ORDER = {'plane': 0, 'polygon': 1, 'box': 2, 'sphere': 3, 'mesh': 4}  # reference geometry.py:46
+
+
+def collision_candidates(root, spec: Dict) -> List[Tuple[int, int]]:
+    """Body-body pairs of ContactTerms.collision_candidates (reference multibody_terms.py:286-297) as indices into
+    geometry_table: what Drake's GetCollisionCandidates (drake_utils.py:178-184) keeps beyond the ground pairs --
+    geometries of two bodies that no joint connects (Drake filters adjacent bodies) and no drake:collision_filter_group
+    excludes (assets/contactnets_elbow.urdf:74-78) -- each pair swapped into the reference's type order (:294-297)."""
+    index = {body['name']: i for i, body in enumerate(spec['bodies'])}
+    groups, ignores = {}, []
+    for element in root:
+        if element.tag.endswith('collision_filter_group'):
+            groups[element.get('name')] = {index[m.get('link')] for m in element if m.tag.endswith('member')}
+            ignores += [(element.get('name'), i.get('name')) for i in element
+                        if i.tag.endswith('ignored_collision_filter_group')]
+    excluded = set()
+    for first, second in ignores:
+        for a in groups.get(first, ()):
+            for b in groups.get(second, ()):
+                excluded.add((min(a, b), max(a, b)))
+    table = geometry_table(spec)
+    pairs = []
+    for ia in range(1, len(table)):
+        for ib in range(ia + 1, len(table)):
+            ba, bb = table[ia]['body'], table[ib]['body']
+            if ba == bb or (min(ba, bb), max(ba, bb)) in excluded:
+                continue
+            if spec['bodies'][bb]['parent'] == ba or spec['bodies'][ba]['parent'] == bb:
+                continue
+            swap = _TYPE_ORDER[table[ia]['kind']] > _TYPE_ORDER[table[ib]['kind']]
+            pairs.append((ib, ia) if swap else (ia, ib))
+    return pairs
 
 
 def geometry_table(spec: Dict) -> List[Dict]:
@@ -468,6 +504,84 @@ def topk_support(directions: Tensor, vertices: Tensor, n_query: int = N_QUERY) -
     return torch.gather(vertices, -2, order.unsqueeze(-1).expand(order.shape + (3,)))
 
 
+def rotation_matrix_from_one_vector(directions: Tensor, axis: int = 2) -> Tensor:
+    """reference tensor_utils.py:305-366 (after Drake's MakeFromOneVector): R with R[:, axis] = d."""
+    a = directions / directions.norm(dim=-1, keepdim=True)
+    flat = a.reshape(-1, 3)
+    rows = torch.arange(flat.shape[0])
+    i = torch.abs(flat).min(dim=-1).indices
+    j, k = (i + 1) % 3, (i + 2) % 3
+    a_i, a_j, a_k = flat[rows, i], flat[rows, j], flat[rows, k]
+    mag = torch.sqrt(1 - a_i * a_i)
+    corr = -a_i / mag
+    col_b = torch.zeros_like(flat)
+    col_b[rows, j] = -a_k / mag
+    col_b[rows, k] = a_j / mag
+    col_c = torch.zeros_like(flat)
+    col_c[rows, i] = mag
+    col_c[rows, j] = corr * a_j
+    col_c[rows, k] = corr * a_k
+    columns = [None, None, None]
+    columns[axis], columns[(axis + 1) % 3], columns[(axis + 2) % 3] = flat, col_b, col_c
+    return torch.stack(columns, -1).reshape(directions.shape + (3,))
+
+
+def _closest_on_triangles(tri):
+    """closest point to the origin on each triangle (T, 3, 3) (Ericson, Real-Time Collision Detection 5.1.5)"""
+    import numpy as np
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    ab, ac, ap = b - a, c - a, -a
+    d1, d2 = (ab * ap).sum(-1), (ac * ap).sum(-1)
+    bp = -b
+    d3, d4 = (ab * bp).sum(-1), (ac * bp).sum(-1)
+    cp = -c
+    d5, d6 = (ab * cp).sum(-1), (ac * cp).sum(-1)
+    va, vb, vc = d3 * d6 - d5 * d4, d5 * d2 - d1 * d6, d1 * d4 - d3 * d2
+    out = np.zeros_like(a)
+    done = np.zeros(len(a), dtype=bool)
+
+    def put(mask, value):
+        nonlocal done
+        mask = mask & ~done
+        out[mask] = value[mask]
+        done |= mask
+    with np.errstate(divide='ignore', invalid='ignore'):
+        put((d1 <= 0) & (d2 <= 0), a)
+        put((d3 >= 0) & (d4 <= d3), b)
+        put((vc <= 0) & (d1 >= 0) & (d3 <= 0), a + (d1 / (d1 - d3))[:, None] * ab)
+        put((d6 >= 0) & (d5 <= d6), c)
+        put((vb <= 0) & (d2 >= 0) & (d6 <= 0), a + (d2 / (d2 - d6))[:, None] * ac)
+        put((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), b + ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[:, None] * (c - b))
+        denom = 1.0 / (va + vb + vc)
+        put(np.ones(len(a), dtype=bool), a + ab * (vb * denom)[:, None] + ac * (vc * denom)[:, None])
+    return out
+
+
+def pair_direction_exact(verts_a, verts_b):
+    """fcl's role in collide_mesh_mesh (reference geometry.py:603-625), exactly: the unit direction from A to B that
+    maximises the separation  min_b d.b - max_a d.a  of two convex vertex sets given in one frame -- the direction
+    between the nearest points when they are apart (what fcl.distance's nearest points give, :621-625), the direction
+    of minimum penetration when they overlap (the canonical stand-in for fcl.collide's first contact normal, :615-618).
+    Computed on the Minkowski difference B - A: its convex hull (qhull) either contains the origin (closest facet) or
+    not (closest point of its triangles).  numpy (n_a, 3), (n_b, 3) -> (3,)."""
+    import numpy as np
+    from scipy.spatial import ConvexHull, QhullError
+    diff = (verts_b[None, :, :] - verts_a[:, None, :]).reshape(-1, 3)
+    if diff.shape[0] == 1:
+        return diff[0] / np.linalg.norm(diff[0])
+    centred = diff - diff.mean(0)
+    rank = np.linalg.matrix_rank(centred, tol=1e-12 * max(1.0, np.abs(diff).max()))
+    if rank < 3:
+        raise NotImplementedError('flat Minkowski difference')
+    hull = ConvexHull(diff)
+    normals, offsets = hull.equations[:, :3], hull.equations[:, 3]
+    if (offsets <= 0).all():  # origin inside: facet plane closest to the origin, direction against its outward normal
+        return -normals[np.argmax(offsets)]
+    closest = _closest_on_triangles(diff[hull.simplices])
+    best = closest[np.argmin((closest ** 2).sum(-1))]
+    return best / np.linalg.norm(best)
+
+
 def icnn_support_point(weights: Dict[str, Tensor], directions: Tensor, negative_slope: float = 0.5) -> Tensor:
     """HomogeneousICNN.forward (reference deep_support_function.py:238-266): returns
     d f / d direction of the depth-D network of :213-236 with |W_h|, |w_out| (:189-194) and
@@ -730,7 +844,7 @@ class OracleSystem:
         self.n_v = 6 + self.n_joints
         self.n_x = self.n_q + self.n_v
         # witness points per geometry: 4 (box: geometry.py:490; mesh: :47-48), 1 for a sphere (:440-452)
-        self.n_contacts = sum(1 if g['kind'] == 'sphere' else N_QUERY for g in self.geoms[1:])
+        self.n_contacts = sum(1 if g['kind'] == 'sphere' else N_QUERY for g in self.geoms[1:]) + len(self.spec['pairs'])
         pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
                               for b in self.spec['bodies']], dtype=torch.float64)
         # theta_0 = pi_o_to_theta(drake inertia), reference multibody_terms.py:186-188
@@ -800,9 +914,60 @@ class OracleSystem:
         weights = {k: v for k, v in params.items() if k != 'perturbations'}
         return mesh_support(weights, params['perturbations'], directions)
 
+    def vertex_set(self, geom_index: int) -> Tuple[Tensor, Tensor]:
+        """(vertices (N, 3), margin) of a geometry for the direction search: a sphere is its centre plus the radius"""
+        params = self.geom_params[geom_index]
+        if 'length_params' in params:
+            return box_vertices(params['length_params']), torch.zeros((), dtype=self.dtype)
+        if 'length_param' in params:
+            return torch.zeros((1, 3), dtype=self.dtype), torch.abs(params['length_param'])
+        if 'vertices' in params:
+            return params['vertices'], torch.zeros((), dtype=self.dtype)
+        raise NotImplementedError('body-body contact of DeepSupportConvex geometries')
+
+    def support_single(self, geom_index: int, directions: Tensor) -> Tensor:
+        """what `geometry.network(directions)` is to collide_mesh_mesh (reference geometry.py:627-629): ONE support point
+        per direction -- the vertex furthest along it (ties: lowest index) plus, for a sphere, the radius along it"""
+        vertices, margin = self.vertex_set(geom_index)
+        dots = (directions @ vertices.transpose(-1, -2)).detach()
+        # the lowest index among the vertices within PAIR_TIE of the furthest one: a direction that is a face or edge
+        # normal of the shape itself ties several vertices up to rounding (a support-function network has no such ties)
+        best = torch.zeros(dots.shape[:-1], dtype=torch.long)
+        value = dots[..., 0].clone()
+        for u in range(1, dots.shape[-1]):
+            better = dots[..., u] > value + PAIR_TIE
+            best = torch.where(better, torch.full_like(best, u), best)
+            value = torch.where(better, dots[..., u], value)
+        return vertices[best] + margin * directions
+
+    def collide_pair(self, a_index: int, b_index: int, R_AB: Tensor, p_AoBo_A: Tensor):
+        """GeometryCollider.collide_mesh_mesh, reference geometry.py:585-643, with fcl's direction replaced by
+        pair_direction_exact and `network(d)` by the geometry's own support function."""
+        import numpy as np
+        batch = p_AoBo_A.shape[:-1]
+        R = R_AB.reshape(-1, 3, 3)
+        p = p_AoBo_A.reshape(-1, 3)
+        va, _ = self.vertex_set(a_index)
+        vb, _ = self.vertex_set(b_index)
+        directions = torch.zeros_like(p)
+        with torch.no_grad():  # "collision directions are piecewise constant" (:597-600)
+            for n in range(p.shape[0]):
+                vb_in_a = vb.detach() @ R[n].detach().t() + p[n].detach()
+                directions[n] = torch.tensor(pair_direction_exact(va.detach().numpy().astype(np.float64),
+                                                                  vb_in_a.numpy().astype(np.float64)), dtype=p.dtype)
+        directions = directions / directions.norm(dim=-1, keepdim=True)
+        R_AC = rotation_matrix_from_one_vector(directions, 2)
+        p_AoAc_A = self.support_single(a_index, directions)
+        p_BoBc_B = self.support_single(b_index, -(directions.unsqueeze(-2) @ R).squeeze(-2))
+        p_BoBc_A = (p_BoBc_B.unsqueeze(-2) @ R.transpose(-1, -2)).squeeze(-2)
+        p_AcBc_A = -p_AoAc_A + p + p_BoBc_A
+        phi = (p_AcBc_A * R_AC[..., 2]).sum(-1)
+        return (phi.reshape(batch + (1,)), R_AC.reshape(batch + (1, 3, 3)), p_AoAc_A.reshape(batch + (1, 3)),
+                p_BoBc_B.reshape(batch + (1, 3)))
+
     def contact_terms(self, q: Tensor) -> Tuple[Tensor, Tensor]:
-        """ContactTerms.forward, reference multibody_terms.py:428-521, for the
-        plane-vs-convex pairs (geometry.py:554-582)."""
+        """ContactTerms.forward, reference multibody_terms.py:428-521: the plane-vs-convex pairs (geometry.py:554-582)
+        first, then the body-body candidates (geometry.py:585-643)."""
         R_WC, p_WoCo_W, Jv_V_WC_W = geometry_kinematics(self.spec, q)
         mu_all = torch.abs(self.friction)  # :321-324
         phis, jacs, mus = [], [], []
@@ -830,6 +995,23 @@ class OracleSystem:
             jacs.append(R_FW @ (J_B - J_A))  # (*, 4, 3, n_v)
             phis.append(phi_i)
             mus.append(mu.repeat(phi_i.shape[-1]))
+        for a_index, b_index in self.spec['pairs']:
+            mu = 2 * mu_all[a_index] * mu_all[b_index] / (mu_all[a_index] + mu_all[b_index])
+            R_WA = R_WC[..., a_index, :, :]
+            R_WB = R_WC[..., b_index, :, :]
+            R_AW = R_WA.transpose(-1, -2)
+            R_AB = R_AW @ R_WB
+            p_AoBo_A = (R_AW @ (p_WoCo_W[..., b_index, :] - p_WoCo_W[..., a_index, :]).unsqueeze(-1)).squeeze(-1)
+            phi_i, R_AF, p_AoAc_A, p_BoBc_B = self.collide_pair(a_index, b_index, R_AB, p_AoBo_A)
+            R_FW = R_AF.transpose(-1, -2) @ R_AW.unsqueeze(-3)  # :494-495
+            p_AoAc_W = p_AoAc_A @ R_AW
+            p_BoBc_W = p_BoBc_B @ R_WB.transpose(-1, -2)
+            eye = torch.eye(3, dtype=q.dtype).expand(p_BoBc_W.shape + (3,))
+            J_A = torch.cat((-skew(p_AoAc_W), eye), -1) @ Jv_V_WC_W[..., a_index, :, :].unsqueeze(-3)
+            J_B = torch.cat((-skew(p_BoBc_W), eye), -1) @ Jv_V_WC_W[..., b_index, :, :].unsqueeze(-3)
+            jacs.append(R_FW @ (J_B - J_A))
+            phis.append(phi_i)
+            mus.append(mu.repeat(1))
         phi = torch.cat(phis, -1)
         Jc = torch.cat(jacs, -3)  # (*, k, 3, n_v)
         mu_rep = torch.cat(mus)

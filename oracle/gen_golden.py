@@ -13,6 +13,12 @@ InertialParameterConverter, state_space, quaternion, TrajectorySliceDataset and
 DrakeMultibodyLearnableExperiment.contactnets_loss -- is the reference's unmodified code,
 and its outputs are what the fixtures record.
 
+Body-body contact (GeometryCollider.collide_mesh_mesh, geometry.py:585-643) asks `fcl` for one direction per pair; here
+`fcl` is `DirectionSearchFcl` below -- the few entry points collide_mesh_mesh calls, answered by the oracle's exact
+direction search (oracle.pair_direction_exact) -- so that the reference's own collide_mesh_mesh / ContactTerms.forward
+arithmetic (contact frame, witness points, signed distance, Jacobian difference, friction combination, contact order)
+runs on the pair fixtures.  The direction itself stays the oracle's: fcl's role is parity-unpinned.
+
     python oracle/gen_golden.py            # rewrites tests/golden/*.npz
 """
 import os
@@ -28,6 +34,75 @@ ASSETS = os.path.join(REFERENCE, 'assets')
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 DT = 0.0068  # reference examples/contactnets_simple.py:52
 
+
+
+class DirectionSearchFcl:
+    """What reference geometry.py:603-625 uses of fcl, for shapes given as (vertices (N, 3), margin): `collide`
+    reports one contact whose normal is the direction of minimum penetration, `distance` nearest points whose difference
+    is the nearest-points direction."""
+
+    class Transform:
+        def __init__(self, rotation=None, translation=None):
+            self.R = np.eye(3) if rotation is None else np.asarray(rotation, dtype=np.float64)
+            self.p = np.zeros(3) if translation is None else np.asarray(translation, dtype=np.float64)
+
+    class CollisionObject:
+        def __init__(self, shape, transform):
+            self.shape, self.transform = shape, transform
+
+        def setTransform(self, transform):  # noqa: N802 (fcl's name)
+            self.transform = transform
+
+        def world(self):
+            vertices, margin = self.shape
+            return vertices @ self.transform.R.T + self.transform.p, margin
+
+    class CollisionRequest:
+        enable_contact = False
+
+    class DistanceRequest:
+        enable_nearest_points = False
+
+    class CollisionResult:
+        def __init__(self):
+            self.contacts = []
+
+    class DistanceResult:
+        def __init__(self):
+            self.nearest_points = [np.zeros(3), np.zeros(3)]
+
+    class _Contact:
+        def __init__(self, normal):
+            self.normal = normal
+
+    @staticmethod
+    def _search(a_obj, b_obj):
+        (va, ma), (vb, mb) = a_obj.world(), b_obj.world()
+        direction = _oracle().pair_direction_exact(va, vb)
+        separation = (vb @ direction).min() - (va @ direction).max() - ma - mb
+        return direction, separation
+
+    @staticmethod
+    def collide(a_obj, b_obj, request, result):
+        direction, separation = DirectionSearchFcl._search(a_obj, b_obj)
+        if separation < 0:
+            result.contacts = [DirectionSearchFcl._Contact(torch.tensor(direction))]
+            return 1
+        return 0
+
+    @staticmethod
+    def distance(a_obj, b_obj, request, result):
+        direction, separation = DirectionSearchFcl._search(a_obj, b_obj)
+        result.nearest_points = [np.zeros(3), separation * direction]
+        return separation
+
+
+def _oracle():
+    from oracle import dpll_oracle
+    return dpll_oracle
+
+
+sys.modules['fcl'] = DirectionSearchFcl
 for _name in ['fcl', 'pywavefront', 'sappy', 'drake_pytorch', 'optuna', 'optuna.trial', 'optuna.logging', 'wandb',
               'pydrake', 'pydrake.geometry', 'pydrake.multibody', 'pydrake.multibody.plant',
               'pydrake.multibody.tree', 'pydrake.multibody.parsing', 'pydrake.symbolic', 'pydrake.systems',
@@ -71,6 +146,50 @@ class RecordingSolver:
         return f
 
 
+class VertexSupport(nn.Module):
+    """`network` of a pair member: one support point per direction, as DeepSupportConvex.network returns it
+    (geometry.py:627-629) -- the vertex furthest along the direction (+ a sphere's radius along it), ties by the
+    oracle's rule (oracle.PAIR_TIE)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, 'owner', owner)  # not a submodule: the owner holds this module
+
+    def forward(self, directions):
+        vertices, margin = self.owner.vertex_set()
+        dots = (directions @ vertices.t()).detach()
+        best = torch.zeros(dots.shape[:-1], dtype=torch.long)
+        value = dots[..., 0].clone()
+        for u in range(1, dots.shape[-1]):
+            better = dots[..., u] > value + O.PAIR_TIE
+            best = torch.where(better, torch.full_like(best, u), best)
+            value = torch.where(better, dots[..., u], value)
+        return vertices[best] + margin * directions
+
+
+def pair_member(base, geometry):
+    """`geometry` (a reference Box / Sphere / Polygon) re-typed so that GeometryCollider.collide dispatches a pair of them
+    to collide_mesh_mesh (geometry.py:543-546 tests for DeepSupportConvex): a class of the same name -- the reference's
+    type order reads the class name (:66-69) -- that also derives from DeepSupportConvex, with `network` the shape's own
+    support function and `get_fcl_geometry` its vertex set for DirectionSearchFcl.  Ground contacts still go through the
+    base class's support_points."""
+    def vertex_set(self):
+        if base is Box:
+            return self.get_vertices(torch.zeros(3)), torch.zeros(())
+        if base is Sphere:
+            return torch.zeros((1, 3)), torch.abs(self.length_param)
+        return self.vertices, torch.zeros(())
+
+    def get_fcl_geometry(self):
+        vertices, margin = self.vertex_set()
+        return vertices.detach().numpy().astype(np.float64), float(margin)
+    cls = type(base.__name__, (base, DeepSupportConvex), {'vertex_set': vertex_set, 'get_fcl_geometry': get_fcl_geometry,
+                                                          'train': nn.Module.train})
+    geometry.__class__ = cls
+    geometry.network = VertexSupport(geometry)
+    return geometry
+
+
 def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0, mesh_representation: str = 'deep_support'):
     """The reference's MultibodyLearnableSystem with Drake-dependent construction bypassed."""
     spec = O.parse_urdf(urdf, mesh_representation)
@@ -109,10 +228,16 @@ def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0, mes
             # one seed per network: mesh_seed for the first (the cube), mesh_seed + 1 for the elbow's second link, ...
             torch.manual_seed(mesh_seed + sum(isinstance(m, DeepSupportConvex) for m in modules))
             modules.append(DeepSupportConvex(torch.tensor(geom['vertices'])))
+    for a_index, b_index in spec['pairs']:  # body-body candidates: both members take the collide_mesh_mesh path
+        for index in (a_index, b_index):
+            if not isinstance(modules[index], DeepSupportConvex):
+                modules[index] = pair_member(type(modules[index]), modules[index])
     ct.geometries = ModuleList(modules)
     ct.friction_params = Parameter(torch.tensor([g['mu'] for g in geoms]), requires_grad=True)
     n_g = len(geoms)
-    ct.collision_candidates = torch.tensor([[0] * (n_g - 1), list(range(1, n_g))]).long()
+    # ground pairs in geometry order, then the body-body candidates (quirk Q8: Drake's order is not specified)
+    ct.collision_candidates = torch.tensor([[0] * (n_g - 1) + [a for a, _ in spec['pairs']],
+                                            list(range(1, n_g)) + [b for _, b in spec['pairs']]]).long()
 
     mt = MultibodyTerms.__new__(MultibodyTerms)
     nn.Module.__init__(mt)
@@ -137,7 +262,7 @@ def named_grads(system) -> dict:
 def named_values(system) -> dict:
     out = {name: param.detach().clone().numpy() for name, param in system.named_parameters()}
     for index, geometry in enumerate(system.multibody_terms.contact_terms.geometries):
-        if isinstance(geometry, DeepSupportConvex):
+        if isinstance(geometry, DeepSupportConvex) and hasattr(geometry, 'perturbations'):  # (not a pair_member)
             out[f'multibody_terms.contact_terms.geometries.{index}.perturbations'] = \
                 geometry.perturbations.detach().clone().numpy()
     return out
@@ -407,6 +532,43 @@ def record_polygon_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, 
                     prepare=jitter)
 
 
+def pair_tosses(urdf: str, representation: str, n_traj: int, steps: int, keep_every: int, seed: int):
+    """`general_tosses` started with the joints folded so that the body-body pair is about to meet: joint angles drawn
+    uniformly, kept when the pair's signed distance (a function of the joints alone) is between 0 and 8 mm."""
+    system, spec = build_reference_system(urdf, 'reference_literal', mesh_representation=representation)
+    n_j = spec['n_joints']
+    gen = torch.Generator().manual_seed(seed)
+    trial = torch.zeros((4000, 7 + n_j))
+    trial[:, 0] = 1.0
+    trial[:, 7:] = (2 * torch.rand((4000, n_j), generator=gen) - 1) * np.pi
+    with torch.no_grad():
+        phi = system.multibody_terms.contact_terms(trial)[0][:, -1]
+    joints = trial[(phi > 0) & (phi < 0.008)][:n_traj, 7:]
+    assert joints.shape[0] == n_traj
+    quat = torch.randn((n_traj, 4), generator=gen)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    pos = torch.cat((0.05 * torch.randn((n_traj, 2), generator=gen), 0.06 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
+    vel = torch.cat((4.0 * torch.randn((n_traj, 3), generator=gen), 0.4 * torch.randn((n_traj, 3), generator=gen),
+                     3.0 * torch.randn((n_traj, n_j), generator=gen)), -1)
+    x_0 = torch.cat((quat, pos, joints, vel), -1)
+    with torch.no_grad():
+        traj, _ = system.simulate(x_0.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
+    x = traj[:, :-1][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+    x_plus = traj[:, 1:][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+    return x, x_plus
+
+
+def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+    """SURVEY 8f-4, body-body contact: the reference's GeometryCollider.collide_mesh_mesh / ContactTerms.forward pair
+    path (geometry.py:585-643, multibody_terms.py:428-521) on a base and a tip that fold onto each other -- box against
+    box, and a sphere against a polygon (the pair swapped into the reference's type order) -- with fcl's direction
+    supplied by DirectionSearchFcl.  Inputs: `pair_tosses`."""
+    for name, representation in (('clasp', 'deep_support'), ('clasp_ball', 'polygon')):
+        urdf = os.path.join(REPO, 'assets', name + '.urdf')
+        x, x_plus = pair_tosses(urdf, representation, n_traj, steps, keep_every, seed)
+        record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3, mesh_representation=representation)
+
+
 def record_elbow_mesh() -> None:
     """contactnets_elbow_mesh.urdf: a DeepSupportConvex on each link (two independent networks), on every 4th of the
     synthetic elbow pairs."""
@@ -433,6 +595,7 @@ def main() -> None:
     record_general_cases()
     record_elbow_mesh()
     record_polygon_cases()
+    record_pair_cases()
 
 
 if __name__ == '__main__':

@@ -47,8 +47,9 @@ def default_opts(dtype) -> SolverOpts:
 
 
 def n_geom_slots(desc: ModelDesc) -> int:
-    """geometry slots of the build that serves this model: one per body (fast builds) or always 3 (general build)"""
-    return 3 if desc.n_geoms > 0 else desc.n_joints + 1
+    """geometry slots of the build that serves this model: one per body (fast builds) or always 4 (general build: three
+    geometries + the slot of a body-body pair)"""
+    return 4 if desc.n_geoms > 0 else desc.n_joints + 1
 
 
 def geo_stride(desc: ModelDesc) -> int:
@@ -62,7 +63,7 @@ def general_params(spec):
     are padded (friction 1, lengths 0)."""
     from dair_pll_amd.inertia import pi_cm_to_theta
     fast = spec.is_fast()
-    slots, stride = (spec.n_joints + 1, 3) if fast else (3, 24)
+    slots, stride = (spec.n_joints + 1, 3) if fast else (4, 24)
     theta = np.stack([pi_cm_to_theta(np.array([b.mass] + [b.mass * c for c in b.com] + list(b.inertia_cm))) for b in spec.bodies])
     friction = np.ones(1 + slots)
     lengths = np.zeros((slots, stride))

@@ -58,7 +58,7 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
   for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
-  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k);
+  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
     const bool polygon = MD::kGeneral && md.geom_kind[k / GP] == kGeomPolygon;
     grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
@@ -208,7 +208,7 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
   for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
-  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k);
+  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
     const bool polygon = MD::kGeneral && md.geom_kind[k / GP] == kGeomPolygon;
     grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
@@ -234,9 +234,9 @@ int hostsim_loss_f64(const ModelDesc* md, const SolverOpts* opt, const double* t
                      double scale, double* loss, double* grad, double* force, int32_t* iters) {
   if (md->n_geoms > 0)
     return general_dispatch<double, double>(
-        md, [&](const GeneralDesc& g) { loss_batch<double, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
-        [&](const GeneralDesc& g) { loss_batch<double, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
-        [&](const GeneralDesc& g) { loss_batch<double, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
+        md, [&](const GeneralDesc& g) { loss_batch<double, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<double, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
   if (md->n_joints == 0) loss_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
   else if (md->n_joints == 1) loss_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
   else return -1;
@@ -249,9 +249,9 @@ int hostsim_loss_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
                      double scale, float* loss, double* grad, float* force, int32_t* iters, int mixed) {
   if (md->n_geoms > 0)
     return general_dispatch<float, double>(
-        md, [&](const GeneralDesc& g) { loss_batch<float, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
-        [&](const GeneralDesc& g) { loss_batch<float, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
-        [&](const GeneralDesc& g) { loss_batch<float, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
+        md, [&](const GeneralDesc& g) { loss_batch<float, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<float, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<float, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
   if (md->n_joints == 0) {
     if (mixed) loss_batch<float, double, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
     else loss_batch<float, float, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
@@ -266,9 +266,9 @@ int hostsim_step_f64(const ModelDesc* md, const SolverOpts* opt, const double* t
                      const double* lengths, const double* x, int64_t B, double* x_next, int32_t* iters) {
   if (md->n_geoms > 0)
     return general_dispatch<double, double>(
-        md, [&](const GeneralDesc& g) { step_batch<double, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
-        [&](const GeneralDesc& g) { step_batch<double, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
-        [&](const GeneralDesc& g) { step_batch<double, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
+        md, [&](const GeneralDesc& g) { step_batch<double, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<double, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
   if (md->n_joints == 0) step_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
   else if (md->n_joints == 1) step_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
   else return -1;
@@ -279,9 +279,9 @@ int hostsim_step_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
                      const float* lengths, const float* x, int64_t B, float* x_next, int32_t* iters, int mixed) {
   if (md->n_geoms > 0)
     return general_dispatch<float, double>(
-        md, [&](const GeneralDesc& g) { step_batch<float, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
-        [&](const GeneralDesc& g) { step_batch<float, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
-        [&](const GeneralDesc& g) { step_batch<float, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
+        md, [&](const GeneralDesc& g) { step_batch<float, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<float, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<float, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
   if (md->n_joints == 0) {
     if (mixed) step_batch<float, double, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
     else step_batch<float, float, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
@@ -314,9 +314,9 @@ int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const 
                               double* xbar) {
   if (md->n_geoms > 0)
     return general_dispatch<double, double>(
-        md, [&](const GeneralDesc& g) { step_backward_batch<double, double, 0, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
-        [&](const GeneralDesc& g) { step_backward_batch<double, double, 1, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
-        [&](const GeneralDesc& g) { step_backward_batch<double, double, 2, kMaxGeoms>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); });
+        md, [&](const GeneralDesc& g) { step_backward_batch<double, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
+        [&](const GeneralDesc& g) { step_backward_batch<double, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
+        [&](const GeneralDesc& g) { step_backward_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); });
   if (md->n_joints == 0) step_backward_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else if (md->n_joints == 1) step_backward_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else return -1;

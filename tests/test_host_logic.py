@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9) + 4 * (2 + 1 + 3 + 3 + 3)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9) + 4 * (2 + 1 + 3 + 3 + 3 + 1 + 1 + 1 + 1)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
@@ -209,10 +209,11 @@ def test_general_models_are_described_for_the_general_build():
     lib = _capi.library()
     expect = {'chain3': (2, [0, 1], [0, 1, 2], [0, 0, 0], 12), 'vee': (2, [0, 0], [0, 1, 2], [0, 0, 0], 12),
               'ballcube': (0, [], [0, 0, 0], [0, 1, 1], 6), 'mace': (1, [0], [0, 1, 1], [0, 1, 0], 9),
-              'wedge': (1, [0], [0, 1, 0], [2, 0, 0], 8)}  # (geom_body / geom_kind entries past n_geoms are zero)
-    block = _capi.GEOM_BLOCK
+              'wedge': (1, [0], [0, 1, 0], [2, 0, 0], 8),  # (geom_body / geom_kind entries past n_geoms are zero)
+              'clasp': (2, [0, 1], [0, 2, 0], [0, 0, 0], 9), 'clasp_ball': (2, [0, 1], [0, 2, 0], [1, 2, 0], 6)}
+    block, slots = _capi.GEOM_BLOCK, _capi.GEN_SLOTS
     for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
-        representation = 'polygon' if name == 'wedge' else 'deep_support'
+        representation = 'polygon' if name in ('wedge', 'clasp_ball') else 'deep_support'
         spec = parse_urdf(os.path.join(ASSET_DIR, name + '.urdf'), representation)
         assert not spec.is_fast() and spec.n_joints == n_joints and spec.n_contacts == n_contacts
         desc = _capi.make_desc(spec, 0.0068)
@@ -221,8 +222,8 @@ def test_general_models_are_described_for_the_general_build():
         assert list(desc.geom_nverts) == [6 if kind == 2 else 0 for kind in kinds]
         handle = ctypes.c_void_p()
         assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
-        assert lib.dpll_n_x(handle) == 13 + 2 * n_joints and lib.dpll_n_contacts(handle) == 12
-        assert lib.dpll_param_count(handle) == 10 * (n_joints + 1) + 4 + 3 * block
+        assert lib.dpll_n_x(handle) == 13 + 2 * n_joints and lib.dpll_n_contacts(handle) == 4 * slots
+        assert lib.dpll_param_count(handle) == 10 * (n_joints + 1) + 1 + slots + slots * block
         system = MultibodyLearnableSystem({name: os.path.join(ASSET_DIR, name + '.urdf')}, 0.0068, device='cpu',
                                           mesh_representation=representation)
         flat = system._packed()
@@ -233,7 +234,7 @@ def test_general_models_are_described_for_the_general_build():
         for g, kind in enumerate(kinds[:len(spec.geoms())]):
             geometry = system.multibody_terms.contact_terms.geometries[g + 1]
             param = {0: 'length_params', 1: 'length_param', 2: 'vertices'}[kind]
-            assert getattr(geometry, param).data_ptr() == flat.data_ptr() + (10 * (n_joints + 1) + 4 + block * g) * flat.element_size()
+            assert getattr(geometry, param).data_ptr() == flat.data_ptr() + (10 * (n_joints + 1) + 1 + slots + block * g) * flat.element_size()
         if name == 'wedge':
             assert names[2].endswith('geometries.1.vertices') and system.multibody_terms.contact_terms.geometries[1].vertices.shape == (6, 3)
             assert 'w_body_v5_z' in system.scalars()
@@ -241,6 +242,17 @@ def test_general_models_are_described_for_the_general_build():
             bad.geom_nverts[0] = 3  # a support query returns 4 vertices (geometry.py:196)
             other = ctypes.c_void_p()
             assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0 and b'4 to 8 vertices' in lib.dpll_last_error()
+        if name.startswith('clasp'):
+            # base and tip: not joined by a joint, not filtered -> a collision candidate, ordered by geometry type
+            expect_pair = (0, 1) if name == 'clasp' else (1, 0)  # (polygon before sphere, geometry.py:46)
+            assert spec.pairs == [expect_pair] and desc.n_pairs == 1 and (desc.pair_a[0], desc.pair_b[0]) == expect_pair
+            assert spec.contact_slots()[-1] == 4 * _capi.MAX_GEOMS
+            bad = _capi.make_desc(spec, 0.0068)
+            bad.pair_b[0] = bad.pair_a[0]
+            other = ctypes.c_void_p()
+            assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0
+        else:
+            assert spec.pairs == [] and desc.n_pairs == 0
         lib.dpll_model_destroy(handle)
     # the cube and the elbow stay on the specialised builds
     assert _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068).n_geoms == 0

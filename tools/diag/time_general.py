@@ -1,0 +1,27 @@
+"""Diagnostic: launch time of the general build's loss (+ gradients) kernel for every general model at B = 4096
+(tiled fixture pairs), f32 and f64.  Run on the MI355X: python tools/diag/time_general.py"""
+import os, sys
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from dair_pll_amd import MultibodyLearnableSystem
+MODELS = {'chain3': ('chain3.urdf', 'deep_support'), 'mace': ('mace.urdf', 'deep_support'), 'wedge': ('wedge.urdf', 'polygon'),
+          'clasp': ('clasp.urdf', 'deep_support'), 'clasp_ball': ('clasp_ball.urdf', 'polygon')}
+for name, (urdf, rep) in MODELS.items():
+    g = np.load(os.path.join(REPO, 'tests', 'golden', name + '_literal.npz'))
+    for dtype in (torch.float32, torch.float64):
+        s = MultibodyLearnableSystem({name: os.path.join(REPO, 'assets', urdf)}, float(g['dt']), dtype=dtype, device='cuda:0',
+                                     mesh_representation=rep)
+        reps = -(-4096 // g['x'].shape[0])
+        x = torch.tensor(np.tile(g['x'], (reps, 1))[:4096], dtype=dtype, device='cuda:0')
+        xp = torch.tensor(np.tile(g['x_plus'], (reps, 1))[:4096], dtype=dtype, device='cuda:0')
+        for _ in range(3):
+            s.contactnets_loss_and_grad(x, xp)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            s.contactnets_loss_and_grad(x, xp)
+        e1.record()
+        torch.cuda.synchronize()
+        print(f'{name:10s} {str(dtype):14s} loss+grad at B=4096: {e0.elapsed_time(e1) * 100:.0f} us per call')
