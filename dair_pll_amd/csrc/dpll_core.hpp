@@ -35,6 +35,13 @@
 #define DPLL_HD inline __attribute__((always_inline))
 #endif
 
+// a real call instead of an inlined copy in every kernel: the body-body direction search (big, rare, off the hot path)
+#if defined(__HIPCC__)
+#define DPLL_HD_CALL __host__ __device__ __attribute__((noinline))
+#else
+#define DPLL_HD_CALL inline __attribute__((noinline))
+#endif
+
 #define DPLL_UNROLL _Pragma("unroll")
 #if defined(__clang__)
 #define DPLL_NOUNROLL _Pragma("clang loop unroll(disable)")
@@ -1158,11 +1165,13 @@ constexpr double kPairTie = 1e-12;   // support values (metres) closer than this
 // rotation_matrix_from_one_vector(d, 2).  fcl's role is taken by an exact search: the unit d maximising the
 // separation  sep(d) = min_b d . b - max_a d . a  of the two vertex sets (apart: the nearest-points direction;
 // overlapping: the direction of minimum penetration), found among the directions the closest features of two convex
-// polytopes can define -- vertex-vertex differences, vertex-edge perpendiculars, normals of vertex triples of either
-// set, cross products of vertex pairs of both (every unit d is a lower bound of the maximum, so candidates that are not
-// real features cost time, never correctness).  A sphere is its centre with the radius as a margin (the margin shifts
+// polytopes can define -- vertex-vertex differences, vertex-edge perpendiculars, face normals of either set, cross
+// products of an edge of each (every unit d is a lower bound of the maximum, so candidates that are not real features
+// -- a polygon's hull is not known: all its vertex pairs and triples are tried -- cost time, never correctness).  A sphere is its centre with the radius as a margin (the margin shifts
 // sep by a constant: same maximiser).
 // ---------------------------------------------------------------------------------------------
+template <typename S> struct IsDual { static constexpr bool value = false; };
+template <typename S> struct IsDual<DualT<S>> { static constexpr bool value = true; };
 template <typename S> struct PairBest {
   S sep;
   S d[3];
@@ -1193,12 +1202,43 @@ DPLL_HD void pair_try(const S (&n)[3], const S (*a)[3], int na, const S (*b)[3],
     DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = -n[i] * inv;
   }
 }
+// Features of a vertex set that can define the direction: its edges (vertex-edge candidates), one edge per edge
+// DIRECTION (edge x edge candidates) and one vertex triple per face normal.  A box: its 12 edges, 3 axis edges and 3
+// faces; a polygon's hull is not known, so every vertex pair and triple stands in (a superset: correct, slower).
+struct PairFeatures {
+  int n_edges, n_dirs, n_tris;
+  unsigned char edges[28][2], dirs[28][2], tris[56][3];
+};
+DPLL_HD void pair_features(int kind, int nv, PairFeatures& f) {
+  f.n_edges = 0; f.n_dirs = 0; f.n_tris = 0;
+  if (kind == kGeomBox) {  // corner u = bits (x y z), reference geometry.py:39-41
+    for (int u = 0; u < 8; ++u)
+      for (int bit = 1; bit <= 4; bit <<= 1)
+        if (!(u & bit)) { f.edges[f.n_edges][0] = (unsigned char)u; f.edges[f.n_edges][1] = (unsigned char)(u | bit); ++f.n_edges; }
+    for (int bit = 1; bit <= 4; bit <<= 1) { f.dirs[f.n_dirs][0] = 0; f.dirs[f.n_dirs][1] = (unsigned char)bit; ++f.n_dirs; }
+    const unsigned char faces[3][3] = {{0, 1, 2}, {0, 1, 4}, {0, 2, 4}};
+    for (int t = 0; t < 3; ++t) { for (int i = 0; i < 3; ++i) f.tris[t][i] = faces[t][i]; }
+    f.n_tris = 3;
+    return;
+  }
+  for (int i = 0; i < nv; ++i)
+    for (int j = i + 1; j < nv; ++j) {
+      f.edges[f.n_edges][0] = f.dirs[f.n_edges][0] = (unsigned char)i;
+      f.edges[f.n_edges][1] = f.dirs[f.n_edges][1] = (unsigned char)j;
+      ++f.n_edges;
+      for (int k = j + 1; k < nv; ++k) { f.tris[f.n_tris][0] = (unsigned char)i; f.tris[f.n_tris][1] = (unsigned char)j; f.tris[f.n_tris][2] = (unsigned char)k; ++f.n_tris; }
+    }
+  f.n_dirs = f.n_edges;
+}
 // vertex sets a (na) and b (nb) in one frame -> unit d from A towards B; runtime loops (the sets live in memory)
 template <typename S>
-DPLL_HD void pair_direction(const S (*a)[3], int na, const S (*b)[3], int nb, S (&d)[3]) {
+DPLL_HD_CALL void pair_direction(const S (*a)[3], int na, int kind_a, const S (*b)[3], int nb, int kind_b, S (&d)[3]) {
   PairBest<S> best;
   best.sep = S(-3.0e38);
   best.d[0] = S(0); best.d[1] = S(0); best.d[2] = S(1);
+  PairFeatures fa, fb;
+  pair_features(kind_a, na, fa);
+  pair_features(kind_b, nb, fb);
   // vertex - vertex
   for (int i = 0; i < na; ++i)
     for (int j = 0; j < nb; ++j) {
@@ -1209,45 +1249,45 @@ DPLL_HD void pair_direction(const S (*a)[3], int na, const S (*b)[3], int nb, S 
   for (int pass = 0; pass < 2; ++pass) {
     const S (*p)[3] = pass == 0 ? a : b;
     const S (*e)[3] = pass == 0 ? b : a;
-    const int np = pass == 0 ? na : nb, ne = pass == 0 ? nb : na;
-    for (int i = 0; i < np; ++i)
-      for (int k = 0; k < ne; ++k)
-        for (int l = k + 1; l < ne; ++l) {
-          const S ed[3] = {e[l][0] - e[k][0], e[l][1] - e[k][1], e[l][2] - e[k][2]};
-          const S w[3] = {e[k][0] - p[i][0], e[k][1] - p[i][1], e[k][2] - p[i][2]};
-          const S ee = ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2];
-          if (!(ee > S(0))) continue;
-          const S t = (w[0] * ed[0] + w[1] * ed[1] + w[2] * ed[2]) / ee;
-          const S n[3] = {w[0] - t * ed[0], w[1] - t * ed[1], w[2] - t * ed[2]};
-          pair_try(n, a, na, b, nb, best);
-        }
-  }
-  // normals of the vertex triples of either set
-  for (int pass = 0; pass < 2; ++pass) {
-    const S (*p)[3] = pass == 0 ? a : b;
+    const PairFeatures& fe = pass == 0 ? fb : fa;
     const int np = pass == 0 ? na : nb;
     for (int i = 0; i < np; ++i)
-      for (int j = i + 1; j < np; ++j)
-        for (int k = j + 1; k < np; ++k) {
-          const S u[3] = {p[j][0] - p[i][0], p[j][1] - p[i][1], p[j][2] - p[i][2]};
-          const S v[3] = {p[k][0] - p[i][0], p[k][1] - p[i][1], p[k][2] - p[i][2]};
-          S n[3];
-          cross(u, v, n);
-          pair_try(n, a, na, b, nb, best);
-        }
+      for (int m = 0; m < fe.n_edges; ++m) {
+        const int k = fe.edges[m][0], l = fe.edges[m][1];
+        const S ed[3] = {e[l][0] - e[k][0], e[l][1] - e[k][1], e[l][2] - e[k][2]};
+        const S w[3] = {e[k][0] - p[i][0], e[k][1] - p[i][1], e[k][2] - p[i][2]};
+        const S ee = ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2];
+        if (!(ee > S(0))) continue;
+        const S t = (w[0] * ed[0] + w[1] * ed[1] + w[2] * ed[2]) / ee;
+        const S n[3] = {w[0] - t * ed[0], w[1] - t * ed[1], w[2] - t * ed[2]};
+        pair_try(n, a, na, b, nb, best);
+      }
   }
-  // edge x edge
-  for (int i = 0; i < na; ++i)
-    for (int j = i + 1; j < na; ++j) {
-      const S u[3] = {a[j][0] - a[i][0], a[j][1] - a[i][1], a[j][2] - a[i][2]};
-      for (int k = 0; k < nb; ++k)
-        for (int l = k + 1; l < nb; ++l) {
-          const S v[3] = {b[l][0] - b[k][0], b[l][1] - b[k][1], b[l][2] - b[k][2]};
-          S n[3];
-          cross(u, v, n);
-          pair_try(n, a, na, b, nb, best);
-        }
+  // face normals of either set
+  for (int pass = 0; pass < 2; ++pass) {
+    const S (*p)[3] = pass == 0 ? a : b;
+    const PairFeatures& fp = pass == 0 ? fa : fb;
+    for (int m = 0; m < fp.n_tris; ++m) {
+      const int i = fp.tris[m][0], j = fp.tris[m][1], k = fp.tris[m][2];
+      const S u[3] = {p[j][0] - p[i][0], p[j][1] - p[i][1], p[j][2] - p[i][2]};
+      const S v[3] = {p[k][0] - p[i][0], p[k][1] - p[i][1], p[k][2] - p[i][2]};
+      S n[3];
+      cross(u, v, n);
+      pair_try(n, a, na, b, nb, best);
     }
+  }
+  // edge direction x edge direction
+  for (int m = 0; m < fa.n_dirs; ++m) {
+    const int i = fa.dirs[m][0], j = fa.dirs[m][1];
+    const S u[3] = {a[j][0] - a[i][0], a[j][1] - a[i][1], a[j][2] - a[i][2]};
+    for (int o = 0; o < fb.n_dirs; ++o) {
+      const int k = fb.dirs[o][0], l = fb.dirs[o][1];
+      const S v[3] = {b[l][0] - b[k][0], b[l][1] - b[k][1], b[l][2] - b[k][2]};
+      S n[3];
+      cross(u, v, n);
+      pair_try(n, a, na, b, nb, best);
+    }
+  }
   DPLL_UNROLL for (int i = 0; i < 3; ++i) d[i] = best.d[i];
 }
 
@@ -1342,6 +1382,9 @@ DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, co
   TA dA[3];
   if (dir_in) {
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dA[i] = dir_in[i];
+  } else if constexpr (IsDual<TA>::value) {
+    // (the dual passes of the state adjoint always get the direction of the primal pass: no search code for them)
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) dA[i] = TA(i == 2 ? 1.0 : 0.0);
   } else {
     // B's vertices in the frame of A: R_A^T (c_B + R_B v - c_A)
     TA vbA[kMaxPolyVerts][3];
@@ -1351,7 +1394,7 @@ DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, co
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rel[i] = w[i] + cB[i] - cA[i];
       mat3t_vec(RA, rel, vbA[u]);
     }
-    pair_direction<TA>(va, na, vbA, nb, dA);
+    pair_direction<TA>(va, na, md.geom_kind[ga], vbA, nb, md.geom_kind[gb], dA);
   }
   TA dW[3], dB[3], ndW[3];
   mat3_vec(RA, dA, dW);

@@ -161,3 +161,13 @@ def step_backward(desc: ModelDesc, theta, friction, lengths, x, xbar_next, opts=
                                              _ptr(lengths), _ptr(x), _ptr(xbar_next), c_int64(x.shape[0]), _ptr(grad), _ptr(xbar))
     assert status == 0
     return (grad, xbar) if want_state else grad
+
+
+def pair_direction(kind_a: int, verts_a, kind_b: int, verts_b):
+    """csrc/dpll_core.hpp pair_direction on two vertex sets (n, 3) in one frame -> unit direction from A to B"""
+    va = np.ascontiguousarray(np.asarray(verts_a, dtype=np.float64))
+    vb = np.ascontiguousarray(np.asarray(verts_b, dtype=np.float64))
+    out = np.zeros(3)
+    status = lib().hostsim_pair_direction(c_int(kind_a), _ptr(va), c_int(va.shape[0]), c_int(kind_b), _ptr(vb), c_int(vb.shape[0]), _ptr(out))
+    assert status == 0
+    return out

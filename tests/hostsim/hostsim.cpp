@@ -60,7 +60,7 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
   for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
-    const bool polygon = MD::kGeneral && md.geom_kind[k / GP] == kGeomPolygon;
+    const bool polygon = MD::kGeneral && k / GP < kMaxGeoms && md.geom_kind[k / GP < kMaxGeoms ? k / GP : 0] == kGeomPolygon;
     grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
   }
 }
@@ -210,7 +210,7 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
   for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
-    const bool polygon = MD::kGeneral && md.geom_kind[k / GP] == kGeomPolygon;
+    const bool polygon = MD::kGeneral && k / GP < kMaxGeoms && md.geom_kind[k / GP < kMaxGeoms ? k / GP : 0] == kGeomPolygon;
     grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
   }
 }
@@ -324,6 +324,17 @@ int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const 
 }
 
 int hostsim_sizeof_model_desc() { return (int)sizeof(ModelDesc); }
+
+// the body-body direction search of csrc/dpll_core.hpp on two vertex sets given in one frame (kinds: dpll_geom_kind)
+int hostsim_pair_direction(int kind_a, const double* va, int na, int kind_b, const double* vb, int nb, double* d) {
+  if (na < 1 || nb < 1 || na > kMaxPolyVerts || nb > kMaxPolyVerts) return -1;
+  double a[kMaxPolyVerts][3], b[kMaxPolyVerts][3], out[3];
+  for (int i = 0; i < na; ++i) for (int c = 0; c < 3; ++c) a[i][c] = va[3 * i + c];
+  for (int i = 0; i < nb; ++i) for (int c = 0; c < 3; ++c) b[i][c] = vb[3 * i + c];
+  pair_direction<double>(a, na, kind_a, b, nb, kind_b, out);
+  for (int c = 0; c < 3; ++c) d[c] = out[c];
+  return 0;
+}
 int64_t hostsim_reject_masks(uint64_t* out, int64_t n) {
   const int64_t m = n < (int64_t)g_reject_masks.size() ? n : (int64_t)g_reject_masks.size();
   for (int64_t i = 0; i < m; ++i) out[i] = g_reject_masks[i];

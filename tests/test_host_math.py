@@ -273,3 +273,39 @@ def test_oracle_implicit_solve_gradient_against_finite_differences():
         dJ = torch.zeros_like(J); dJ[index] = h
         fd = ((O.sap_solve(J.detach() + dJ, q.detach(), eps) - O.sap_solve(J.detach() - dJ, q.detach(), eps)) * w).sum() / (2 * h)
         assert abs(fd.item() - J.grad[index].item()) <= 1e-5 * max(1.0, abs(fd.item())), (index, fd.item(), J.grad[index].item())
+
+
+def test_pair_direction_search_is_exact():
+    """The body-body direction search of the kernels (candidate directions of the closest features, csrc/dpll_core.hpp
+    pair_direction) against the oracle's independent exact method (convex hull of the Minkowski difference, closest facet
+    or closest point): same direction -- apart, touching and overlapping -- for boxes (true edges / faces), polygons
+    (all vertex pairs / triples), a sphere's centre, in every combination."""
+    from scipy.spatial.transform import Rotation
+    from oracle import dpll_oracle as O
+    rng = np.random.default_rng(0)
+
+    def shape(kind):
+        if kind == 0:  # box, corner order of geometry.py:39-41
+            half = rng.uniform(0.01, 0.06, 3)
+            return np.array([[(1 if (u >> (2 - i)) & 1 else -1) * half[i] for i in range(3)] for u in range(8)])
+        if kind == 1:
+            return np.zeros((1, 3))
+        n = int(rng.integers(4, 9))
+        return rng.normal(size=(n, 3)) * 0.03
+    worst, n_apart, n_overlap = 0.0, 0, 0
+    for trial in range(240):
+        kind_a, kind_b = trial % 3, (trial // 3) % 3
+        if kind_a == 1 and kind_b == 1:
+            continue
+        a = shape(kind_a)
+        b = shape(kind_b) @ Rotation.random(random_state=trial).as_matrix().T + rng.normal(size=3) * 0.035
+        mine = hostsim.pair_direction(kind_a, a, kind_b, b)
+        ref = O.pair_direction_exact(a, b)
+        sep = lambda d: (b @ d).min() - (a @ d).max()
+        assert abs(np.linalg.norm(mine) - 1) < 1e-12
+        assert abs(sep(mine) - sep(ref)) < 1e-12, (trial, sep(mine), sep(ref))
+        assert np.abs(mine - ref).max() < 1e-7, (trial, mine, ref)
+        worst = max(worst, np.abs(mine - ref).max())
+        n_apart += sep(ref) > 0
+        n_overlap += sep(ref) < 0
+    assert n_apart > 40 and n_overlap > 40
