@@ -16,7 +16,8 @@ The printed JSON line also carries `roofline` (algorithmic bytes of the loss ker
 duration, against the 8 TB/s HBM peak), on rank 0 at N = 1 `cpu_baseline` (the oracle -- a PyTorch CPU
 float64 restatement of the reference path -- timed on this host's cores on a bounded sample) and
 `configs`: the other BASELINE.json configurations measured in the same run (elbow 4096, mesh 4096, cube f64,
-65,536 pairs in f32 / f64, fused rollouts), each with its own value / kernel time / roofline.
+65,536 pairs in f32 / f64, fused rollouts; plus the elbow with a learned mesh on both links and a general-build model
+with a body-body pair), each with its own value / kernel time / roofline.
 """
 import argparse
 import glob
@@ -35,10 +36,11 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix rate: 256 CUs x 256 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32: 64 cyc/SIMD)
 VALU_F64_PEAK_TFLOPS = 78.6   # f64 vector FMA rate
-N_X = {'cube': 13, 'elbow': 15, 'mesh': 13}
+N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17}
 ELEM = {'f32': 4, 'f64': 8}
-URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf'}
-FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz'}
+URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf', 'elbow_mesh': 'elbow_mesh.urdf', 'clasp': 'clasp.urdf'}
+FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz', 'elbow_mesh': 'elbow_box_4096.npz',
+           'clasp': 'clasp_literal.npz'}
 DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set (tests/golden/cube_box_4096.npz, '
                 'seed 0); ranks > 0 take the same pairs in a permuted order, other batch sizes resample with replacement (SURVEY 8d '
                 'config 5); URDF-initial parameters',
@@ -160,6 +162,8 @@ class Timer:
 def loss_roofline(system, workload, dtype, batch, x, xp):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
+    if workload in ('elbow_mesh', 'clasp'):
+        return None  # no per-kernel utility for these pipelines: run_loss_config prices the whole step
     if workload == 'mesh':
         mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
         # the mesh pipeline is bounded by its four N x 256 x 256 f32 GEMMs (SURVEY 8d: MFMA); the dominant kernel is
@@ -219,6 +223,16 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
     timer = Timer(step, steps, warmup, use_graph, steps_per_graph, torch.cuda.synchronize, lambda t: t)
     elapsed, times = timer.measure(repeats)
     roof = loss_roofline(system, workload, dtype_name, batch, x, xp)
+    if roof is None:  # whole-step roofline (an upper bound on every kernel's time, so a lower bound on its fraction)
+        step_ms = elapsed / steps * 1e3
+        if workload == 'elbow_mesh':  # 2 networks x 4 GEMMs of (4 batch) x 256 x 256 (per link)
+            tflops = 8 * 2.0 * (4 * batch) * 256 * 256 / (step_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / MFMA_F32_PEAK_TFLOPS,
+                    'kernel': 'whole step: 8 GEMM launches (one ICNN per link) + item kernel + reductions', 'kernel_ms': step_ms}
+        else:
+            gbs = bytes_per_step(workload, dtype_name) * batch / (step_ms * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                    'kernel': 'gen_loss_kernel + finalize (general build: one lane per item, coverage build)', 'kernel_ms': step_ms}
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
             'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
@@ -404,7 +418,8 @@ def main() -> None:
             # the other BASELINE.json configurations, same process, after the headline (about a minute in total)
             configs = []
             for w, d, b, k in (('elbow', 'f32', 4096, 1000), ('elbow', 'f64', 4096, 500), ('mesh', 'f32', 4096, 200),
-                               ('cube', 'f64', 4096, 1000), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100)):
+                               ('cube', 'f64', 4096, 1000), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100),
+                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50)):
                 try:
                     configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
                 except Exception as exc:  # noqa: BLE001
