@@ -36,19 +36,21 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
   const unsigned long long r = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
   return __builtin_bit_cast(double, r);
 }
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
 constexpr int kQuadXor1 = 0xB1;       // quad_perm [1,0,3,2]
 constexpr int kQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
 constexpr int kRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
 constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
 
 template <int G> struct GpuLanes {
-  static_assert(G == 1 || G == 4 || G == 8, "lanes per item: one per contact (4 or 8), or 1 (wide build)");
+  static_assert(G == 1 || G == 4 || G == 8 || G == 16, "lanes per item: one per contact slot (4, 8 or 16), or 1 (wide build)");
   static constexpr int kGroup = G;
   template <typename T> static __device__ __forceinline__ T group_sum(T x) {
     if (G == 1) return x;
     x += dpp_mov<kQuadXor1>(x);
     x += dpp_mov<kQuadXor2>(x);
-    if (G == 8) x += dpp_mov<kRowHalfMirror>(x);  // both quads hold their own sum -> mirror pairs them
+    if (G >= 8) x += dpp_mov<kRowHalfMirror>(x);  // both quads hold their own sum -> mirror pairs them
+    if (G == 16) x += dpp_mov<kRowMirror>(x);     // both halves of the 16-lane row
     return x;
   }
   static __device__ __forceinline__ bool group_any(bool x) {
@@ -58,6 +60,30 @@ template <int G> struct GpuLanes {
     return ((b >> base) & ((1ull << G) - 1ull)) != 0ull;
   }
   static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
+  static __device__ __forceinline__ int lane_in_group() { return (int)(threadIdx.x & (G - 1)); }
+  // the best (largest value; ties: smallest index) candidate over the lanes of the group, left in every lane
+  template <int CTRL, typename S> static __device__ __forceinline__ void best_step(S& value, int& index, S (&d)[3]) {
+    const S ov = dpp_mov<CTRL>(value);
+    const int oi = dpp_mov<CTRL>(index);
+    const S o0 = dpp_mov<CTRL>(d[0]), o1 = dpp_mov<CTRL>(d[1]), o2 = dpp_mov<CTRL>(d[2]);
+    const bool take = ov > value || (ov == value && oi < index);
+    value = take ? ov : value;
+    index = take ? oi : index;
+    d[0] = take ? o0 : d[0]; d[1] = take ? o1 : d[1]; d[2] = take ? o2 : d[2];
+  }
+  template <typename S> static __device__ __forceinline__ void group_best(S& value, int& index, S (&d)[3]) {
+    if (G == 1) return;
+    best_step<kQuadXor1>(value, index, d);
+    best_step<kQuadXor2>(value, index, d);
+    if (G >= 8) best_step<kRowHalfMirror>(value, index, d);
+    if (G == 16) best_step<kRowMirror>(value, index, d);
+  }
+  // where the group keeps a vertex set (0 / 1) of the direction search: LDS, one block per group of the wave
+  template <typename S> static __device__ __forceinline__ S (*pair_storage(int which, S (*local)[3]))[3] {
+    if (G == 1) return local;
+    __shared__ S sets[kWave / G][2][kMaxPolyVerts][3];
+    return sets[(threadIdx.x & (kWave - 1)) / G][which];
+  }
 };
 
 // sum over the whole wave of a value that is already uniform inside each group of G lanes, counting every
@@ -91,7 +117,7 @@ template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x
     x += dpp_mov<kQuadXor2>(x);
   }
   if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
-  x += dpp_mov<kRowMirror>(x);
+  if (G <= 8) x += dpp_mov<kRowMirror>(x);
   x += dpp_rows<kRowBcast15, 0xA>(x);
   x += dpp_rows<kRowBcast31, 0xC>(x);
   return read_lane63(x);
@@ -195,7 +221,7 @@ template <int G, typename T> __device__ __forceinline__ T wave_sum_to_lane63(T x
     x += dpp_mov<kQuadXor2>(x);
   }
   if (G <= 4) x += dpp_mov<kRowHalfMirror>(x);
-  x += dpp_mov<kRowMirror>(x);
+  if (G <= 8) x += dpp_mov<kRowMirror>(x);
   x += dpp_rows<kRowBcast15, 0xA>(x);
   x += dpp_rows<kRowBcast31, 0xC>(x);
   return x;  // the total over the groups in lane 63; other lanes hold partial sums

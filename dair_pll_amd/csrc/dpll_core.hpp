@@ -1170,14 +1170,28 @@ constexpr double kPairTie = 1e-12;   // support values (metres) closer than this
 // -- a polygon's hull is not known: all its vertex pairs and triples are tried -- cost time, never correctness).  A sphere is its centre with the radius as a margin (the margin shifts
 // sep by a constant: same maximiser).
 // ---------------------------------------------------------------------------------------------
+// host/one-lane implementation of the lane-group primitives
+struct OneLane {
+  static constexpr int kGroup = 1;  // lanes that share one item
+  template <typename T> static DPLL_HD T group_sum(T x) { return x; }
+  static DPLL_HD bool group_any(bool x) { return x; }
+  static DPLL_HD bool wave_any(bool x) { return x; }
+  static DPLL_HD int lane_in_group() { return 0; }
+  // the best (largest value; ties: smallest index) candidate over the lanes of the group, left in every lane
+  template <typename S> static DPLL_HD void group_best(S&, int&, S (&)[3]) {}
+  // where the group keeps a vertex set of the direction search (the host: the caller's array)
+  template <typename S> static DPLL_HD S (*pair_storage(int, S (*local)[3]))[3] { return local; }
+};
+
 template <typename S> struct IsDual { static constexpr bool value = false; };
 template <typename S> struct IsDual<DualT<S>> { static constexpr bool value = true; };
 template <typename S> struct PairBest {
   S sep;
   S d[3];
+  int k;  // number of the candidate that set it (ties between lanes: the earliest candidate wins, as in one lane)
 };
 template <typename S>
-DPLL_HD void pair_try(const S (&n)[3], const S (*a)[3], int na, const S (*b)[3], int nb, PairBest<S>& best) {
+DPLL_HD void pair_try(const S (&n)[3], int k, const S (*a)[3], int na, const S (*b)[3], int nb, PairBest<S>& best) {
   const S n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
   if (!(n2 > S(0))) return;
   S amax = S(-3.0e38), amin = S(3.0e38), bmax = S(-3.0e38), bmin = S(3.0e38);
@@ -1195,10 +1209,12 @@ DPLL_HD void pair_try(const S (&n)[3], const S (*a)[3], int na, const S (*b)[3],
   const S sp = (bmin - amax) * inv, sm = (amin - bmax) * inv;
   if (sp > best.sep) {
     best.sep = sp;
+    best.k = k;
     DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = n[i] * inv;
   }
   if (sm > best.sep) {
     best.sep = sm;
+    best.k = k;
     DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = -n[i] * inv;
   }
 }
@@ -1230,64 +1246,63 @@ DPLL_HD void pair_features(int kind, int nv, PairFeatures& f) {
     }
   f.n_dirs = f.n_edges;
 }
-// vertex sets a (na) and b (nb) in one frame -> unit d from A towards B; runtime loops (the sets live in memory)
-template <typename S>
+// vertex sets a (na) and b (nb) in one frame -> unit d from A towards B; runtime loops (the sets live in memory).
+// The candidates are numbered -- vertex-vertex, vertex(A)-edge(B), vertex(B)-edge(A), faces of A, faces of B, edge x edge
+// -- and the lanes of the item's group take 16 consecutive numbers at a time (all of them busy at once), then agree on
+// the best with one butterfly; one lane alone walks the same numbers in order.
+template <typename S, class Lanes>
 DPLL_HD_CALL void pair_direction(const S (*a)[3], int na, int kind_a, const S (*b)[3], int nb, int kind_b, S (&d)[3]) {
   PairBest<S> best;
   best.sep = S(-3.0e38);
   best.d[0] = S(0); best.d[1] = S(0); best.d[2] = S(1);
+  best.k = 0x7fffffff;
   PairFeatures fa, fb;
   pair_features(kind_a, na, fa);
   pair_features(kind_b, nb, fb);
-  // vertex - vertex
-  for (int i = 0; i < na; ++i)
-    for (int j = 0; j < nb; ++j) {
-      const S n[3] = {b[j][0] - a[i][0], b[j][1] - a[i][1], b[j][2] - a[i][2]};
-      pair_try(n, a, na, b, nb, best);
-    }
-  // vertex of one set - edge of the other: the part of the difference perpendicular to the edge
-  for (int pass = 0; pass < 2; ++pass) {
-    const S (*p)[3] = pass == 0 ? a : b;
-    const S (*e)[3] = pass == 0 ? b : a;
-    const PairFeatures& fe = pass == 0 ? fb : fa;
-    const int np = pass == 0 ? na : nb;
-    for (int i = 0; i < np; ++i)
-      for (int m = 0; m < fe.n_edges; ++m) {
-        const int k = fe.edges[m][0], l = fe.edges[m][1];
-        const S ed[3] = {e[l][0] - e[k][0], e[l][1] - e[k][1], e[l][2] - e[k][2]};
-        const S w[3] = {e[k][0] - p[i][0], e[k][1] - p[i][1], e[k][2] - p[i][2]};
-        const S ee = ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2];
-        if (!(ee > S(0))) continue;
-        const S t = (w[0] * ed[0] + w[1] * ed[1] + w[2] * ed[2]) / ee;
-        const S n[3] = {w[0] - t * ed[0], w[1] - t * ed[1], w[2] - t * ed[2]};
-        pair_try(n, a, na, b, nb, best);
-      }
-  }
-  // face normals of either set
-  for (int pass = 0; pass < 2; ++pass) {
-    const S (*p)[3] = pass == 0 ? a : b;
-    const PairFeatures& fp = pass == 0 ? fa : fb;
-    for (int m = 0; m < fp.n_tris; ++m) {
-      const int i = fp.tris[m][0], j = fp.tris[m][1], k = fp.tris[m][2];
+  const int n_vv = na * nb, n_veb = na * fb.n_edges, n_vea = nb * fa.n_edges, n_ta = fa.n_tris, n_tb = fb.n_tris;
+  const int total = n_vv + n_veb + n_vea + n_ta + n_tb + fa.n_dirs * fb.n_dirs;
+  const int lane = Lanes::lane_in_group();
+  for (int base = 0; base < total; base += Lanes::kGroup) {
+    const int c = base + lane;
+    if (c >= total) continue;
+    int r = c;
+    S n[3];
+    if (r < n_vv) {  // vertex - vertex
+      const int i = r / nb, j = r % nb;
+      DPLL_UNROLL for (int t = 0; t < 3; ++t) n[t] = b[j][t] - a[i][t];
+    } else if ((r -= n_vv) < n_veb + n_vea) {  // vertex of one set - edge of the other: the perpendicular part
+      const bool first = r < n_veb;
+      if (!first) r -= n_veb;
+      const S (*p)[3] = first ? a : b;
+      const S (*e)[3] = first ? b : a;
+      const PairFeatures& fe = first ? fb : fa;
+      const int i = r / fe.n_edges, m = r % fe.n_edges;
+      const int k = fe.edges[m][0], l = fe.edges[m][1];
+      const S ed[3] = {e[l][0] - e[k][0], e[l][1] - e[k][1], e[l][2] - e[k][2]};
+      const S w[3] = {e[k][0] - p[i][0], e[k][1] - p[i][1], e[k][2] - p[i][2]};
+      const S ee = ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2];
+      const S t = ee > S(0) ? (w[0] * ed[0] + w[1] * ed[1] + w[2] * ed[2]) / ee : S(0);
+      DPLL_UNROLL for (int q = 0; q < 3; ++q) n[q] = ee > S(0) ? w[q] - t * ed[q] : S(0);
+    } else if ((r -= n_veb + n_vea) < n_ta + n_tb) {  // face normals of either set
+      const bool first = r < n_ta;
+      if (!first) r -= n_ta;
+      const S (*p)[3] = first ? a : b;
+      const PairFeatures& fp = first ? fa : fb;
+      const int i = fp.tris[r][0], j = fp.tris[r][1], k = fp.tris[r][2];
       const S u[3] = {p[j][0] - p[i][0], p[j][1] - p[i][1], p[j][2] - p[i][2]};
       const S v[3] = {p[k][0] - p[i][0], p[k][1] - p[i][1], p[k][2] - p[i][2]};
-      S n[3];
       cross(u, v, n);
-      pair_try(n, a, na, b, nb, best);
-    }
-  }
-  // edge direction x edge direction
-  for (int m = 0; m < fa.n_dirs; ++m) {
-    const int i = fa.dirs[m][0], j = fa.dirs[m][1];
-    const S u[3] = {a[j][0] - a[i][0], a[j][1] - a[i][1], a[j][2] - a[i][2]};
-    for (int o = 0; o < fb.n_dirs; ++o) {
-      const int k = fb.dirs[o][0], l = fb.dirs[o][1];
+    } else {  // edge direction x edge direction
+      r -= n_ta + n_tb;
+      const int m = r / fb.n_dirs, o = r % fb.n_dirs;
+      const int i = fa.dirs[m][0], j = fa.dirs[m][1], k = fb.dirs[o][0], l = fb.dirs[o][1];
+      const S u[3] = {a[j][0] - a[i][0], a[j][1] - a[i][1], a[j][2] - a[i][2]};
       const S v[3] = {b[l][0] - b[k][0], b[l][1] - b[k][1], b[l][2] - b[k][2]};
-      S n[3];
       cross(u, v, n);
-      pair_try(n, a, na, b, nb, best);
     }
+    pair_try(n, c, a, na, b, nb, best);
   }
+  Lanes::group_best(best.sep, best.k, best.d);
   DPLL_UNROLL for (int i = 0; i < 3; ++i) d[i] = best.d[i];
 }
 
@@ -1331,6 +1346,79 @@ DPLL_HD void geometry_vertices(const MD& md, const Derived<T, NJ, NG>& dp, int g
   }
 }
 
+// the two geometry frames of a pair in the world and their vertex sets
+template <typename S> struct PairSetup {
+  S RA[3][3], RB[3][3], oA[3], oB[3], gorgA[3], gorgB[3], cA[3], cB[3];
+  S va[kMaxPolyVerts][3], vb[kMaxPolyVerts][3], marginA, marginB;
+  int na, nb;
+};
+template <typename T, typename TA, int NJ, int NG, class MD>
+DPLL_HD void pair_setup(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<TA, NJ>& kinA, int ga, int gb, PairSetup<TA>& ps) {
+  constexpr int NB = NJ + 1;
+  const int ba = md.geom_body[ga], bb = md.geom_body[gb];
+  // geometry frames in the world (TA): rotation of the body, origin = body origin + R * geometry origin
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) { ps.RA[r][c] = kinA.R[0][r][c]; ps.RB[r][c] = kinA.R[0][r][c]; }
+    ps.oA[r] = kinA.o[0][r]; ps.oB[r] = kinA.o[0][r];
+  }
+  DPLL_UNROLL for (int j = 1; j < NB; ++j)
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+      DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+        ps.RA[r][c] = ba == j ? kinA.R[j][r][c] : ps.RA[r][c];
+        ps.RB[r][c] = bb == j ? kinA.R[j][r][c] : ps.RB[r][c];
+      }
+      ps.oA[r] = ba == j ? kinA.o[j][r] : ps.oA[r];
+      ps.oB[r] = bb == j ? kinA.o[j][r] : ps.oB[r];
+    }
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { ps.gorgA[i] = TA(md.geom_origin[ga][i]); ps.gorgB[i] = TA(md.geom_origin[gb][i]); }
+  mat3_vec(ps.RA, ps.gorgA, ps.cA);
+  mat3_vec(ps.RB, ps.gorgB, ps.cB);
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) { ps.cA[i] += ps.oA[i]; ps.cB[i] += ps.oB[i]; }
+  geometry_vertices<TA>(md, dp, ga, ps.va, ps.na, ps.marginA);
+  geometry_vertices<TA>(md, dp, gb, ps.vb, ps.nb, ps.marginB);
+}
+// the pair's direction in the frame of A, searched by the lanes of the item's group together
+template <typename TA, class Lanes>
+DPLL_HD void pair_search(const PairSetup<TA>& ps, int kind_a, int kind_b, TA (&dA)[3]) {
+  // both sets where the candidate loops read them from: the group's on-chip storage on the device (every lane of the
+  // group writes the same values), plain arrays on the host
+  TA la[kMaxPolyVerts][3], lb[kMaxPolyVerts][3];
+  TA (*sa)[3] = Lanes::template pair_storage<TA>(0, la);
+  TA (*sb)[3] = Lanes::template pair_storage<TA>(1, lb);
+  for (int u = 0; u < ps.na; ++u)
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) sa[u][i] = ps.va[u][i];
+  // B's vertices in the frame of A: R_A^T (c_B + R_B v - c_A)
+  for (int u = 0; u < ps.nb; ++u) {
+    TA w[3], rel[3], out[3];
+    mat3_vec(ps.RB, ps.vb[u], w);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) rel[i] = w[i] + ps.cB[i] - ps.cA[i];
+    mat3t_vec(ps.RA, rel, out);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) sb[u][i] = out[i];
+  }
+  pair_direction<TA, Lanes>(sa, ps.na, kind_a, sb, ps.nb, kind_b, dA);
+}
+// every body-body candidate's direction, before the contacts are set up (all lanes of the group take part)
+template <typename T, typename TA, class Lanes, int NJ, int NG, class MD>
+DPLL_HD bool pair_find_directions(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<TA, NJ>& kinA, TA (&dirs)[kMaxPairs][3]) {
+  DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) { dirs[p][0] = TA(0); dirs[p][1] = TA(0); dirs[p][2] = TA(1); }
+  if constexpr (MD::kGeneral && !IsDual<TA>::value) {
+    if (md.n_pairs <= 0) return false;
+    for (int p = 0; p < kMaxPairs; ++p) {
+      if (p >= md.n_pairs) break;
+      PairSetup<TA> ps;
+      pair_setup<T, TA, NJ>(md, dp, kinA, md.pair_a[p], md.pair_b[p], ps);
+      pair_search<TA, Lanes>(ps, md.geom_kind[md.pair_a[p]], md.geom_kind[md.pair_b[p]], dirs[p]);
+    }
+    return true;
+  }
+  return false;
+}
+// the found direction of the pair contact `contact` sits in, or nullptr (not a pair slot / nothing found up front)
+template <typename TA> DPLL_HD const TA* pair_dir_of(bool have, const TA (&dirs)[kMaxPairs][3], int contact) {
+  const int p = contact / kQuery - kMaxGeoms;
+  return (have && p >= 0 && p < kMaxPairs) ? dirs[p] : nullptr;
+}
+
 // `witness` (mesh geometry, DeepSupportConvex): the support point of this contact in the geometry frame, already
 // evaluated by the ICNN kernels (geometry.py:309-325); nullptr = box corner / sphere point chosen here.
 template <typename T, typename TA, int NJ, int NG, class MD>
@@ -1354,30 +1442,13 @@ DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, co
     DPLL_UNROLL for (int c = 0; c < 6 + NJ; ++c) cg.J.m[r][c] = T(0);
   cg.phi = T(kMaskedPhi);
   if (masked) return;
-  // geometry frames in the world (TA): rotation of the body, origin = body origin + R * geometry origin
-  TA RA[3][3], RB[3][3], oA[3], oB[3];
-  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-    DPLL_UNROLL for (int c = 0; c < 3; ++c) { RA[r][c] = kinA.R[0][r][c]; RB[r][c] = kinA.R[0][r][c]; }
-    oA[r] = kinA.o[0][r]; oB[r] = kinA.o[0][r];
-  }
-  DPLL_UNROLL for (int j = 1; j < NB; ++j)
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) {
-      DPLL_UNROLL for (int c = 0; c < 3; ++c) {
-        RA[r][c] = ba == j ? kinA.R[j][r][c] : RA[r][c];
-        RB[r][c] = bb == j ? kinA.R[j][r][c] : RB[r][c];
-      }
-      oA[r] = ba == j ? kinA.o[j][r] : oA[r];
-      oB[r] = bb == j ? kinA.o[j][r] : oB[r];
-    }
-  TA gorgA[3], gorgB[3], cA[3], cB[3];
-  DPLL_UNROLL for (int i = 0; i < 3; ++i) { gorgA[i] = TA(md.geom_origin[ga][i]); gorgB[i] = TA(md.geom_origin[gb][i]); }
-  mat3_vec(RA, gorgA, cA);
-  mat3_vec(RB, gorgB, cB);
-  DPLL_UNROLL for (int i = 0; i < 3; ++i) { cA[i] += oA[i]; cB[i] += oB[i]; }
-  TA va[kMaxPolyVerts][3], vb[kMaxPolyVerts][3], marginA, marginB;
-  int na, nb;
-  geometry_vertices<TA>(md, dp, ga, va, na, marginA);
-  geometry_vertices<TA>(md, dp, gb, vb, nb, marginB);
+  PairSetup<TA> ps;
+  pair_setup<T, TA, NJ>(md, dp, kinA, ga, gb, ps);
+  TA (&RA)[3][3] = ps.RA; TA (&RB)[3][3] = ps.RB;
+  TA (&oA)[3] = ps.oA; TA (&oB)[3] = ps.oB; TA (&gorgA)[3] = ps.gorgA; TA (&gorgB)[3] = ps.gorgB;
+  TA (&va)[kMaxPolyVerts][3] = ps.va; TA (&vb)[kMaxPolyVerts][3] = ps.vb;
+  const TA marginA = ps.marginA, marginB = ps.marginB;
+  const int na = ps.na, nb = ps.nb;
   // direction, in the frame of A
   TA dA[3];
   if (dir_in) {
@@ -1386,15 +1457,7 @@ DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, co
     // (the dual passes of the state adjoint always get the direction of the primal pass: no search code for them)
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dA[i] = TA(i == 2 ? 1.0 : 0.0);
   } else {
-    // B's vertices in the frame of A: R_A^T (c_B + R_B v - c_A)
-    TA vbA[kMaxPolyVerts][3];
-    for (int u = 0; u < nb; ++u) {
-      TA w[3], rel[3];
-      mat3_vec(RB, vb[u], w);
-      DPLL_UNROLL for (int i = 0; i < 3; ++i) rel[i] = w[i] + cB[i] - cA[i];
-      mat3t_vec(RA, rel, vbA[u]);
-    }
-    pair_direction<TA>(va, na, md.geom_kind[ga], vbA, nb, md.geom_kind[gb], dA);
+    pair_search<TA, OneLane>(ps, md.geom_kind[ga], md.geom_kind[gb], dA);  // (callers with a lane group search up front)
   }
   TA dW[3], dB[3], ndW[3];
   mat3_vec(RA, dA, dW);
@@ -1681,8 +1744,11 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
   CJac<T, NJ, MD::kGeneral> Jc[KPL];
   T mu[KPL], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
   T pen = T(0);
+  TA pdirs[kMaxPairs][3];
+  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr,
+                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c));
     Jc[c] = cg[c].J;
     mu[c] = cg[c].mu;
     T jdv[3];
@@ -1817,9 +1883,12 @@ DPLL_HD void step_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverO
   CJac<T, NJ, MD::kGeneral> Jc[KPL];
   T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
+  TA pdirs[kMaxPairs][3];
+  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     ContactGeom<T, NJ, MD::kGeneral> cg;
-    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg, witness ? witness[c] : nullptr);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg, witness ? witness[c] : nullptr,
+                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c));
     Jc[c] = cg.J;
     mu[c] = cg.mu;
     T jv[3];
@@ -1895,8 +1964,11 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
   CJac<T, NJ, MD::kGeneral> Jc[KPL];
   T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
+  TA pdirs[kMaxPairs][3];
+  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr);
+    compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr,
+                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c));
     Jc[c] = cg[c].J;
     mu[c] = cg[c].mu;
     T jv[3];
@@ -2138,12 +2210,5 @@ DPLL_HD double length_grad_component(const double* lengths, const double* g_len,
   return g_len[k] * (p > 0.0 ? 1.0 : (p < 0.0 ? -1.0 : 0.0));
 }
 
-// host/one-lane implementation of the lane-group primitives
-struct OneLane {
-  static constexpr int kGroup = 1;  // lanes that share one item
-  template <typename T> static DPLL_HD T group_sum(T x) { return x; }
-  static DPLL_HD bool group_any(bool x) { return x; }
-  static DPLL_HD bool wave_any(bool x) { return x; }
-};
 
 }  // namespace dpll

@@ -5,10 +5,10 @@
 // (multibody_terms.py:328-382, 428-521), the state space inferred from the tree (drake_utils.py:309-335), Sphere next
 // to Box (geometry.py:367-456) -- beyond the two topologies the specialised builds of dpll_kernels.hip are written for
 // (cube, elbow).  Same per-item math (dpll_core.hpp, with the tree / geometry-table branches selected by GeneralDesc),
-// same C ABI, same partial-row + chain-matrix gradient reduction; the mapping is ONE LANE PER ITEM with all contacts of
-// the item in that lane (always kMaxGeoms x 4 contact slots: geometries a model does not have and the three slots a
-// sphere does not use are masked to "far away", which costs arithmetic but no branch).  This build is about coverage,
-// not speed: 12 contact slots and an 8 x 8 Newton system per lane spill registers, and it is not on the benchmark path.
+// same C ABI, same partial-row + chain-matrix gradient reduction; the mapping is one lane per contact SLOT, 16 lanes (a
+// DPP row) per item: always kMaxGeoms x 4 geometry slots + the 4 of a body-body pair, where geometries a model does not
+// have, the three slots a sphere or a pair does not use are masked to "far away" (idle lanes, no branch in the solver).
+// Coverage before speed: every contact Jacobian is dense, the Newton system up to 8 x 8.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -24,8 +24,12 @@ constexpr int kNG = kGenSlots;  // the geometries + the slot of a body-body pair
 constexpr int kGP = GeneralDesc::kGeoStride;  // numbers per geometry parameter block
 template <typename T, int NJ> using GD = Dims<T, NJ, kNG, kGP>;
 template <typename T, int NJ> using GenGrad = LossGrad<T, NJ, kNG, kGP>;
-using Lanes1 = GpuLanes<1>;
+using GenLanes = GpuLanes<kQuery * kNG>;  // one lane per contact slot
 
+// One lane per contact SLOT: an item is owned by the 16 lanes of a DPP row (3 geometries x 4 witnesses + the pair's
+// slot and its three idle ones), four items per wave -- the mapping of the specialised builds (cube 4, elbow 8 lanes per
+// item), so each lane's contact state stays in registers and 4096 items are 1024 waves, one per SIMD.
+constexpr int kIPW = kWave / (kQuery * kNG);  // items per wave
 template <typename T, int NJ>
 __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
@@ -34,7 +38,8 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
                                                          double scale, T* __restrict__ loss, T* __restrict__ force,
                                                          int* __restrict__ iters, double* __restrict__ partials, int want_grad) {
   using D = GD<T, NJ>;
-  const int lane = threadIdx.x;
+  static_assert(D::G == 16 && kIPW == 4, "16 contact slots per item");
+  const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
     if (want_grad)
@@ -46,53 +51,73 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
   GenGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
-  const long long stride = (long long)item_blocks * kWave;
-  for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
-    const long long item = base + lane;
+  const long long stride = (long long)item_blocks * kIPW;
+  for (long long base = (long long)blockIdx.x * kIPW; base < batch; base += stride) {
+    const long long item = base + slot;
     const bool valid = item < batch;
-    const long long it = valid ? item : batch - 1;
+    const long long it = valid ? item : batch - 1;  // idle groups shadow the last item: every lane stays live for DPP
     T xr[D::NX], xpr[D::NX];
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
     const T w = valid ? T(scale) * (weights ? weights[it] : T(1)) : T(0);
-    T f[D::K][3];
+    T f[1][3];
     int n_it = 0;
-    const T L = loss_item<T, typename Acc<T>::type, NJ, D::K, Lanes1>(md, dp, opt, xr, xpr, 0, w, want_grad != 0, acc, f, n_it);
+    const T L = loss_item<T, typename Acc<T>::type, NJ, 1, GenLanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it);
     if (valid) {
-      if (loss) loss[it] = L;
-      if (iters) iters[it] = n_it;
+      if (cidx == 0) {
+        if (loss) loss[it] = L;
+        if (iters) iters[it] = n_it;
+      }
       if (force) {
         T* row = force + it * (3 * D::K);
-#pragma unroll
-        for (int c = 0; c < D::K; ++c) {
-          row[c] = f[c][2];
-          row[D::K + 2 * c] = f[c][0];
-          row[D::K + 2 * c + 1] = f[c][1];
-        }
+        row[cidx] = f[0][2];
+        row[D::K + 2 * cidx] = f[0][0];
+        row[D::K + 2 * cidx + 1] = f[0][1];
       }
     }
-    loss_acc += double(w) * double(L);
+    loss_acc += (cidx == 0) ? double(w) * double(L) : 0.0;
   }
   if (!want_grad) return;
-  store_iota_row<T, NJ, 1, kNG, kGP>(acc, loss_acc, partials);
+  store_iota_row<T, NJ, D::G, kNG, kGP>(acc, loss_acc, partials);
 }
 
-// fixed-order sum of the partial rows + the chain to the parameters; one thread per column
+// Fixed-order sum of the partial rows in two stages (a 4096-pair launch leaves 1024 rows, one per wave): blocks of
+// kFoldRows rows are folded first, eight loads in flight per thread, into a second row array behind the chain matrix; the
+// finalize kernel sums that (<= 32 rows) and applies the chain to the parameters.  One thread per column.
+constexpr int kFoldRows = 64;
 template <typename T, int NJ>
-__global__ __launch_bounds__(256) void gen_finalize_kernel(const double* __restrict__ partials, int n_rows, T* __restrict__ grad,
-                                                           T* __restrict__ loss_total) {
+__global__ __launch_bounds__(256) void gen_fold_rows_kernel(const double* __restrict__ partials, int n_rows, double* __restrict__ folded) {
+  using D = GD<T, NJ>;
+  const int col = threadIdx.x;
+  if (col >= D::PIOTA) return;
+  const int r0 = (int)blockIdx.x * kFoldRows, r1 = r0 + kFoldRows < n_rows ? r0 + kFoldRows : n_rows;
+  double s = 0.0;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partials[(long long)(r + u) * D::PI + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; r < r1; ++r) s += partials[(long long)r * D::PI + col];
+  folded[(long long)blockIdx.x * D::PI + col] = s;
+}
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void gen_finalize_kernel(const double* __restrict__ folded, int n_rows, const double* __restrict__ chain,
+                                                           T* __restrict__ grad, T* __restrict__ loss_total) {
   using D = GD<T, NJ>;
   static_assert(D::PI <= 256, "row must fit 256 columns");
   __shared__ double tot[256];
   const int col = threadIdx.x;
   double s = 0.0;
   if (col < D::PIOTA)
-    for (int r = 0; r < n_rows; ++r) s += partials[(long long)r * D::PI + col];
+    for (int r = 0; r < n_rows; ++r) s += folded[(long long)r * D::PI + col];
   tot[col] = s;
   __syncthreads();
   if (threadIdx.x < D::PI) {
     const int k = (int)threadIdx.x - 1;
-    const double v = k < 0 ? tot[0] : apply_chain<D::NB, kNG, kGP>(tot, partials + (long long)n_rows * D::PI, k);
+    const double v = k < 0 ? tot[0] : apply_chain<D::NB, kNG, kGP>(tot, chain, k);
     if (k < 0) {
       if (loss_total) *loss_total = T(v);
     } else {
@@ -108,20 +133,21 @@ __global__ __launch_bounds__(kWave) void gen_simulate_kernel(GeneralDesc md, Sol
                                                              long long steps, T* __restrict__ out, long long ld_item,
                                                              long long ld_step, int write_x0, int* __restrict__ iters) {
   using D = GD<T, NJ>;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
   Derived<T, NJ, kNG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  const long long stride = (long long)gridDim.x * kWave;
-  for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
-    const long long item = base + lane;
+  const long long stride = (long long)gridDim.x * kIPW;
+  for (long long base = (long long)blockIdx.x * kIPW; base < batch; base += stride) {
+    const long long item = base + slot;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;
+    const bool writer = valid && cidx == 0;
     T xr[D::NX];
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) xr[i] = x0[it * ld_x + i];
     T* dst = out + it * ld_item;
     if (write_x0) {
-      if (valid) {
+      if (writer) {
 #pragma unroll
         for (int i = 0; i < D::NX; ++i) dst[i] = xr[i];
       }
@@ -129,19 +155,19 @@ __global__ __launch_bounds__(kWave) void gen_simulate_kernel(GeneralDesc md, Sol
     }
     int total = 0;
     for (long long s = 0; s < steps; ++s) {
-      T xn[D::NX], imp[D::K][3];
+      T xn[D::NX], imp[1][3];
       int n_it = 0;
-      step_item<T, typename Acc<T>::type, NJ, D::K, Lanes1>(md, dp, opt, xr, 0, xn, imp, n_it);
+      step_item<T, typename Acc<T>::type, NJ, 1, GenLanes>(md, dp, opt, xr, cidx, xn, imp, n_it);
       total += n_it;
 #pragma unroll
       for (int i = 0; i < D::NX; ++i) xr[i] = xn[i];
-      if (valid) {
+      if (writer) {
 #pragma unroll
         for (int i = 0; i < D::NX; ++i) dst[i] = xr[i];
       }
       dst += ld_step;
     }
-    if (iters && valid) iters[it] = total;
+    if (iters && writer) iters[it] = total;
   }
 }
 
@@ -155,50 +181,39 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
                                                                   long long ld_xb) {
   using D = GD<T, NJ>;
   using C = double;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
   const int item_blocks = (int)gridDim.x - 1;
   if ((int)blockIdx.x == item_blocks) {
     write_chain_matrix<C, T, D::NB, kNG, kGP>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI, &md);
     return;
   }
+  // the parameters in double: local copies (a polygon's vertices are read through dp.geo)
   C theta_c[D::NB * 10], friction_c[kNG + 1], lengths_c[kNG * kGP];
 #pragma unroll
   for (int i = 0; i < D::NB * 10; ++i) theta_c[i] = C(theta[i]);
 #pragma unroll
   for (int i = 0; i < kNG + 1; ++i) friction_c[i] = C(friction[i]);
-#pragma unroll
   for (int i = 0; i < kNG * kGP; ++i) lengths_c[i] = C(lengths[i]);
   Derived<C, NJ, kNG> dp;
   derive_params<C, NJ>(md, theta_c, friction_c, lengths_c, dp);
   GenGrad<C, NJ> acc;
   zero_grad(acc);
-  const long long stride = (long long)item_blocks * kWave;
-  for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
-    const long long item = base + lane;
+  const long long stride = (long long)item_blocks * kIPW;
+  for (long long base = (long long)blockIdx.x * kIPW; base < batch; base += stride) {
+    const long long item = base + slot;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;
     C xr[D::NX], gr[D::NX], xb[D::NX];
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = C(x[it * ld_x + i]); gr[i] = valid ? C(gx[it * ld_g + i]) : C(0); xb[i] = C(0); }
-    GenGrad<C, NJ> g;
-    zero_grad(g);
-    step_item_backward<C, C, NJ, D::K, Lanes1>(md, dp, opt, xr, 0, gr, g, nullptr, nullptr, &xb);
-    if (xbar_out && valid) {
+    // (an idle group's seed is zero, so what it adds to the sums below is zero)
+    step_item_backward<C, C, NJ, 1, GenLanes>(md, dp, opt, xr, cidx, gr, acc, nullptr, nullptr, &xb);
+    if (xbar_out && valid && cidx == 0) {
 #pragma unroll
       for (int i = 0; i < D::NX; ++i) xbar_out[it * ld_xb + i] = T(xb[i]);
     }
-#pragma unroll
-    for (int b = 0; b < D::NB; ++b)
-#pragma unroll
-      for (int i = 0; i < kIota; ++i) acc.g_iota[b][i] += g.g_iota[b][i];
-#pragma unroll
-    for (int gg = 0; gg < kNG; ++gg) {
-      acc.g_mu[gg] += g.g_mu[gg];
-#pragma unroll
-      for (int i = 0; i < kGP; ++i) acc.g_len[gg][i] += g.g_len[gg][i];
-    }
   }
-  store_iota_row<C, NJ, 1, kNG, kGP>(acc, 0.0, partials);
+  store_iota_row<C, NJ, D::G, kNG, kGP>(acc, 0.0, partials);
 }
 
 // MultibodyTerms.forward (multibody_terms.py:584-609) over all kMaxGeoms x 4 contact slots; the host keeps the real ones
@@ -263,10 +278,27 @@ GeneralDesc general_desc(const dpll_model* m) {
 }
 
 int row_blocks(long long batch) {
-  long long blocks = (batch + kWave - 1) / kWave;
+  long long blocks = (batch + kIPW - 1) / kIPW;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
+}
+
+// workspace: [rows (n, PI) | chain matrix | folded rows (ceil(n / kFoldRows), PI)]
+long long folded_rows(long long rows) { return (rows + kFoldRows - 1) / kFoldRows; }
+template <typename T, int NJ>
+int finalize_rows(double* workspace, int rows, T* grad, T* loss_total, hipStream_t stream) {
+  using D = GD<T, NJ>;
+  double* chain = workspace + (long long)rows * D::PI;
+  double* folded = chain + D::CHAIN;
+  const int n_folded = (int)folded_rows(rows);
+  if (n_folded > 0) {
+    hipLaunchKernelGGL((gen_fold_rows_kernel<T, NJ>), dim3(n_folded), dim3(256), 0, stream, (const double*)workspace, rows, folded);
+    if (int rc = dpll_check_launch("gen_fold_rows_kernel")) return rc;
+  }
+  hipLaunchKernelGGL((gen_finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)folded, n_folded, (const double*)chain,
+                     grad, loss_total);
+  return dpll_check_launch("gen_finalize_kernel");
 }
 
 template <typename T, int NJ>
@@ -277,7 +309,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   const int rows = batch > 0 ? row_blocks(batch) : 0;
   const int want_grad = grad != nullptr;
   if (want_grad) {
-    if (!workspace || workspace_bytes < ((long long)row_blocks(batch) * D::PI + D::CHAIN) * (long long)sizeof(double))
+    if (!workspace || workspace_bytes < dpll_general::workspace_bytes(m, batch))
       return dpll_fail(-3, "dpll_contactnets_loss: workspace too small%s");
   } else if (loss_total) {
     return dpll_fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
@@ -286,11 +318,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad);
   if (int rc = dpll_check_launch("gen_loss_kernel")) return rc;
-  if (want_grad) {
-    hipLaunchKernelGGL((gen_finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)workspace, rows, (T*)grad,
-                       (T*)loss_total);
-    return dpll_check_launch("gen_finalize_kernel");
-  }
+  if (want_grad) return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)loss_total, stream);
   return 0;
 }
 
@@ -298,7 +326,7 @@ template <typename T, int NJ>
 int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch,
                     long long steps, void* out, long long ld_item, long long ld_step, int write_x0, int32_t* iters,
                     hipStream_t stream) {
-  long long blocks = (batch + kWave - 1) / kWave;
+  long long blocks = (batch + kIPW - 1) / kIPW;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL((gen_simulate_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, general_desc(m), m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps, (T*)out,
@@ -312,15 +340,13 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
                          long long workspace_bytes, hipStream_t stream) {
   using D = GD<T, NJ>;
   const int rows = row_blocks(batch);
-  if (!workspace || workspace_bytes < ((long long)rows * D::PI + D::CHAIN) * (long long)sizeof(double))
+  if (!workspace || workspace_bytes < dpll_general::workspace_bytes(m, batch))
     return dpll_fail(-3, "dpll_step_backward: workspace too small%s");
   hipLaunchKernelGGL((gen_step_backward_kernel<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, general_desc(m), m->opts[DPLL_F64],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch,
                      (double*)workspace, (T*)grad_x, ld_gx);
   if (int rc = dpll_check_launch("gen_step_backward_kernel")) return rc;
-  hipLaunchKernelGGL((gen_finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)workspace, rows, (T*)grad,
-                     (T*)nullptr);
-  return dpll_check_launch("gen_finalize_kernel");
+  return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)nullptr, stream);
 }
 
 template <typename T, int NJ>
@@ -354,7 +380,8 @@ int param_count(const dpll_model* m) { return 10 * (m->desc.n_joints + 1) + (kNG
 long long workspace_bytes(const dpll_model* m, long long batch) {
   const long long nb = m->desc.n_joints + 1;
   const long long pi = 1 + 10 * nb + (kNG + 1) + kGP * kNG, chain = 100 * nb + (kNG + 1) * kNG + kGP * kNG;
-  return ((long long)row_blocks(batch) * pi + chain) * (long long)sizeof(double);
+  const long long rows = row_blocks(batch);
+  return ((rows + folded_rows(rows)) * pi + chain) * (long long)sizeof(double);
 }
 
 int loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp,

@@ -331,7 +331,7 @@ int hostsim_pair_direction(int kind_a, const double* va, int na, int kind_b, con
   double a[kMaxPolyVerts][3], b[kMaxPolyVerts][3], out[3];
   for (int i = 0; i < na; ++i) for (int c = 0; c < 3; ++c) a[i][c] = va[3 * i + c];
   for (int i = 0; i < nb; ++i) for (int c = 0; c < 3; ++c) b[i][c] = vb[3 * i + c];
-  pair_direction<double>(a, na, kind_a, b, nb, kind_b, out);
+  pair_direction<double, OneLane>(a, na, kind_a, b, nb, kind_b, out);
   for (int c = 0; c < 3; ++c) d[c] = out[c];
   return 0;
 }
