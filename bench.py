@@ -260,6 +260,13 @@ def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device):
             torch.cuda.synchronize()
             times.append(start.elapsed_time(end))  # ms; the kernel is launched on torch's current stream
     ms = float(np.median(times))
+    if workload == 'mesh':  # per step two forward GEMMs of (4 batch) x 256 x 256 (the support points follow the state)
+        tflops = 2 * 2.0 * (4 * batch) * 256 * 256 * horizon / (ms * 1e-3) / 1e12
+        return {'workload': f'simulate ({workload}, {horizon} steps per call)', 'dtype': dtype_name, 'batch': batch,
+                'value': batch * horizon / (ms * 1e-3), 'unit': 'trajectory-steps/s (forward only)', 'ms_per_step': ms / horizon,
+                'kernel_ms': ms, 'launch': 'dpll_simulate_mesh: weights prepared once, 4 kernels per step enqueued by the library',
+                'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': tflops / MFMA_F32_PEAK_TFLOPS, 'kernel': 'whole step: icnn_fwd1 + icnn_fwd2 + simulate_kernel'}}
     alg = 2 * N_X[workload] * ELEM[dtype_name] * batch * horizon
     achieved = alg / (ms * 1e-3) / 1e9
     return {'workload': f'simulate ({workload}, {horizon} steps per launch)', 'dtype': dtype_name, 'batch': batch,
@@ -424,7 +431,7 @@ def main() -> None:
                     configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
                 except Exception as exc:  # noqa: BLE001
                     configs.append({'workload': w, 'dtype': d, 'batch': b, 'error': repr(exc)})
-            for w, d, b, h in (('cube', 'f32', 4096, 80), ('cube', 'f32', 65536, 80), ('elbow', 'f32', 4096, 120)):
+            for w, d, b, h in (('cube', 'f32', 4096, 80), ('cube', 'f32', 65536, 80), ('elbow', 'f32', 4096, 120), ('mesh', 'f32', 4096, 80)):
                 try:
                     configs.append(run_simulate_config(w, d, b, h, 5, device))
                 except Exception as exc:  # noqa: BLE001

@@ -19,7 +19,7 @@ GEN_SLOTS = MAX_GEOMS + MAX_PAIRS  # geometry slots of the general build (DPLL_G
 GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 11  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 12  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -140,6 +140,8 @@ def library() -> ctypes.CDLL:
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]
     lib.dpll_step_mesh.argtypes = [c_void_p, c_int, POINTER(Params), POINTER(MeshParams), c_void_p, c_int64, c_int64,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+    lib.dpll_simulate_mesh.argtypes = [c_void_p, c_int, POINTER(Params), POINTER(MeshParams), c_void_p, c_int64, c_int64, c_int64,
+                                       c_void_p, c_void_p, c_int64, c_void_p]
     lib.dpll_mesh_support_points.argtypes = [c_void_p, c_int, POINTER(MeshParams), c_void_p, c_int64, c_int64, c_void_p,
                                              c_void_p, c_int64, c_void_p]
     lib.dpll_ar_handle_bytes.restype = c_int64
@@ -169,5 +171,5 @@ EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 
                     'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_step_backward', 'dpll_simulate',
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
                     'dpll_profile_contactnets_loss_mesh',
-                    'dpll_step_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
+                    'dpll_step_mesh', 'dpll_simulate_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
                     'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh']

@@ -872,13 +872,14 @@ int mesh_body_quats(const dpll_model* m, const MeshPlan& pl, char* ws, const T* 
 // forward half of network g: prep + the two forward GEMMs -> its support points (and M1, U0 for the backward half)
 template <typename T>
 int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, hipStream_t stream,
-                 bool for_backward = false) {
+                 bool for_backward = false, bool prep = true) {
   char* nb = pl.net(ws, g);
   T* A = (T*)(nb + pl.off_A); T* AT = (T*)(nb + pl.off_AT); T* a = (T*)(nb + pl.off_a);
   T* P = (T*)(ws + pl.off_P) + 12 * g;
   constexpr bool kMfmaPath = std::is_same<T, float>::value;
-  hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
-                     kMfmaPath ? (T*)(nb + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + pl.off_ATf) : (T*)nullptr);
+  if (prep)  // (|W| in GEMM order: only the weights enter, so the steps of a rollout after the first skip it)
+    hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
+                       kMfmaPath ? (T*)(nb + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + pl.off_ATf) : (T*)nullptr);
   mesh_mark(stream);
   if constexpr (std::is_same<T, float>::value) {
     hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
@@ -945,11 +946,12 @@ int mesh_backward_all(const MeshPlan& pl, const dpll_mesh_params_t* mp, char* ws
 
 template <typename T, int NJ>
 int mesh_forward_all(const dpll_model* m, const MeshPlan& pl, const dpll_mesh_params_t* mp, char* ws, const T* state,
-                     long long ld, long long batch, hipStream_t stream, bool for_backward) {
+                     long long ld, long long batch, hipStream_t stream, bool for_backward, bool prep = true) {
   constexpr int NB = NJ + 1;
   if (int rc = mesh_body_quats<T, NJ>(m, pl, ws, state, ld, batch, stream)) return rc;
   for (int g = 0; g < NB; ++g)
-    if (int rc = mesh_forward<T>(pl, g, mesh_weights<T>(mp, g, NB), ws, quat_source<T, NJ>(pl, ws, state, ld, g), stream, for_backward))
+    if (int rc = mesh_forward<T>(pl, g, mesh_weights<T>(mp, g, NB), ws, quat_source<T, NJ>(pl, ws, state, ld, g), stream, for_backward,
+                                 prep))
       return rc;
   return 0;
 }
@@ -974,6 +976,31 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
   return mesh_backward_all<T, NJ>(pl, mp, ws, (const T*)xp, ld_xp, grad, loss_total, stream);
+}
+
+// Integrator.simulate with the network shapes: per step the two forward GEMMs of every network on the current state
+// (the support points depend on it) and the one-step kernel, enqueued back to back; the weights are prepared once.
+template <typename T, int NJ>
+int launch_mesh_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x0,
+                         long long ld_x, long long batch, long long steps, void* traj, void* workspace,
+                         long long workspace_bytes, hipStream_t stream) {
+  using D = Dims<T, NJ>;
+  const MeshPlan pl = mesh_plan<T, NJ>(batch);
+  if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_simulate_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  dpll_params_t q = *p;
+  q.lengths = nullptr;
+  const long long ld_item = (steps + 1) * D::NX;
+  for (long long s = 0; s < steps; ++s) {
+    const T* state = s == 0 ? (const T*)x0 : (const T*)traj + s * D::NX;
+    const long long ld = s == 0 ? ld_x : ld_item;
+    if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, state, ld, batch, stream, false, s == 0)) return rc;
+    // the first step also writes x0 into traj[:, 0]
+    if (int rc = launch_simulate<T, NJ>(m, dtype, &q, state, ld, batch, 1, (T*)traj + (s == 0 ? 0 : (s + 1) * D::NX), ld_item, D::NX,
+                                        s == 0 ? 1 : 0, nullptr, stream, ws + pl.off_P))
+      return rc;
+  }
+  return 0;
 }
 
 template <typename T, int NJ>
@@ -1085,7 +1112,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 11; }
+int dpll_abi_version(void) { return 12; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1337,6 +1364,17 @@ int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* pa
   const int nx = dpll_n_x(model);
   if (batch < 1 || !x || !x_next || ld_x < nx || ld_next < nx) return fail(-1, "dpll_step_mesh: bad state arguments%s");
   DPLL_MESH_DISPATCH(launch_mesh_step, model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}
+
+int dpll_simulate_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                       const void* x0, int64_t ld_x, int64_t batch, int64_t steps, void* traj, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+  if (!params) return fail(-1, "dpll_simulate_mesh: null parameter pointer%s");
+  if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_simulate_mesh")) return rc;
+  const int nx = dpll_n_x(model);
+  if (batch < 1 || steps < 1 || !x0 || !traj || ld_x < nx) return fail(-1, "dpll_simulate_mesh: bad state arguments%s");
+  DPLL_MESH_DISPATCH(launch_mesh_simulate, model, dtype, params, mesh, x0, ld_x, batch, steps, traj, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }
 

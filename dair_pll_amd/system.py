@@ -643,10 +643,16 @@ class MultibodyLearnableSystem(Module):
             return torch.stack(states, dim=1).reshape(batch_shape + (steps + 1, self.space.n_x))
         x = x.detach()
         traj = torch.empty((x.shape[0], steps + 1, self.space.n_x), dtype=self.dtype, device=x.device)
-        if self._mesh() is not None:  # support points depend on the state: one kernel sequence per step
-            traj[:, 0] = x
-            for step in range(steps):
-                traj[:, step + 1] = self._step(traj[:, step])
+        if self._mesh() is not None:  # support points depend on the state: the networks' forward kernels run every step
+            if steps == 0:
+                traj[:, 0] = x
+            else:
+                params = self._params_struct(flat)
+                workspace = self._mesh_workspace(x.shape[0], x.device)
+                mesh = self._mesh_struct(flat)
+                _capi.check(lib.dpll_simulate_mesh(self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh, _ptr(x),
+                                                   x.stride(0), x.shape[0], steps, _ptr(traj), _ptr(workspace),
+                                                   workspace.numel(), self._stream()))
             return traj.reshape(batch_shape + (steps + 1, self.space.n_x))
         params = self._params_struct(flat)
         _capi.check(lib.dpll_simulate(self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(x), x.stride(0),

@@ -220,6 +220,13 @@ int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* pa
                    const void* x, int64_t ld_x, int64_t batch, void* x_next, int64_t ld_next, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* dpll_simulate with the network shapes: x0 (batch, n_x) -> traj (batch, steps + 1, n_x) contiguous, traj[:, 0] = x0;
+ * steps >= 1.  The weights are prepared once, then every step enqueues the networks' forward kernels on the current state
+ * and the one-step kernel (no host work between the steps). */
+int dpll_simulate_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                       const void* x0, int64_t ld_x, int64_t batch, int64_t steps, void* traj, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
 /* DeepSupportConvex.get_vertices for the ground-contact direction of every state and body: points (batch, 4 n_bodies, 3),
  * each body's four in its own frame. */
 int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_mesh_params_t* mesh, const void* x,
