@@ -169,3 +169,33 @@ def test_empty_shard_contributes_a_zero_row():
     system.global_batch = 0
     with pytest.raises(_capi.DpllError):
         system.contactnets_loss_and_grad(x[:0], xp[:0])
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_training_a_general_model_with_a_body_body_pair(use_graph):
+    """The general build under the trainer (clasp_ball: a sphere base, a polygon tip, one body-body candidate): the data are
+    the model's own rollouts, the student starts with a wrong radius, jittered vertices and wrong frictions; the fused
+    loss + Adam (parameters are views of the packed [theta | friction (5) | geometry blocks (4, 24)] buffer, eager and
+    replayed as a hipGraph) reduce the loss and move the radius back."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.trainer import ContactNetsTrainer
+    g = np.load(os.path.join(GOLDEN_DIR, 'clasp_ball_literal.npz'))
+    x = torch.tensor(g['x'], dtype=torch.float32, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=torch.float32, device='cuda:0')
+    system = MultibodyLearnableSystem({'clasp_ball': os.path.join(ASSET_DIR, 'clasp_ball.urdf')}, float(g['dt']), dtype=torch.float32,
+                                      device='cuda:0', mesh_representation='polygon')
+    geometries = system.multibody_terms.contact_terms.geometries
+    true_radius = geometries[1].length_param.item()
+    gen = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        geometries[1].length_param.mul_(1.3)
+        geometries[2].vertices.add_(0.004 * torch.randn(geometries[2].vertices.shape, generator=gen).to('cuda:0'))
+        system.multibody_terms.contact_terms.friction_params.mul_(1.5)
+    start_radius = geometries[1].length_param.item()
+    trainer = ContactNetsTrainer(system, lr=1e-3, batch_size=x.shape[0], use_graph=use_graph)
+    log = trainer.fit(x, xp, epochs=60)
+    assert np.isfinite(log.epoch_losses).all() and log.epoch_losses[-1] < 0.7 * log.epoch_losses[0]
+    assert abs(geometries[1].length_param.item() - true_radius) < abs(start_radius - true_radius)
+    # the parameters are still views of the packed buffer the kernels read
+    flat = system._packed()
+    assert geometries[2].vertices.data_ptr() == flat.data_ptr() + (30 + 5 + 24) * flat.element_size()
