@@ -561,9 +561,10 @@ def pair_tosses(urdf: str, representation: str, n_traj: int, steps: int, keep_ev
 def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
     """SURVEY 8f-4, body-body contact: the reference's GeometryCollider.collide_mesh_mesh / ContactTerms.forward pair
     path (geometry.py:585-643, multibody_terms.py:428-521) on a base and a tip that fold onto each other -- box against
-    box, and a sphere against a polygon (the pair swapped into the reference's type order) -- with fcl's direction
-    supplied by DirectionSearchFcl.  Inputs: `pair_tosses`."""
-    for name, representation in (('clasp', 'deep_support'), ('clasp_ball', 'polygon')):
+    box, a sphere against a polygon (the pair swapped into the reference's type order), and the two arms of a branching
+    tree against each other (both members move with a joint of their own) -- with fcl's direction supplied by
+    DirectionSearchFcl.  Inputs: `pair_tosses`."""
+    for name, representation in (('clasp', 'deep_support'), ('clasp_ball', 'polygon'), ('vee_pair', 'deep_support')):
         urdf = os.path.join(REPO, 'assets', name + '.urdf')
         x, x_plus = pair_tosses(urdf, representation, n_traj, steps, keep_every, seed)
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3, mesh_representation=representation)

@@ -210,7 +210,8 @@ def test_general_models_are_described_for_the_general_build():
     expect = {'chain3': (2, [0, 1], [0, 1, 2], [0, 0, 0], 12), 'vee': (2, [0, 0], [0, 1, 2], [0, 0, 0], 12),
               'ballcube': (0, [], [0, 0, 0], [0, 1, 1], 6), 'mace': (1, [0], [0, 1, 1], [0, 1, 0], 9),
               'wedge': (1, [0], [0, 1, 0], [2, 0, 0], 8),  # (geom_body / geom_kind entries past n_geoms are zero)
-              'clasp': (2, [0, 1], [0, 2, 0], [0, 0, 0], 9), 'clasp_ball': (2, [0, 1], [0, 2, 0], [1, 2, 0], 6)}
+              'clasp': (2, [0, 1], [0, 2, 0], [0, 0, 0], 9), 'clasp_ball': (2, [0, 1], [0, 2, 0], [1, 2, 0], 6),
+              'vee_pair': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13)}
     block, slots = _capi.GEOM_BLOCK, _capi.GEN_SLOTS
     for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
         representation = 'polygon' if name in ('wedge', 'clasp_ball') else 'deep_support'
@@ -242,9 +243,9 @@ def test_general_models_are_described_for_the_general_build():
             bad.geom_nverts[0] = 3  # a support query returns 4 vertices (geometry.py:196)
             other = ctypes.c_void_p()
             assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0 and b'4 to 8 vertices' in lib.dpll_last_error()
-        if name.startswith('clasp'):
-            # base and tip: not joined by a joint, not filtered -> a collision candidate, ordered by geometry type
-            expect_pair = (0, 1) if name == 'clasp' else (1, 0)  # (polygon before sphere, geometry.py:46)
+        if name.startswith('clasp') or name == 'vee_pair':
+            # two bodies not joined by a joint, not filtered -> a collision candidate, ordered by geometry type
+            expect_pair = {'clasp': (0, 1), 'clasp_ball': (1, 0), 'vee_pair': (1, 2)}[name]  # (polygon before sphere, geometry.py:46)
             assert spec.pairs == [expect_pair] and desc.n_pairs == 1 and (desc.pair_a[0], desc.pair_b[0]) == expect_pair
             assert spec.contact_slots()[-1] == 4 * _capi.MAX_GEOMS
             bad = _capi.make_desc(spec, 0.0068)
