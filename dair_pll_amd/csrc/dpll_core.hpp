@@ -48,6 +48,9 @@
 #else
 #define DPLL_NOUNROLL _Pragma("GCC unroll 1")
 #endif
+#ifndef DPLL_INCREMENTAL
+#define DPLL_INCREMENTAL 1
+#endif
 #ifndef DPLL_PHASE_BEGIN
 #define DPLL_PHASE_BEGIN() do {} while (0)
 #define DPLL_PHASE(slot) do {} while (0)
@@ -855,6 +858,29 @@ DPLL_HD void sap_evaluate(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], con
   else p.nsum = p.jtg[5];
 }
 
+// The state at y + a d from the state at y WITHOUT going back to y: zs moves by -a (J d) and M y by a (M d).  The float
+// kernels iterate this way: forming J y + q afresh cancels O(1) terms down to O(eps |f|) and needs double, while the
+// increment J d is itself small -- an update in float loses 1 ulp of zs per iteration and nothing to cancellation -- so
+// the iteration carries no double arithmetic at all (the residual starts exactly: y = 0 gives zs = -q).
+template <typename T, int NJ, int KPL, class Lanes, class JT>
+DPLL_HD void sap_advance(const JT (&Jc)[KPL], const T (&mu)[KPL], const SapPoint<T, 6 + NJ, KPL>& cur,
+                         const T (&jd)[KPL][3], const T (&Md)[6 + NJ], const T (&d)[6 + NJ], T a,
+                         SapPoint<T, 6 + NJ, KPL>& p) {
+  constexpr int NV = 6 + NJ;
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) { p.yT[i] = cur.yT[i] + a * d[i]; p.My[i] = cur.My[i] + a * Md[i]; p.jtg[i] = T(0); }
+  T ns = T(0);
+  DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) p.zs[c][r] = cur.zs[c][r] - a * jd[c][r];
+    lorentz_project(p.zs[c], p.pr[c]);
+    const T g[3] = {mu[c] * p.pr[c].g[0], mu[c] * p.pr[c].g[1], p.pr[c].g[2]};
+    cjac_apply_t_add<T, NJ>(Jc[c], g, p.jtg);
+    ns += p.pr[c].g[2];
+  }
+  DPLL_UNROLL for (int i = 0; i < NV; ++i) p.jtg[i] = Lanes::group_sum(p.jtg[i]);
+  if constexpr (JacIsDense<JT>::value) p.nsum = Lanes::group_sum(ns);
+  else p.nsum = p.jtg[5];
+}
+
 // One iteration: Newton direction d from the state at y, then the state at y + d is evaluated -- it is both the line
 // search's probe of alpha = 1 (l'(1) = grad(y + d) . d) and, when that step is accepted (99 % of the item-iterations on
 // the benchmark batch), the next iteration's starting state, so an accepted iteration costs one evaluation, one
@@ -865,6 +891,8 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
                        const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3],
                        const T (&y0)[6 + NJ], bool use_y0) {
   constexpr int NV = 6 + NJ;
+  // float storage with a wider accumulation type: iterate on increments, all in float (sap_advance)
+  constexpr bool kIncremental = DPLL_INCREMENTAL && sizeof(T) < sizeof(TA);
   const T tol2 = T(opt.tol * opt.tol), stol2 = T(opt.stall_tol * opt.stall_tol), ls_tol = T(opt.ls_tol);
   const T stage_tol2 = T(opt.stage_tol * opt.stage_tol), inv_factor = T(1.0 / opt.stage_factor);
   const int last_stage = opt.n_stages - 1;
@@ -937,8 +965,21 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     // The state at y + d: l'(1) = grad(y + d) . d.
     TA yt[NV];
     T alpha = T(1);
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) yt[i] = y[i] + (moving ? TA(d[i]) : TA(0));
-    sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
+    T jd[KPL][3], Md[NV];
+    if constexpr (kIncremental) {
+      DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
+        T t[3];
+        cjac_apply<T, T, NJ>(Jc[c], d, t);
+        jd[c][0] = mu[c] * t[0];
+        jd[c][1] = mu[c] * t[1];
+        jd[c][2] = t[2];
+      }
+      symv<T, NV>(M, d, Md);
+      sap_advance<T, NJ, KPL, Lanes>(Jc, mu, cur, jd, Md, d, moving ? T(1) : T(0), trial);
+    } else {
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) yt[i] = y[i] + (moving ? TA(d[i]) : TA(0));
+      sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
+    }
     T first1 = T(0);
     DPLL_UNROLL for (int i = 0; i < NV; ++i) first1 += (trial.My[i] - ieps * trial.jtg[i]) * d[i];
     // alpha = 1 stands when the slope there is small enough, and also -- while the search is capped at one probe --
@@ -950,18 +991,21 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
       DPLL_PHASE_COUNT(6);
       // l'(alpha) = y.Md + alpha d.Md - sum_c gamma_c(alpha) . (J_c d); from H d = -grad:
       //   d.Md = dec2 - (1/eps) sum_c (J_c d)^T dP_c (J_c d),      l''(alpha) = d.Md + (1/eps) sum_c (J_c d)^T dP_c(alpha) (J_c d)
-      T jd[KPL][3];
       T curv = T(0), curv1 = T(0);
       DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-        T t[3];
-        cjac_apply<T, T, NJ>(Jc[c], d, t);
-        jd[c][0] = mu[c] * t[0];
-        jd[c][1] = mu[c] * t[1];
-        jd[c][2] = t[2];
-        curv += proj_quadratic(cur.pr[c], jd[c]);
+        if constexpr (!kIncremental) {
+          T t[3];
+          cjac_apply<T, T, NJ>(Jc[c], d, t);
+          jd[c][0] = mu[c] * t[0];
+          jd[c][1] = mu[c] * t[1];
+          jd[c][2] = t[2];
+          curv += proj_quadratic(cur.pr[c], jd[c]);
+        }
         curv1 += proj_quadratic(trial.pr[c], jd[c]);
       }
-      const T dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
+      T dMd;
+      if constexpr (kIncremental) dMd = tmax(dotn<T, NV>(d, Md), T(0));
+      else dMd = tmax(dec2 - ieps * Lanes::group_sum(curv), T(0));
       // capped search, l'(1) > 0 (overshoot): one safeguarded Newton step on l' back from alpha = 1, whose projections
       // are the trial state's
       {
@@ -1010,8 +1054,12 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
       }
       // The state at y + alpha d.  Items that kept alpha = 1 recompute the state they already have (same expressions,
       // same values): an item's result does not depend on which other items share its wave.
-      DPLL_UNROLL for (int i = 0; i < NV; ++i) yt[i] = y[i] + (moving ? TA(alpha) * TA(d[i]) : TA(0));
-      sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
+      if constexpr (kIncremental) {
+        sap_advance<T, NJ, KPL, Lanes>(Jc, mu, cur, jd, Md, d, moving ? alpha : T(0), trial);
+      } else {
+        DPLL_UNROLL for (int i = 0; i < NV; ++i) yt[i] = y[i] + (moving ? TA(alpha) * TA(d[i]) : TA(0));
+        sap_evaluate<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, yt, trial);
+      }
     }
     DPLL_PHASE(4);
     DPLL_PHASE_EVENT(7, fell_back);
@@ -1023,7 +1071,9 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     }
 #endif
     DPLL_ITER_HOOK(it, moving, alpha);
-    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = yt[i];
+    if constexpr (!kIncremental) {
+      DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = yt[i];
+    }
     iters = active ? it + 1 : iters;
     const bool stage_done = converged || stalled || (!final_stage && it_stage + 1 >= opt.stage_max_iter);
     const bool advance = active && !final_stage && stage_done && !force_free;
@@ -1044,6 +1094,9 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     if (!iterate(it + 1, pb, pa)) break;
   }
   DPLL_PHASE_END();
+  if constexpr (kIncremental) {
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = TA(in_b ? pb.yT[i] : pa.yT[i]);
+  }
   // forces at the final iterate, with the reference's eps: f = P_K(zs / eps) = gs / eps
   const T ieps = fast_rcp(eps);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c)
