@@ -1478,7 +1478,6 @@ template <typename T, typename TA, int NJ, int NG, class MD>
 DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
                                   const Kin<TA, NJ>& kinA, int p, int slot, ContactGeom<T, NJ, true>& cg,
                                   const TA* dir_in) {
-  constexpr int NB = NJ + 1;
   const bool masked = p >= md.n_pairs || slot != 0;
   const int ga = masked ? 0 : md.pair_a[p], gb = masked ? 0 : md.pair_b[p];
   const int ba = md.geom_body[ga], bb = md.geom_body[gb];
