@@ -504,6 +504,14 @@ def topk_support(directions: Tensor, vertices: Tensor, n_query: int = N_QUERY) -
     return torch.gather(vertices, -2, order.unsqueeze(-1).expand(order.shape + (3,)))
 
 
+def surface_directions() -> Tensor:
+    """reference deep_support_function.py:12-16: unit directions through the boundary nodes of an 8 x 8 x 8 grid on [-1, 1]^3"""
+    line = torch.linspace(-1, 1, steps=8, dtype=torch.float64)
+    grid = torch.cartesian_prod(line, line, line)
+    surface = grid[grid.abs().max(dim=-1).values >= 1.0]
+    return surface / surface.norm(dim=-1, keepdim=True)
+
+
 def rotation_matrix_from_one_vector(directions: Tensor, axis: int = 2) -> Tensor:
     """reference tensor_utils.py:305-366 (after Drake's MakeFromOneVector): R with R[:, axis] = d."""
     a = directions / directions.norm(dim=-1, keepdim=True)
@@ -923,11 +931,24 @@ class OracleSystem:
             return torch.zeros((1, 3), dtype=self.dtype), torch.abs(params['length_param'])
         if 'vertices' in params:
             return params['vertices'], torch.zeros((), dtype=self.dtype)
-        raise NotImplementedError('body-body contact of DeepSupportConvex geometries')
+        # DeepSupportConvex.get_fcl_geometry (reference geometry.py:343-358): the mesh extract_mesh builds from the network,
+        # i.e. its distinct support points over the 296 surface directions (deep_support_function.py:12-16, 92-113)
+        weights = {k: v.detach() for k, v in params.items() if k != 'perturbations'}
+        points = icnn_support_point(weights, surface_directions().to(self.dtype))
+        seen, unique = set(), []
+        for point in points:
+            key = point.numpy().tobytes()
+            if key not in seen:
+                seen.add(key)
+                unique.append(point)
+        return torch.stack(unique), torch.zeros((), dtype=self.dtype)
 
     def support_single(self, geom_index: int, directions: Tensor) -> Tensor:
         """what `geometry.network(directions)` is to collide_mesh_mesh (reference geometry.py:627-629): ONE support point
         per direction -- the vertex furthest along it (ties: lowest index) plus, for a sphere, the radius along it"""
+        params = self.geom_params[geom_index]
+        if 'output_weight' in params:  # DeepSupportConvex: the network itself, geometry.network(directions) (:627-629)
+            return icnn_support_point({k: v for k, v in params.items() if k != 'perturbations'}, directions)
         vertices, margin = self.vertex_set(geom_index)
         dots = (directions @ vertices.transpose(-1, -2)).detach()
         # the lowest index among the vertices within PAIR_TIE of the furthest one: a direction that is a face or edge

@@ -54,8 +54,20 @@ class DirectionSearchFcl:
             self.transform = transform
 
         def world(self):
-            vertices, margin = self.shape
+            vertices, margin = (self.shape.vertices, 0.0) if isinstance(self.shape, DirectionSearchFcl.BVHModel) else self.shape
             return vertices @ self.transform.R.T + self.transform.p, margin
+
+    class BVHModel:
+        """DeepSupportConvex.get_fcl_geometry (geometry.py:343-358) hands its extracted mesh over through this interface"""
+
+        def beginModel(self, n_vertices, n_faces):  # noqa: N802 (fcl's name)
+            self.vertices = np.zeros((0, 3))
+
+        def addSubModel(self, vertices, faces):  # noqa: N802
+            self.vertices = np.asarray(vertices, dtype=np.float64)
+
+        def endModel(self):  # noqa: N802
+            pass
 
     class CollisionRequest:
         enable_contact = False
@@ -130,6 +142,14 @@ from dair_pll.system import System  # noqa: E402
 from oracle import dpll_oracle as O  # noqa: E402
 
 assert torch.get_default_dtype() == torch.float64  # reference inertia.py:96
+# deep_support_function.py:12-16 builds its surface directions at import, in whatever default dtype the import order left
+# (here float32: geometry was imported before inertia); extract_mesh then multiplies them with float64 weights.  As the
+# module would have built them under the float64 default:
+import dair_pll.deep_support_function as _dsf  # noqa: E402
+_line = torch.linspace(-1, 1, steps=8)
+_grid = torch.cartesian_prod(_line, _line, _line)
+_dsf._SURFACE = _grid[_grid.abs().max(dim=-1).values >= 1.0]
+_dsf._SURFACE = _dsf._SURFACE / _dsf._SURFACE.norm(dim=-1, keepdim=True)
 
 
 class RecordingSolver:
@@ -568,6 +588,10 @@ def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, se
         urdf = os.path.join(REPO, 'assets', name + '.urdf')
         x, x_plus = pair_tosses(urdf, representation, n_traj, steps, keep_every, seed)
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3, mesh_representation=representation)
+    # the reference's own case: two DeepSupportConvex shapes (its classes unmodified; fcl sees their extracted meshes)
+    urdf = os.path.join(REPO, 'assets', 'clasp_mesh.urdf')
+    x, x_plus = pair_tosses(urdf, 'deep_support', 6, 36, 3, seed)
+    record_case('clasp_mesh_literal', urdf, x, x_plus, 'reference_literal', sim_steps=2)
 
 
 def record_elbow_mesh() -> None:
