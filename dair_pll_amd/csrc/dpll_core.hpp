@@ -805,6 +805,13 @@ struct SolverOpts {
   int warm_start;
   // build of the loss kernel: -1 picked from the batch size, 0 always one lane per contact, 1 always one lane per item
   int wide;
+  // continuation schedule of the LOSS solve when it should differ from the dynamics solve's (n_stages / stage_factor above):
+  // the loss regularises with eps = 1e-3, the dynamics with 1e-4, and the worst case of one is not the worst case of the
+  // other (elbow, 4096 pairs: loss 21 -> 18 iterations with 5 stages of 2.5, where the dynamics solve goes 19 -> 36).
+  // loss_n_stages = 0: same schedule for both.
+  double loss_stage_factor;
+  int loss_n_stages;
+  int reserved;
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
@@ -1818,7 +1825,12 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
   pen = Lanes::group_sum(pen);
   TA y[NV];
   DPLL_CORE_STAMP(4);
-  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, force, dv, opt.warm_start != 0);
+  SolverOpts loss_opt = opt;
+  if (opt.loss_n_stages > 0) {
+    loss_opt.n_stages = opt.loss_n_stages;
+    loss_opt.stage_factor = opt.loss_stage_factor;
+  }
+  iters = sap_newton<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, loss_opt, y, force, dv, opt.warm_start != 0);
   DPLL_CORE_STAMP(5);
   // invalid-solve mask (multibody_learnable_system.py:186-192)
   bool bad = false;

@@ -92,6 +92,9 @@ typedef struct dpll_solver_opts {
   int32_t fast_ls;        /* probes per iteration while the decrement keeps falling; 0 = always the full search */
   int32_t warm_start;     /* loss solve starts from the observed velocity jump dv instead of 0 */
   int32_t wide;           /* loss-kernel build: -1 = by batch size, 0 = one lane per contact, 1 = one lane per item */
+  double loss_stage_factor; /* continuation schedule of the loss solve (eps 1e-3) when it differs from the dynamics solve's */
+  int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves */
+  int32_t reserved;
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;
