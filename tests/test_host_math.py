@@ -99,7 +99,7 @@ def test_free_flight_has_zero_force_and_tiny_loss(golden):
     assert np.abs(out['force']).max() == 0.0
     assert out['loss'].max() < 5e-4  # measurement noise of real data: 1/2 dv^T M dv with no contact impulse
     assert np.abs(out['loss'] - g['loss'][airborne]).max() < 1e-15
-    assert out['iters'].max() <= 1
+    assert out['iters'].max() <= 2  # one iteration of the float phase + one of the double phase confirm y = 0
 
 
 def test_sanitized_build_runs_clean(golden):
