@@ -19,7 +19,7 @@ GEN_SLOTS = MAX_GEOMS + MAX_PAIRS  # geometry slots of the general build (DPLL_G
 GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 13  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 14  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -41,7 +41,7 @@ class SolverOpts(ctypes.Structure):
                 ('ls_tol', c_double), ('n_stages', c_int32), ('stage_max_iter', c_int32), ('stage_factor', c_double),
                 ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('fast_ls', c_int32),
                 ('warm_start', c_int32), ('wide', c_int32), ('loss_stage_factor', c_double), ('loss_n_stages', c_int32),
-                ('reserved', c_int32)]
+                ('f64_refine', c_int32)]
 
 
 class Params(ctypes.Structure):

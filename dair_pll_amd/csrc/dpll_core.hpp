@@ -811,7 +811,8 @@ struct SolverOpts {
   // loss_n_stages = 0: same schedule for both.
   double loss_stage_factor;
   int loss_n_stages;
-  int reserved;
+  // double-precision solves: 1 = float iterations refined in double (sap_solve), 0 = every iteration in double
+  int f64_refine;
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
@@ -1132,6 +1133,7 @@ DPLL_HD int sap_solve(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ, DENSE> (&J
                       const T (&y0)[6 + NJ], bool use_y0) {
   constexpr int NV = 6 + NJ;
   if constexpr (DPLL_MIXED_F64 && sizeof(T) == 8 && sizeof(TA) == 8) {
+    if (opt.f64_refine == 0) return sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, opt, y, f, y0, use_y0);
     float Mf[NV][NV], muf[KPL], qcf[KPL][3], ff[KPL][3], y0f[NV];
     CJac<float, NJ, DENSE> Jf[KPL];
     DPLL_UNROLL for (int i = 0; i < NV; ++i) {

@@ -572,7 +572,7 @@ SolverOpts default_opts(int dtype, int n_joints = 0, bool general = false) {
   // the cube keeps 6 x 3.0: 14 against 15; the general build is not tuned)
   o.loss_n_stages = (!general && n_joints == 1) ? 5 : 0;
   o.loss_stage_factor = 2.5;
-  o.reserved = 0;
+  o.f64_refine = 1;
   return o;
 }
 
@@ -1117,7 +1117,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 13; }
+int dpll_abi_version(void) { return 14; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");

@@ -94,7 +94,7 @@ typedef struct dpll_solver_opts {
   int32_t wide;           /* loss-kernel build: -1 = by batch size, 0 = one lane per contact, 1 = one lane per item */
   double loss_stage_factor; /* continuation schedule of the loss solve (eps 1e-3) when it differs from the dynamics solve's */
   int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves */
-  int32_t reserved;
+  int32_t f64_refine;       /* DPLL_F64 solves: 1 = float iterations refined in double to `tol` (default), 0 = all double */
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;
