@@ -266,3 +266,41 @@ def test_gpu_step_backward_against_oracle_autograd(golden, name):
     q = x_np[:, :4] / np.linalg.norm(x_np[:, :4], axis=-1, keepdims=True)
     diff[:, :4] -= (diff[:, :4] * q).sum(-1, keepdims=True) * q
     assert np.abs(diff).max() <= 1e-7 * x_ref.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['clasp', 'clasp_ball', 'vee_pair'])
+def test_gpu_pair_models_on_random_states(golden, name):
+    """Body-body contact away from the rollouts of the fixtures: 192 seeded states with the joints anywhere (the pair far
+    apart, touching, and overlapping by centimetres), parameters as recorded -- loss, every gradient and the next state of
+    the kernels against the oracle (whose direction comes from the convex hull of the Minkowski difference)."""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, torch.float64)
+    oracle = oracle_from(g, name).requires_grad_()
+    gen = torch.Generator().manual_seed(11)
+    n, n_j = 192, system.spec.n_joints
+    quat = torch.randn((n, 4), generator=gen, dtype=torch.float64)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    q = torch.cat((quat, 0.05 * torch.randn((n, 2), generator=gen, dtype=torch.float64),
+                   0.06 + 0.05 * torch.rand((n, 1), generator=gen, dtype=torch.float64),
+                   2.5 * torch.randn((n, n_j), generator=gen, dtype=torch.float64)), -1)
+    v = torch.cat((3 * torch.randn((n, 3), generator=gen, dtype=torch.float64), 0.5 * torch.randn((n, 3), generator=gen, dtype=torch.float64),
+                   3 * torch.randn((n, n_j), generator=gen, dtype=torch.float64)), -1)
+    x = torch.cat((q, v), -1)
+    with torch.no_grad():
+        x_next_ref = oracle.step(x)
+        phi_pair = oracle.contact_terms(oracle.q_v(x_next_ref)[0])[0][:, -1]
+    assert (phi_pair < -0.002).sum() >= 5 and (phi_pair > 0.01).sum() >= 50  # overlapping and apart both occur
+    loss_ref = oracle.contactnets_loss(x, x_next_ref)
+    loss_ref.mean().backward()
+    xd, xpd = x.cuda(), x_next_ref.cuda()
+    x_next = system.step(xd)
+    assert (x_next.detach().cpu() - x_next_ref).abs().max() < 1e-9 * max(1.0, x_next_ref.abs().max().item())
+    loss = system.contactnets_loss(xd, torch.zeros((n, 0), device='cuda:0'), xpd)
+    assert (loss.detach().cpu() - loss_ref.detach()).abs().max() < 1e-10 * max(1.0, loss_ref.abs().max().item())
+    loss.mean().backward()
+    ref_named = oracle.named_parameters()
+    for key, param in system.named_parameters():
+        ref = ref_named[key].grad.numpy()
+        err = np.abs(param.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-8 * max(np.abs(ref).max(), 1e-3), (key, err, np.abs(ref).max())
