@@ -67,7 +67,7 @@
 
 namespace dpll {
 
-constexpr int kMaxJoints = 2;   // revolute joints of the tree hanging off the floating base
+constexpr int kMaxJoints = 3;   // revolute joints of the tree hanging off the floating base
 constexpr int kMaxBodies = kMaxJoints + 1;
 constexpr int kMaxGeoms = 3;    // convex collision geometries of a model (each against the ground half-space)
 constexpr int kGeomBox = 0, kGeomSphere = 1, kGeomPolygon = 2;

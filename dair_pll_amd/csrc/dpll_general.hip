@@ -365,10 +365,12 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
     if (dtype == DPLL_F32 && nj == 0) return FN<float, 0>(__VA_ARGS__);                       \
     if (dtype == DPLL_F32 && nj == 1) return FN<float, 1>(__VA_ARGS__);                       \
     if (dtype == DPLL_F32 && nj == 2) return FN<float, 2>(__VA_ARGS__);                       \
+    if (dtype == DPLL_F32 && nj == 3) return FN<float, 3>(__VA_ARGS__);                       \
     if (dtype == DPLL_F64 && nj == 0) return FN<double, 0>(__VA_ARGS__);                      \
     if (dtype == DPLL_F64 && nj == 1) return FN<double, 1>(__VA_ARGS__);                      \
     if (dtype == DPLL_F64 && nj == 2) return FN<double, 2>(__VA_ARGS__);                      \
-    return dpll_fail(-2, "%s: the general build covers 0 to 2 joints", #FN);                   \
+    if (dtype == DPLL_F64 && nj == 3) return FN<double, 3>(__VA_ARGS__);                      \
+    return dpll_fail(-2, "%s: the general build covers 0 to 3 joints", #FN);                   \
   } while (0)
 
 }  // namespace

@@ -21,7 +21,7 @@ from typing import List, Optional, Tuple
 
 GROUND_MU = 1.0  # dair_pll/drake_utils.py:280-288
 GRAVITY_Z = -9.81  # Drake's default UniformGravityField
-MAX_JOINTS = 2  # dpll_core.hpp kMaxJoints
+MAX_JOINTS = 3  # dpll_core.hpp kMaxJoints
 MAX_GEOMS = 3  # dpll_core.hpp kMaxGeoms
 MAX_POLYGON_VERTICES = 8  # dpll_core.hpp kMaxPolyVerts
 MAX_PAIRS = 1  # dpll_core.hpp kMaxPairs

@@ -35,8 +35,8 @@
 extern "C" {
 #endif
 
-#define DPLL_MAX_JOINTS 2
-#define DPLL_MAX_BODIES 3
+#define DPLL_MAX_JOINTS 3
+#define DPLL_MAX_BODIES 4
 #define DPLL_MAX_GEOMS 3
 #define DPLL_MAX_PAIRS 1                         /* body-body collision candidates */
 #define DPLL_GEN_SLOTS (DPLL_MAX_GEOMS + DPLL_MAX_PAIRS) /* geometry slots of the general build: a pair sits behind the geometries */

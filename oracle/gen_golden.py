@@ -523,12 +523,14 @@ def general_tosses(urdf: str, n_traj: int, steps: int, keep_every: int, seed: in
     return x, x_plus
 
 
-def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0,
+                         names=('chain3', 'vee', 'ballcube', 'mace', 'gripper')) -> None:
     """models beyond the cube / elbow topologies -- three-link serial chain, branching tree, several
-    geometries on one body, spheres (this repository's own URDFs under assets/) -- through the reference's own
+    geometries on one body, spheres, four links on three hinges with one link bare of geometry (this repository's own
+    URDFs under assets/) -- through the reference's own
     MultibodyTerms / contactnets_loss / forward_dynamics / simulate, exactly as `record_case` does for the reference's
     assets.  Inputs: `general_tosses`."""
-    for name in ('chain3', 'vee', 'ballcube', 'mace'):
+    for name in names:
         urdf = os.path.join(REPO, 'assets', name + '.urdf')
         x, x_plus = general_tosses(urdf, n_traj, steps, keep_every, seed)
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3)

@@ -216,11 +216,13 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
 }
 
 // general models (tree topology, geometry table): always three geometry slots, the unused ones masked
-template <typename T, typename TA, class F0, class F1, class F2> int general_dispatch(const ModelDesc* md, F0 f0, F1 f1, F2 f2) {
+template <typename T, typename TA, class F0, class F1, class F2, class F3>
+int general_dispatch(const ModelDesc* md, F0 f0, F1 f1, F2 f2, F3 f3) {
   const GeneralDesc& gd = *static_cast<const GeneralDesc*>(md);
   if (md->n_joints == 0) f0(gd);
   else if (md->n_joints == 1) f1(gd);
   else if (md->n_joints == 2) f2(gd);
+  else if (md->n_joints == 3) f3(gd);
   else return -1;
   return 0;
 }
@@ -236,7 +238,8 @@ int hostsim_loss_f64(const ModelDesc* md, const SolverOpts* opt, const double* t
     return general_dispatch<double, double>(
         md, [&](const GeneralDesc& g) { loss_batch<double, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
         [&](const GeneralDesc& g) { loss_batch<double, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
-        [&](const GeneralDesc& g) { loss_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
+        [&](const GeneralDesc& g) { loss_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<double, double, 3, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
   if (md->n_joints == 0) loss_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
   else if (md->n_joints == 1) loss_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
   else return -1;
@@ -251,7 +254,8 @@ int hostsim_loss_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
     return general_dispatch<float, double>(
         md, [&](const GeneralDesc& g) { loss_batch<float, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
         [&](const GeneralDesc& g) { loss_batch<float, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
-        [&](const GeneralDesc& g) { loss_batch<float, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
+        [&](const GeneralDesc& g) { loss_batch<float, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); },
+        [&](const GeneralDesc& g) { loss_batch<float, double, 3, kGenSlots>(g, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters); });
   if (md->n_joints == 0) {
     if (mixed) loss_batch<float, double, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
     else loss_batch<float, float, 0>(*md, *opt, theta, friction, lengths, x, xp, B, weights, scale, loss, grad, force, iters);
@@ -268,7 +272,8 @@ int hostsim_step_f64(const ModelDesc* md, const SolverOpts* opt, const double* t
     return general_dispatch<double, double>(
         md, [&](const GeneralDesc& g) { step_batch<double, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
         [&](const GeneralDesc& g) { step_batch<double, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
-        [&](const GeneralDesc& g) { step_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
+        [&](const GeneralDesc& g) { step_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<double, double, 3, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
   if (md->n_joints == 0) step_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
   else if (md->n_joints == 1) step_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
   else return -1;
@@ -281,7 +286,8 @@ int hostsim_step_f32(const ModelDesc* md, const SolverOpts* opt, const float* th
     return general_dispatch<float, double>(
         md, [&](const GeneralDesc& g) { step_batch<float, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
         [&](const GeneralDesc& g) { step_batch<float, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
-        [&](const GeneralDesc& g) { step_batch<float, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
+        [&](const GeneralDesc& g) { step_batch<float, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); },
+        [&](const GeneralDesc& g) { step_batch<float, double, 3, kGenSlots>(g, *opt, theta, friction, lengths, x, B, x_next, iters); });
   if (md->n_joints == 0) {
     if (mixed) step_batch<float, double, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
     else step_batch<float, float, 0>(*md, *opt, theta, friction, lengths, x, B, x_next, iters);
@@ -316,7 +322,8 @@ int hostsim_step_backward_f64(const ModelDesc* md, const SolverOpts* opt, const 
     return general_dispatch<double, double>(
         md, [&](const GeneralDesc& g) { step_backward_batch<double, double, 0, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
         [&](const GeneralDesc& g) { step_backward_batch<double, double, 1, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
-        [&](const GeneralDesc& g) { step_backward_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); });
+        [&](const GeneralDesc& g) { step_backward_batch<double, double, 2, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); },
+        [&](const GeneralDesc& g) { step_backward_batch<double, double, 3, kGenSlots>(g, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar); });
   if (md->n_joints == 0) step_backward_batch<double, double, 0>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else if (md->n_joints == 1) step_backward_batch<double, double, 1>(*md, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
   else return -1;

@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (6 + 6 + 9) + 4 * (2 + 1 + 3 + 3 + 3 + 1 + 1 + 1 + 1)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 1 + 1 + 1) + 4  # (tail padding)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
@@ -211,7 +211,8 @@ def test_general_models_are_described_for_the_general_build():
               'ballcube': (0, [], [0, 0, 0], [0, 1, 1], 6), 'mace': (1, [0], [0, 1, 1], [0, 1, 0], 9),
               'wedge': (1, [0], [0, 1, 0], [2, 0, 0], 8),  # (geom_body / geom_kind entries past n_geoms are zero)
               'clasp': (2, [0, 1], [0, 2, 0], [0, 0, 0], 9), 'clasp_ball': (2, [0, 1], [0, 2, 0], [1, 2, 0], 6),
-              'vee_pair': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13)}
+              'vee_pair': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13),
+              'gripper': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 9)}  # body 1 carries no geometry
     block, slots = _capi.GEOM_BLOCK, _capi.GEN_SLOTS
     for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
         representation = 'polygon' if name in ('wedge', 'clasp_ball') else 'deep_support'

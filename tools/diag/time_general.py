@@ -5,7 +5,7 @@ import numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 from dair_pll_amd import MultibodyLearnableSystem
-MODELS = {'chain3': ('chain3.urdf', 'deep_support'), 'mace': ('mace.urdf', 'deep_support'), 'wedge': ('wedge.urdf', 'polygon'),
+MODELS = {'chain3': ('chain3.urdf', 'deep_support'), 'gripper': ('gripper.urdf', 'deep_support'), 'mace': ('mace.urdf', 'deep_support'), 'wedge': ('wedge.urdf', 'polygon'),
           'clasp': ('clasp.urdf', 'deep_support'), 'clasp_ball': ('clasp_ball.urdf', 'polygon')}
 for name, (urdf, rep) in MODELS.items():
     g = np.load(os.path.join(REPO, 'tests', 'golden', name + '_literal.npz'))
