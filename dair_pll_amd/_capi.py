@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
 
-from .urdf import ModelSpec, check_supported
+from .urdf import ModelSpec, _differs, _matmul, _matvec, _transpose, check_supported
 
 MAX_JOINTS = 3
 MAX_BODIES = 4
@@ -32,7 +32,8 @@ class ModelDesc(ctypes.Structure):
                 ('joint_origin', (c_double * 3) * MAX_JOINTS), ('joint_axis', (c_double * 3) * MAX_JOINTS),
                 ('geom_origin', (c_double * 3) * MAX_GEOMS), ('parent', c_int32 * MAX_JOINTS), ('n_geoms', c_int32),
                 ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('geom_nverts', c_int32 * MAX_GEOMS), ('n_pairs', c_int32),
-                ('pair_a', c_int32 * MAX_PAIRS), ('pair_b', c_int32 * MAX_PAIRS), ('reserved', c_int32)]
+                ('pair_a', c_int32 * MAX_PAIRS), ('pair_b', c_int32 * MAX_PAIRS), ('rotated', c_int32),
+                ('body_rot', ((c_double * 3) * 3) * MAX_BODIES), ('geom_rot', ((c_double * 3) * 3) * MAX_GEOMS)]
 
 
 class SolverOpts(ctypes.Structure):
@@ -64,19 +65,42 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
     desc.inertia_mode = INERTIA_MODES[inertia_mode]
     desc.dt = dt
     desc.gravity_z = spec.gravity_z
+    # The kernels' body frames all coincide at zero joint angles.  A URDF whose joint <origin>s carry a rotation is
+    # re-expressed in such frames: body b's is its URDF frame turned back by A_b (ModelSpec.body_alignment), so the joint
+    # data is rotated by A here, the inertial parameters -- learnable, in the URDF's frames like the reference's -- by
+    # body_rot in the kernels, and a geometry's own orientation R_BG becomes geom_rot = A_b R_BG (its origin is given
+    # in that geometry frame).
+    eye = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+    align = spec.body_alignment()
     for index, body in enumerate(spec.bodies):
+        for r in range(3):
+            for c in range(3):
+                desc.body_rot[index][r][c] = align[index][r][c]
         if index > 0:
             desc.parent[index - 1] = body.parent
+            origin, hinge = _matvec(align[body.parent], body.joint_origin), _matvec(align[index], body.joint_axis)
             for axis in range(3):
-                desc.joint_origin[index - 1][axis] = body.joint_origin[axis]
-                desc.joint_axis[index - 1][axis] = body.joint_axis[axis]
+                desc.joint_origin[index - 1][axis] = origin[axis]
+                desc.joint_axis[index - 1][axis] = hinge[axis]
+    for index in range(len(spec.bodies), MAX_BODIES):
+        for r in range(3):
+            desc.body_rot[index][r][r] = 1.0
     geoms = spec.geoms()
+    for g in range(MAX_GEOMS):
+        for r in range(3):
+            desc.geom_rot[g][r][r] = 1.0
     for g, (body_index, geom) in enumerate(geoms):
         desc.geom_body[g] = body_index
         desc.geom_kind[g] = GEOM_KINDS.get(geom.kind, 0)
         desc.geom_nverts[g] = len(geom.vertices) if geom.kind == 'polygon' else 0
-        for axis in range(3):
-            desc.geom_origin[g][axis] = geom.origin[axis]
+        frame = _matmul(align[body_index], geom.rotation)
+        origin = _matvec(_transpose(geom.rotation), geom.origin)
+        for r in range(3):
+            desc.geom_origin[g][r] = origin[r]
+            for c in range(3):
+                desc.geom_rot[g][r][c] = frame[r][c]
+    desc.rotated = ((1 if any(_differs(a, eye) for a in align) else 0)
+                    | (2 if any(_differs(_matmul(align[b], geom.rotation), eye) for b, geom in geoms) else 0))
     desc.n_geoms = 0 if spec.is_fast() else len(geoms)
     for p, (a, b) in enumerate(spec.pairs):
         desc.pair_a[p], desc.pair_b[p] = a, b

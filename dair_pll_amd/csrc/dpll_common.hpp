@@ -128,11 +128,14 @@ template <int G, typename T> __device__ __forceinline__ T wave_sum_of_groups(T x
 // owns no items and runs on a SIMD the launch leaves idle) writes that matrix behind the partial rows while the other
 // workgroups solve; the finalize kernel then applies it with <= 10 multiply-adds per parameter -- the theta -> iota
 // duals are on nobody's critical path.
-template <typename S> __device__ __forceinline__ void theta_jacobian_column(int inertia_mode, const S* theta_b, int c, S (&dio)[kIota]) {
+template <typename S>
+__device__ __forceinline__ void theta_jacobian_column(int inertia_mode, const S* theta_b, int c, S (&dio)[kIota],
+                                                      const double (*body_rot)[3][3] = nullptr) {
   DualT<S> th[10], io[kIota];
 #pragma unroll
   for (int i = 0; i < 10; ++i) th[i] = DualT<S>(theta_b[i], i == c ? S(1) : S(0));
   theta_to_iota<DualT<S>>(th, inertia_mode, io);
+  if (body_rot) rotate_iota<DualT<S>>(*body_rot, io);
 #pragma unroll
   for (int i = 0; i < kIota; ++i) dio[i] = io[i].d;
 }
@@ -148,7 +151,7 @@ __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __
     T th[10], dio[kIota];
 #pragma unroll
     for (int i = 0; i < 10; ++i) th[i] = T(theta[10 * (lane / 10) + i]);
-    theta_jacobian_column<T>(inertia_mode, th, lane % 10, dio);
+    theta_jacobian_column<T>(inertia_mode, th, lane % 10, dio, (gd && (gd->rotated & 1)) ? &gd->body_rot[lane / 10] : nullptr);
 #pragma unroll
     for (int i = 0; i < kIota; ++i) chain[lane * kIota + i] = double(dio[i]);
   }

@@ -77,6 +77,9 @@ constexpr int kGenSlots = kMaxGeoms + kMaxPairs;  // geometry slots of the gener
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
 
+#ifndef DPLL_ROTATED  // (diagnostic builds define it to 0: the code for turned frames compiled out)
+#define DPLL_ROTATED(md) ((md).rotated)
+#endif
 // Plain-old-data model description, passed to kernels by value.
 struct ModelDesc {
   int32_t n_joints;
@@ -99,7 +102,10 @@ struct ModelDesc {
   int32_t n_pairs;
   int32_t pair_a[kMaxPairs];
   int32_t pair_b[kMaxPairs];
-  int32_t reserved;
+  // frames turned against each other (URDF rpy; general build only, see include/dpll.h): bit 0 = body_rot, bit 1 = geom_rot
+  int32_t rotated;
+  double body_rot[kMaxBodies][3][3];  // inertial parameters' frame -> the kernels' frame of the body
+  double geom_rot[kMaxGeoms][3][3];   // geometry frame in the kernels' frame of its body; geom_origin is in the geometry frame
   static constexpr bool kGeneral = false;
   static constexpr int kGeoStride = 3;  // numbers per geometry in the `lengths` parameter block: a box's length_params
 };
@@ -257,6 +263,44 @@ template <typename S> DPLL_HD void theta_to_iota(const S (&th)[10], int inertia_
   iota[7] = oxy * im + k * (c0 * c1);
   iota[8] = oxz * im + k * (c0 * c2);
   iota[9] = oyz * im + k * (c1 * c2);
+}
+
+// the inertial vector of a body taken to a frame turned by A (coordinates v -> A v):  h -> A h,  I_o -> A I_o A^T
+template <typename S> DPLL_HD void rotate_iota(const double (&A)[3][3], S (&iota)[kIota]) {
+  const S h[3] = {iota[1], iota[2], iota[3]};
+  const S I[3][3] = {{iota[4], iota[7], iota[8]}, {iota[7], iota[5], iota[9]}, {iota[8], iota[9], iota[6]}};
+  S AI[3][3];
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    iota[1 + r] = S(A[r][0]) * h[0] + S(A[r][1]) * h[1] + S(A[r][2]) * h[2];
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) AI[r][c] = S(A[r][0]) * I[0][c] + S(A[r][1]) * I[1][c] + S(A[r][2]) * I[2][c];
+  }
+  auto out = [&](int r, int c) { return AI[r][0] * S(A[c][0]) + AI[r][1] * S(A[c][1]) + AI[r][2] * S(A[c][2]); };
+  iota[4] = out(0, 0); iota[5] = out(1, 1); iota[6] = out(2, 2);
+  iota[7] = out(0, 1); iota[8] = out(0, 2); iota[9] = out(1, 2);
+}
+// R <- R G: a body's world rotation taken to the frame of a geometry that sits turned in the body
+template <typename S> DPLL_HD void mat3_mul_const(S (&R)[3][3], const double (&G)[3][3]) {
+  DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+    const S a = R[r][0], b = R[r][1], c = R[r][2];
+    DPLL_UNROLL for (int k = 0; k < 3; ++k) R[r][k] = a * S(G[0][k]) + b * S(G[1][k]) + c * S(G[2][k]);
+  }
+}
+
+// A geometry turned in its body: R (the body's world rotation) becomes the geometry's, R_WB R_BG, and so does its third
+// row Rz.  (Inlined: as a real call it was no cheaper.  Models without turned frames skip it on a uniform branch; its
+// presence alone costs the double-precision general kernels of 2-joint models ~10 %, tools/diag/time_general.py with
+// -DDPLL_ROTATED(md)=0 as the other build.)
+template <typename T, typename TA>
+DPLL_HD void turn_to_geometry(const double (&geom_rot)[kMaxGeoms][3][3], int g, T (&R)[3][3], TA (&Rz)[3]) {
+  double G[3][3];
+  DPLL_UNROLL for (int r = 0; r < 3; ++r)
+    DPLL_UNROLL for (int c = 0; c < 3; ++c) {
+      G[r][c] = geom_rot[0][r][c];
+      DPLL_UNROLL for (int gg = 1; gg < kMaxGeoms; ++gg) G[r][c] = (g == gg) ? geom_rot[gg][r][c] : G[r][c];
+    }
+  mat3_mul_const<T>(R, G);
+  const TA z0 = Rz[0], z1 = Rz[1], z2 = Rz[2];
+  DPLL_UNROLL for (int k = 0; k < 3; ++k) Rz[k] = z0 * TA(G[0][k]) + z1 * TA(G[1][k]) + z2 * TA(G[2][k]);
 }
 
 // spatial inertia applied to a motion vector (w, u):  n = I_o w + h x u,  f = m u - h x w
@@ -1179,6 +1223,9 @@ DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, cons
     T th[10];
     DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = theta[10 * b + i];
     theta_to_iota<T>(th, md.inertia_mode, dp.iota[b]);
+    if constexpr (MD::kGeneral) {
+      if (DPLL_ROTATED(md) & 1) rotate_iota<T>(md.body_rot[b], dp.iota[b]);
+    }
   }
   DPLL_UNROLL for (int g = 0; g < NG; ++g) {
     const T mug = tabs(friction[1 + g]);
@@ -1479,6 +1526,10 @@ DPLL_HD void pair_setup(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<TA
       ps.oA[r] = ba == j ? kinA.o[j][r] : ps.oA[r];
       ps.oB[r] = bb == j ? kinA.o[j][r] : ps.oB[r];
     }
+  if (DPLL_ROTATED(md) & 2) {  // geometries turned in their bodies: from here on "the frame of A / B" is the geometry's own
+    mat3_mul_const<TA>(ps.RA, md.geom_rot[ga]);
+    mat3_mul_const<TA>(ps.RB, md.geom_rot[gb]);
+  }
   DPLL_UNROLL for (int i = 0; i < 3; ++i) { ps.gorgA[i] = TA(md.geom_origin[ga][i]); ps.gorgB[i] = TA(md.geom_origin[gb][i]); }
   mat3_vec(ps.RA, ps.gorgA, ps.cA);
   mat3_vec(ps.RB, ps.gorgB, ps.cB);
@@ -1681,7 +1732,10 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
     }
     oz = pick ? kinA.o[j][2] : oz;
   }
-  // support direction in the body frame: -(row 2 of R_AB) (geometry.py:560-564)
+  if constexpr (MD::kGeneral) {
+    if (DPLL_ROTATED(md) & 2) turn_to_geometry<T, TA>(md.geom_rot, g, cg.R, Rz);
+  }
+  // support direction in the geometry frame: -(row 2 of R_AB) (geometry.py:560-564)
   const T d[3] = {-cg.R[2][0], -cg.R[2][1], -cg.R[2][2]};
   T wit[3];
   DPLL_UNROLL for (int i = 0; i < 3; ++i) cg.drad[i] = T(0);
@@ -2289,10 +2343,12 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
 using Dual = DualT<double>;
 
 // d(sum_i g_iota[i] iota_i(theta)) / d theta_k for one body
-DPLL_HD double theta_grad_component(int inertia_mode, const double* theta, const double* g_iota, int k) {
+DPLL_HD double theta_grad_component(int inertia_mode, const double* theta, const double* g_iota, int k,
+                                    const double (*body_rot)[3][3] = nullptr) {
   Dual th[10], io[kIota];
   DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = Dual(theta[i], i == k ? 1.0 : 0.0);
   theta_to_iota<Dual>(th, inertia_mode, io);
+  if (body_rot) rotate_iota<Dual>(*body_rot, io);
   double s = 0.0;
   DPLL_UNROLL for (int i = 0; i < kIota; ++i) s += g_iota[i] * io[i].d;
   return s;

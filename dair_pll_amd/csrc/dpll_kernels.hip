@@ -1123,7 +1123,7 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
   const bool general = desc->n_geoms > 0;
   if (desc->n_joints < 0 || desc->n_joints > (general ? DPLL_MAX_JOINTS : 1))
-    return fail(-2, "dpll_model_create: the specialised builds take 0 or 1 revolute joints, the general build (n_geoms > 0) up to 2%s");
+    return fail(-2, "dpll_model_create: the specialised builds take 0 or 1 revolute joints, the general build (n_geoms > 0) up to 3%s");
   if (general) {
     if (desc->n_geoms > DPLL_MAX_GEOMS) return fail(-2, "dpll_model_create: at most 3 collision geometries%s");
     for (int j = 0; j < desc->n_joints; ++j)
@@ -1142,8 +1142,29 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       if (a < 0 || b < 0 || a >= desc->n_geoms || b >= desc->n_geoms || a == b) return fail(-1, "dpll_model_create: pair geometry out of range%s");
       if (desc->geom_body[a] == desc->geom_body[b]) return fail(-1, "dpll_model_create: a collision candidate joins geometries of two different bodies%s");
     }
+    if (desc->rotated & ~3) return fail(-1, "dpll_model_create: rotated holds bits 0 and 1 only%s");
+    // a frame rotation is a proper rotation; identities where the flag says so
+    auto proper = [](const double (&R)[3][3], bool identity) {
+      double worst = 0.0;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double dot = 0.0;
+          for (int k = 0; k < 3; ++k) dot += R[r][k] * R[c][k];
+          worst = std::fmax(worst, std::fabs(dot - (r == c ? 1.0 : 0.0)));
+          if (identity) worst = std::fmax(worst, std::fabs(R[r][c] - (r == c ? 1.0 : 0.0)));
+        }
+      const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                         R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+      return worst < 1e-9 && det > 0.0;
+    };
+    for (int b = 0; b <= desc->n_joints; ++b)
+      if (!proper(desc->body_rot[b], !(desc->rotated & 1))) return fail(-1, "dpll_model_create: body_rot must hold rotations (identities unless rotated & 1)%s");
+    for (int g = 0; g < desc->n_geoms; ++g)
+      if (!proper(desc->geom_rot[g], !(desc->rotated & 2))) return fail(-1, "dpll_model_create: geom_rot must hold rotations (identities unless rotated & 2)%s");
   } else if (desc->n_pairs != 0) {
     return fail(-2, "dpll_model_create: body-body collision candidates need the general build (n_geoms > 0)%s");
+  } else if (desc->rotated != 0) {
+    return fail(-2, "dpll_model_create: rotated frames need the general build (n_geoms > 0)%s");
   }
   if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");
   if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL)

@@ -90,7 +90,11 @@ def fill_link(link: ET.Element, pi_cm: Sequence[float], shapes: List[Tuple[Tuple
     zero3 = {'xyz': '0. 0. 0.', 'rpy': '0. 0. 0.'}
     inertial = _find_or_add(link, 'inertial', {})
     _find_or_add(inertial, 'mass', {'value': '0.'}).set('value', repr(float(pi_cm[0])))
-    _find_or_add(inertial, 'origin', zero3).set('xyz', ' '.join(repr(float(c) / float(pi_cm[0])) for c in pi_cm[1:4]))
+    origin = _find_or_add(inertial, 'origin', zero3)
+    origin.set('xyz', ' '.join(repr(float(c) / float(pi_cm[0])) for c in pi_cm[1:4]))
+    # the written tensor is the body-frame one, so the inertial frame is the body's: the reference leaves a source
+    # URDF's inertial rpy in place (urdf_utils.py:290 sets xyz only), which would turn the tensor it wrote once more
+    origin.set('rpy', zero3['rpy'])
     _find_or_add(inertial, 'inertia', {}).attrib = {k: repr(float(v)) for k, v in zip(INERTIA_ATTRIBUTES, pi_cm[4:])}
     collisions = link.findall('collision')
     while len(collisions) < len(shapes):

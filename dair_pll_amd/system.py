@@ -768,7 +768,7 @@ class MultibodyLearnableSystem(Module):
                     half = geometry.get_half_lengths().detach().double().cpu().numpy().reshape(-1)
                     shape = ('box', {'size': ' '.join(repr(2.0 * float(h)) for h in half)})
                 elif isinstance(geometry, Sphere):
-                    shape = ('sphere', {'radius': repr(float(geometry.get_radius()))})
+                    shape = ('sphere', {'radius': repr(float(geometry.get_radius().detach()))})
                 elif isinstance(geometry, Polygon):
                     raise NotImplementedError('Polygon URDF representation not yet implemented')  # urdf_utils.py:224-228
                 else:

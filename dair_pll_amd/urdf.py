@@ -4,7 +4,7 @@ The reference obtains the same facts from Drake's parser and symbolic plant
 (``dair_pll/drake_utils.py:248-335``, ``dair_pll/multibody_terms.py:161-207, 355-376``): per body
 mass / centre of mass / central inertia, the joint tree, collision geometry with
 ``drake:mu_static``, and a ground half-space with friction 1.0 added to every plant
-(``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to two revolute
+(``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to three revolute
 joints with up to three box / sphere / polygon collision geometries on any of its bodies (or a learned mesh on every
 body of a cube / elbow), all of it touching only the ground (the elbow's links are collision filtered,
 ``assets/contactnets_elbow.urdf``).  The cube and elbow systems of the reference's ContactNets example
@@ -38,6 +38,7 @@ class GeomSpec:
     radius: Optional[float] = None
     mesh_file: Optional[str] = None
     vertices: Optional[List[List[float]]] = None
+    rotation: List[List[float]] = field(default_factory=lambda: _identity())  # R_BG: the geometry frame in its body's
 
 
 @dataclass
@@ -49,6 +50,8 @@ class BodySpec:
     parent: int = -1
     joint_origin: Optional[List[float]] = None
     joint_axis: Optional[List[float]] = None
+    # the joint frame (= this body's frame at joint angle 0) in the parent's frame: the rpy of the joint's <origin>
+    joint_rotation: List[List[float]] = field(default_factory=lambda: _identity())
     geoms: List[GeomSpec] = field(default_factory=list)
 
 
@@ -92,10 +95,24 @@ class ModelSpec:
             out += [4 * g] if geom.kind == 'sphere' else [4 * g + s for s in range(4)]
         return out + [4 * (MAX_GEOMS + p) for p in range(len(self.pairs))]  # a pair: slot 0 behind the geometries' slots
 
+    def body_alignment(self) -> List[List[List[float]]]:
+        """``A_b``: the orientation of body b's frame in the root's when every joint angle is zero (the product of the
+        joint rotations down the tree).  The kernels work in body frames that all coincide at zero angles; a vector with
+        coordinates ``v`` in the URDF's frame of body b has coordinates ``A_b v`` there (``_capi.make_desc``)."""
+        out = []
+        for body in self.bodies:
+            out.append(_identity() if body.parent < 0 else _matmul(out[body.parent], body.joint_rotation))
+        return out
+
+    def rotated(self) -> bool:
+        """some joint or collision <origin> carries a rotation"""
+        eye = _identity()
+        return any(_differs(b.joint_rotation, eye) or any(_differs(g.rotation, eye) for g in b.geoms) for b in self.bodies)
+
     def is_fast(self) -> bool:
         """the cube / elbow topology the specialised builds are written for: a serial chain of at most one joint with
-        exactly one box (or mesh) per body"""
-        return (self.n_joints <= 1 and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
+        exactly one box (or mesh) per body, no frame turned against its parent's"""
+        return (self.n_joints <= 1 and not self.rotated() and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
                 and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0) and not self.pairs)
 
     def friction_init(self) -> List[float]:
@@ -113,9 +130,35 @@ def _vec(text: Optional[str], n: int = 3) -> List[float]:
     return vals
 
 
-def _no_rotation(element, what: str) -> None:
-    if element is not None and any(abs(r) > 0 for r in _vec(element.get('rpy'))):
-        raise NotImplementedError(f'{what}: rpy != 0 is not supported')
+def _identity() -> List[List[float]]:
+    return [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
+
+
+def _matmul(a, b):
+    return [[sum(a[i][k] * b[k][j] for k in range(3)) for j in range(3)] for i in range(3)]
+
+
+def _transpose(a):
+    return [[a[j][i] for j in range(3)] for i in range(3)]
+
+
+def _matvec(a, v):
+    return [sum(a[i][k] * v[k] for k in range(3)) for i in range(3)]
+
+
+def _differs(a, b, tol: float = 0.0) -> bool:
+    return any(abs(a[i][j] - b[i][j]) > tol for i in range(3) for j in range(3))
+
+
+def _rotation(element) -> List[List[float]]:
+    """the rotation of an <origin>: URDF rpy = fixed-axis roll (x), pitch (y), yaw (z), R = Rz(yaw) Ry(pitch) Rx(roll),
+    as Drake's parser reads it (the reference sees the result through the plant: CalcSpatialInertiaInBodyFrame,
+    inspector.GetPoseInFrame, multibody_terms.py:161-207, 355-376)"""
+    roll, pitch, yaw = _vec(element.get('rpy') if element is not None else None)
+    cr, sr, cp, sp, cy, sy = math.cos(roll), math.sin(roll), math.cos(pitch), math.sin(pitch), math.cos(yaw), math.sin(yaw)
+    return [[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+            [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+            [-sp, cp * sr, cp * cr]]
 
 
 def _obj_vertices(path: str) -> List[List[float]]:
@@ -143,15 +186,16 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
         if inertial is None:
             raise ValueError(f'link {link.get("name")} has no <inertial>')
         origin = inertial.find('origin')
-        _no_rotation(origin, 'inertial origin')
         inertia = inertial.find('inertia')
+        ixx, iyy, izz, ixy, ixz, iyz = [float(inertia.get(k)) for k in ('ixx', 'iyy', 'izz', 'ixy', 'ixz', 'iyz')]
+        r_bi = _rotation(origin)  # the tensor is given in the inertial frame: I_B = R I R^T in the body frame
+        i_b = _matmul(_matmul(r_bi, [[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]), _transpose(r_bi))
         body = BodySpec(name=link.get('name'),
                         mass=float(inertial.find('mass').get('value')),
                         com=_vec(origin.get('xyz') if origin is not None else None),
-                        inertia_cm=[float(inertia.get(k)) for k in ('ixx', 'iyy', 'izz', 'ixy', 'ixz', 'iyz')])
+                        inertia_cm=[i_b[0][0], i_b[1][1], i_b[2][2], i_b[0][1], i_b[0][2], i_b[1][2]])
         for col in link.findall('collision'):
             c_origin = col.find('origin')
-            _no_rotation(c_origin, 'collision origin')
             mu = None
             for element in col.iter():
                 if element.tag.endswith('mu_static'):
@@ -160,6 +204,7 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
                 raise ValueError('collision geometry without drake:mu_static')
             geometry = col.find('geometry')
             xyz = _vec(c_origin.get('xyz') if c_origin is not None else None)
+            first = len(body.geoms)
             if geometry.find('box') is not None:
                 size = _vec(geometry.find('box').get('size'))
                 body.geoms.append(GeomSpec('box', xyz, mu, half_lengths=[0.5 * s for s in size]))
@@ -172,6 +217,7 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
                 body.geoms.append(GeomSpec(kind, xyz, mu, mesh_file=filename, vertices=_obj_vertices(mesh_path)))
             else:
                 raise NotImplementedError('only <box>, <sphere> and <mesh> collision geometry is supported')
+            body.geoms[first].rotation = _rotation(c_origin)
         by_name[body.name] = body
         order.append(body.name)
     joints = []
@@ -180,23 +226,24 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
         if joint.get('type') not in ('continuous', 'revolute'):
             raise NotImplementedError(f'joint type {joint.get("type")!r} is not supported')
         j_origin = joint.find('origin')
-        _no_rotation(j_origin, 'joint origin')
         axis = _vec(joint.find('axis').get('xyz')) if joint.find('axis') is not None else [1.0, 0.0, 0.0]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((joint.find('parent').get('link'), joint.find('child').get('link'),
-                       _vec(j_origin.get('xyz') if j_origin is not None else None), [a / norm for a in axis]))
+                       _vec(j_origin.get('xyz') if j_origin is not None else None), [a / norm for a in axis],
+                       _rotation(j_origin)))
         children.add(joints[-1][1])
     roots = [name for name in order if name not in children]
     if len(roots) != 1:
         raise ValueError('expected exactly one root link per URDF (dair_pll/drake_utils.py:309-335)')
     chain = [roots[0]]
     for name in chain:
-        for parent, child, origin, axis in joints:
+        for parent, child, origin, axis, rotation in joints:
             if parent == name:
                 body = by_name[child]
                 body.parent = chain.index(parent)
                 body.joint_origin = origin
                 body.joint_axis = axis
+                body.joint_rotation = rotation
                 chain.append(child)
     if len(chain) != len(order):
         raise ValueError('disconnected links')
@@ -249,7 +296,7 @@ def check_supported(spec: ModelSpec) -> None:
     if len(spec.pairs) > MAX_PAIRS:
         raise NotImplementedError(f'at most {MAX_PAIRS} body-body collision candidate (exclude the others with a '
                                   'drake:collision_filter_group)')
-    if any(geom.kind == 'mesh' for _, geom in geoms):
+    if any(geom.kind == 'mesh' for _, geom in geoms):  # (is_fast: no joint or collision frame is rotated, either)
         if not (spec.is_fast() and all(geom.kind == 'mesh' for _, geom in geoms)):
             raise NotImplementedError('mesh (DeepSupportConvex) geometry: a serial chain of at most one joint with exactly '
                                       'one mesh on every body and no body-body candidates (contactnets_cube_mesh.urdf, '

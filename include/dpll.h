@@ -60,7 +60,7 @@ typedef struct dpll_model_desc {
   double gravity_z;
   double joint_origin[DPLL_MAX_JOINTS][3]; /* joint j+1: origin in the parent body frame */
   double joint_axis[DPLL_MAX_JOINTS][3];   /* unit axis */
-  double geom_origin[DPLL_MAX_GEOMS][3];   /* collision geometry origin in the frame of its body */
+  double geom_origin[DPLL_MAX_GEOMS][3];   /* collision geometry origin in the frame of its body (see geom_rot) */
   int32_t parent[DPLL_MAX_JOINTS];         /* general build: parent body of body j + 1 */
   int32_t n_geoms;                         /* 0: fast builds */
   int32_t geom_body[DPLL_MAX_GEOMS];
@@ -72,7 +72,15 @@ typedef struct dpll_model_desc {
   int32_t n_pairs;
   int32_t pair_a[DPLL_MAX_PAIRS];
   int32_t pair_b[DPLL_MAX_PAIRS];
-  int32_t reserved;
+  /* General build, URDFs whose <origin>s carry a rotation (rpy).  The kernels' body frames all coincide at zero joint
+   * angles; joint_origin / joint_axis are given in those frames.  body_rot[b] takes a vector from the frame the inertial
+   * parameters of body b are expressed in (the URDF's link frame, as the reference's parameters are) to the kernels'
+   * frame of body b; geom_rot[g] is the orientation of geometry g's own frame in the kernels' frame of its body, and
+   * geom_origin[g] is then given in that geometry frame.  rotated: bit 0 = some body_rot, bit 1 = some geom_rot is
+   * not the identity (both arrays must hold identities otherwise). */
+  int32_t rotated;
+  double body_rot[DPLL_MAX_BODIES][3][3];
+  double geom_rot[DPLL_MAX_GEOMS][3][3];
 } dpll_model_desc_t;
 
 typedef struct dpll_solver_opts {

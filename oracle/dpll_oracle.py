@@ -72,6 +72,20 @@ def _load_obj_vertices(path: str) -> List[List[float]]:
     return verts
 
 
+def rpy_matrix(rpy: List[float]) -> List[List[float]]:
+    """URDF ``rpy``: fixed-axis roll (x), pitch (y), yaw (z), i.e. R = Rz(yaw) Ry(pitch) Rx(roll) -- the convention
+    Drake's parser applies to every ``<origin>`` (RollPitchYaw)."""
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return [[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+            [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+            [-sp, cp * sr, cp * cr]]
+
+
+def _origin_rotation(origin) -> List[List[float]]:
+    return rpy_matrix(_floats(origin.get('rpy') if origin is not None else None, 3))
+
+
 def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     """Parses one floating-base serial chain with revolute joints and box / mesh collision
     geometry.  Mirrors what the reference obtains from Drake: bodies with (m, com, I_cm)
@@ -86,29 +100,35 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
         name = link.get('name')
         inertial = link.find('inertial')
         origin = inertial.find('origin')
-        assert _floats(origin.get('rpy') if origin is not None else None, 3) == [0., 0., 0.], \
-            'inertial rpy != 0 unsupported'
         inertia = inertial.find('inertia')
+        # the inertia tensor is given in the inertial frame; Drake hands the reference the body-frame one
+        # (CalcSpatialInertiaInBodyFrame, multibody_terms.py:161-207): I_B = R I R^T
+        r_bi = _origin_rotation(origin)
+        ixx, iyy, izz, ixy, ixz, iyz = [float(inertia.get(k)) for k in ('ixx', 'iyy', 'izz', 'ixy', 'ixz', 'iyz')]
+        i_in = [[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]
+        i_b = [[sum(r_bi[a][k] * i_in[k][l] * r_bi[b][l] for k in range(3) for l in range(3)) for b in range(3)]
+               for a in range(3)]
         body = {
             'name': name,
             'mass': float(inertial.find('mass').get('value')),
             'com': _floats(origin.get('xyz') if origin is not None else None, 3),
-            'inertia_cm': [float(inertia.get(k)) for k in ('ixx', 'iyy', 'izz', 'ixy', 'ixz', 'iyz')],
+            'inertia_cm': [i_b[0][0], i_b[1][1], i_b[2][2], i_b[0][1], i_b[0][2], i_b[1][2]],
             'geoms': [],
             'parent': -1,
             'joint_origin': None,
             'joint_axis': None,
+            'joint_rot': None,  # orientation of the joint (= child at angle 0) frame in the parent frame
         }
         for col in link.findall('collision'):
             c_origin = col.find('origin')
-            assert _floats(c_origin.get('rpy') if c_origin is not None else None, 3) == [0., 0., 0.]
             mu = None
             for element in col.iter():
                 if element.tag.endswith('mu_static'):
                     mu = float(element.get('value'))
             assert mu is not None, 'collision without drake:mu_static'
             geometry = col.find('geometry')
-            geom = {'origin': _floats(c_origin.get('xyz') if c_origin is not None else None, 3), 'mu': mu}
+            geom = {'origin': _floats(c_origin.get('xyz') if c_origin is not None else None, 3), 'mu': mu,
+                    'rot': _origin_rotation(c_origin)}  # R_BG (inspector.GetPoseInFrame, multibody_terms.py:356)
             if geometry.find('box') is not None:
                 size = _floats(geometry.find('box').get('size'), 3)
                 geom.update(kind='box', half=[0.5 * s for s in size])
@@ -129,24 +149,24 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     for joint in root.findall('joint'):
         assert joint.get('type') in ('continuous', 'revolute'), 'only revolute joints supported'
         j_origin = joint.find('origin')
-        assert _floats(j_origin.get('rpy') if j_origin is not None else None, 3) == [0., 0., 0.]
         parent = joint.find('parent').get('link')
         child = joint.find('child').get('link')
         axis = _floats(joint.find('axis').get('xyz'), 3) if joint.find('axis') is not None else [1., 0., 0.]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((parent, child, _floats(j_origin.get('xyz') if j_origin is not None else None, 3),
-                       [a / norm for a in axis]))
+                       [a / norm for a in axis], _origin_rotation(j_origin)))
         children.add(child)
     roots = [n for n in order if n not in children]
     assert len(roots) == 1, 'one chain per file (reference drake_utils.py:309-335)'
     # breadth-first order from the root: body 0 is the floating base.
     sorted_names = [roots[0]]
     for name in sorted_names:
-        for parent, child, origin, axis in joints:
+        for parent, child, origin, axis, rotation in joints:
             if parent == name:
                 links[child]['parent'] = sorted_names.index(parent)
                 links[child]['joint_origin'] = origin
                 links[child]['joint_axis'] = axis
+                links[child]['joint_rot'] = rotation
                 sorted_names.append(child)
     assert len(sorted_names) == len(order)
     bodies = [links[n] for n in sorted_names]
@@ -400,7 +420,8 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
             joint = index - 1  # joint j drives body j+1 (breadth-first order)
             axis = torch.tensor(body['joint_axis'], dtype=dtype)
             p_j = torch.tensor(body['joint_origin'], dtype=dtype)
-            r_pc = axis_rotation(axis, q[..., 7 + joint])
+            # child frame = joint frame (the <origin> of the joint, rpy included) turned about the axis by the angle
+            r_pc = torch.tensor(body['joint_rot'], dtype=dtype) @ axis_rotation(axis, q[..., 7 + joint])
             e_cp = r_pc.transpose(-1, -2)
             r_b = rot[parent] @ r_pc
             o_b = org[parent] + (rot[parent] @ p_j.unsqueeze(-1)).squeeze(-1)
@@ -473,7 +494,7 @@ def geometry_kinematics(spec: Dict, q: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         b = geom['body']
         c = torch.tensor(geom['origin'], dtype=q.dtype)
         r_b = rot[b]
-        rots.append(r_b)
+        rots.append(r_b @ torch.tensor(geom['rot'], dtype=q.dtype))
         trans.append(org[b] + (r_b @ c.unsqueeze(-1)).squeeze(-1))
         ang = jac[b][..., :3, :]
         lin = jac[b][..., 3:, :] - skew(c) @ ang

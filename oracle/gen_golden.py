@@ -524,10 +524,10 @@ def general_tosses(urdf: str, n_traj: int, steps: int, keep_every: int, seed: in
 
 
 def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0,
-                         names=('chain3', 'vee', 'ballcube', 'mace', 'gripper')) -> None:
+                         names=('chain3', 'vee', 'ballcube', 'mace', 'gripper', 'crank')) -> None:
     """models beyond the cube / elbow topologies -- three-link serial chain, branching tree, several
-    geometries on one body, spheres, four links on three hinges with one link bare of geometry (this repository's own
-    URDFs under assets/) -- through the reference's own
+    geometries on one body, spheres, four links on three hinges with one link bare of geometry, links whose
+    inertial / collision / joint frames are all turned by an rpy (this repository's own URDFs under assets/) -- through the reference's own
     MultibodyTerms / contactnets_loss / forward_dynamics / simulate, exactly as `record_case` does for the reference's
     assets.  Inputs: `general_tosses`."""
     for name in names:
@@ -580,16 +580,21 @@ def pair_tosses(urdf: str, representation: str, n_traj: int, steps: int, keep_ev
     return x, x_plus
 
 
-def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, seed: int = 0,
+                      cases=(('clasp', 'deep_support'), ('clasp_ball', 'polygon'), ('vee_pair', 'deep_support'),
+                             ('pincer', 'deep_support')), mesh_case: bool = True) -> None:
     """SURVEY 8f-4, body-body contact: the reference's GeometryCollider.collide_mesh_mesh / ContactTerms.forward pair
     path (geometry.py:585-643, multibody_terms.py:428-521) on a base and a tip that fold onto each other -- box against
     box, a sphere against a polygon (the pair swapped into the reference's type order), and the two arms of a branching
-    tree against each other (both members move with a joint of their own) -- with fcl's direction supplied by
+    tree against each other (both members move with a joint of their own; `pincer`: the same with every frame turned by an
+    rpy) -- with fcl's direction supplied by
     DirectionSearchFcl.  Inputs: `pair_tosses`."""
-    for name, representation in (('clasp', 'deep_support'), ('clasp_ball', 'polygon'), ('vee_pair', 'deep_support')):
+    for name, representation in cases:
         urdf = os.path.join(REPO, 'assets', name + '.urdf')
         x, x_plus = pair_tosses(urdf, representation, n_traj, steps, keep_every, seed)
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3, mesh_representation=representation)
+    if not mesh_case:
+        return
     # the reference's own case: two DeepSupportConvex shapes (its classes unmodified; fcl sees their extracted meshes)
     urdf = os.path.join(REPO, 'assets', 'clasp_mesh.urdf')
     x, x_plus = pair_tosses(urdf, 'deep_support', 6, 36, 3, seed)

@@ -16,6 +16,11 @@ static std::vector<uint64_t> g_reject_masks;
 using namespace dpll;
 
 namespace {
+// the rotation the inertial parameters of body b go through (general models whose frames are turned), or nullptr
+template <class MD> const double (*body_rot_of(const MD& md, int b))[3][3] {
+  if constexpr (MD::kGeneral) return (md.rotated & 1) ? &md.body_rot[b] : nullptr;
+  return nullptr;
+}
 
 template <typename T, typename TA, int NJ, int NG = NJ + 1, class MD = ModelDesc>
 void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* friction, const T* lengths,
@@ -57,7 +62,7 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
   for (int i = 0; i < NG + 1; ++i) fr[i] = double(friction[i]);
   for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
-    for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
+    for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k, body_rot_of(md, b));
   for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
     const bool polygon = MD::kGeneral && k / GP < kMaxGeoms && md.geom_kind[k / GP < kMaxGeoms ? k / GP : 0] == kGeomPolygon;
@@ -207,7 +212,7 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
   for (int i = 0; i < NG + 1; ++i) fr[i] = double(friction[i]);
   for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
-    for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k);
+    for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k, body_rot_of(md, b));
   for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
     const bool polygon = MD::kGeneral && k / GP < kMaxGeoms && md.geom_kind[k / GP < kMaxGeoms ? k / GP : 0] == kGeomPolygon;

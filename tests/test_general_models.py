@@ -2,7 +2,7 @@
 geometries on one body, spheres, polygons (learnable vertex sets), body-body contact (clasp: box against box; clasp_ball:
 a sphere against a polygon; vee_pair: the two arms of a branching tree) -- the GENERAL build (csrc/dpll_general.hip, GeneralDesc branches of csrc/dpll_core.hpp).
 
-Fixtures `{chain3, vee, ballcube, mace, gripper, polycube, wedge}_literal.npz` were recorded by running the reference's own
+Fixtures `{chain3, vee, ballcube, mace, gripper, crank, polycube, wedge}_literal.npz` were recorded by running the reference's own
 MultibodyTerms / contactnets_loss / forward_dynamics / simulate (and its Sphere / Polygon classes) on these URDFs
 (oracle/gen_golden.py record_general_cases, record_polygon_cases, record_pair_cases -- the last through the reference's
 collide_mesh_mesh with fcl's direction supplied by the oracle's exact search).  CPU tests:
@@ -19,7 +19,8 @@ from dair_pll_amd._capi import make_desc
 from dair_pll_amd.urdf import parse_urdf
 from oracle import dpll_oracle as O
 
-MODELS = ['chain3', 'vee', 'ballcube', 'mace', 'polycube', 'wedge', 'clasp', 'clasp_ball', 'vee_pair', 'gripper']
+MODELS = ['chain3', 'vee', 'ballcube', 'mace', 'polycube', 'wedge', 'clasp', 'clasp_ball', 'vee_pair', 'gripper', 'crank',
+          'pincer']
 # model -> (URDF under assets/, what a <mesh> element is read as)
 SOURCES = {'polycube': ('cube_mesh.urdf', 'polygon'), 'wedge': ('wedge.urdf', 'polygon'), 'clasp_ball': ('clasp_ball.urdf', 'polygon')}
 P = 'multibody_terms.'
@@ -269,7 +270,7 @@ def test_gpu_step_backward_against_oracle_autograd(golden, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['clasp', 'clasp_ball', 'vee_pair'])
+@pytest.mark.parametrize('name', ['clasp', 'clasp_ball', 'vee_pair', 'pincer'])
 def test_gpu_pair_models_on_random_states(golden, name):
     """Body-body contact away from the rollouts of the fixtures: 192 seeded states with the joints anywhere (the pair far
     apart, touching, and overlapping by centimetres), parameters as recorded -- loss, every gradient and the next state of

@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 1 + 1 + 1) + 4  # (tail padding)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 1 + 1 + 1) + 4 + 8 * 9 * (4 + 3)  # (+ 4: padding)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
@@ -166,6 +166,24 @@ def test_generate_updated_urdfs_round_trip(tmp_path):
     assert meshes == {}
 
 
+def test_generate_updated_urdfs_keeps_turned_frames(tmp_path):
+    """a URDF whose inertial / collision / joint <origin>s carry an rpy: the export writes body-frame inertia (inertial rpy
+    zeroed), leaves joint and collision poses alone, and a system built on the export starts from the same parameters"""
+    source = os.path.join(ASSET_DIR, 'crank.urdf')
+    system = MultibodyLearnableSystem({'crank': source}, 0.0068, output_urdfs_dir=str(tmp_path), dtype=torch.float64, device='cpu')
+    new = system.generate_updated_urdfs()
+    spec, old = parse_urdf(new['crank']), parse_urdf(source)
+    for mine, theirs in zip(spec.bodies, old.bodies):
+        assert np.allclose(mine.inertia_cm, theirs.inertia_cm, atol=1e-15) and np.allclose(mine.com, theirs.com, atol=1e-15)
+        assert mine.joint_rotation == theirs.joint_rotation and mine.joint_axis == theirs.joint_axis
+        assert [g.rotation for g in mine.geoms] == [g.rotation for g in theirs.geoms]
+    # (the source tensor of k_base is given in a turned inertial frame: the parsed body-frame one differs from it)
+    assert not np.allclose(old.bodies[0].inertia_cm, [0.0005, 0.0008, 0.0006, 2e-05, -1e-05, 3e-05], atol=1e-6)
+    again = MultibodyLearnableSystem(new, 0.0068, dtype=torch.float64, device='cpu')
+    assert torch.allclose(again.multibody_terms.lagrangian_terms.inertial_parameters,
+                          system.multibody_terms.lagrangian_terms.inertial_parameters, atol=1e-9)
+
+
 def test_extract_mesh_of_an_analytic_support_function():
     """deep_support_function.py:93-123 on the support function of a box: its 8 corners, 12 outward
     counter-clockwise triangles; the OBJ text carries one normal per face."""
@@ -212,7 +230,8 @@ def test_general_models_are_described_for_the_general_build():
               'wedge': (1, [0], [0, 1, 0], [2, 0, 0], 8),  # (geom_body / geom_kind entries past n_geoms are zero)
               'clasp': (2, [0, 1], [0, 2, 0], [0, 0, 0], 9), 'clasp_ball': (2, [0, 1], [0, 2, 0], [1, 2, 0], 6),
               'vee_pair': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13),
-              'gripper': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 9)}  # body 1 carries no geometry
+              'gripper': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 9),  # body 1 carries no geometry
+              'crank': (2, [0, 1], [0, 1, 2], [0, 0, 1], 9), 'pincer': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13)}
     block, slots = _capi.GEOM_BLOCK, _capi.GEN_SLOTS
     for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
         representation = 'polygon' if name in ('wedge', 'clasp_ball') else 'deep_support'
@@ -222,6 +241,8 @@ def test_general_models_are_described_for_the_general_build():
         assert desc.n_geoms == len(spec.geoms()) and list(desc.parent)[:n_joints] == parents
         assert list(desc.geom_body) == geom_body and list(desc.geom_kind) == kinds
         assert list(desc.geom_nverts) == [6 if kind == 2 else 0 for kind in kinds]
+        # frames turned by an rpy (joint / collision <origin>): re-expressed for the kernels, flagged in the descriptor
+        assert desc.rotated == (3 if name in ('crank', 'pincer') else 0) and spec.rotated() == (desc.rotated != 0)
         handle = ctypes.c_void_p()
         assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
         assert lib.dpll_n_x(handle) == 13 + 2 * n_joints and lib.dpll_n_contacts(handle) == 4 * slots
@@ -244,9 +265,9 @@ def test_general_models_are_described_for_the_general_build():
             bad.geom_nverts[0] = 3  # a support query returns 4 vertices (geometry.py:196)
             other = ctypes.c_void_p()
             assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0 and b'4 to 8 vertices' in lib.dpll_last_error()
-        if name.startswith('clasp') or name == 'vee_pair':
+        if name.startswith('clasp') or name in ('vee_pair', 'pincer'):
             # two bodies not joined by a joint, not filtered -> a collision candidate, ordered by geometry type
-            expect_pair = {'clasp': (0, 1), 'clasp_ball': (1, 0), 'vee_pair': (1, 2)}[name]  # (polygon before sphere, geometry.py:46)
+            expect_pair = {'clasp': (0, 1), 'clasp_ball': (1, 0), 'vee_pair': (1, 2), 'pincer': (1, 2)}[name]  # (polygon before sphere, geometry.py:46)
             assert spec.pairs == [expect_pair] and desc.n_pairs == 1 and (desc.pair_a[0], desc.pair_b[0]) == expect_pair
             assert spec.contact_slots()[-1] == 4 * _capi.MAX_GEOMS
             bad = _capi.make_desc(spec, 0.0068)

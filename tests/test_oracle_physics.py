@@ -22,7 +22,8 @@ DT = 0.0068
 
 
 # every tree topology the kernels take: serial chains of 0 / 1 / 2 joints, a branching tree, bodies without geometry
-TREES = ['cube.urdf', 'elbow.urdf', 'chain3.urdf', 'vee.urdf', 'mace.urdf', 'clasp.urdf', 'gripper.urdf']
+TREES = ['cube.urdf', 'elbow.urdf', 'chain3.urdf', 'vee.urdf', 'mace.urdf', 'clasp.urdf', 'gripper.urdf', 'crank.urdf',
+         'pincer.urdf']
 # ... and every kind of contact: boxes, spheres, polygons against the ground, body-body pairs (box-box, polygon-sphere,
 # the two arms of a branching tree)
 CONTACTS = TREES + ['ballcube.urdf', 'wedge.urdf:polygon', 'clasp_ball.urdf:polygon', 'vee_pair.urdf']
