@@ -276,6 +276,24 @@ def test_general_models_are_described_for_the_general_build():
             assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0
         else:
             assert spec.pairs == [] and desc.n_pairs == 0
+        if name == 'crank':
+            # the kernels' frames: a vector of body b's URDF frame is A_b v there; geom_rot = A_b R_BG, origin in that frame
+            align = np.array(spec.body_alignment())
+            assert np.allclose(np.array(desc.body_rot)[:3], align) and np.allclose(align[0], np.eye(3))
+            assert np.allclose(align[2], align[1] @ np.array(spec.bodies[2].joint_rotation))
+            assert np.allclose(np.array(desc.joint_axis)[1], align[2] @ np.array(spec.bodies[2].joint_axis))
+            assert np.allclose(np.array(desc.joint_origin)[1], align[1] @ np.array(spec.bodies[2].joint_origin))
+            geom = spec.bodies[1].geoms[0]
+            assert np.allclose(np.array(desc.geom_rot)[1], align[1] @ np.array(geom.rotation))
+            assert np.allclose(np.array(desc.geom_rot)[1] @ np.array(desc.geom_origin)[1], align[1] @ np.array(geom.origin))
+            for field, message in (('body_rot', b'body_rot'), ('geom_rot', b'geom_rot')):
+                bad = _capi.make_desc(spec, 0.0068)
+                getattr(bad, field)[1][0][0] += 0.01  # no longer a rotation
+                other = ctypes.c_void_p()
+                assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0 and message in lib.dpll_last_error()
+            bad = _capi.make_desc(spec, 0.0068)
+            bad.rotated = 0  # ... and a flag that says "identities" over matrices that are not
+            assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0
         lib.dpll_model_destroy(handle)
     # the cube and the elbow stay on the specialised builds
     assert _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068).n_geoms == 0
@@ -283,3 +301,6 @@ def test_general_models_are_described_for_the_general_build():
     bad.parent[1] = 2
     handle = ctypes.c_void_p()
     assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(handle)) != 0
+    bad = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
+    bad.rotated = 1  # turned frames are the general build's
+    assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(handle)) != 0 and b'general build' in lib.dpll_last_error()
