@@ -14,12 +14,12 @@ from .urdf import ModelSpec, _differs, _matmul, _matvec, _transpose, check_suppo
 MAX_JOINTS = 3
 MAX_BODIES = 4
 MAX_GEOMS = 3
-MAX_PAIRS = 1
-GEN_SLOTS = MAX_GEOMS + MAX_PAIRS  # geometry slots of the general build (DPLL_GEN_SLOTS)
+MAX_PAIRS = 4
+GEN_SLOTS = MAX_GEOMS + 1  # geometry slots of the general build (DPLL_GEN_SLOTS): the geometries + the pairs' group
 GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 15  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 16  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

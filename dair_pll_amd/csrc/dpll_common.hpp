@@ -157,16 +157,9 @@ __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __
   }
   double* fr_fac = chain + 100 * NB;
   double* len_sign = fr_fac + (NG + 1) * NG;
-  if (lane < (NG + 1) * NG) {  // lane = (friction entry k, geometry b): d (2 m0 mb / (m0 + mb)) / d friction_k, mu = |friction|
-    const int k = lane / NG, b = lane % NG;
-    // slot b combines friction entries ia and ib: the ground (0) with geometry b, or the two geometries of a pair
-    int ia = 0, ib = 1 + b;
-    if (gd && b >= kMaxGeoms) {
-      const int p = b - kMaxGeoms;
-      const bool on = p < gd->n_pairs;
-      ia = 1 + (on ? gd->pair_a[p < kMaxPairs ? p : 0] : 0);
-      ib = 1 + (on ? gd->pair_b[p < kMaxPairs ? p : 0] : 0);
-    }
+  double* fr_pair = len_sign + GP * NG;  // (general build) (NG + 1 k, kMaxPairs p)
+  // d (2 ma mb / (ma + mb)) / d friction_k for the coefficient that combines friction entries ia and ib, mu = |friction|
+  auto factor = [&](int k, int ia, int ib) {
     const double m0 = fabs(double(friction[ia])), mb = fabs(double(friction[ib]));
     const double den = (m0 + mb) * (m0 + mb);
     const double pk = double(friction[k]);
@@ -174,26 +167,46 @@ __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __
     double fac = 0.0;
     if (k == ia) fac += 2.0 * mb * mb / den;
     if (k == ib) fac += 2.0 * m0 * m0 / den;
-    fr_fac[lane] = fac * sign;
+    return fac * sign;
+  };
+  if (lane < (NG + 1) * NG) {  // lane = (friction entry k, geometry b): slot b combines the ground (entry 0) with geometry b
+    const int k = lane / NG, b = lane % NG;
+    fr_fac[lane] = (gd && b >= kMaxGeoms) ? 0.0 : factor(k, 0, 1 + b);  // (the group behind the geometries has no coefficient)
+  }
+  if (gd && lane < (NG + 1) * kMaxPairs) {  // lane = (friction entry k, body-body candidate p): its two geometries
+    const int k = lane / kMaxPairs, p = lane % kMaxPairs;
+    fr_pair[lane] = p < gd->n_pairs ? factor(k, 1 + gd->pair_a[p], 1 + gd->pair_b[p]) : 0.0;
   }
   for (int e = lane; e < GP * NG; e += kWave) {
     const double pl = lengths ? double(lengths[e]) : 0.0;
     const bool polygon = gd && e / GP < kMaxGeoms && gd->geom_kind[e / GP] == kGeomPolygon;
-    len_sign[e] = polygon ? 1.0 : (pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0));
+    // (general build: the block behind the geometries holds no parameters -- its row entries carry the pairs' d/d mu)
+    len_sign[e] = (gd && e / GP >= kMaxGeoms) ? 0.0 : (polygon ? 1.0 : (pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0)));
   }
 }
 // learnable parameter k = sum_{j < count} tot[tot0 + j] * chain[coef0 + j] with the row sum `tot` ([loss | iota | mu_pair | length])
-struct ChainRow { int coef0, tot0, count; };
+// (a friction entry of the general build has a second segment: the body-body candidates' d/d mu, which sit in the first
+// kMaxPairs entries of the row's length block behind the geometries)
+struct ChainRow { int coef0, tot0, count, coef1, tot1, count1; };
 template <int NB, int NG = NB, int GP = 3> __device__ __forceinline__ ChainRow chain_row(int k) {
-  if (k < 10 * NB) return ChainRow{k * kIota, 1 + kIota * (k / 10), kIota};
-  if (k < 10 * NB + NG + 1) return ChainRow{100 * NB + (k - 10 * NB) * NG, 1 + kIota * NB, NG};
+  if (k < 10 * NB) return ChainRow{k * kIota, 1 + kIota * (k / 10), kIota, 0, 0, 0};
+  if (k < 10 * NB + NG + 1) {
+    ChainRow cr{100 * NB + (k - 10 * NB) * NG, 1 + kIota * NB, NG, 0, 0, 0};
+    if (GP > 3) {
+      cr.coef1 = 100 * NB + (NG + 1) * NG + GP * NG + (k - 10 * NB) * kMaxPairs;
+      cr.tot1 = 1 + kIota * NB + NG + GP * kMaxGeoms;
+      cr.count1 = kMaxPairs;
+    }
+    return cr;
+  }
   const int i = k - (10 * NB + NG + 1);
-  return ChainRow{100 * NB + (NG + 1) * NG + i, 1 + kIota * NB + NG + i, 1};
+  return ChainRow{100 * NB + (NG + 1) * NG + i, 1 + kIota * NB + NG + i, 1, 0, 0, 0};
 }
 template <int NB, int NG = NB, int GP = 3> __device__ __forceinline__ double apply_chain(const double* tot, const double* __restrict__ chain, int k) {
   const ChainRow cr = chain_row<NB, NG, GP>(k);
   double v = 0.0;
   for (int j = 0; j < cr.count; ++j) v += tot[cr.tot0 + j] * chain[cr.coef0 + j];
+  for (int j = 0; j < cr.count1; ++j) v += tot[cr.tot1 + j] * chain[cr.coef1 + j];
   return v;
 }
 
@@ -207,7 +220,8 @@ template <typename T, int NJ, int NG_ = NJ + 1, int GP_ = 3> struct Dims {
   static constexpr int PIOTA = 1 + 10 * NB + (1 + GP) * NG;   // a partial row: [loss | d/d iota | d/d mu_pair | d/d |length|]
   // the chain matrix behind the rows: [d iota_b,i / d theta_b,c (NB, 10 c, 10 i) | d mu_pair,g / d friction_k (NG + 1 k, NG g) |
   // sign(length_params) (GP NG)], doubles
-  static constexpr int CHAIN = 100 * NB + (NG + 1) * NG + GP * NG;
+  // (general build, GP > 3: + d mu_pair,p / d friction_k (NG + 1 k, kMaxPairs p) of the body-body candidates)
+  static constexpr int CHAIN = 100 * NB + (NG + 1) * NG + GP * NG + (GP > 3 ? (NG + 1) * kMaxPairs : 0);
 };
 
 template <typename T> struct Acc { using type = double; };  // cone residual / y accumulate in double

@@ -72,8 +72,11 @@ constexpr int kMaxBodies = kMaxJoints + 1;
 constexpr int kMaxGeoms = 3;    // convex collision geometries of a model (each against the ground half-space)
 constexpr int kGeomBox = 0, kGeomSphere = 1, kGeomPolygon = 2;
 constexpr int kMaxPolyVerts = 8;  // vertices of a Polygon (geometry.py:220-252); the general build only
-constexpr int kMaxPairs = 1;      // body-body collision candidates (geometry.py:585-643); the general build only
-constexpr int kGenSlots = kMaxGeoms + kMaxPairs;  // geometry slots of the general build: a pair sits behind the geometries
+constexpr int kMaxPairs = 4;      // body-body collision candidates (geometry.py:585-643); the general build only
+// geometry slots of the general build: behind the geometries one more group of kQuery contact slots, one per pair (a pair
+// makes ONE contact, geometry.py:639-643)
+constexpr int kGenSlots = kMaxGeoms + 1;
+static_assert(kMaxPairs <= 4, "the pairs share the kQuery contact slots of one group");
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
 
@@ -1213,6 +1216,7 @@ template <typename T, int NJ, int NG = NJ + 1> struct Derived {
   T iota[NB][kIota];
   T mu[NG];       // pair coefficient ground-vs-geometry g: 2 mu_0 mu_g / (mu_0 + mu_g), mu = |friction_params| (multibody_terms.py:321-324, :471)
   T habs[NG][3];  // |length_params| of a box (geometry.py:393-403); [0] = |length_param|, the radius of a sphere (:415-456)
+  T mu_pair[kMaxPairs];  // general build: pair coefficient of the two geometries of body-body candidate p
   const T* geo;   // the raw geometry parameter blocks (stride MD::kGeoStride): a Polygon's vertices are read from here
 };
 
@@ -1234,14 +1238,13 @@ DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, cons
   }
   dp.geo = lengths;
   if constexpr (MD::kGeneral) {
-    // the slots behind the geometries: pair coefficient of the two geometries of a body-body candidate
+    // pair coefficient of the two geometries of a body-body candidate (the group behind the geometries has none of its own)
     DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) {
-      if (kMaxGeoms + p < NG) {
-        const bool on = p < md.n_pairs;
-        const T ma = tabs(friction[1 + (on ? md.pair_a[p] : 0)]), mb = tabs(friction[1 + (on ? md.pair_b[p] : 0)]);
-        dp.mu[kMaxGeoms + p < NG ? kMaxGeoms + p : 0] = T(2) * ma * mb / (ma + mb);
-      }
+      const bool on = p < md.n_pairs;
+      const T ma = tabs(friction[1 + (on ? md.pair_a[p] : 0)]), mb = tabs(friction[1 + (on ? md.pair_b[p] : 0)]);
+      dp.mu_pair[p] = T(2) * ma * mb / (ma + mb);
     }
+    if constexpr (NG > kMaxGeoms) dp.mu[NG > kMaxGeoms ? kMaxGeoms : 0] = T(1);
   }
 }
 
@@ -1290,6 +1293,7 @@ DPLL_HD void compute_terms(const MD& md, const Derived<T, NJ, NG>& dp, const T* 
 template <typename T, int NJ, bool GEN> struct ContactPair {};
 template <typename T, int NJ> struct ContactPair<T, NJ, true> {
   bool pair;       // body-body contact: geometry A (fields below) against geometry B (the fields of ContactGeom)
+  int pidx;        // ... of candidate pidx (-1: a ground contact)
   int gpar;        // geometry whose parameters the witness of ContactGeom belongs to (a ground contact: = geom)
   int body_a, gpar_a;
   T sgn_a[3], drad_a[3];
@@ -1575,7 +1579,7 @@ DPLL_HD bool pair_find_directions(const MD& md, const Derived<T, NJ, NG>& dp, co
 }
 // the found direction of the pair contact `contact` sits in, or nullptr (not a pair slot / nothing found up front)
 template <typename TA> DPLL_HD const TA* pair_dir_of(bool have, const TA (&dirs)[kMaxPairs][3], int contact) {
-  const int p = contact / kQuery - kMaxGeoms;
+  const int p = contact - kQuery * kMaxGeoms;
   return (have && p >= 0 && p < kMaxPairs) ? dirs[p] : nullptr;
 }
 
@@ -1583,14 +1587,16 @@ template <typename TA> DPLL_HD const TA* pair_dir_of(bool have, const TA (&dirs)
 // evaluated by the ICNN kernels (geometry.py:309-325); nullptr = box corner / sphere point chosen here.
 template <typename T, typename TA, int NJ, int NG, class MD>
 DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
-                                  const Kin<TA, NJ>& kinA, int p, int slot, ContactGeom<T, NJ, true>& cg,
+                                  const Kin<TA, NJ>& kinA, int p, ContactGeom<T, NJ, true>& cg,
                                   const TA* dir_in) {
-  const bool masked = p >= md.n_pairs || slot != 0;
+  const bool masked = p >= md.n_pairs;
   const int ga = masked ? 0 : md.pair_a[p], gb = masked ? 0 : md.pair_b[p];
   const int ba = md.geom_body[ga], bb = md.geom_body[gb];
   cg.pair = true;
-  cg.geom = kMaxGeoms + p;
-  cg.mu = dp.mu[(kMaxGeoms + p) < NG ? kMaxGeoms + p : 0];
+  cg.geom = kMaxGeoms;
+  cg.pidx = p;
+  cg.mu = dp.mu_pair[0];
+  DPLL_UNROLL for (int pp = 1; pp < kMaxPairs; ++pp) cg.mu = (p == pp) ? dp.mu_pair[pp] : cg.mu;
   cg.body = bb; cg.gpar = gb;
   cg.body_a = ba; cg.gpar_a = ga;
   cg.vidx = -1; cg.vidx_a = -1;
@@ -1685,8 +1691,8 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
   const int g = contact / kQuery;
   const int slot = contact % kQuery;
   if constexpr (MD::kGeneral) {
-    if (g >= kMaxGeoms) {  // the slots behind the geometries: body-body pairs
-      compute_pair_contact<T, TA, NJ>(md, dp, kin, kinA, g - kMaxGeoms, slot, cg, pair_dir);
+    if (g >= kMaxGeoms) {  // the group behind the geometries: slot p is body-body pair p
+      compute_pair_contact<T, TA, NJ>(md, dp, kin, kinA, slot, cg, pair_dir);
       return;
     }
   }
@@ -1785,6 +1791,7 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
   cg.phi = masked ? T(kMaskedPhi) : T(phiA);
   if constexpr (MD::kGeneral) {
     cg.pair = false;
+    cg.pidx = -1;
     cg.gpar = g;
     cg.body_a = 0; cg.gpar_a = 0; cg.vidx_a = -1;
     DPLL_UNROLL for (int r = 0; r < 3; ++r) {
@@ -1874,7 +1881,13 @@ DPLL_HD void add_witness_grad(int gpar, const T (&sgn)[3], const T (&drad)[3], i
 template <typename T, int NJ, bool GEN, int NG, int GP>
 DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ, GEN>& cg, T gmu, const T (&rbar)[3], const T (&rbar_a)[3],
                                LossGrad<T, NJ, NG, GP>& grad) {
-  DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) grad.g_mu[gg] += (cg.geom == gg) ? gmu : T(0);
+  if constexpr (GEN && NG > kMaxGeoms && GP >= kMaxPairs) {
+    // a body-body contact's coefficient has a column of its own: entry p of the (parameterless) block behind the geometries
+    DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) grad.g_mu[gg] += (!cg.pair && cg.geom == gg) ? gmu : T(0);
+    DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) grad.g_len[NG > kMaxGeoms ? kMaxGeoms : 0][p] += (cg.pair && cg.pidx == p) ? gmu : T(0);
+  } else {
+    DPLL_UNROLL for (int gg = 0; gg < NG; ++gg) grad.g_mu[gg] += (cg.geom == gg) ? gmu : T(0);
+  }
   if constexpr (GEN) {
     add_witness_grad<T, NJ>(cg.gpar, cg.sgn, cg.drad, cg.vidx, rbar, grad);
     add_witness_grad<T, NJ>(cg.pair ? cg.gpar_a : -1, cg.sgn_a, cg.drad_a, cg.vidx_a, rbar_a, grad);
@@ -2189,8 +2202,8 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
     T pdir[kMaxPairs][3] = {};
     if constexpr (MD::kGeneral) {
       DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
-        const int cc = first_contact + c, pp = cc / kQuery - kMaxGeoms;
-        if (pp >= 0 && pp < kMaxPairs && cc % kQuery == 0) {
+        const int pp = first_contact + c - kQuery * kMaxGeoms;
+        if (pp >= 0 && pp < kMaxPairs) {
           DPLL_UNROLL for (int i = 0; i < 3; ++i) pdir[pp][i] = cg[c].dir[i];
         }
       }
@@ -2269,6 +2282,7 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
     dps.mu[g] = S(TA(dp.mu[g]));
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dps.habs[g][i] = S(TA(dp.habs[g][i]));
   }
+  DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) dps.mu_pair[p] = S(TA(dp.mu_pair[p]));
   dps.geo = nullptr;
   S geo_s[MD::kGeneral ? NG * MD::kGeoStride : 1];  // a polygon's vertices as constants of the dual passes
   if constexpr (MD::kGeneral) {
@@ -2308,7 +2322,7 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
         DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = S(TA(witness[c][i]));
       }
       S pd[3] = {S(TA(0)), S(TA(0)), S(TA(1))};
-      const int pp = (first_contact + c) / kQuery - kMaxGeoms;
+      const int pp = first_contact + c - kQuery * kMaxGeoms;
       const bool is_pair = MD::kGeneral && pair_dir && pp >= 0 && pp < kMaxPairs;
       if (is_pair) {
         DPLL_UNROLL for (int i = 0; i < 3; ++i) pd[i] = S(TA(pair_dir[pp][i]));
@@ -2354,23 +2368,20 @@ DPLL_HD double theta_grad_component(int inertia_mode, const double* theta, const
   return s;
 }
 // friction_params gradient: entry 0 is the ground, entry 1 + b geometry b; slot b of g_mu combines the ground with
-// geometry b or (general build, the slots behind the geometries) the two geometries of a body-body candidate
+// geometry b; (general build) g_mu_pair[p] belongs to the coefficient of the two geometries of body-body candidate p
 DPLL_HD double friction_grad_component(int n_slots, const double* friction, const double* g_mu, int k,
-                                       const ModelDesc* gd = nullptr) {
+                                       const ModelDesc* gd = nullptr, const double* g_mu_pair = nullptr) {
   double s = 0.0;
-  for (int b = 0; b < n_slots; ++b) {
-    int ia = 0, ib = 1 + b;
-    if (gd && b >= kMaxGeoms) {
-      const int p = b - kMaxGeoms;
-      const bool on = p < gd->n_pairs;
-      ia = 1 + (on ? gd->pair_a[p] : 0);
-      ib = 1 + (on ? gd->pair_b[p] : 0);
-    }
+  auto add = [&](int ia, int ib, double g) {
     const double m0 = fabs(friction[ia]), mb = fabs(friction[ib]);
     const double den = (m0 + mb) * (m0 + mb);
-    if (k == ia) s += g_mu[b] * 2.0 * mb * mb / den;
-    if (k == ib) s += g_mu[b] * 2.0 * m0 * m0 / den;
-  }
+    if (k == ia) s += g * 2.0 * mb * mb / den;
+    if (k == ib) s += g * 2.0 * m0 * m0 / den;
+  };
+  for (int b = 0; b < n_slots; ++b)
+    if (!gd || b < kMaxGeoms) add(0, 1 + b, g_mu[b]);
+  if (gd && g_mu_pair)
+    for (int p = 0; p < gd->n_pairs && p < kMaxPairs; ++p) add(1 + gd->pair_a[p], 1 + gd->pair_b[p], g_mu_pair[p]);
   const double p = friction[k];
   return s * (p > 0.0 ? 1.0 : (p < 0.0 ? -1.0 : 0.0));
 }

@@ -6,8 +6,8 @@
 // to Box (geometry.py:367-456) -- beyond the two topologies the specialised builds of dpll_kernels.hip are written for
 // (cube, elbow).  Same per-item math (dpll_core.hpp, with the tree / geometry-table branches selected by GeneralDesc),
 // same C ABI, same partial-row + chain-matrix gradient reduction; the mapping is one lane per contact SLOT, 16 lanes (a
-// DPP row) per item: always kMaxGeoms x 4 geometry slots + the 4 of a body-body pair, where geometries a model does not
-// have, the three slots a sphere or a pair does not use are masked to "far away" (idle lanes, no branch in the solver).
+// DPP row) per item: always kMaxGeoms x 4 geometry slots + 4 for the body-body candidates (one contact each), where geometries
+// or candidates a model does not have and the three slots a sphere does not use are masked to "far away" (idle lanes, no branch in the solver).
 // Coverage before speed: every contact Jacobian is dense, the Newton system up to 8 x 8.
 #include <hip/hip_runtime.h>
 
@@ -26,8 +26,8 @@ template <typename T, int NJ> using GD = Dims<T, NJ, kNG, kGP>;
 template <typename T, int NJ> using GenGrad = LossGrad<T, NJ, kNG, kGP>;
 using GenLanes = GpuLanes<kQuery * kNG>;  // one lane per contact slot
 
-// One lane per contact SLOT: an item is owned by the 16 lanes of a DPP row (3 geometries x 4 witnesses + the pair's
-// slot and its three idle ones), four items per wave -- the mapping of the specialised builds (cube 4, elbow 8 lanes per
+// One lane per contact SLOT: an item is owned by the 16 lanes of a DPP row (3 geometries x 4 witnesses + up to 4
+// body-body candidates), four items per wave -- the mapping of the specialised builds (cube 4, elbow 8 lanes per
 // item), so each lane's contact state stays in registers and 4096 items are 1024 waves, one per SIMD.
 constexpr int kIPW = kWave / (kQuery * kNG);  // items per wave
 template <typename T, int NJ>

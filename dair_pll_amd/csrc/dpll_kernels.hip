@@ -1117,7 +1117,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 15; }
+int dpll_abi_version(void) { return 16; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1136,7 +1136,7 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       if (desc->geom_kind[g] == DPLL_GEOM_POLYGON && (desc->geom_nverts[g] < 4 || desc->geom_nverts[g] > DPLL_MAX_POLYGON_VERTICES))
         return fail(-2, "dpll_model_create: a polygon has 4 to 8 vertices%s");
     }
-    if (desc->n_pairs < 0 || desc->n_pairs > DPLL_MAX_PAIRS) return fail(-2, "dpll_model_create: at most 1 body-body collision candidate%s");
+    if (desc->n_pairs < 0 || desc->n_pairs > DPLL_MAX_PAIRS) return fail(-2, "dpll_model_create: at most 4 body-body collision candidates%s");
     for (int p = 0; p < desc->n_pairs; ++p) {
       const int a = desc->pair_a[p], b = desc->pair_b[p];
       if (a < 0 || b < 0 || a >= desc->n_geoms || b >= desc->n_geoms || a == b) return fail(-1, "dpll_model_create: pair geometry out of range%s");

@@ -24,7 +24,7 @@ GRAVITY_Z = -9.81  # Drake's default UniformGravityField
 MAX_JOINTS = 3  # dpll_core.hpp kMaxJoints
 MAX_GEOMS = 3  # dpll_core.hpp kMaxGeoms
 MAX_POLYGON_VERTICES = 8  # dpll_core.hpp kMaxPolyVerts
-MAX_PAIRS = 1  # dpll_core.hpp kMaxPairs
+MAX_PAIRS = 4  # dpll_core.hpp kMaxPairs
 # GeometryCollider orders a pair by type (geometry.py:46, 66-74; multibody_terms.py:294-297)
 TYPE_ORDER = {'polygon': 1, 'box': 2, 'sphere': 3, 'mesh': 4}
 
@@ -93,7 +93,7 @@ class ModelSpec:
         out = []
         for g, (_, geom) in enumerate(self.geoms()):
             out += [4 * g] if geom.kind == 'sphere' else [4 * g + s for s in range(4)]
-        return out + [4 * (MAX_GEOMS + p) for p in range(len(self.pairs))]  # a pair: slot 0 behind the geometries' slots
+        return out + [4 * MAX_GEOMS + p for p in range(len(self.pairs))]  # pair p: slot p of the group behind the geometries
 
     def body_alignment(self) -> List[List[List[float]]]:
         """``A_b``: the orientation of body b's frame in the root's when every joint angle is zero (the product of the
@@ -294,7 +294,7 @@ def check_supported(spec: ModelSpec) -> None:
         if geom.kind == 'polygon' and not 4 <= len(geom.vertices) <= MAX_POLYGON_VERTICES:
             raise NotImplementedError(f'a polygon has 4 to {MAX_POLYGON_VERTICES} vertices (support queries return 4 of them)')
     if len(spec.pairs) > MAX_PAIRS:
-        raise NotImplementedError(f'at most {MAX_PAIRS} body-body collision candidate (exclude the others with a '
+        raise NotImplementedError(f'at most {MAX_PAIRS} body-body collision candidates (exclude the others with a '
                                   'drake:collision_filter_group)')
     if any(geom.kind == 'mesh' for _, geom in geoms):  # (is_fast: no joint or collision frame is rotated, either)
         if not (spec.is_fast() and all(geom.kind == 'mesh' for _, geom in geoms)):

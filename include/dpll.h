@@ -38,8 +38,9 @@ extern "C" {
 #define DPLL_MAX_JOINTS 3
 #define DPLL_MAX_BODIES 4
 #define DPLL_MAX_GEOMS 3
-#define DPLL_MAX_PAIRS 1                         /* body-body collision candidates */
-#define DPLL_GEN_SLOTS (DPLL_MAX_GEOMS + DPLL_MAX_PAIRS) /* geometry slots of the general build: a pair sits behind the geometries */
+#define DPLL_MAX_PAIRS 4                         /* body-body collision candidates */
+/* geometry slots of the general build: behind the geometries one group of 4 contact slots, slot p = candidate p */
+#define DPLL_GEN_SLOTS (DPLL_MAX_GEOMS + 1)
 
 enum dpll_dtype { DPLL_F32 = 0, DPLL_F64 = 1 };
 enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1 };
@@ -110,10 +111,12 @@ typedef struct dpll_model dpll_model_t;
 /* Learnable parameters of one call: device pointers, caller owned, never written. */
 typedef struct dpll_params {
   const void* theta;    /* (n_bodies, 10) */
-  const void* friction; /* fast builds (1 + n_bodies,); general build (1 + DPLL_GEN_SLOTS,): ground, the geometries, padding (any non-zero number) */
+  const void* friction; /* fast builds (1 + n_bodies,); general build (1 + DPLL_GEN_SLOTS,): ground, the geometries, padding (any non-zero number).
+                           A body-body candidate has no entry: its coefficient combines its two geometries' entries */
   const void* lengths;  /* fast builds (n_bodies, 3): length_params of the boxes.  General build (DPLL_GEN_SLOTS, DPLL_GEOM_BLOCK),
                            geometry g's block: box length_params (3) | sphere length_param (1) | polygon vertices
-                           (geom_nverts, 3) row-major; the rest of a block is padding (its gradient comes back zero) */
+                           (geom_nverts, 3) row-major; the rest of a block, and the whole block behind the geometries', is padding
+                           (its gradient comes back zero) */
 } dpll_params_t;
 
 const char* dpll_last_error(void);
@@ -126,7 +129,9 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
 int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts_t* opts);
 
 int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
-int dpll_n_contacts(const dpll_model_t* model);   /* 4 n_bodies */
+int dpll_n_contacts(const dpll_model_t* model);   /* fast builds 4 n_bodies; general build 4 DPLL_GEN_SLOTS contact SLOTS: slot
+                                                     4 g + s = witness s of geometry g (a sphere: s = 0 only), slot
+                                                     4 DPLL_MAX_GEOMS + p = body-body candidate p; the others are masked */
 int dpll_param_count(const dpll_model_t* model);  /* layout [theta | friction | lengths] as in dpll_params_t: fast builds
                                                      10 n_b + (1 + n_b) + 3 n_b, general build 10 n_b + (1 + DPLL_GEN_SLOTS) + DPLL_GEN_SLOTS DPLL_GEOM_BLOCK */
 

@@ -564,8 +564,11 @@ def pair_tosses(urdf: str, representation: str, n_traj: int, steps: int, keep_ev
     trial[:, 0] = 1.0
     trial[:, 7:] = (2 * torch.rand((4000, n_j), generator=gen) - 1) * np.pi
     with torch.no_grad():
-        phi = system.multibody_terms.contact_terms(trial)[0][:, -1]
-    joints = trial[(phi > 0) & (phi < 0.008)][:n_traj, 7:]
+        phi = system.multibody_terms.contact_terms(trial)[0][:, -len(spec['pairs']):]
+    # several candidates: toss i starts with candidate i mod n about to meet, none overlapping
+    free = (phi > 0).all(dim=-1)
+    picks = [trial[free & (phi[:, p] < 0.008)][:-(-n_traj // phi.shape[1]), 7:] for p in range(phi.shape[1])]
+    joints = torch.stack([picks[i % len(picks)][i // len(picks)] for i in range(n_traj)])
     assert joints.shape[0] == n_traj
     quat = torch.randn((n_traj, 4), generator=gen)
     quat = quat / quat.norm(dim=-1, keepdim=True)
@@ -582,12 +585,12 @@ def pair_tosses(urdf: str, representation: str, n_traj: int, steps: int, keep_ev
 
 def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, seed: int = 0,
                       cases=(('clasp', 'deep_support'), ('clasp_ball', 'polygon'), ('vee_pair', 'deep_support'),
-                             ('pincer', 'deep_support')), mesh_case: bool = True) -> None:
+                             ('pincer', 'deep_support'), ('grasp', 'deep_support')), mesh_case: bool = True) -> None:
     """SURVEY 8f-4, body-body contact: the reference's GeometryCollider.collide_mesh_mesh / ContactTerms.forward pair
     path (geometry.py:585-643, multibody_terms.py:428-521) on a base and a tip that fold onto each other -- box against
     box, a sphere against a polygon (the pair swapped into the reference's type order), and the two arms of a branching
     tree against each other (both members move with a joint of their own; `pincer`: the same with every frame turned by an
-    rpy) -- with fcl's direction supplied by
+    rpy), and a fingertip that can meet the palm or the thumb (`grasp`: two candidates) -- with fcl's direction supplied by
     DirectionSearchFcl.  Inputs: `pair_tosses`."""
     for name, representation in cases:
         urdf = os.path.join(REPO, 'assets', name + '.urdf')

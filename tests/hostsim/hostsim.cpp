@@ -63,10 +63,12 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
   for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k, body_rot_of(md, b));
-  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
+  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr,
+                                                                                  MD::kGeneral ? g_len[NG > kMaxGeoms ? kMaxGeoms : 0] : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
     const bool polygon = MD::kGeneral && k / GP < kMaxGeoms && md.geom_kind[k / GP < kMaxGeoms ? k / GP : 0] == kGeomPolygon;
     grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
+    if (MD::kGeneral && k / GP >= kMaxGeoms) grad[NB * 10 + NG + 1 + k] = 0.0;  // (no parameters there: the pairs' d/d mu)
   }
 }
 
@@ -213,10 +215,12 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
   for (int i = 0; i < NG * GP; ++i) ln[i] = double(lengths[i]);
   for (int b = 0; b < NB; ++b)
     for (int k = 0; k < 10; ++k) grad[b * 10 + k] = theta_grad_component(md.inertia_mode, th + 10 * b, g_iota[b], k, body_rot_of(md, b));
-  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr);
+  for (int k = 0; k < NG + 1; ++k) grad[NB * 10 + k] = friction_grad_component(NG, fr, g_mu, k, MD::kGeneral ? &md : nullptr,
+                                                                                  MD::kGeneral ? g_len[NG > kMaxGeoms ? kMaxGeoms : 0] : nullptr);
   for (int k = 0; k < NG * GP; ++k) {  // a polygon's vertices are signed parameters; lengths and radii enter through |.|
     const bool polygon = MD::kGeneral && k / GP < kMaxGeoms && md.geom_kind[k / GP < kMaxGeoms ? k / GP : 0] == kGeomPolygon;
     grad[NB * 10 + NG + 1 + k] = polygon ? (&g_len[0][0])[k] : length_grad_component(ln, &g_len[0][0], k);
+    if (MD::kGeneral && k / GP >= kMaxGeoms) grad[NB * 10 + NG + 1 + k] = 0.0;  // (no parameters there: the pairs' d/d mu)
   }
 }
 

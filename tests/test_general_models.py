@@ -20,7 +20,7 @@ from dair_pll_amd.urdf import parse_urdf
 from oracle import dpll_oracle as O
 
 MODELS = ['chain3', 'vee', 'ballcube', 'mace', 'polycube', 'wedge', 'clasp', 'clasp_ball', 'vee_pair', 'gripper', 'crank',
-          'pincer']
+          'pincer', 'grasp']
 # model -> (URDF under assets/, what a <mesh> element is read as)
 SOURCES = {'polycube': ('cube_mesh.urdf', 'polygon'), 'wedge': ('wedge.urdf', 'polygon'), 'clasp_ball': ('clasp_ball.urdf', 'polygon')}
 P = 'multibody_terms.'
@@ -170,6 +170,31 @@ def test_host_build_of_the_kernel_math(golden, name):
     assert np.abs(x_next32 - g['dynamics/x_next']).max() < 1e-4 * scale
 
 
+@pytest.mark.parametrize('name', MODELS)
+def test_host_build_step_backward_against_oracle_autograd(golden, name):
+    """the backward of one step (step_item_backward + step_state_adjoint of csrc/dpll_core.hpp, host build): parameter
+    gradient and state adjoint of a seeded linear functional of the next state against torch autograd through the
+    oracle's step (differentiable cone solve); the state adjoint on the unit-quaternion tangent space (Q2)"""
+    g = golden(name + '_literal')
+    spec = spec_of(name)
+    desc = make_desc(spec, float(g['dt']))
+    theta, friction, lengths = fixture_params(g, spec)
+    rows = np.linspace(0, g['x'].shape[0] - 1, 12).astype(int)
+    x_np = g['x'][rows]
+    w = torch.rand(x_np.shape, generator=torch.Generator().manual_seed(11), dtype=torch.float64) - 0.5
+    oracle = oracle_from(g, name).requires_grad_()
+    x_ref = torch.tensor(x_np).requires_grad_(True)
+    (oracle.step(x_ref) * w).sum().backward()
+    grad, xbar = hostsim.step_backward(desc, theta, friction, lengths, x_np, w.numpy(), want_state=True)
+    named = {key: value.grad.numpy() for key, value in oracle.named_parameters().items()}
+    ref = reference_gradient({'grad/' + key: value for key, value in named.items()}, spec)
+    assert np.abs(grad - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-3)
+    diff = xbar - x_ref.grad.numpy()
+    q = x_np[:, :4] / np.linalg.norm(x_np[:, :4], axis=-1, keepdims=True)
+    diff[:, :4] -= (diff[:, :4] * q).sum(-1, keepdims=True) * q
+    assert np.abs(diff).max() <= 1e-7 * np.abs(x_ref.grad.numpy()).max()
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------------------
 def gpu_system(g, name, dtype):
     from dair_pll_amd import MultibodyLearnableSystem
@@ -270,7 +295,7 @@ def test_gpu_step_backward_against_oracle_autograd(golden, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['clasp', 'clasp_ball', 'vee_pair', 'pincer'])
+@pytest.mark.parametrize('name', ['clasp', 'clasp_ball', 'vee_pair', 'pincer', 'grasp'])
 def test_gpu_pair_models_on_random_states(golden, name):
     """Body-body contact away from the rollouts of the fixtures: 192 seeded states with the joints anywhere (the pair far
     apart, touching, and overlapping by centimetres), parameters as recorded -- loss, every gradient and the next state of
@@ -290,8 +315,10 @@ def test_gpu_pair_models_on_random_states(golden, name):
     x = torch.cat((q, v), -1)
     with torch.no_grad():
         x_next_ref = oracle.step(x)
-        phi_pair = oracle.contact_terms(oracle.q_v(x_next_ref)[0])[0][:, -1]
-    assert (phi_pair < -0.002).sum() >= 5 and (phi_pair > 0.01).sum() >= 50  # overlapping and apart both occur
+        phi_pair = oracle.contact_terms(oracle.q_v(x_next_ref)[0])[0][:, -len(system.spec.pairs):]
+    for p in range(phi_pair.shape[1]):  # every candidate occurs overlapping and apart
+        assert (phi_pair[:, p] < -0.002).sum() >= 3 and (phi_pair[:, p] > 0.01).sum() >= 50
+    assert (phi_pair.min(dim=-1).values < -0.002).sum() >= 5
     loss_ref = oracle.contactnets_loss(x, x_next_ref)
     loss_ref.mean().backward()
     xd, xpd = x.cuda(), x_next_ref.cuda()

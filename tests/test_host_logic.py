@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 1 + 1 + 1) + 4 + 8 * 9 * (4 + 3)  # (+ 4: padding)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 4 + 4 + 1) + 4 + 8 * 9 * (4 + 3)  # (+ 4: padding)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
@@ -231,7 +231,8 @@ def test_general_models_are_described_for_the_general_build():
               'clasp': (2, [0, 1], [0, 2, 0], [0, 0, 0], 9), 'clasp_ball': (2, [0, 1], [0, 2, 0], [1, 2, 0], 6),
               'vee_pair': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13),
               'gripper': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 9),  # body 1 carries no geometry
-              'crank': (2, [0, 1], [0, 1, 2], [0, 0, 1], 9), 'pincer': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13)}
+              'crank': (2, [0, 1], [0, 1, 2], [0, 0, 1], 9), 'pincer': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13),
+              'grasp': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 11)}  # two candidates: palm - fingertip, thumb - fingertip
     block, slots = _capi.GEOM_BLOCK, _capi.GEN_SLOTS
     for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
         representation = 'polygon' if name in ('wedge', 'clasp_ball') else 'deep_support'
@@ -274,6 +275,11 @@ def test_general_models_are_described_for_the_general_build():
             bad.pair_b[0] = bad.pair_a[0]
             other = ctypes.c_void_p()
             assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(other)) != 0
+        elif name == 'grasp':
+            # several candidates share the group of contact slots behind the geometries: candidate p is slot p of it
+            assert spec.pairs == [(0, 2), (1, 2)] and desc.n_pairs == 2
+            assert (list(desc.pair_a)[:2], list(desc.pair_b)[:2]) == ([0, 1], [2, 2])
+            assert spec.contact_slots()[-2:] == [4 * _capi.MAX_GEOMS, 4 * _capi.MAX_GEOMS + 1]
         else:
             assert spec.pairs == [] and desc.n_pairs == 0
         if name == 'crank':

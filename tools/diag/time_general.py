@@ -10,7 +10,7 @@ if os.environ.get('DPLL_LIB'):  # another build of the library (A/B runs)
 ONLY = sys.argv[1:]
 MODELS = {'chain3': ('chain3.urdf', 'deep_support'), 'gripper': ('gripper.urdf', 'deep_support'), 'mace': ('mace.urdf', 'deep_support'), 'wedge': ('wedge.urdf', 'polygon'),
           'clasp': ('clasp.urdf', 'deep_support'), 'clasp_ball': ('clasp_ball.urdf', 'polygon'), 'crank': ('crank.urdf', 'deep_support'),
-          'pincer': ('pincer.urdf', 'deep_support')}
+          'pincer': ('pincer.urdf', 'deep_support'), 'grasp': ('grasp.urdf', 'deep_support')}
 for name, (urdf, rep) in MODELS.items():
     if ONLY and name not in ONLY:
         continue
