@@ -295,6 +295,47 @@ def test_gpu_step_backward_against_oracle_autograd(golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', ['chain3', 'grasp', 'crank'])
+def test_gpu_batch_sizes_of_the_general_build(golden, name):
+    """Size-independent properties (the reference's batch is any leading shape): an item's loss, next state and rollout
+    do not depend on the batch it sits in -- ragged sizes that leave lanes of the last wave idle (1, 3, 5, 4097 items at
+    four items per wave), an empty batch, and 40,000 items, where the capped grid loops over the items -- and the
+    gradient of a mean is the mean of the gradients (fixed-order partial rows: rows of one wave, folded rows, looped grid)."""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, torch.float64)
+    n = g['x'].shape[0]
+    x = torch.tensor(g['x'], device='cuda:0')
+    xp = torch.tensor(g['x_plus'], device='cuda:0')
+    u = lambda t: torch.zeros(t.shape[:-1] + (0,), device='cuda:0')
+    with torch.no_grad():
+        base_loss, base_next = system.contactnets_loss(x, u(x), xp), system.step(x)
+    assert (base_loss.cpu().numpy() - g['loss']).__abs__().max() < 1e-10
+    gen = torch.Generator().manual_seed(4)
+    for size in (0, 1, 3, 5, 4097, 40000):
+        pick = torch.randint(0, n, (size,), generator=gen).cuda()
+        with torch.no_grad():
+            loss, nxt = system.contactnets_loss(x[pick], u(x[pick]), xp[pick]), system.step(x[pick])
+        assert loss.shape == (size,) and nxt.shape == (size, x.shape[1])
+        assert torch.equal(loss, base_loss[pick]) and torch.equal(nxt, base_next[pick])  # bit for bit, wherever the item sits
+    # gradients: the batch repeated k times under .mean() gives the same gradient; one item alone gives its own
+    def grads(xb, xpb):
+        system.zero_grad()
+        system.contactnets_loss(xb, u(xb), xpb).mean().backward()
+        return torch.cat([p.grad.reshape(-1) for _, p in system.named_parameters()]).clone()
+    whole = grads(x, xp)
+    tiled = grads(x.repeat(334, 1), xp.repeat(334, 1))  # (> 8192 waves of four items: the looped grid)
+    assert (tiled - whole).abs().max() <= 1e-12 * max(1.0, whole.abs().max().item())
+    per_item = torch.stack([grads(x[i:i + 1], xp[i:i + 1]) for i in range(0, n, max(1, n // 6))])
+    subset = grads(x[::max(1, n // 6)], xp[::max(1, n // 6)])
+    assert (per_item.mean(0) - subset).abs().max() <= 1e-12 * max(1.0, subset.abs().max().item())
+    # rollouts: trajectories of a ragged batch equal those of the items alone
+    with torch.no_grad():
+        traj, _ = system.simulate(x[:7].unsqueeze(-2), torch.zeros((7, 1), device='cuda:0'), 3)
+        one, _ = system.simulate(x[6:7].unsqueeze(-2), torch.zeros((1, 1), device='cuda:0'), 3)
+    assert torch.equal(traj[6], one[0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['clasp', 'clasp_ball', 'vee_pair', 'pincer', 'grasp'])
 def test_gpu_pair_models_on_random_states(golden, name):
     """Body-body contact away from the rollouts of the fixtures: 192 seeded states with the joints anywhere (the pair far
