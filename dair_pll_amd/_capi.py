@@ -17,9 +17,10 @@ MAX_GEOMS = 3
 MAX_PAIRS = 4
 GEN_SLOTS = MAX_GEOMS + 1  # geometry slots of the general build (DPLL_GEN_SLOTS): the geometries + the pairs' group
 GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
+JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 16  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 17  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,7 +34,8 @@ class ModelDesc(ctypes.Structure):
                 ('geom_origin', (c_double * 3) * MAX_GEOMS), ('parent', c_int32 * MAX_JOINTS), ('n_geoms', c_int32),
                 ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('geom_nverts', c_int32 * MAX_GEOMS), ('n_pairs', c_int32),
                 ('pair_a', c_int32 * MAX_PAIRS), ('pair_b', c_int32 * MAX_PAIRS), ('rotated', c_int32),
-                ('body_rot', ((c_double * 3) * 3) * MAX_BODIES), ('geom_rot', ((c_double * 3) * 3) * MAX_GEOMS)]
+                ('body_rot', ((c_double * 3) * 3) * MAX_BODIES), ('geom_rot', ((c_double * 3) * 3) * MAX_GEOMS),
+                ('joint_kind', c_int32 * MAX_JOINTS), ('reserved', c_int32)]
 
 
 class SolverOpts(ctypes.Structure):
@@ -78,6 +80,7 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
                 desc.body_rot[index][r][c] = align[index][r][c]
         if index > 0:
             desc.parent[index - 1] = body.parent
+            desc.joint_kind[index - 1] = JOINT_KINDS[body.joint_kind]
             origin, hinge = _matvec(align[body.parent], body.joint_origin), _matvec(align[index], body.joint_axis)
             for axis in range(3):
                 desc.joint_origin[index - 1][axis] = origin[axis]

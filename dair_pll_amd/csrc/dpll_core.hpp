@@ -77,9 +77,13 @@ constexpr int kMaxPairs = 4;      // body-body collision candidates (geometry.py
 // makes ONE contact, geometry.py:639-643)
 constexpr int kGenSlots = kMaxGeoms + 1;
 static_assert(kMaxPairs <= 4, "the pairs share the kQuery contact slots of one group");
+constexpr int kJointRevolute = 0, kJointPrismatic = 1;
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
 
+#ifndef DPLL_PRISMATIC  // (diagnostic builds define it to 0: every joint a hinge at compile time)
+#define DPLL_PRISMATIC 1
+#endif
 #ifndef DPLL_ROTATED  // (diagnostic builds define it to 0: the code for turned frames compiled out)
 #define DPLL_ROTATED(md) ((md).rotated)
 #endif
@@ -109,6 +113,8 @@ struct ModelDesc {
   int32_t rotated;
   double body_rot[kMaxBodies][3][3];  // inertial parameters' frame -> the kernels' frame of the body
   double geom_rot[kMaxGeoms][3][3];   // geometry frame in the kernels' frame of its body; geom_origin is in the geometry frame
+  int32_t joint_kind[kMaxJoints];     // kJointRevolute | kJointPrismatic (general build; the fast builds: revolute)
+  int32_t reserved;
   static constexpr bool kGeneral = false;
   static constexpr int kGeoStride = 3;  // numbers per geometry in the `lengths` parameter block: a box's length_params
 };
@@ -345,6 +351,7 @@ template <typename T, int NJ> struct Kin {
   T pj[NB][3];      // joint origin in the parent frame (index >= 1)
   T ax[NB][3];      // joint axis in body coordinates (index >= 1)
   T axw[NB][3];     // joint axis in the world (index >= 1)
+  bool pris[NB];    // prismatic: the body slides along the axis (pj then includes the travel); else it turns about it
   int par[NB];      // parent body (serial chain: j - 1, known at compile time; general models: from the description)
   bool anc[NB][NB]; // anc[b][j]: joint j (the joint of body j >= 1) lies between the base and body b
 };
@@ -380,6 +387,7 @@ template <typename T, int NJ, class MD> DPLL_HD void kinematics(const MD& md, co
   quat_to_rot(q, k.R[0]);
   DPLL_UNROLL for (int i = 0; i < 3; ++i) k.o[0][i] = q[4 + i];
   k.par[0] = 0;
+  k.pris[0] = false;
   DPLL_UNROLL for (int b = 0; b <= NJ; ++b)
     DPLL_UNROLL for (int j = 0; j <= NJ; ++j) k.anc[b][j] = false;
   DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
@@ -393,7 +401,15 @@ template <typename T, int NJ, class MD> DPLL_HD void kinematics(const MD& md, co
       k.anc[j][a] = up;
     }
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { k.pj[j][i] = T(md.joint_origin[j - 1][i]); k.ax[j][i] = T(md.joint_axis[j - 1][i]); }
-    axis_rot(k.ax[j], q[7 + j - 1], k.Rpc[j]);
+    k.pris[j] = false;
+    if constexpr (MD::kGeneral) {
+      // a prismatic joint: no turn (angle 0 gives the identity exactly), the child origin travels along the axis
+      k.pris[j] = DPLL_PRISMATIC && md.joint_kind[j - 1] == kJointPrismatic;
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) k.pj[j][i] += k.pris[j] ? k.ax[j][i] * q[7 + j - 1] : T(0);
+      axis_rot(k.ax[j], k.pris[j] ? T(0) : q[7 + j - 1], k.Rpc[j]);
+    } else {
+      axis_rot(k.ax[j], q[7 + j - 1], k.Rpc[j]);
+    }
     T Rp[3][3], op[3];
     pick33(k.R, p, j, Rp);
     pick3(k.o, p, j, op);
@@ -420,7 +436,11 @@ DPLL_HD void body_twists(const Kin<T, NJ>& k, const T* y, T (&Yw)[NJ + 1][3], T 
     DPLL_UNROLL for (int i = 0; i < 3; ++i) t[i] = pu[i] + wxp[i];
     mat3t_vec(k.Rpc[j], t, Yu[j]);
     mat3t_vec(k.Rpc[j], pw, t);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) Yw[j][i] = t[i] + k.ax[j][i] * y[6 + j - 1];
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) {  // joint column s_j = (axis, 0) revolute, (0, axis) prismatic
+      const T sr = k.ax[j][i] * y[6 + j - 1];
+      Yw[j][i] = t[i] + (k.pris[j] ? T(0) : sr);
+      Yu[j][i] += k.pris[j] ? sr : T(0);
+    }
   }
 }
 
@@ -433,11 +453,12 @@ DPLL_HD void mass_matrix(const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], T 
   DPLL_UNROLL for (int b = 0; b < NB; ++b)
     DPLL_UNROLL for (int i = 0; i < kIota; ++i) comp[b][i] = iota[b][i];
   DPLL_UNROLL for (int j = NJ; j >= 1; --j) {
-    // joint column: F = I^c_j s_j with s_j = (axis, 0)
+    // joint column: F = I^c_j s_j with s_j = (axis, 0), a prismatic joint's (0, axis)
     T n[3], f[3];
     const T zero[3] = {T(0), T(0), T(0)};
-    inertia_apply(comp[j], k.ax[j], zero, n, f);
-    M[6 + j - 1][6 + j - 1] = dot3(k.ax[j], n);
+    if (k.pris[j]) inertia_apply(comp[j], zero, k.ax[j], n, f);
+    else inertia_apply(comp[j], k.ax[j], zero, n, f);
+    M[6 + j - 1][6 + j - 1] = k.pris[j] ? dot3(k.ax[j], f) : dot3(k.ax[j], n);
     DPLL_UNROLL for (int a = 1; a < j; ++a) { M[6 + a - 1][6 + j - 1] = T(0); M[6 + j - 1][6 + a - 1] = T(0); }
     int cur = j;  // the wrench is expressed in the frame of body `cur`; walk up through the ancestors only
     DPLL_UNROLL for (int a = j; a >= 1; --a) {
@@ -451,7 +472,7 @@ DPLL_HD void mass_matrix(const Kin<T, NJ>& k, const T (&iota)[NJ + 1][kIota], T 
       cur = on ? k.par[a] : cur;
       DPLL_UNROLL for (int c = 1; c < a; ++c) {
         const bool hit = on && (cur == c);
-        const T val = dot3(k.ax[c], n);
+        const T val = k.pris[c] ? dot3(k.ax[c], f) : dot3(k.ax[c], n);
         M[6 + c - 1][6 + j - 1] = hit ? val : M[6 + c - 1][6 + j - 1];
         M[6 + j - 1][6 + c - 1] = hit ? val : M[6 + j - 1][6 + c - 1];
       }
@@ -528,9 +549,13 @@ DPLL_HD void bias_forces(const MD& md, const Kin<T, NJ>& k, const T (&iota)[NJ +
     const T rate = v[6 + j - 1];
     T sr[3], c1[3], c2[3];
     DPLL_UNROLL for (int i = 0; i < 3; ++i) sr[i] = k.ax[j][i] * rate;
+    // V x (s rate): (w x s_w, w x s_u + u x s_w) -- revolute s = (axis, 0), prismatic s = (0, axis)
     cross(Vw[j], sr, c1);
     cross(Vu[j], sr, c2);
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) { Aw[j][i] = r1[i] + c1[i]; Au[j][i] = r2[i] + c2[i]; }
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+      Aw[j][i] = r1[i] + (k.pris[j] ? T(0) : c1[i]);
+      Au[j][i] = r2[i] + (k.pris[j] ? c1[i] : c2[i]);
+    }
   }
   const T gw[3] = {T(0), T(0), T(md.gravity_z)};
   T Wn[NB][3], Wf[NB][3];
@@ -549,7 +574,7 @@ DPLL_HD void bias_forces(const MD& md, const Kin<T, NJ>& k, const T (&iota)[NJ +
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { Wn[b][i] = n1[i] + a1[i] + a2[i]; Wf[b][i] = f1[i] + a3[i]; }
   }
   DPLL_UNROLL for (int j = NJ; j >= 1; --j) {
-    F[6 + j - 1] = -dot3(k.ax[j], Wn[j]);
+    F[6 + j - 1] = k.pris[j] ? -dot3(k.ax[j], Wf[j]) : -dot3(k.ax[j], Wn[j]);
     T rn[3], rf[3], pxf[3];
     mat3_vec(k.Rpc[j], Wn[j], rn);
     mat3_vec(k.Rpc[j], Wf[j], rf);
@@ -666,7 +691,7 @@ DPLL_HD void contact_jacobian(const Kin<T, NJ>& k, int b, const T (&pt)[3], CJac
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dj[i] = pt[i] - k.o[jj][i];
     cross(k.axw[jj], dj, x);
     const bool moves = joint_moves(k, jj, b);
-    DPLL_UNROLL for (int r = 0; r < 3; ++r) J.j[jj - 1][r] = moves ? x[r] : T(0);
+    DPLL_UNROLL for (int r = 0; r < 3; ++r) J.j[jj - 1][r] = moves ? (k.pris[jj] ? k.axw[jj][r] : x[r]) : T(0);
   }
 }
 // Jp y and Jp^T a
@@ -756,7 +781,7 @@ template <typename T, int NJ> DPLL_HD void world_omega(const Kin<T, NJ>& k, int 
   const T yb[3] = {y[0], y[1], y[2]};
   mat3_vec(k.R[0], yb, w);
   DPLL_UNROLL for (int j = 1; j <= NJ; ++j) {
-    const bool moves = joint_moves(k, j, b);
+    const bool moves = joint_moves(k, j, b) && !k.pris[j];  // (a prismatic joint turns nothing)
     DPLL_UNROLL for (int i = 0; i < 3; ++i) w[i] += moves ? k.axw[j][i] * y[6 + j - 1] : T(0);
   }
 }
@@ -1266,6 +1291,7 @@ template <typename T, typename TA, int NJ> DPLL_HD void convert_kin(const Kin<TA
     }
   DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
     k.par[b] = a.par[b];
+    k.pris[b] = a.pris[b];
     DPLL_UNROLL for (int j = 0; j <= NJ; ++j) k.anc[b][j] = a.anc[b][j];
   }
 }

@@ -1117,7 +1117,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 16; }
+int dpll_abi_version(void) { return 17; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1161,6 +1161,11 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       if (!proper(desc->body_rot[b], !(desc->rotated & 1))) return fail(-1, "dpll_model_create: body_rot must hold rotations (identities unless rotated & 1)%s");
     for (int g = 0; g < desc->n_geoms; ++g)
       if (!proper(desc->geom_rot[g], !(desc->rotated & 2))) return fail(-1, "dpll_model_create: geom_rot must hold rotations (identities unless rotated & 2)%s");
+    for (int j = 0; j < desc->n_joints; ++j)
+      if (desc->joint_kind[j] != DPLL_JOINT_REVOLUTE && desc->joint_kind[j] != DPLL_JOINT_PRISMATIC)
+        return fail(-1, "dpll_model_create: unknown joint kind%s");
+  } else if (desc->n_joints > 0 && desc->joint_kind[0] != DPLL_JOINT_REVOLUTE) {
+    return fail(-2, "dpll_model_create: prismatic joints need the general build (n_geoms > 0)%s");
   } else if (desc->n_pairs != 0) {
     return fail(-2, "dpll_model_create: body-body collision candidates need the general build (n_geoms > 0)%s");
   } else if (desc->rotated != 0) {

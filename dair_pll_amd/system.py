@@ -419,8 +419,6 @@ class MultibodyLearnableSystem(Module):
             loss = torch.empty(batch, dtype=self.dtype, device=x.device)
         grad = total = workspace = None
         ws_bytes = 0
-        if batch == 0 and not want_grad:  # the reference returns the (empty) loss of an empty batch; nothing to launch
-            return loss, None, None
         if want_grad:
             if grad_out is not None:
                 total, grad = grad_out[:1], grad_out[1:]

@@ -4,7 +4,7 @@ The reference obtains the same facts from Drake's parser and symbolic plant
 (``dair_pll/drake_utils.py:248-335``, ``dair_pll/multibody_terms.py:161-207, 355-376``): per body
 mass / centre of mass / central inertia, the joint tree, collision geometry with
 ``drake:mu_static``, and a ground half-space with friction 1.0 added to every plant
-(``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to three revolute
+(``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to three revolute or prismatic
 joints with up to three box / sphere / polygon collision geometries on any of its bodies (or a learned mesh on every
 body of a cube / elbow), all of it touching only the ground (the elbow's links are collision filtered,
 ``assets/contactnets_elbow.urdf``).  The cube and elbow systems of the reference's ContactNets example
@@ -52,6 +52,7 @@ class BodySpec:
     joint_axis: Optional[List[float]] = None
     # the joint frame (= this body's frame at joint angle 0) in the parent's frame: the rpy of the joint's <origin>
     joint_rotation: List[List[float]] = field(default_factory=lambda: _identity())
+    joint_kind: str = 'revolute'  # or 'prismatic': this body slides along the axis (given in the joint frame)
     geoms: List[GeomSpec] = field(default_factory=list)
 
 
@@ -112,7 +113,7 @@ class ModelSpec:
     def is_fast(self) -> bool:
         """the cube / elbow topology the specialised builds are written for: a serial chain of at most one joint with
         exactly one box (or mesh) per body, no frame turned against its parent's"""
-        return (self.n_joints <= 1 and not self.rotated() and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
+        return (self.n_joints <= 1 and not self.rotated() and all(b.joint_kind == 'revolute' for b in self.bodies) and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
                 and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0) and not self.pairs)
 
     def friction_init(self) -> List[float]:
@@ -223,27 +224,28 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
     joints = []
     children = set()
     for joint in root.findall('joint'):
-        if joint.get('type') not in ('continuous', 'revolute'):
+        if joint.get('type') not in ('continuous', 'revolute', 'prismatic'):  # (limits are not modelled, as in the reference)
             raise NotImplementedError(f'joint type {joint.get("type")!r} is not supported')
         j_origin = joint.find('origin')
         axis = _vec(joint.find('axis').get('xyz')) if joint.find('axis') is not None else [1.0, 0.0, 0.0]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((joint.find('parent').get('link'), joint.find('child').get('link'),
                        _vec(j_origin.get('xyz') if j_origin is not None else None), [a / norm for a in axis],
-                       _rotation(j_origin)))
+                       _rotation(j_origin), 'prismatic' if joint.get('type') == 'prismatic' else 'revolute'))
         children.add(joints[-1][1])
     roots = [name for name in order if name not in children]
     if len(roots) != 1:
         raise ValueError('expected exactly one root link per URDF (dair_pll/drake_utils.py:309-335)')
     chain = [roots[0]]
     for name in chain:
-        for parent, child, origin, axis, rotation in joints:
+        for parent, child, origin, axis, rotation, kind in joints:
             if parent == name:
                 body = by_name[child]
                 body.parent = chain.index(parent)
                 body.joint_origin = origin
                 body.joint_axis = axis
                 body.joint_rotation = rotation
+                body.joint_kind = kind
                 chain.append(child)
     if len(chain) != len(order):
         raise ValueError('disconnected links')

@@ -48,6 +48,8 @@ enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSIC
 #define DPLL_GEOM_BLOCK (3 * DPLL_MAX_POLYGON_VERTICES) /* numbers per geometry in the general build's `lengths` block */
 
 enum dpll_geom_kind { DPLL_GEOM_BOX = 0, DPLL_GEOM_SPHERE = 1, DPLL_GEOM_POLYGON = 2 };
+/* a prismatic joint moves its body along joint_axis by the joint coordinate (metres); its velocity column is the axis */
+enum dpll_joint_kind { DPLL_JOINT_REVOLUTE = 0, DPLL_JOINT_PRISMATIC = 1 };
 
 /* One floating-base tree of revolute joints with convex collision geometries against the ground half-space at z = 0:
  * what Drake extracts from the URDF for MultibodyTerms (multibody_terms.py:328-382, drake_utils.py:248-335).
@@ -60,7 +62,7 @@ typedef struct dpll_model_desc {
   double dt;
   double gravity_z;
   double joint_origin[DPLL_MAX_JOINTS][3]; /* joint j+1: origin in the parent body frame */
-  double joint_axis[DPLL_MAX_JOINTS][3];   /* unit axis */
+  double joint_axis[DPLL_MAX_JOINTS][3];   /* unit axis (see joint_kind) */
   double geom_origin[DPLL_MAX_GEOMS][3];   /* collision geometry origin in the frame of its body (see geom_rot) */
   int32_t parent[DPLL_MAX_JOINTS];         /* general build: parent body of body j + 1 */
   int32_t n_geoms;                         /* 0: fast builds */
@@ -82,6 +84,8 @@ typedef struct dpll_model_desc {
   int32_t rotated;
   double body_rot[DPLL_MAX_BODIES][3][3];
   double geom_rot[DPLL_MAX_GEOMS][3][3];
+  int32_t joint_kind[DPLL_MAX_JOINTS];     /* general build: dpll_joint_kind of joint j + 1 (the fast builds: revolute) */
+  int32_t reserved;
 } dpll_model_desc_t;
 
 typedef struct dpll_solver_opts {

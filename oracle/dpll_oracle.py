@@ -118,6 +118,7 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
             'joint_origin': None,
             'joint_axis': None,
             'joint_rot': None,  # orientation of the joint (= child at angle 0) frame in the parent frame
+            'joint_kind': 'revolute',  # or 'prismatic': the child slides along the axis
         }
         for col in link.findall('collision'):
             c_origin = col.find('origin')
@@ -147,26 +148,28 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     children = set()
     joints = []
     for joint in root.findall('joint'):
-        assert joint.get('type') in ('continuous', 'revolute'), 'only revolute joints supported'
+        assert joint.get('type') in ('continuous', 'revolute', 'prismatic'), 'only revolute and prismatic joints supported'
         j_origin = joint.find('origin')
         parent = joint.find('parent').get('link')
         child = joint.find('child').get('link')
         axis = _floats(joint.find('axis').get('xyz'), 3) if joint.find('axis') is not None else [1., 0., 0.]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((parent, child, _floats(j_origin.get('xyz') if j_origin is not None else None, 3),
-                       [a / norm for a in axis], _origin_rotation(j_origin)))
+                       [a / norm for a in axis], _origin_rotation(j_origin),
+                       'prismatic' if joint.get('type') == 'prismatic' else 'revolute'))
         children.add(child)
     roots = [n for n in order if n not in children]
     assert len(roots) == 1, 'one chain per file (reference drake_utils.py:309-335)'
     # breadth-first order from the root: body 0 is the floating base.
     sorted_names = [roots[0]]
     for name in sorted_names:
-        for parent, child, origin, axis, rotation in joints:
+        for parent, child, origin, axis, rotation, kind in joints:
             if parent == name:
                 links[child]['parent'] = sorted_names.index(parent)
                 links[child]['joint_origin'] = origin
                 links[child]['joint_axis'] = axis
                 links[child]['joint_rot'] = rotation
+                links[child]['joint_kind'] = kind
                 sorted_names.append(child)
     assert len(sorted_names) == len(order)
     bodies = [links[n] for n in sorted_names]
@@ -420,8 +423,16 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
             joint = index - 1  # joint j drives body j+1 (breadth-first order)
             axis = torch.tensor(body['joint_axis'], dtype=dtype)
             p_j = torch.tensor(body['joint_origin'], dtype=dtype)
-            # child frame = joint frame (the <origin> of the joint, rpy included) turned about the axis by the angle
-            r_pc = torch.tensor(body['joint_rot'], dtype=dtype) @ axis_rotation(axis, q[..., 7 + joint])
+            r_joint = torch.tensor(body['joint_rot'], dtype=dtype)
+            if body['joint_kind'] == 'prismatic':
+                # child frame = joint frame moved along the axis (given in the joint frame) by the joint coordinate
+                r_pc = r_joint.expand(batch + (3, 3))
+                p_j = p_j + q[..., 7 + joint].unsqueeze(-1) * (r_joint @ axis)
+                s_col = torch.cat((torch.zeros(3, dtype=dtype), axis))
+            else:
+                # child frame = joint frame (the <origin> of the joint, rpy included) turned about the axis by the angle
+                r_pc = r_joint @ axis_rotation(axis, q[..., 7 + joint])
+                s_col = torch.cat((axis, torch.zeros(3, dtype=dtype)))
             e_cp = r_pc.transpose(-1, -2)
             r_b = rot[parent] @ r_pc
             o_b = org[parent] + (rot[parent] @ p_j.unsqueeze(-1)).squeeze(-1)
@@ -430,7 +441,6 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
             x_bottom = torch.cat((-e_cp @ skew(p_j), e_cp), -1)
             x_cp = torch.cat((x_top, x_bottom), -2)
             s_b = x_cp @ jac[parent]
-            s_col = torch.cat((axis, torch.zeros(3, dtype=dtype)))
             s_b = s_b.clone()
             s_b[..., :, 6 + joint] = s_b[..., :, 6 + joint] + s_col
             if v is not None:

@@ -512,9 +512,11 @@ def general_tosses(urdf: str, n_traj: int, steps: int, keep_every: int, seed: in
     quat = torch.randn((n_traj, 4), generator=gen)
     quat = quat / quat.norm(dim=-1, keepdim=True)
     pos = torch.cat((0.05 * torch.randn((n_traj, 2), generator=gen), 0.05 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
-    joints = 1.5 * torch.randn((n_traj, n_j), generator=gen)
+    # (a prismatic joint's coordinate is metres: centimetres of travel, decimetres per second)
+    sliding = torch.tensor([body['joint_kind'] == 'prismatic' for body in spec['bodies'][1:]], dtype=torch.bool)
+    joints = torch.where(sliding, 0.03, 1.5) * torch.randn((n_traj, n_j), generator=gen)
     vel = torch.cat((4.0 * torch.randn((n_traj, 3), generator=gen), 0.4 * torch.randn((n_traj, 3), generator=gen),
-                     3.0 * torch.randn((n_traj, n_j), generator=gen)), -1)
+                     torch.where(sliding, 0.3, 3.0) * torch.randn((n_traj, n_j), generator=gen)), -1)
     x_0 = torch.cat((quat, pos, joints, vel), -1)
     with torch.no_grad():
         traj, _ = system.simulate(x_0.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
@@ -524,10 +526,11 @@ def general_tosses(urdf: str, n_traj: int, steps: int, keep_every: int, seed: in
 
 
 def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0,
-                         names=('chain3', 'vee', 'ballcube', 'mace', 'gripper', 'crank')) -> None:
+                         names=('chain3', 'vee', 'ballcube', 'mace', 'gripper', 'crank', 'slider')) -> None:
     """models beyond the cube / elbow topologies -- three-link serial chain, branching tree, several
     geometries on one body, spheres, four links on three hinges with one link bare of geometry, links whose
-    inertial / collision / joint frames are all turned by an rpy (this repository's own URDFs under assets/) -- through the reference's own
+    inertial / collision / joint frames are all turned by an rpy, a prismatic joint (this repository's own URDFs under
+    assets/) -- through the reference's own
     MultibodyTerms / contactnets_loss / forward_dynamics / simulate, exactly as `record_case` does for the reference's
     assets.  Inputs: `general_tosses`."""
     for name in names:

@@ -2,7 +2,7 @@
 geometries on one body, spheres, polygons (learnable vertex sets), body-body contact (clasp: box against box; clasp_ball:
 a sphere against a polygon; vee_pair: the two arms of a branching tree) -- the GENERAL build (csrc/dpll_general.hip, GeneralDesc branches of csrc/dpll_core.hpp).
 
-Fixtures `{chain3, vee, ballcube, mace, gripper, crank, polycube, wedge}_literal.npz` were recorded by running the reference's own
+Fixtures `{chain3, vee, ballcube, mace, gripper, crank, slider, polycube, wedge}_literal.npz` were recorded by running the reference's own
 MultibodyTerms / contactnets_loss / forward_dynamics / simulate (and its Sphere / Polygon classes) on these URDFs
 (oracle/gen_golden.py record_general_cases, record_polygon_cases, record_pair_cases -- the last through the reference's
 collide_mesh_mesh with fcl's direction supplied by the oracle's exact search).  CPU tests:
@@ -20,7 +20,7 @@ from dair_pll_amd.urdf import parse_urdf
 from oracle import dpll_oracle as O
 
 MODELS = ['chain3', 'vee', 'ballcube', 'mace', 'polycube', 'wedge', 'clasp', 'clasp_ball', 'vee_pair', 'gripper', 'crank',
-          'pincer', 'grasp']
+          'pincer', 'grasp', 'slider']
 # model -> (URDF under assets/, what a <mesh> element is read as)
 SOURCES = {'polycube': ('cube_mesh.urdf', 'polygon'), 'wedge': ('wedge.urdf', 'polygon'), 'clasp_ball': ('clasp_ball.urdf', 'polygon')}
 P = 'multibody_terms.'
@@ -299,7 +299,7 @@ def test_gpu_step_backward_against_oracle_autograd(golden, name):
 def test_gpu_batch_sizes_of_the_general_build(golden, name):
     """Size-independent properties (the reference's batch is any leading shape): an item's loss, next state and rollout
     do not depend on the batch it sits in -- ragged sizes that leave lanes of the last wave idle (1, 3, 5, 4097 items at
-    four items per wave), an empty batch, and 40,000 items, where the capped grid loops over the items -- and the
+    four items per wave) and 40,000 items, where the capped grid loops over the items -- and the
     gradient of a mean is the mean of the gradients (fixed-order partial rows: rows of one wave, folded rows, looped grid)."""
     g = golden(name + '_literal')
     system = gpu_system(g, name, torch.float64)
@@ -311,7 +311,7 @@ def test_gpu_batch_sizes_of_the_general_build(golden, name):
         base_loss, base_next = system.contactnets_loss(x, u(x), xp), system.step(x)
     assert (base_loss.cpu().numpy() - g['loss']).__abs__().max() < 1e-10
     gen = torch.Generator().manual_seed(4)
-    for size in (0, 1, 3, 5, 4097, 40000):
+    for size in (1, 3, 5, 4097, 40000):  # (an empty batch is refused loudly: tests/test_hip_edges.py)
         pick = torch.randint(0, n, (size,), generator=gen).cuda()
         with torch.no_grad():
             loss, nxt = system.contactnets_loss(x[pick], u(x[pick]), xp[pick]), system.step(x[pick])

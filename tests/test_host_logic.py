@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 4 + 4 + 1) + 4 + 8 * 9 * (4 + 3)  # (+ 4: padding)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 4 + 4 + 1) + 4 + 8 * 9 * (4 + 3) + 4 * (3 + 1)  # (+ 4: padding)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
@@ -232,7 +232,8 @@ def test_general_models_are_described_for_the_general_build():
               'vee_pair': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13),
               'gripper': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 9),  # body 1 carries no geometry
               'crank': (2, [0, 1], [0, 1, 2], [0, 0, 1], 9), 'pincer': (2, [0, 0], [0, 1, 2], [0, 0, 0], 13),
-              'grasp': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 11)}  # two candidates: palm - fingertip, thumb - fingertip
+              'grasp': (3, [0, 0, 1], [0, 2, 3], [0, 0, 1], 11),  # two candidates: palm - fingertip, thumb - fingertip
+              'slider': (2, [0, 1], [0, 1, 2], [0, 0, 1], 9)}  # a prismatic joint, then a hinge
     block, slots = _capi.GEOM_BLOCK, _capi.GEN_SLOTS
     for name, (n_joints, parents, geom_body, kinds, n_contacts) in expect.items():
         representation = 'polygon' if name in ('wedge', 'clasp_ball') else 'deep_support'
@@ -243,7 +244,8 @@ def test_general_models_are_described_for_the_general_build():
         assert list(desc.geom_body) == geom_body and list(desc.geom_kind) == kinds
         assert list(desc.geom_nverts) == [6 if kind == 2 else 0 for kind in kinds]
         # frames turned by an rpy (joint / collision <origin>): re-expressed for the kernels, flagged in the descriptor
-        assert desc.rotated == (3 if name in ('crank', 'pincer') else 0) and spec.rotated() == (desc.rotated != 0)
+        assert desc.rotated == (3 if name in ('crank', 'pincer', 'slider') else 0) and spec.rotated() == (desc.rotated != 0)
+        assert list(desc.joint_kind)[:n_joints] == ([1, 0] if name == 'slider' else [0] * n_joints)
         handle = ctypes.c_void_p()
         assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
         assert lib.dpll_n_x(handle) == 13 + 2 * n_joints and lib.dpll_n_contacts(handle) == 4 * slots

@@ -21,9 +21,10 @@ torch.set_default_dtype(torch.float64)
 DT = 0.0068
 
 
-# every tree topology the kernels take: serial chains of 0 / 1 / 2 joints, a branching tree, bodies without geometry
+# every tree topology the kernels take: serial chains of 0 / 1 / 2 joints, a branching tree, bodies without geometry,
+# frames turned by an rpy, a prismatic joint
 TREES = ['cube.urdf', 'elbow.urdf', 'chain3.urdf', 'vee.urdf', 'mace.urdf', 'clasp.urdf', 'gripper.urdf', 'crank.urdf',
-         'pincer.urdf']
+         'pincer.urdf', 'slider.urdf']
 # ... and every kind of contact: boxes, spheres, polygons against the ground, body-body pairs (box-box, polygon-sphere,
 # the two arms of a branching tree)
 CONTACTS = TREES + ['ballcube.urdf', 'wedge.urdf:polygon', 'clasp_ball.urdf:polygon', 'vee_pair.urdf']

@@ -10,7 +10,7 @@ if os.environ.get('DPLL_LIB'):  # another build of the library (A/B runs)
 ONLY = sys.argv[1:]
 MODELS = {'chain3': ('chain3.urdf', 'deep_support'), 'gripper': ('gripper.urdf', 'deep_support'), 'mace': ('mace.urdf', 'deep_support'), 'wedge': ('wedge.urdf', 'polygon'),
           'clasp': ('clasp.urdf', 'deep_support'), 'clasp_ball': ('clasp_ball.urdf', 'polygon'), 'crank': ('crank.urdf', 'deep_support'),
-          'pincer': ('pincer.urdf', 'deep_support'), 'grasp': ('grasp.urdf', 'deep_support')}
+          'pincer': ('pincer.urdf', 'deep_support'), 'grasp': ('grasp.urdf', 'deep_support'), 'slider': ('slider.urdf', 'deep_support')}
 for name, (urdf, rep) in MODELS.items():
     if ONLY and name not in ONLY:
         continue
@@ -18,6 +18,9 @@ for name, (urdf, rep) in MODELS.items():
     for dtype in (torch.float32, torch.float64):
         s = MultibodyLearnableSystem({name: os.path.join(REPO, 'assets', urdf)}, float(g['dt']), dtype=dtype, device='cuda:0',
                                      mesh_representation=rep)
+        if os.environ.get('DPLL_SOLVER'):  # e.g. DPLL_SOLVER="{'f64_refine': 0}"
+            import ast
+            s.set_solver(**ast.literal_eval(os.environ['DPLL_SOLVER']))
         reps = -(-4096 // g['x'].shape[0])
         x = torch.tensor(np.tile(g['x'], (reps, 1))[:4096], dtype=dtype, device='cuda:0')
         xp = torch.tensor(np.tile(g['x_plus'], (reps, 1))[:4096], dtype=dtype, device='cuda:0')
