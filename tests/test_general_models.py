@@ -295,6 +295,39 @@ def test_gpu_step_backward_against_oracle_autograd(golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', MODELS)
+def test_gpu_float32_terms_and_step_backward(golden, name):
+    """the float32 instantiations of the kernels the two tests above run in float64 (every instantiation is compiled on its
+    own: DESIGN.md 4a "compiler fragility"): terms against the fixture, the gradient of a 2-step rollout against the
+    float64 kernels, at float32 accuracy"""
+    g = golden(name + '_literal')
+    s32, s64 = gpu_system(g, name, torch.float32), gpu_system(g, name, torch.float64)
+    xp = torch.tensor(g['x_plus'], device='cuda:0')
+    k = s32.spec.n_contacts
+    q, v = s32.space.q_v(xp.float())
+    D, M, J, phi, a = s32.multibody_terms(q, v, torch.zeros(xp.shape[:-1] + (0,), device='cuda:0'))
+    assert np.abs(M.cpu().double().numpy() - g['terms/M']).max() < 1e-5 * max(1.0, np.abs(g['terms/M']).max())
+    assert np.abs(a.cpu().double().numpy() - g['terms/a']).max() < 2e-3 * max(1.0, np.abs(g['terms/a']).max())
+    J_np, D_np = align_pair_frames(s32.spec, J.cpu().double().numpy(), D.cpu().double().numpy(), g['terms/J'])
+    mine = canonical(s32.spec, np.round(phi.cpu().double().numpy(), 5), J_np, D_np)
+    ref = canonical(s32.spec, np.round(g['terms/phi'], 5), g['terms/J'], g['terms/D'])
+    assert np.abs(canonical(s32.spec, phi.cpu().double().numpy())[0] - canonical(s32.spec, g['terms/phi'])[0]).max() < 1e-5  # (sorted: Q3)
+    assert np.abs(np.sort(np.abs(mine[1]).sum(-1), axis=-1) - np.sort(np.abs(ref[1]).sum(-1), axis=-1)).max() < 1e-3 * max(1.0, np.abs(ref[1]).max())
+    rows = np.linspace(0, g['x'].shape[0] - 1, 24).astype(int)
+    w = torch.rand((len(rows), 2, g['x'].shape[1]), generator=torch.Generator().manual_seed(5), dtype=torch.float64) - 0.5
+    grads = []
+    for system, dtype in ((s32, torch.float32), (s64, torch.float64)):
+        x = torch.tensor(g['x'][rows], dtype=dtype, device='cuda:0').requires_grad_(True)
+        traj, _ = system.simulate(x.unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), 2)
+        (traj[:, 1:] * w.to(dtype).cuda()).sum().backward()
+        grads.append((torch.cat([p.grad.reshape(-1).double() for _, p in system.named_parameters()]).cpu(), x.grad.double().cpu()))
+    (p32, x32), (p64, x64) = grads
+    assert torch.isfinite(p32).all() and torch.isfinite(x32).all()
+    # (float32 rollouts through contact: the two precisions agree to a few per cent of the largest entry)
+    assert (p32 - p64).abs().max() <= 5e-2 * p64.abs().max() and (x32 - x64).abs().max() <= 5e-2 * x64.abs().max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['chain3', 'grasp', 'crank'])
 def test_gpu_batch_sizes_of_the_general_build(golden, name):
     """Size-independent properties (the reference's batch is any leading shape): an item's loss, next state and rollout
