@@ -328,6 +328,68 @@ def test_gpu_float32_terms_and_step_backward(golden, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name', MODELS)
+def test_gpu_matches_the_host_build_on_many_random_states(golden, name):
+    """2048 seeded states per model near the ground (contacts engaged, sliding, airborne; joints anywhere, so body-body
+    candidates apart and overlapping), far more solver paths than the 96-120 pairs of a fixture: next state, loss and
+    every gradient of the kernels against the SAME templates compiled for the host (one lane per item) in float64 --
+    what would catch an instantiation that the device compiler got wrong only on a path the fixtures do not take."""
+    g = golden(name + '_literal')
+    spec = spec_of(name)
+    desc = make_desc(spec, float(g['dt']))
+    theta, friction, lengths = fixture_params(g, spec)
+    system = gpu_system(g, name, torch.float64)
+    gen = torch.Generator().manual_seed(23)
+    n, n_j = 2048, spec.n_joints
+    sliding = torch.tensor([b.joint_kind == 'prismatic' for b in spec.bodies[1:]], dtype=torch.bool)
+    quat = torch.randn((n, 4), generator=gen, dtype=torch.float64)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    q = torch.cat((quat, 0.05 * torch.randn((n, 2), generator=gen, dtype=torch.float64),
+                   0.03 + 0.08 * torch.rand((n, 1), generator=gen, dtype=torch.float64),
+                   torch.where(sliding, 0.03, 2.0) * torch.randn((n, n_j), generator=gen, dtype=torch.float64)), -1)
+    v = torch.cat((3 * torch.randn((n, 3), generator=gen, dtype=torch.float64), 0.5 * torch.randn((n, 3), generator=gen, dtype=torch.float64),
+                   torch.where(sliding, 0.3, 3.0) * torch.randn((n, n_j), generator=gen, dtype=torch.float64)), -1)
+    x = torch.cat((q, v), -1)
+    x_next_host, iters = hostsim.step(desc, theta, friction, lengths, x.numpy())
+    assert iters.max() < 100
+    xd = x.cuda()
+    x_next = system.step(xd).detach().cpu().numpy()
+    # Deeply overlapping boxes have several directions of (nearly) equal penetration: which one wins is decided by the
+    # last bits of the candidates' values (the device contracts multiply-adds, the host compiler does not), and the two
+    # answers are different contacts -- a handful of items in 2048 for the models with box-box candidates; those are
+    # left out of the comparison, every other item must agree
+    row_scale = np.maximum(1.0, np.abs(x_next_host).max(axis=1))
+    same = np.abs(x_next - x_next_host).max(axis=1) < 1e-8 * row_scale
+    assert same.all() if not spec.pairs else (~same).sum() <= 8, (~same).sum()
+    # the loss of the transition to a perturbed next state (so that its solve is not the dynamics' own)
+    xp = torch.tensor(x_next_host)
+    xp[:, -(6 + n_j):] += 0.05 * torch.randn((n, 6 + n_j), generator=gen, dtype=torch.float64)
+    host = hostsim.loss(desc, theta, friction, lengths, x.numpy(), xp.numpy())
+    loss = system.contactnets_loss(xd, torch.zeros((n, 0), device='cuda:0'), xp.cuda())
+    same_loss = np.abs(loss.detach().cpu().numpy() - host['loss']) < 1e-9 * np.maximum(1.0, np.abs(host['loss']))
+    assert same_loss.all() if not spec.pairs else (~same_loss).sum() <= 8, (~same_loss).sum()
+    if not same_loss.all():  # gradients of the items both builds see alike
+        keep = np.where(same_loss)[0]
+        host = hostsim.loss(desc, theta, friction, lengths, x.numpy()[keep], xp.numpy()[keep])
+        loss = system.contactnets_loss(xd[keep], torch.zeros((len(keep), 0), device='cuda:0'), xp.cuda()[keep])
+    loss.mean().backward()
+    ref = host['grad']  # (kernel layout: [theta | friction (1 + 4 slots) | lengths (4 slots, 24)]; the module's parameters in order)
+    mine = reference_gradient({'grad/' + key: p.grad.cpu().numpy() for key, p in system.named_parameters()}, spec)
+    assert np.abs(mine - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
+    # the float32 kernels on the same states: finite everywhere, and the float64 answer at float32 accuracy for all but
+    # the few items whose active set sits on an edge
+    s32 = gpu_system(g, name, torch.float32)
+    with torch.no_grad():
+        next32 = s32.step(xd.float()).double().cpu().numpy()
+        loss32 = s32.contactnets_loss(xd.float(), torch.zeros((n, 0), device='cuda:0'), xp.cuda().float()).double().cpu().numpy()
+        loss64 = system.contactnets_loss(xd, torch.zeros((n, 0), device='cuda:0'), xp.cuda()).cpu().numpy()
+    assert np.isfinite(next32).all() and np.isfinite(loss32).all()
+    close_next = np.abs(next32 - x_next).max(axis=1) < 2e-3 * row_scale
+    close_loss = np.abs(loss32 - loss64) < 2e-3 * np.maximum(1.0, np.abs(loss64))
+    assert close_next.mean() > 0.98 and close_loss.mean() > 0.98, (close_next.mean(), close_loss.mean())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('name', ['chain3', 'grasp', 'crank'])
 def test_gpu_batch_sizes_of_the_general_build(golden, name):
     """Size-independent properties (the reference's batch is any leading shape): an item's loss, next state and rollout
