@@ -141,7 +141,7 @@ __device__ __forceinline__ void theta_jacobian_column(int inertia_mode, const S*
 }
 // GP = numbers per geometry in the `lengths` block (3: a box; the general build: 3 kMaxPolyVerts); gd (general build
 // only): a polygon's vertices are signed parameters (chain factor 1), lengths and radii enter through their absolute value;
-// the slots behind the geometries hold the pair coefficient of a body-body candidate's two geometries
+// the body-body candidates' coefficients (each of its two geometries' friction entries) get a block of their own, fr_pair
 template <typename T, typename P, int NB, int NG = NB, int GP = 3>
 __device__ __forceinline__ void write_chain_matrix(int inertia_mode, const P* __restrict__ theta, const P* __restrict__ friction,
                                                    const P* __restrict__ lengths, double* __restrict__ chain,
