@@ -16,8 +16,8 @@ The printed JSON line also carries `roofline` (algorithmic bytes of the loss ker
 duration, against the 8 TB/s HBM peak), on rank 0 at N = 1 `cpu_baseline` (the oracle -- a PyTorch CPU
 float64 restatement of the reference path -- timed on this host's cores on a bounded sample) and
 `configs`: the other BASELINE.json configurations measured in the same run (elbow 4096, mesh 4096, cube f64,
-65,536 pairs in f32 / f64, fused rollouts; plus the elbow with a learned mesh on both links and a general-build model
-with a body-body pair), each with its own value / kernel time / roofline.
+65,536 pairs in f32 / f64, fused rollouts; plus the elbow with a learned mesh on both links and two general-build models:
+one with a body-body pair, one with a prismatic joint and turned frames), each with its own value / kernel time / roofline.
 """
 import argparse
 import glob
@@ -36,11 +36,12 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix rate: 256 CUs x 256 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32: 64 cyc/SIMD)
 VALU_F64_PEAK_TFLOPS = 78.6   # f64 vector FMA rate
-N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17}
+N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17, 'slider': 17}
 ELEM = {'f32': 4, 'f64': 8}
-URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf', 'elbow_mesh': 'elbow_mesh.urdf', 'clasp': 'clasp.urdf'}
+URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf', 'elbow_mesh': 'elbow_mesh.urdf', 'clasp': 'clasp.urdf',
+        'slider': 'slider.urdf'}  # (clasp: a box-box body-body candidate; slider: a prismatic joint, turned frames -- the general build)
 FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz', 'elbow_mesh': 'elbow_box_4096.npz',
-           'clasp': 'clasp_literal.npz'}
+           'clasp': 'clasp_literal.npz', 'slider': 'slider_literal.npz'}
 DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set (tests/golden/cube_box_4096.npz, '
                 'seed 0); ranks > 0 take the same pairs in a permuted order, other batch sizes resample with replacement (SURVEY 8d '
                 'config 5); URDF-initial parameters',
@@ -162,7 +163,7 @@ class Timer:
 def loss_roofline(system, workload, dtype, batch, x, xp):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
-    if workload in ('elbow_mesh', 'clasp'):
+    if workload in ('elbow_mesh', 'clasp', 'slider'):
         return None  # no per-kernel utility for these pipelines: run_loss_config prices the whole step
     if workload == 'mesh':
         mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
@@ -232,7 +233,7 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
         else:
             gbs = bytes_per_step(workload, dtype_name) * batch / (step_ms * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                    'kernel': 'gen_loss_kernel + finalize (general build: one lane per item, coverage build)', 'kernel_ms': step_ms}
+                    'kernel': 'gen_loss_kernel + row fold + finalize (general build: one lane per contact slot)', 'kernel_ms': step_ms}
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
             'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
@@ -427,7 +428,7 @@ def main() -> None:
             configs = []
             for w, d, b, k in (('elbow', 'f32', 4096, 1000), ('elbow', 'f64', 4096, 500), ('mesh', 'f32', 4096, 200),
                                ('cube', 'f64', 4096, 1000), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100),
-                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50)):
+                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50), ('slider', 'f32', 4096, 50)):
                 try:
                     configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
                 except Exception as exc:  # noqa: BLE001
