@@ -1,0 +1,50 @@
+"""The driver's contract with bench.py: one JSON line on stdout with the agreed keys, `roofline` and (N = 1)
+`cpu_baseline` objects, exactly --steps timed steps.  The GPU test runs the real script as a child process."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+REQUIRED = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data', 'config', 'roofline'}
+
+
+def test_bench_helpers_without_a_gpu():
+    """algorithmic bytes per step (read x, x+, write the loss), the fixture loader's resampling rule and the
+    graph-size rule (largest divisor of --steps that is <= 50, whatever --warmup is)"""
+    import bench
+    assert bench.bytes_per_step('cube', 'f32') == 108 and bench.bytes_per_step('elbow', 'f64') == 248
+    x, xp, dt = bench.load_pairs(4096, 0)
+    assert x.shape == (4096, 13) and xp.shape == (4096, 13) and dt == pytest.approx(0.0068, rel=0.2)
+    x1, _, _ = bench.load_pairs(4096, 1)  # another rank: the same pairs in another order
+    assert not np.array_equal(x, x1) and np.array_equal(np.sort(x[:, 4]), np.sort(x1[:, 4]))
+    x2, _, _ = bench.load_pairs(65536, 0)
+    assert x2.shape == (65536, 13)
+    baseline = json.load(open(os.path.join(REPO, 'BASELINE.json')))
+    assert 'trajectory' in baseline['metric'].lower() or 'step' in baseline['metric'].lower()
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5', '--no-configs'],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [line for line in out.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert REQUIRED <= set(line), REQUIRED - set(line)
+    assert line['n_gpus'] == 1 and line['steps'] == 20 and line['warmup'] == 5 and line['higher_is_better'] is True
+    assert line['scaling'] == 'weak' and line['vs_baseline'] is None and 'workload' in line['config']
+    assert line['value'] == pytest.approx(4096 * 20 / (line['ms_per_step'] * 20 / 1e3), rel=1e-6)
+    roof = line['roofline']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(roof) and roof['bound'] == 'hbm' and roof['peak'] == 8000.0
+    assert roof['frac'] == pytest.approx(roof['achieved'] / roof['peak'], rel=1e-9) and 0 < roof['frac'] < 1
+    cpu = line['cpu_baseline']
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(cpu) and cpu['kind'] in ('port', 'reference') and cpu['value'] > 0
+    assert line['value'] > 1000 * cpu['value']  # (orders of magnitude, not a target: the roofline fraction is the measure)
