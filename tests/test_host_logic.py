@@ -182,6 +182,12 @@ def test_generate_updated_urdfs_keeps_turned_frames(tmp_path):
     again = MultibodyLearnableSystem(new, 0.0068, dtype=torch.float64, device='cpu')
     assert torch.allclose(again.multibody_terms.lagrangian_terms.inertial_parameters,
                           system.multibody_terms.lagrangian_terms.inertial_parameters, atol=1e-9)
+    # a prismatic joint survives the export as it is (the export touches links only)
+    slider = MultibodyLearnableSystem({'slider': os.path.join(ASSET_DIR, 'slider.urdf')}, 0.0068, output_urdfs_dir=str(tmp_path),
+                                      dtype=torch.float64, device='cpu')
+    exported = parse_urdf(slider.generate_updated_urdfs()['slider'])
+    assert [b.joint_kind for b in exported.bodies] == ['revolute', 'prismatic', 'revolute'] and not exported.is_fast()
+    assert exported.bodies[1].joint_axis == parse_urdf(os.path.join(ASSET_DIR, 'slider.urdf')).bodies[1].joint_axis
 
 
 def test_extract_mesh_of_an_analytic_support_function():
