@@ -201,3 +201,30 @@ def test_training_a_general_model_with_a_body_body_pair(use_graph):
     # the parameters are still views of the packed buffer the kernels read
     flat = system._packed()
     assert geometries[2].vertices.data_ptr() == flat.data_ptr() + (30 + 5 + 24) * flat.element_size()
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_training_a_model_with_a_prismatic_joint_and_turned_frames(use_graph):
+    """slider.urdf under the trainer (a prismatic joint, rpy on the joint and on a collision box): the data are the
+    model's own rollouts (the reference-run fixture), the student starts with the carriage box 25 % too large, the knob's
+    radius 20 % too small and wrong masses; the fused loss + Adam, eager and replayed as a hipGraph, reduce the loss and
+    move both shapes back towards the truth."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.trainer import ContactNetsTrainer
+    g = np.load(os.path.join(GOLDEN_DIR, 'slider_literal.npz'))
+    x = torch.tensor(g['x'], dtype=torch.float32, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=torch.float32, device='cuda:0')
+    system = MultibodyLearnableSystem({'slider': os.path.join(ASSET_DIR, 'slider.urdf')}, float(g['dt']), dtype=torch.float32, device='cuda:0')
+    assert system.spec.bodies[1].joint_kind == 'prismatic' and system.spec.rotated()
+    geometries = system.multibody_terms.contact_terms.geometries
+    true_box, true_radius = geometries[2].length_params.detach().clone(), geometries[3].length_param.item()
+    with torch.no_grad():
+        geometries[2].length_params.mul_(1.25)
+        geometries[3].length_param.mul_(0.8)
+        system.multibody_terms.lagrangian_terms.inertial_parameters[:, 0].add_(0.1)
+    start_box, start_radius = geometries[2].length_params.detach().clone(), geometries[3].length_param.item()
+    trainer = ContactNetsTrainer(system, lr=2e-4, batch_size=x.shape[0], use_graph=use_graph)
+    log = trainer.fit(x, xp, epochs=60)
+    assert np.isfinite(log.epoch_losses).all() and log.epoch_losses[-1] < 0.8 * log.epoch_losses[0]
+    assert (geometries[2].length_params.detach().abs() - true_box.abs()).abs().sum() < (start_box.abs() - true_box.abs()).abs().sum()
+    assert abs(abs(geometries[3].length_param.item()) - true_radius) < abs(start_radius - true_radius)
