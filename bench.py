@@ -42,12 +42,10 @@ URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf', 'e
         'slider': 'slider.urdf'}  # (clasp: a box-box body-body candidate; slider: a prismatic joint, turned frames -- the general build)
 FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz', 'elbow_mesh': 'elbow_box_4096.npz',
            'clasp': 'clasp_literal.npz', 'slider': 'slider_literal.npz'}
-DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss (x, x+) pairs of the reference data set (tests/golden/cube_box_4096.npz, '
-                'seed 0); ranks > 0 take the same pairs in a permuted order, other batch sizes resample with replacement (SURVEY 8d '
-                'config 5); URDF-initial parameters',
-        'elbow': 'fixture: 4096 seeded pairs of 40 synthetic 120-step elbow tosses around ELBOW_X_0 (SURVEY 8d config 3, '
-                 'tests/golden/elbow_box_4096.npz: reference UniformSampler + reference simulate); URDF-initial parameters',
-        'mesh': 'the cube fixture pairs; ICNN weights drawn from the reference\'s init distributions, torch.manual_seed(0) (SURVEY 8d config 4)'}
+# (what the fixtures are: DESIGN.md section 2; ranks > 0 take the same pairs permuted, other batch sizes resample with replacement)
+DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss pairs of the reference data set (tests/golden/cube_box_4096.npz), URDF-initial parameters',
+        'elbow': 'fixture: 4096 seeded pairs of 40 synthetic elbow tosses (tests/golden/elbow_box_4096.npz), URDF-initial parameters',
+        'mesh': 'the cube fixture pairs; ICNN weights from the reference init distributions, seed 0'}
 
 
 def bytes_per_step(workload: str, dtype: str) -> int:
@@ -100,6 +98,25 @@ def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
                       ', '.join(f'{rate:.0f} steps/s with {n} threads' for rate, n, _ in results)}
 
 
+def compact(value, digits: int = 6):
+    """floats rounded to `digits` significant digits, recursively: the whole JSON line has to survive the driver's 8 KB
+    tail window (a 14 KB line lost its first configs)"""
+    if isinstance(value, float):
+        return float(f'{value:.{digits}g}') if np.isfinite(value) else None
+    if isinstance(value, dict):
+        return {k: compact(v, digits) for k, v in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [compact(v, digits) for v in value]
+    return value
+
+
+def library_sha256() -> str:
+    import hashlib
+    from dair_pll_amd import _capi
+    with open(_capi.LIB_PATH, 'rb') as handle:
+        return hashlib.sha256(handle.read()).hexdigest()
+
+
 def newest_profile(pattern: str):
     """profiles/rNN_<pattern>, newest round first"""
     found = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r[0-9][0-9]_' + pattern)), reverse=True)
@@ -142,9 +159,13 @@ class Timer:
         if flag.item() == 0 and self.graph is not None:
             self.graph, self.per_graph, self.run = None, 1, self.step
 
-    def measure(self, repeats: int):
+    def measure(self, repeats: int, min_total_s: float = 0.0, max_repeats: int = 5000):
+        """The timed region -- exactly `steps` steps between two fences, MAX over ranks -- at least `repeats` times and until
+        `min_total_s` seconds have been measured in total (a 20-step region of the headline workload lasts 0.4 ms: one of
+        them alone is below what any outside observer of the GPU can see); the MEDIAN region is the reported time.  The
+        repeat count is decided on the max-over-ranks times, which every rank holds alike."""
         times = []
-        for _ in range(repeats):
+        while len(times) < repeats or (sum(times) < min_total_s and len(times) < max_repeats):
             self.fence()
             t0 = time.perf_counter()
             for _ in range(self.steps // self.per_graph):
@@ -182,26 +203,31 @@ def loss_roofline(system, workload, dtype, batch, x, xp):
                         if dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
     ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
     achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
-    traffic = valu_frac = source = None
+    traffic = valu_frac = source = lib_match = None
     path = newest_profile('hbm_traffic.json')
     try:  # HBM bytes per launch / VALU issue slots from the committed PMC passes, only for the configuration they measured
         with open(path) as handle:
             pmc = json.load(handle)
         if (pmc['workload'], pmc['dtype'], pmc['batch']) == (workload, dtype, batch):
             traffic, source = pmc['traffic_bytes_per_launch'], os.path.relpath(path, REPO)
-            with open(path.replace('hbm_traffic.json', 'loss_kernel_pmc.csv')) as handle:
-                counters = {row.split(',')[0]: float(row.split(',')[1]) for row in handle.read().splitlines()[1:]}
-            valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * 2.4e9 * 1024)
-    except (OSError, KeyError, ValueError, IndexError, TypeError):
+            # counters of one binary must not be mixed with timings of another: the issue fraction is only
+            # formed when the profiled library IS the loaded one; clock and SIMD count come from the device
+            lib_match = pmc.get('lib_sha256') == library_sha256()
+            if lib_match:
+                with open(path.replace('hbm_traffic.json', 'loss_kernel_pmc.csv')) as handle:
+                    counters = {row.split(',')[0]: float(row.split(',')[1]) for row in handle.read().splitlines()[1:]}
+                props = torch.cuda.get_device_properties(torch.cuda.current_device())
+                simds, hz = 4 * props.multi_processor_count, props.clock_rate * 1e3
+                valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * hz * simds)
+    except (OSError, KeyError, ValueError, IndexError, TypeError, AttributeError):
         pass
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic,
             'traffic_source': f'{source} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' if traffic else None,
+            'traffic_of_loaded_library': lib_match,
             'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
             'algorithmic_bytes_per_launch': alg_bytes, 'valu_issue_frac': valu_frac,
-            'note': 'latency/instruction bound by construction (SURVEY 8d): the batch is independent 6-7-dimensional cone '
-                    'problems with data-dependent Newton iteration counts, a few hundred KB per launch; valu_issue_frac = '
-                    'SQ_INSTS_VALU per launch (committed PMC pass) x 4 cycles / (kernel time x 2.4 GHz x 1024 SIMDs)'}
+            'note': 'latency bound by construction (SURVEY 8d, DESIGN 5): independent 6-7-dimensional cone solves, 0.44 MB per launch'}
 
 
 def build_system(workload, dtype_name, dt, device):
@@ -277,6 +303,23 @@ def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device):
                          'kernel': 'simulate_kernel'}}
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of `python -m torch.distributed.run`
+    (the command the driver documents), relay what they print, return their worst exit code.  The parent never touches
+    the GPU (nothing is exec'ed either: a process that has initialised the GPU must not be replaced)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL and the peer exchange both need it on this pool
+    env.setdefault('OMP_NUM_THREADS', '1')
+    command = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(command, env=env, check=False).returncode
+
+
 def main() -> None:
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
@@ -294,20 +337,43 @@ def main() -> None:
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (N = 1 only)')
     parser.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl = RCCL)')
-    parser.add_argument('--allreduce', choices=['auto', 'peer', 'collective'], default='auto',
-                        help='gradient exchange: peer = one-shot kernel over xGMI peer memory, collective = the '
-                             'backend all_reduce (RCCL); auto = peer if its start-up self-test passes')
+    parser.add_argument('--allreduce', choices=['auto', 'peer', 'collective'], default='collective',
+                        help='gradient exchange of the REPORTED value: collective = the backend all_reduce (RCCL, what north_star '
+                             'names; the default), peer = one-shot kernel over xGMI peer memory, auto = peer if its start-up '
+                             'self-test passes.  With collective the peer route is timed too and reported as collective_alt')
     parser.add_argument('--no-fuse', action='store_true',
                         help='peer transport: run the exchange as its own kernel after the loss launch instead of inside its finalize kernel')
     parser.add_argument('--single-device', action='store_true',
                         help='testing aid: every rank uses cuda:0 (with --backend gloo on a 1-GPU box)')
+    parser.add_argument('--launch-check', action='store_true',
+                        help='testing aid for the N > 1 launcher: the ranks rendezvous, count themselves with one all-reduce of '
+                             'the backend and rank 0 prints a JSON line; no GPU is touched')
+    parser.add_argument('--min-timed-s', type=float, default=0.5,
+                        help='the timed region (exactly --steps steps) is repeated until at least this much time has been '
+                             'measured in total (and at least --repeats times); the median region is reported')
     args = parser.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # bare `python bench.py --gpus N`: this process becomes the launcher -- it has made no GPU call and makes none -- and
+        # the N ranks are children started through torch.distributed.run (one per GPU, rendezvous on 127.0.0.1)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.launch_check:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo' if args.backend == 'nccl' and not torch.cuda.is_available() else args.backend)
+        probe = torch.ones(1, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(probe)
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'n_gpus': world, 'rccl_ranks': int(probe.item()), 'backend': dist.get_backend()}),
+                  flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -357,7 +423,7 @@ def main() -> None:
         timer = Timer(step, args.steps, args.warmup, use_graph, args.steps_per_graph, fence, max_over_ranks)
         if distributed:
             timer.agree_on_graph(dist, device)
-        elapsed, times = timer.measure(args.repeats)
+        elapsed, times = timer.measure(args.repeats, args.min_timed_s)
         if reducer is not None:
             reducer.check_healthy()  # raises if a peer exchange timed out: never report numbers of a broken exchange
         return timer, elapsed, times
@@ -365,6 +431,13 @@ def main() -> None:
     reducer = alt = None
     rccl_ranks = None
     error = None
+
+    def describe(red):
+        if red.transport == 'peer':
+            return ('one-shot peer-memory all-reduce (xGMI stores + in-order sum) of [loss, gradients] per step, '
+                    + ('inside the finalize kernel of the loss launch' if red.fused else 'one kernel after the loss launch'))
+        return f'one {args.backend} all-reduce of [loss, gradients] per step'
+
     try:
         if distributed:
             reducer = GradientAllReduce(system, transport=args.allreduce, fuse=not args.no_fuse)
@@ -372,12 +445,18 @@ def main() -> None:
             dist.all_reduce(probe)  # an actual collective of the backend (RCCL for nccl): counts the ranks that took part
             rccl_ranks = int(probe.item())
         timer, elapsed, times = timed(reducer)
-        if distributed and reducer.transport == 'peer' and not host_staged:
-            # north_star names a single RCCL all-reduce: time that route in the same run too
-            other = GradientAllReduce(system, transport='collective')
-            alt_timer, alt_elapsed, _ = timed(other)
-            alt = {'collective': f'one {args.backend} all-reduce of [loss, gradients] per step', 'launch': alt_timer.launch,
-                   'ms_per_step': alt_elapsed / args.steps * 1e3, 'value': args.batch * world * args.steps / alt_elapsed}
+        if distributed:
+            # the other route in the same run: north_star names a single RCCL all-reduce (the reported default); the
+            # hand-written peer exchange is its alternative until a multi-GPU run has shown it sound (and vice versa)
+            try:
+                other = GradientAllReduce(system, transport='peer' if reducer.transport == 'collective' else 'collective',
+                                          fuse=not args.no_fuse)
+                if other.transport != reducer.transport:
+                    alt_timer, alt_elapsed, _ = timed(other)
+                    alt = {'collective': describe(other), 'launch': alt_timer.launch, 'ms_per_step': alt_elapsed / args.steps * 1e3,
+                           'value': args.batch * world * args.steps / alt_elapsed}
+            except Exception as exc:  # noqa: BLE001 -- the alternative route is informational
+                alt = {'collective': 'alternative route failed', 'error': repr(exc)}
             system._fused_ar = reducer.peer._ar if reducer.fused else None  # back to the reported route
     except Exception as exc:  # noqa: BLE001 -- one JSON error line, non-zero exit
         error = repr(exc)
@@ -398,11 +477,7 @@ def main() -> None:
     if rank == 0:
         names = {'cube': 'contactnets_cube.urdf, 4 friction contacts', 'elbow': 'contactnets_elbow.urdf, 8 friction contacts',
                  'mesh': 'contactnets_cube_mesh.urdf, DeepSupportConvex (ICNN 2x256) geometry incl. 67,328 network weights'}
-        collective = 'none'
-        if distributed:
-            collective = ('one-shot peer-memory all-reduce (xGMI stores + in-order sum) of [loss, gradients] per step, '
-                          + ('inside the finalize kernel of the loss launch' if reducer.fused else 'one kernel after the loss launch')
-                          ) if reducer.transport == 'peer' else f'one {args.backend} all-reduce of [loss, gradients] per step'
+        collective = describe(reducer) if distributed else 'none'
         line = {
             'metric': 'trajectory-steps/sec (fwd+bwd), batched cube-toss contact sim',
             'value': args.batch * world * args.steps / elapsed,
@@ -410,19 +485,21 @@ def main() -> None:
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype + (' (body kinematics and the first cone residual in f64; the Newton iteration in f32)' if args.dtype == 'f32'
-                                   else ' (cone solve: f32 iterations refined to 1e-13 in f64)'),
+            'dtype': args.dtype,
             'data': DATA[args.workload],
             'config': {'workload': f'{names[args.workload]}, batch={args.batch} per GPU, fwd+bwd contactnets_loss',
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'launch': timer.launch,
-                       'timing': f'median of {args.repeats} repeats of the {args.steps}-step timed region',
-                       'repeat_ms': [t * 1e3 for t in times], 'collective': collective, 'mean_loss': total_loss},
+                       'timing': f'median of {len(times)} repeats of the {args.steps}-step timed region '
+                                 f'({sum(times):.2f} s measured in total)',
+                       'repeats': len(times), 'repeat_ms': [round(t * 1e3, 5) for t in times[:5]],
+                       'repeat_ms_min_max': [round(min(times) * 1e3, 5), round(max(times) * 1e3, 5)],
+                       'collective': collective, 'mean_loss': total_loss},
             'roofline': roof,
         }
         if distributed:
             line['config']['rccl_ranks'] = rccl_ranks
             line['config']['collective_alt'] = alt
-            line['config']['collective_alt_ms'] = alt['ms_per_step'] if alt else None
+            line['config']['collective_alt_ms'] = alt.get('ms_per_step') if alt else None
         if world == 1 and not args.no_configs and args.workload == 'cube' and args.batch == 4096:
             # the other BASELINE.json configurations, same process, after the headline (about a minute in total)
             configs = []
@@ -438,10 +515,11 @@ def main() -> None:
                     configs.append(run_simulate_config(w, d, b, h, 5, device))
                 except Exception as exc:  # noqa: BLE001
                     configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
-            line['configs'] = configs
+            # compact: no launch / note strings (DESIGN.md section 5 has them), the kernel name only inside `roofline`
+            line['configs'] = [{k: v for k, v in c.items() if k not in ('launch', 'unit', 'steps')} for c in configs]
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(compact(line), separators=(',', ':')), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

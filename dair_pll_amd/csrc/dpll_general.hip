@@ -379,11 +379,23 @@ namespace dpll_general {
 
 int param_count(const dpll_model* m) { return 10 * (m->desc.n_joints + 1) + (kNG + 1) + kGP * kNG; }
 
+// [rows (n, PI) | chain matrix (CHAIN) | folded rows (ceil(n / kFoldRows), PI)] with the constants of the very Dims the
+// kernels lay the workspace out with (round 2 restated them by hand and left out the body-body block of the chain
+// matrix: the last folded row was written 152 bytes past the end)
+template <int NJ> long long workspace_doubles(long long rows) {
+  using D = GD<double, NJ>;
+  return (rows + folded_rows(rows)) * D::PI + D::CHAIN;
+}
 long long workspace_bytes(const dpll_model* m, long long batch) {
-  const long long nb = m->desc.n_joints + 1;
-  const long long pi = 1 + 10 * nb + (kNG + 1) + kGP * kNG, chain = 100 * nb + (kNG + 1) * kNG + kGP * kNG;
   const long long rows = row_blocks(batch);
-  return ((rows + folded_rows(rows)) * pi + chain) * (long long)sizeof(double);
+  long long doubles = 0;
+  switch (m->desc.n_joints) {
+    case 0: doubles = workspace_doubles<0>(rows); break;
+    case 1: doubles = workspace_doubles<1>(rows); break;
+    case 2: doubles = workspace_doubles<2>(rows); break;
+    default: doubles = workspace_doubles<3>(rows); break;
+  }
+  return doubles * (long long)sizeof(double);
 }
 
 int loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp,

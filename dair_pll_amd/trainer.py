@@ -82,6 +82,7 @@ class ContactNetsTrainer:
         self._graph = None
         self._static = None
         self.generator = torch.Generator().manual_seed(seed)
+        self.health_every = 16  # steps between looks at the peer exchange's error word (each look synchronises)
         self.reducer: Optional[GradientAllReduce] = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 torch.distributed.get_world_size() > 1:
@@ -104,6 +105,11 @@ class ContactNetsTrainer:
                 lo, hi = shard_bounds(idx.numel(), torch.distributed.get_rank(), self.reducer.world)
                 self.system.global_batch = idx.numel()
                 idx = idx[lo:hi]
+            if self.reducer is not None and len(losses) % self.health_every == self.health_every - 1:
+                # a timed-out peer exchange turns the gradient rows into NaN and the optimizer would apply them: look at
+                # the error word every few steps (it synchronises), so that the abort leaves parameters at most
+                # `health_every` steps old instead of an epoch of NaN updates
+                self.reducer.check_healthy()
             if self.use_graph and idx.numel() == self._graph_rows():
                 losses.append(self._graph_step(x, x_plus, idx))
                 continue

@@ -256,6 +256,12 @@ def test_general_models_are_described_for_the_general_build():
         assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
         assert lib.dpll_n_x(handle) == 13 + 2 * n_joints and lib.dpll_n_contacts(handle) == 4 * slots
         assert lib.dpll_param_count(handle) == 10 * (n_joints + 1) + 1 + slots + slots * block
+        # workspace: [rows | chain matrix incl. the body-body block | rows folded 64 at a time] (the chain's
+        # (1 + slots) x 4 pair block was left out of the size)
+        row = 1 + 10 * (n_joints + 1) + 1 + slots + slots * block
+        chain = 100 * (n_joints + 1) + (slots + 1) * slots + block * slots + (slots + 1) * 4
+        for batch, rows in ((1, 1), (4, 1), (5, 2), (512, 128), (4096, 1024), (8192, 2048), (100000, 2048)):
+            assert lib.dpll_workspace_bytes(handle, batch) == ((rows + -(-rows // 64)) * row + chain) * 8, (name, batch)
         system = MultibodyLearnableSystem({name: os.path.join(ASSET_DIR, name + '.urdf')}, 0.0068, device='cpu',
                                           mesh_representation=representation)
         flat = system._packed()

@@ -5,7 +5,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out/${TAG}p
 rm -rf $O; mkdir -p $O
 B="--no-cpu-baseline --no-configs"

@@ -2,9 +2,9 @@
 import csv, json, os, re, shutil, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r02p')
+SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r03p')
 DST = os.path.join(REPO, 'profiles')
-TAG = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r03'
 KERNEL = 'loss_kernel<float, 0, false'  # <T, NJ, MESH, DENSE>: the box builds
 
 
@@ -47,6 +47,8 @@ write_kb, n_w = traffic['WRITE_SIZE']
 template = os.path.join(DST, f'{TAG}_hbm_traffic.json')
 old = json.load(open(template if os.path.exists(template) else os.path.join(DST, 'r01_hbm_traffic.json')))
 old['kernel'] = 'loss_kernel<float,0,false,false>'
+import hashlib
+old['lib_sha256'] = hashlib.sha256(open(os.path.join(REPO, 'dair_pll_amd', 'csrc', 'libdpll_hip.so'), 'rb').read()).hexdigest()  # the library the passes ran (built here, shipped to the box)
 old.update({'FETCH_SIZE_KB_per_launch': round(fetch_kb, 2), 'WRITE_SIZE_KB_per_launch': round(write_kb, 2),
             'traffic_bytes_per_launch': int(round((fetch_kb + write_kb) * 1024)),
             'method': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no trace domains), means over {n_f} / {n_w} '

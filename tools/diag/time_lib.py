@@ -7,7 +7,6 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, REPO)
 from dair_pll_amd import _capi
 _capi.LIB_PATH = os.path.abspath(sys.argv[1])
-_capi.ABI_VERSION = int(os.environ.get('DPLL_ABI', _capi.ABI_VERSION))  # diagnostic: older builds for A/B
 from dair_pll_amd import MultibodyLearnableSystem
 case = sys.argv[2] if len(sys.argv) > 2 else 'cube_box_4096'
 dtype = torch.float64 if (len(sys.argv) > 3 and sys.argv[3] == 'f64') else torch.float32
