@@ -36,12 +36,13 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix rate: 256 CUs x 256 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32: 64 cyc/SIMD)
 VALU_F64_PEAK_TFLOPS = 78.6   # f64 vector FMA rate
-N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17, 'slider': 17}
+N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17, 'slider': 17, 'clasp_mesh': 17}
 ELEM = {'f32': 4, 'f64': 8}
 URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf', 'elbow_mesh': 'elbow_mesh.urdf', 'clasp': 'clasp.urdf',
-        'slider': 'slider.urdf'}  # (clasp: a box-box body-body candidate; slider: a prismatic joint, turned frames -- the general build)
+        'slider': 'slider.urdf', 'clasp_mesh': 'clasp_mesh.urdf'}  # (clasp: a box-box body-body candidate; slider: a prismatic joint, turned frames -- the general build)
 FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz', 'elbow_mesh': 'elbow_box_4096.npz',
-           'clasp': 'clasp_literal.npz', 'slider': 'slider_literal.npz'}
+           'clasp': 'clasp_literal.npz', 'slider': 'slider_literal.npz', 'clasp_mesh': 'clasp_mesh_literal.npz'}
+# (clasp_mesh: two learned shapes whose pair is a collision candidate -- the reference's own body-body case: GJK / EPA + ICNN)
 # (what the fixtures are: DESIGN.md section 2; ranks > 0 take the same pairs permuted, other batch sizes resample with replacement)
 DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss pairs of the reference data set (tests/golden/cube_box_4096.npz), URDF-initial parameters',
         'elbow': 'fixture: 4096 seeded pairs of 40 synthetic elbow tosses (tests/golden/elbow_box_4096.npz), URDF-initial parameters',
@@ -65,13 +66,17 @@ def load_pairs(batch: int, seed: int, workload: str = 'cube'):
     return x, xp, float(g['dt'])
 
 
-def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
-    """Oracle timing (checker code; measured, never shipped): PyTorch CPU fwd+bwd of the restated reference path on
-    the box's host threads in float64 (the reference's dtype, dair_pll/inertia.py:96; the oracle's solver is not
-    tuned for float32, where it runs 10x slower), 3 warm-up passes then >= 10 timed passes."""
+def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 24.0):
+    """Oracle timing (checker code; measured, never shipped): PyTorch CPU fwd+bwd of the restated reference path over the
+    WHOLE workload batch on the box's host threads, float64 (the reference's dtype, dair_pll/inertia.py:96), 2 warm-up
+    passes then timed passes for about `budget_s` seconds (at least 4).  Beside it the same graph with the cone solve
+    replaced by a zero-force stub ("graph only": what BASELINE.md section 2 measured for the reference's own torch graph,
+    58 k steps/s on 8 cores), so that the two can be set against each other.  The restated path is thousands of small
+    batched ops: more than 16 threads slow it down (round 2: 1.2 k steps/s with 128 threads, 8.3 k with 16)."""
     from oracle import dpll_oracle as O
-    threads = torch.get_num_threads()
-    sample = min(1024, x.shape[0])
+    available = torch.get_num_threads()
+    threads = min(16, available)
+    sample = x.shape[0]
     system = O.OracleSystem(os.path.join(REPO, 'assets', URDF[workload]), dt).requires_grad_()
     xs, xps = torch.tensor(x[:sample]), torch.tensor(xp[:sample])
 
@@ -79,23 +84,29 @@ def cpu_baseline(x, xp, dt, workload: str = 'cube', budget_s: float = 20.0):
         system.zero_grad()
         system.contactnets_loss(xs, xps).mean().backward()
 
-    # all host threads and 16: the restated path is thousands of small batched ops, which many threads slow down
-    results = []
-    for n_threads in dict.fromkeys((threads, min(16, threads))):
-        torch.set_num_threads(n_threads)
-        for _ in range(3):
+    def rate(seconds, least):
+        for _ in range(2):
             one()
         reps, t0 = 0, time.perf_counter()
-        while reps < 10 or (time.perf_counter() - t0 < budget_s / 2 and reps < 50):
+        while reps < least or time.perf_counter() - t0 < seconds:
             one()
             reps += 1
-        results.append((sample * reps / (time.perf_counter() - t0), n_threads, reps))
+        return sample * reps / (time.perf_counter() - t0), reps
+
     torch.set_num_threads(threads)
-    best = max(results)
-    return {'value': best[0], 'unit': 'trajectory-steps/s', 'cores': best[1], 'kind': 'port',
-            'sample': f'{best[2]} fwd+bwd passes over the first {sample} pairs of the workload after 3 warm-up passes, float64, '
-                      f'oracle/dpll_oracle.py (PyTorch CPU); ' +
-                      ', '.join(f'{rate:.0f} steps/s with {n} threads' for rate, n, _ in results)}
+    full, reps = rate(0.7 * budget_s, 4)
+    solver = O.sap_solve
+    try:  # graph only: the same autograd graph around a solver that returns no force
+        O.sap_solve = lambda J, q, eps, *args, **kwargs: torch.zeros_like(q)
+        graph_only, graph_reps = rate(0.15 * budget_s, 3)
+    finally:
+        O.sap_solve = solver
+        torch.set_num_threads(available)
+    return {'value': full, 'unit': 'trajectory-steps/s', 'cores': threads, 'kind': 'port', 'graph_only_value': graph_only,
+            'sample': f'{reps} fwd+bwd passes over all {sample} pairs of the workload after 2 warm-up passes, float64, '
+                      f'oracle/dpll_oracle.py (PyTorch CPU, {threads} of {available} host threads); graph_only_value: '
+                      f'{graph_reps} passes with the cone solve stubbed out (cf. BASELINE.md section 2: 58 k steps/s for the '
+                      f'reference graph, 8 cores)'}
 
 
 def compact(value, digits: int = 6):
@@ -184,7 +195,7 @@ class Timer:
 def loss_roofline(system, workload, dtype, batch, x, xp):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
-    if workload in ('elbow_mesh', 'clasp', 'slider'):
+    if workload in ('elbow_mesh', 'clasp', 'slider', 'clasp_mesh'):
         return None  # no per-kernel utility for these pipelines: run_loss_config prices the whole step
     if workload == 'mesh':
         mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
@@ -256,6 +267,10 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
             tflops = 8 * 2.0 * (4 * batch) * 256 * 256 / (step_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / MFMA_F32_PEAK_TFLOPS,
                     'kernel': 'whole step: 8 GEMM launches (one ICNN per link) + item kernel + reductions', 'kernel_ms': step_ms}
+        elif workload == 'clasp_mesh':  # 2 networks x 4 GEMMs of (5 batch) x 256 x 256: 4 ground queries + the pair's per item
+            tflops = 8 * 2.0 * (5 * batch) * 256 * 256 / (step_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / MFMA_F32_PEAK_TFLOPS,
+                    'kernel': 'whole step: hull extraction + GJK/EPA query kernel + 8 GEMM launches + general item kernel + reductions', 'kernel_ms': step_ms}
         else:
             gbs = bytes_per_step(workload, dtype_name) * batch / (step_ms * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
@@ -318,6 +333,37 @@ def self_launch(n_gpus: int) -> int:
     command = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}', '--master-addr', '127.0.0.1',
                '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(command, env=env, check=False).returncode
+
+
+def run_train_config(dtype_name, batch, steps, device, fused):
+    """One training step of the loop the kernel lives in (experiment.py:332-363 with the optimizer of :213-228): the mean
+    ContactNets loss of a 4096-pair batch, its gradients and the Adam update of every parameter -- 20 steps per hipGraph,
+    median of 5 repeats of `steps` steps.  `fused`: the update is done by the finalize kernel of the loss launch
+    (dpll_contactnets_train_step: two launches per step); otherwise torch.optim.Adam(capturable=True)'s kernels follow it.
+    (The batch is fixed: the shuffled gather of a real epoch is two index_select launches more, ContactNetsTrainer.)"""
+    from dair_pll_amd.system import FusedAdamState
+    dtype = torch.float32 if dtype_name == 'f32' else torch.float64
+    x_np, xp_np, dt = load_pairs(batch, 0, 'cube')
+    system = build_system('cube', dtype_name, dt, device)
+    x, xp = torch.tensor(x_np, dtype=dtype, device=device), torch.tensor(xp_np, dtype=dtype, device=device)
+    if fused:
+        adam = FusedAdamState(lr=1e-3)
+        step = lambda: system.contactnets_train_step(x, xp, adam)
+    else:
+        optimizer = torch.optim.Adam(system.parameters(), lr=1e-3, capturable=True)
+
+        def step():
+            total = system.contactnets_loss_and_grad(x, xp)
+            optimizer.step()
+            return total
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    timer = Timer(step, steps, 20, True, 20, torch.cuda.synchronize, lambda t: t)
+    elapsed, _ = timer.measure(5)
+    return {'workload': 'train_step (cube: loss + gradients + ' + ('Adam in the finalize kernel' if fused else 'torch.optim.Adam') + ')',
+            'dtype': dtype_name, 'batch': batch, 'value': steps * batch / elapsed, 'optimizer_steps_per_s': steps / elapsed,
+            'ms_per_step': elapsed / steps * 1e3, 'launch': timer.launch, 'mean_loss': step().item()}
 
 
 def main() -> None:
@@ -505,7 +551,7 @@ def main() -> None:
             configs = []
             for w, d, b, k in (('elbow', 'f32', 4096, 1000), ('elbow', 'f64', 4096, 500), ('mesh', 'f32', 4096, 200),
                                ('cube', 'f64', 4096, 1000), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100),
-                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50), ('slider', 'f32', 4096, 50)):
+                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50), ('slider', 'f32', 4096, 50), ('clasp_mesh', 'f32', 4096, 20)):
                 try:
                     configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
                 except Exception as exc:  # noqa: BLE001
@@ -515,6 +561,11 @@ def main() -> None:
                     configs.append(run_simulate_config(w, d, b, h, 5, device))
                 except Exception as exc:  # noqa: BLE001
                     configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
+            for fused in (False, True):
+                try:
+                    configs.append(run_train_config('f32', 4096, 400, device, fused))
+                except Exception as exc:  # noqa: BLE001
+                    configs.append({'workload': 'train_step', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
             # compact: no launch / note strings (DESIGN.md section 5 has them), the kernel name only inside `roofline`
             line['configs'] = [{k: v for k, v in c.items() if k not in ('launch', 'unit', 'steps')} for c in configs]
         if world == 1 and not args.no_cpu_baseline:

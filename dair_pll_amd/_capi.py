@@ -16,11 +16,11 @@ MAX_BODIES = 4
 MAX_GEOMS = 3
 MAX_PAIRS = 4
 GEN_SLOTS = MAX_GEOMS + 1  # geometry slots of the general build (DPLL_GEN_SLOTS): the geometries + the pairs' group
-GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2}
+GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 17  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 19  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +50,12 @@ class SolverOpts(ctypes.Structure):
 class Params(ctypes.Structure):
     """``dpll_params_t``"""
     _fields_ = [('theta', c_void_p), ('friction', c_void_p), ('lengths', c_void_p)]
+
+
+class AdamState(ctypes.Structure):
+    """``dpll_adam_t``"""
+    _fields_ = [('params', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p), ('state', c_void_p), ('lr', c_double),
+                ('beta1', c_double), ('beta2', c_double), ('eps', c_double), ('weight_decay', c_double)]
 
 
 class MeshParams(ctypes.Structure):
@@ -180,6 +186,9 @@ def library() -> ctypes.CDLL:
     lib.dpll_contactnets_loss_allreduce.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64,
                                                     c_int64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int64,
                                                     c_void_p, c_void_p]
+    lib.dpll_contactnets_train_step.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                                c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                                POINTER(AdamState), c_void_p]
     lib.dpll_ar_destroy.argtypes = [c_void_p]
     lib.dpll_ar_destroy.restype = None
     lib.dpll_terms.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_void_p,
@@ -200,4 +209,4 @@ EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
                     'dpll_profile_contactnets_loss_mesh',
                     'dpll_step_mesh', 'dpll_simulate_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
-                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh']
+                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh', 'dpll_contactnets_train_step']

@@ -16,7 +16,7 @@ using namespace dpll;
 static_assert(sizeof(ModelDesc) == sizeof(dpll_model_desc_t), "ModelDesc must mirror dpll_model_desc_t");
 static_assert(sizeof(SolverOpts) == sizeof(dpll_solver_opts_t), "SolverOpts must mirror dpll_solver_opts_t");
 static_assert(kMaxJoints == DPLL_MAX_JOINTS && kMaxBodies == DPLL_MAX_BODIES && kMaxGeoms == DPLL_MAX_GEOMS, "limits");
-static_assert(kGeomBox == DPLL_GEOM_BOX && kGeomSphere == DPLL_GEOM_SPHERE, "geometry kinds");
+static_assert(kGeomBox == DPLL_GEOM_BOX && kGeomSphere == DPLL_GEOM_SPHERE && kGeomPolygon == DPLL_GEOM_POLYGON && kGeomMesh == DPLL_GEOM_MESH, "geometry kinds");
 
 constexpr int kWave = 64;
 constexpr int kMaxLossBlocks = 2048;  // partial-sum rows; 8 one-wave workgroups per CU
@@ -61,6 +61,18 @@ template <int G> struct GpuLanes {
   }
   static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
   static __device__ __forceinline__ int lane_in_group() { return (int)(threadIdx.x & (G - 1)); }
+  // where an item's shared terms live (ItemStore, dpll_core.hpp): the general build (16 lanes per item) keeps one copy per
+  // item in LDS, the specialised builds the caller's registers.  The per-item stride is padded so that the four groups of
+  // a wave, which read the same member in one instruction, fall on different LDS banks.
+  template <class Store> static __device__ __forceinline__ Store& item_store(Store& local) {
+    if constexpr (G == 16) {
+      struct Padded { Store s; char pad[(sizeof(Store) % 256 < 64 ? 64 : 0) + 8]; };
+      __shared__ Padded items[kWave / G];
+      return items[(threadIdx.x & (kWave - 1)) / G].s;
+    } else {
+      return local;
+    }
+  }
   // the best (largest value; ties: smallest index) candidate over the lanes of the group, left in every lane
   template <int CTRL, typename S> static __device__ __forceinline__ void best_step(S& value, int& index, S (&d)[3]) {
     const S ov = dpp_mov<CTRL>(value);

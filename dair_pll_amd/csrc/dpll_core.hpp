@@ -76,6 +76,9 @@ constexpr int kMaxJoints = 3;   // revolute joints of the tree hanging off the f
 constexpr int kMaxBodies = kMaxJoints + 1;
 constexpr int kMaxGeoms = 3;    // convex collision geometries of a model (each against the ground half-space)
 constexpr int kGeomBox = 0, kGeomSphere = 1, kGeomPolygon = 2;
+// a learned convex shape (DeepSupportConvex, geometry.py:255-364): its support points come from the ICNN kernels as
+// `witness` inputs; the general build with mesh geometry (csrc/dpll_genmesh.hip)
+constexpr int kGeomMesh = 3;
 constexpr int kMaxPolyVerts = 8;  // vertices of a Polygon (geometry.py:220-252); the general build only
 constexpr int kMaxPairs = 4;      // body-body collision candidates (geometry.py:585-643); the general build only
 // geometry slots of the general build: behind the geometries one more group of kQuery contact slots, one per pair (a pair
@@ -1288,6 +1291,17 @@ template <typename T, int NJ> struct Terms {
   T Vw[NB][3], Vu[NB][3], AGw[NB][3], AGu[NB][3];
 };
 
+// What an item's lanes all hold alike -- the rigid-body terms and the kinematics in the accumulation type: 350 numbers for
+// a three-joint tree.  The specialised builds keep it in registers; the general build keeps ONE copy per item in LDS
+// (`Lanes::item_store`, csrc/dpll_common.hpp): replicated in the registers of a lone wave it left the double-precision kernels
+// living on kilobytes of scratch spills -- the regime in which the compiler produced kernels whose results depended on
+// unrelated code.  Every lane of the group writes the same values to the same addresses and reads back
+// what it wrote itself, so no lane depends on another lane's store.
+template <typename T, typename TA, int NJ> struct ItemStore {
+  Terms<T, NJ> t;
+  Kin<TA, NJ> kinA;
+};
+
 template <typename T, typename TA, int NJ> DPLL_HD void convert_kin(const Kin<TA, NJ>& a, Kin<T, NJ>& k) {
   DPLL_UNROLL for (int b = 0; b <= NJ; ++b)
     DPLL_UNROLL for (int r = 0; r < 3; ++r) {
@@ -1368,6 +1382,8 @@ struct OneLane {
   static DPLL_HD bool group_any(bool x) { return x; }
   static DPLL_HD bool wave_any(bool x) { return x; }
   static DPLL_HD int lane_in_group() { return 0; }
+  // where an item's shared terms live: the caller's own object (registers / stack)
+  template <class Store> static DPLL_HD Store& item_store(Store& local) { return local; }
   // the best (largest value; ties: smallest index) candidate over the lanes of the group, left in every lane
   template <typename S> static DPLL_HD void group_best(S&, int&, S (&)[3]) {}
   // where the group keeps a vertex set of the direction search (the host: the caller's array)
@@ -1524,7 +1540,10 @@ template <typename S, typename T, int NJ, int NG, class MD>
 DPLL_HD void geometry_vertices(const MD& md, const Derived<T, NJ, NG>& dp, int g, S (*v)[3], int& nv, S& margin) {
   const int kind = md.geom_kind[g];
   margin = S(0);
-  if (kind == kGeomSphere) {
+  if (kind == kGeomMesh) {
+    nv = 0;  // (its witnesses are support points of the network, handed in)
+    v[0][0] = S(0); v[0][1] = S(0); v[0][2] = S(0);
+  } else if (kind == kGeomSphere) {
     nv = 1;
     v[0][0] = S(0); v[0][1] = S(0); v[0][2] = S(0);
     margin = S(dp.habs[g][0]);
@@ -1595,13 +1614,22 @@ DPLL_HD void pair_search(const PairSetup<TA>& ps, int kind_a, int kind_b, TA (&d
   pair_direction<TA, Lanes>(sa, ps.na, kind_a, sb, ps.nb, kind_b, dA);
 }
 // every body-body candidate's direction, before the contacts are set up (all lanes of the group take part)
+// `mesh_dirs` (general build with mesh geometry): the directions of the candidates between two learned shapes, found by the
+// GJK / EPA kernel (csrc/dpll_gjk.hpp) before this kernel ran; the other candidates are searched here
 template <typename T, typename TA, class Lanes, int NJ, int NG, class MD>
-DPLL_HD bool pair_find_directions(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<TA, NJ>& kinA, TA (&dirs)[kMaxPairs][3]) {
+DPLL_HD bool pair_find_directions(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<TA, NJ>& kinA, TA (&dirs)[kMaxPairs][3],
+                                  const TA (*mesh_dirs)[3] = nullptr) {
   DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) { dirs[p][0] = TA(0); dirs[p][1] = TA(0); dirs[p][2] = TA(1); }
   if constexpr (MD::kGeneral && !IsDual<TA>::value) {
     if (md.n_pairs <= 0) return false;
     for (int p = 0; p < kMaxPairs; ++p) {
       if (p >= md.n_pairs) break;
+      if (md.geom_kind[md.pair_a[p]] == kGeomMesh || md.geom_kind[md.pair_b[p]] == kGeomMesh) {
+        if (mesh_dirs) {
+          DPLL_UNROLL for (int i = 0; i < 3; ++i) dirs[p][i] = mesh_dirs[p][i];
+        }
+        continue;
+      }
       PairSetup<TA> ps;
       pair_setup<T, TA, NJ>(md, dp, kinA, md.pair_a[p], md.pair_b[p], ps);
       pair_search<TA, Lanes>(ps, md.geom_kind[md.pair_a[p]], md.geom_kind[md.pair_b[p]], dirs[p]);
@@ -1621,7 +1649,7 @@ template <typename TA> DPLL_HD const TA* pair_dir_of(bool have, const TA (&dirs)
 template <typename T, typename TA, int NJ, int NG, class MD>
 DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
                                   const Kin<TA, NJ>& kinA, int p, ContactGeom<T, NJ, true>& cg,
-                                  const TA* dir_in) {
+                                  const TA* dir_in, const T* wit_b = nullptr, const T* wit_a = nullptr) {
   const bool masked = p >= md.n_pairs;
   const int ga = masked ? 0 : md.pair_a[p], gb = masked ? 0 : md.pair_b[p];
   const int ba = md.geom_body[ga], bb = md.geom_body[gb];
@@ -1674,10 +1702,15 @@ DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, co
     const TA t = dB[0] * vb[u][0] + dB[1] * vb[u][1] + dB[2] * vb[u][2];
     if (t > bestb + TA(kPairTie)) { bestb = t; ib = u; }
   }
-  TA witA[3], witB[3];
-  DPLL_UNROLL for (int i = 0; i < 3; ++i) { witA[i] = va[ia][i] + marginA * dA[i]; witB[i] = vb[ib][i] + marginB * dB[i]; }
-  // d witness / d parameters
   const int kindA = md.geom_kind[ga], kindB = md.geom_kind[gb];
+  TA witA[3], witB[3];
+  DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+    // learned shapes: geometry.network(d), geometry.network(-d) of collide_mesh_mesh (geometry.py:627-629), evaluated by the
+    // ICNN kernels at the direction the GJK / EPA kernel found; otherwise the vertex furthest along the direction
+    witA[i] = (kindA == kGeomMesh) ? (wit_a ? TA(wit_a[i]) : TA(0)) : va[na > 0 ? ia : 0][i] + marginA * dA[i];
+    witB[i] = (kindB == kGeomMesh) ? (wit_b ? TA(wit_b[i]) : TA(0)) : vb[nb > 0 ? ib : 0][i] + marginB * dB[i];
+  }
+  // d witness / d parameters
   DPLL_UNROLL for (int i = 0; i < 3; ++i) {
     cg.sgn_a[i] = kindA == kGeomBox ? (((ia >> (2 - i)) & 1) ? T(1) : T(-1)) : T(0);
     cg.sgn[i] = kindB == kGeomBox ? (((ib >> (2 - i)) & 1) ? T(1) : T(-1)) : T(0);
@@ -1719,13 +1752,13 @@ DPLL_HD void compute_pair_contact(const MD& md, const Derived<T, NJ, NG>& dp, co
 template <typename T, typename TA, int NJ, int NG, class MD>
 DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const Kin<T, NJ>& kin,
                              const Kin<TA, NJ>& kinA, int contact, ContactGeom<T, NJ, MD::kGeneral>& cg,
-                             const T* witness = nullptr, const TA* pair_dir = nullptr) {
+                             const T* witness = nullptr, const TA* pair_dir = nullptr, const T* witness_a = nullptr) {
   constexpr int NB = NJ + 1;
   const int g = contact / kQuery;
   const int slot = contact % kQuery;
   if constexpr (MD::kGeneral) {
     if (g >= kMaxGeoms) {  // the group behind the geometries: slot p is body-body pair p
-      compute_pair_contact<T, TA, NJ>(md, dp, kin, kinA, slot, cg, pair_dir);
+      compute_pair_contact<T, TA, NJ>(md, dp, kin, kinA, slot, cg, pair_dir, witness, witness_a);
       return;
     }
   }
@@ -1779,7 +1812,9 @@ DPLL_HD void compute_contact(const MD& md, const Derived<T, NJ, NG>& dp, const K
   T wit[3];
   DPLL_UNROLL for (int i = 0; i < 3; ++i) cg.drad[i] = T(0);
   cg.vidx = -1;
-  if (witness) {
+  bool use_witness = witness != nullptr;
+  if constexpr (MD::kGeneral) use_witness = use_witness && kind == kGeomMesh;  // (the model's other geometries: chosen here)
+  if (use_witness) {
     DPLL_UNROLL for (int i = 0; i < 3; ++i) { cg.sgn[i] = T(0); wit[i] = witness[i]; }
   } else {
     box_corner_signs(d, habs, slot, cg.sgn);
@@ -1929,6 +1964,13 @@ DPLL_HD void add_geometry_grad(const ContactGeom<T, NJ, GEN>& cg, T gmu, const T
   }
 }
 
+// General build with learned shapes: what a lane needs beyond `witness` (the support point of its contact's geometry; for
+// a body-body contact the one of B along -d)
+template <typename T, typename TA, int KPL> struct MeshPairIn {
+  T wit_a[KPL][3];        // body-body contact of two learned shapes: A's support point along d
+  TA dirs[kMaxPairs][3];  // the candidates' directions in the frame of A, found by the GJK / EPA kernel (csrc/dpll_gjk.hpp)
+};
+
 constexpr double kLossEps = 1e-3;       // multibody_learnable_system.py:130
 constexpr double kDynamicsEps = 1e-4;   // multibody_learnable_system.py:283, 298
 constexpr double kInvalidForce = 1e3;   // multibody_learnable_system.py:187
@@ -1936,14 +1978,17 @@ constexpr double kInvalidForce = 1e3;   // multibody_learnable_system.py:187
 template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD, int GP>
 DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x, const T* xp,
                     int first_contact, T weight, bool want_grad, LossGrad<T, NJ, NG, GP>& grad, T (&force)[KPL][3],
-                    int& iters, const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr) {
+                    int& iters, const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr,
+                    const MeshPairIn<T, TA, KPL>* mesh_in = nullptr, T (*rbar_a_out)[3] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kLossEps);
   const T* v = x + NQ;
   const T* qp = xp;
   const T* vp = xp + NQ;
-  Terms<T, NJ> t;
-  Kin<TA, NJ> kinA;
+  ItemStore<T, TA, NJ> own_store;
+  ItemStore<T, TA, NJ>& store = Lanes::template item_store<ItemStore<T, TA, NJ>>(own_store);
+  Terms<T, NJ>& t = store.t;
+  Kin<TA, NJ>& kinA = store.kinA;
   compute_terms<T, TA, NJ>(md, dp, qp, vp, t, kinA);  // terms at the NEXT state (quirk Q6)
   T dv[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) dv[i] = vp[i] - (v[i] + t.a[i] * dt);
@@ -1953,10 +1998,10 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
   T mu[KPL], qc[KPL][3], slide[KPL][2], speed[KPL], jpv[KPL][3];
   T pen = T(0);
   TA pdirs[kMaxPairs][3];
-  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs);
+  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs, mesh_in ? mesh_in->dirs : nullptr);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr,
-                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c));
+                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c), mesh_in ? mesh_in->wit_a[c] : nullptr);
     Jc[c] = cg[c].J;
     mu[c] = cg[c].mu;
     T jdv[3];
@@ -2055,6 +2100,9 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
     if (rbar_out) {
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = wt * rbar[i];
     }
+    if (rbar_a_out) {
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_a_out[c][i] = wt * rbar_a[i];
+    }
     const T wrbar[3] = {wt * rbar[0], wt * rbar[1], wt * rbar[2]};
     const T wrbar_a[3] = {wt * rbar_a[0], wt * rbar_a[1], wt * rbar_a[2]};
     add_geometry_grad(cg[c], wt * gmu, wrbar, wrbar_a, grad);
@@ -2083,13 +2131,15 @@ template <typename T> DPLL_HD void quat_exp_mul(const T* q, const T (&r)[3], T* 
 template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD>
 DPLL_HD void step_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x,
                        int first_contact, T* x_next, T (&impulse)[KPL][3], int& iters,
-                       const T (*witness)[3] = nullptr) {
+                       const T (*witness)[3] = nullptr, const MeshPairIn<T, TA, KPL>* mesh_in = nullptr) {
   constexpr int NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kDynamicsEps);
   const T* q = x;
   const T* v = x + NQ;
-  Terms<T, NJ> t;
-  Kin<TA, NJ> kinA;
+  ItemStore<T, TA, NJ> own_store;
+  ItemStore<T, TA, NJ>& store = Lanes::template item_store<ItemStore<T, TA, NJ>>(own_store);
+  Terms<T, NJ>& t = store.t;
+  Kin<TA, NJ>& kinA = store.kinA;
   compute_terms<T, TA, NJ>(md, dp, q, v, t, kinA);
   T vm[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];
@@ -2097,11 +2147,11 @@ DPLL_HD void step_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverO
   T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
   TA pdirs[kMaxPairs][3];
-  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs);
+  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs, mesh_in ? mesh_in->dirs : nullptr);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     ContactGeom<T, NJ, MD::kGeneral> cg;
     compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg, witness ? witness[c] : nullptr,
-                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c));
+                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c), mesh_in ? mesh_in->wit_a[c] : nullptr);
     Jc[c] = cg.J;
     mu[c] = cg.mu;
     T jv[3];
@@ -2168,8 +2218,10 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
   const T* q = x;
   const T* v = x + NQ;
   // ---- forward (recomputed, nothing is stored between the passes) --------------------------------
-  Terms<T, NJ> t;
-  Kin<TA, NJ> kinA;
+  ItemStore<T, TA, NJ> own_store;
+  ItemStore<T, TA, NJ>& store = Lanes::template item_store<ItemStore<T, TA, NJ>>(own_store);
+  Terms<T, NJ>& t = store.t;
+  Kin<TA, NJ>& kinA = store.kinA;
   compute_terms<T, TA, NJ>(md, dp, q, v, t, kinA);
   T vm[NV];
   DPLL_UNROLL for (int i = 0; i < NV; ++i) vm[i] = v[i] + dt * t.a[i];

@@ -24,12 +24,26 @@ template <typename T> struct IcnnWeights {
   const T* Wd1;   // (3, 256)   input_weights.1
   const T* wout;  // (256,)     output_weight
   const T* pert;  // (4, 3)     perturbations, row 0 is zero (geometry.py:306-307)
-  // support points / their adjoints of query n = 4 item + s sit at element (n / 4) * point_stride + 3 s of the arrays the
-  // kernels are given: 12 when this geometry is the item's only one, 3 * (contacts per item) when it is one of several
-  // (the arrays are then offset by 12 * geometry index)
+  // Queries: n = qpi * item + j.  By default (dirs == nullptr, qpi = 4) query j of an item is the ground direction seen from
+  // the body whose quaternion the kernels are given, plus perturbation row j.  With `dirs` (N, 3) the unit directions are
+  // read from memory instead: the general build with learned shapes (csrc/dpll_genmesh.hip) writes the four ground queries
+  // of the geometry there and, behind them, one query per body-body candidate the geometry is part of; the mesh extraction
+  // (the 296 surface directions, deep_support_function.py:12-16) is the same with qpi = 1.
+  const T* dirs = nullptr;
+  int qpi = 4;
+  // support points / their adjoints of query (item, j) sit at element item * point_stride + qoff[j] of the arrays the
+  // kernels are given: one geometry alone 12 and {0, 3, 6, 9}; one of several: 3 * (contacts per item) with the arrays
+  // offset by 12 * geometry index; the general build: its (slot, side) layout, see dpll_general_kernels.hpp
   int point_stride = 12;
+  int qoff[8] = {0, 3, 6, 9, 0, 0, 0, 0};
 };
-DPLL_HD long long icnn_point_index(long long n, int point_stride) { return (n >> 2) * point_stride + (n & 3) * 3; }
+template <typename T> DPLL_HD long long icnn_point_index(long long n, const IcnnWeights<T>& w) {
+  const long long item = n / w.qpi;
+  const int j = (int)(n - item * w.qpi);
+  int off = w.qoff[0];
+  DPLL_UNROLL for (int c = 1; c < 8; ++c) off = (j == c) ? w.qoff[c] : off;
+  return item * w.point_stride + off;
+}
 
 // un-normalised rotation row 2 from the quaternion (same polynomial as quat_to_rot) -> query direction
 template <typename T> DPLL_HD void icnn_query(const T* quat, const T* pert3, T (&q)[3]) {

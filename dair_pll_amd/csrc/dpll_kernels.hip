@@ -71,6 +71,8 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
 
 #include "dpll_common.hpp"
 #include "dpll_general.hpp"
+#include "dpll_genmesh.hpp"
+#include "dpll_gjk.hpp"
 #include "dpll_mesh_kernels.hpp"
 namespace {
 
@@ -253,11 +255,23 @@ __device__ __forceinline__ double finalize_column(const double* __restrict__ par
 // FUSED: the row [loss | gradients] is summed over the ranks of a data-parallel job before it is written, with the
 // one-shot peer-memory exchange of dpll_allreduce.hpp (same protocol and call counter as dpll_ar_allreduce): the
 // gradient exchange costs no launch of its own.
+// Adam on the (<= 30) learnable parameters, done by the threads that have just written their gradient entry
+// (experiment.py:213-228: torch.optim.Adam; the update of torch's _single_tensor_adam, no amsgrad): a training step is
+// then the loss launch and this kernel -- the optimizer costs no launch of its own.  params == nullptr: no update.
+struct AdamArgs {
+  void* params;      // (P,) the flat buffer the kernels read their parameters from: updated in place
+  void* exp_avg;     // (P,)
+  void* exp_avg_sq;  // (P,)
+  double* state;     // (3,) [steps taken, beta1^steps, beta2^steps]: advanced by the kernel (no pow on the device)
+  double lr, beta1, beta2, eps, weight_decay;
+};
+
 template <typename T, int NJ, bool FUSED = false>
 __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double* __restrict__ partials, int n_rows,
                                                                     T* __restrict__ grad, T* __restrict__ loss_total,
                                                                     dpll_arx::Peers peers, int rank, int world,
-                                                                    uint32_t* __restrict__ seq_ptr, uint32_t* __restrict__ err) {
+                                                                    uint32_t* __restrict__ seq_ptr, uint32_t* __restrict__ err,
+                                                                    AdamArgs adam) {
   using D = Dims<T, NJ>;
   static_assert(D::PI <= 32, "partial row must fit 32 columns");
   __shared__ double red[32][33];
@@ -301,6 +315,24 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
       if (loss_total) *loss_total = value;
     } else {
       grad[threadIdx.x - 1] = value;
+    }
+  }
+  if (adam.params) {  // (uniform: a kernel argument)
+    const double steps = adam.state[0] + 1.0, pow1 = adam.state[1] * adam.beta1, pow2 = adam.state[2] * adam.beta2;
+    __syncthreads();  // every thread has read the state before thread 0 advances it
+    if (threadIdx.x == 0) { adam.state[0] = steps; adam.state[1] = pow1; adam.state[2] = pow2; }
+    if (threadIdx.x >= 1 && threadIdx.x < D::PI) {
+      const int k = (int)threadIdx.x - 1;
+      T* p = (T*)adam.params + k;
+      T* m = (T*)adam.exp_avg + k;
+      T* v = (T*)adam.exp_avg_sq + k;
+      const double g = double(value) + adam.weight_decay * double(*p);
+      const double m1 = double(*m) + (g - double(*m)) * (1.0 - adam.beta1);
+      const double v1 = adam.beta2 * double(*v) + (1.0 - adam.beta2) * g * g;
+      const double denom = sqrt(v1) / sqrt(1.0 - pow2) + adam.eps;
+      *m = T(m1);
+      *v = T(v1);
+      *p = T(double(*p) - (adam.lr / (1.0 - pow1)) * m1 / denom);
     }
   }
 }
@@ -636,7 +668,7 @@ template <typename T, int NJ>
 int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
                 long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* grad,
                 void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
-                hipStream_t stream, const dpll_ar* ar = nullptr) {
+                hipStream_t stream, const dpll_ar* ar = nullptr, AdamArgs adam = AdamArgs{}) {
   using D = Dims<T, NJ>;
   const int blocks = loss_blocks<T, NJ>(batch);
   const int want_grad = grad != nullptr;
@@ -653,11 +685,11 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
     if (ar)
       hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
                          rows, (T*)grad,
-                         (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1);
+                         (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1, adam);
     else
       hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
                          rows, (T*)grad,
-                         (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                         (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, adam);
     if (int rc = check_launch("finalize_kernel")) return rc;
   }
   return 0;
@@ -692,7 +724,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
     for (int r = 0; r < reps; ++r) {
       launch_loss_only();
       hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         rows, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                         rows, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, AdamArgs{});
     }
     ok = ok && hipEventRecord(ev[3], stream) == hipSuccess;
     rc = check_launch("profile launches");
@@ -746,7 +778,7 @@ int launch_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p,
   if (int rc = check_launch("step_backward_kernel")) return rc;
   hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, blocks,
                      (T*)grad, (T*)nullptr,
-                     dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                     dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, AdamArgs{});
   return check_launch("finalize_kernel");
 }
 
@@ -776,13 +808,10 @@ struct MeshPlan {
   char* net(char* ws, int g) const { return ws + off_nets + (size_t)g * net_bytes; }
 };
 
-template <typename T, int NJ> MeshPlan mesh_plan(long long batch) {
-  using D = Dims<T, NJ>;
-  MeshPlan pl;
-  pl.N = 4 * batch;
-  pl.n_nets = D::NB;
-  pl.row_stride = D::PI;
-  pl.loss_blocks = loss_blocks<T, NJ>(batch);
+// buffers of ONE network for N support queries (offsets relative to the network's block); the weight-preparation outputs
+// (A, AT, Af, ATf, a) come first, at offsets that do not depend on N
+template <typename T> void plan_network_block(MeshPlan& pl, long long N) {
+  pl.N = N;
   constexpr bool kMfma = std::is_same<T, float>::value;  // float: MFMA kernels on 32-row tiles
   const long long tiles = (pl.N + (kMfma ? kMfmaRows : kTileRows) - 1) / (kMfma ? kMfmaRows : kTileRows);
   const long long cap = kMfma ? 256 : 2048;  // MFMA blocks keep their 256 x 32 weight block in registers: one per CU
@@ -806,7 +835,17 @@ template <typename T, int NJ> MeshPlan mesh_plan(long long batch) {
   pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
   pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
   pl.net_bytes = off;
-  off = 0;
+}
+
+template <typename T, int NJ> MeshPlan mesh_plan(long long batch) {
+  using D = Dims<T, NJ>;
+  MeshPlan pl;
+  pl.n_nets = D::NB;
+  pl.row_stride = D::PI;
+  pl.loss_blocks = loss_blocks<T, NJ>(batch);
+  plan_network_block<T>(pl, 4 * batch);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   pl.off_P = take(sizeof(T) * 3 * pl.N * pl.n_nets);
   pl.off_RB = take(sizeof(T) * 3 * pl.N * pl.n_nets);
   pl.off_rows = take(sizeof(double) * ((size_t)D::PI * pl.loss_blocks + D::CHAIN));
@@ -877,10 +916,11 @@ int mesh_body_quats(const dpll_model* m, const MeshPlan& pl, char* ws, const T* 
 // forward half of network g: prep + the two forward GEMMs -> its support points (and M1, U0 for the backward half)
 template <typename T>
 int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, hipStream_t stream,
-                 bool for_backward = false, bool prep = true) {
+                 bool for_backward = false, bool prep = true, T* points = nullptr) {
   char* nb = pl.net(ws, g);
   T* A = (T*)(nb + pl.off_A); T* AT = (T*)(nb + pl.off_AT); T* a = (T*)(nb + pl.off_a);
-  T* P = (T*)(ws + pl.off_P) + 12 * g;
+  // (`points`: where this launch's support points go when it is not the shared (batch, 4 n_nets, 3) array)
+  T* P = points ? points : (T*)(ws + pl.off_P) + 12 * g;
   constexpr bool kMfmaPath = std::is_same<T, float>::value;
   if (prep)  // (|W| in GEMM order: only the weights enter, so the steps of a rollout after the first skip it)
     hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
@@ -908,9 +948,9 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
 // are in place; grad_w = this network's slice of the gradient, grad_head / loss_total only with the first network
 template <typename T, int NB>
 int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, T* grad_w, T* grad_head,
-                  T* loss_total, hipStream_t stream) {
+                  T* loss_total, hipStream_t stream, const T* adjoints = nullptr) {
   char* nb = pl.net(ws, g);
-  const T* RB = (const T*)(ws + pl.off_RB) + 12 * g;
+  const T* RB = adjoints ? adjoints : (const T*)(ws + pl.off_RB) + 12 * g;
   if constexpr (std::is_same<T, float>::value) {
     hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
                        (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
@@ -1068,15 +1108,256 @@ int launch_mesh_terms(const dpll_model* m, const dpll_params_t* p, const dpll_me
   return launch_terms<T, NJ>(m, &q, x, ld_x, batch, Dm, M, J, phi, a, stream, ws + pl.off_P);
 }
 
+// ---- the general build with learned shapes (csrc/dpll_genmesh.hip): any tree, DeepSupportConvex next to other geometries,
+// body-body candidates between two learned shapes (GeometryCollider.collide_mesh_mesh, geometry.py:585-643) -------------
+struct GenMeshPlan {
+  int n_mesh;                  // learned geometries, in geometry order
+  int geom_of[kMaxGeoms];      // k-th learned geometry -> geometry index
+  int net_of[kMaxGeoms];       // geometry index -> k (or -1)
+  int qpi[kMaxGeoms];          // by geometry index: 4 ground queries + one per candidate the geometry is part of
+  int query_a[kMaxPairs], query_b[kMaxPairs];
+  int qoff[kMaxGeoms][dpll_genmesh::kMaxQueries];
+  long long max_N;
+  size_t net_bytes;            // block of one network, sized for the largest query count
+  size_t off_W, off_RB, off_PD, off_rows, off_surf, off_hull[kMaxGeoms], off_dirs[kMaxGeoms], off_nets, total;
+};
+
+template <typename T> GenMeshPlan genmesh_plan(const dpll_model* m, long long batch) {
+  const ModelDesc& md = m->desc;
+  GenMeshPlan gp;
+  std::memset(&gp, 0, sizeof(gp));
+  for (int g = 0; g < kMaxGeoms; ++g) {
+    gp.net_of[g] = -1;
+    if (g < md.n_geoms && md.geom_kind[g] == kGeomMesh) {
+      gp.net_of[g] = gp.n_mesh;
+      gp.geom_of[gp.n_mesh++] = g;
+      gp.qpi[g] = kQuery;
+      for (int s = 0; s < kQuery; ++s) gp.qoff[g][s] = dpll_genmesh::wit_offset(kQuery * g + s, 0);
+    }
+  }
+  for (int p = 0; p < md.n_pairs && p < kMaxPairs; ++p) {
+    const int a = md.pair_a[p], b = md.pair_b[p];
+    if (md.geom_kind[a] != kGeomMesh || md.geom_kind[b] != kGeomMesh) continue;
+    gp.query_a[p] = gp.qpi[a];
+    gp.qoff[a][gp.qpi[a]++] = dpll_genmesh::wit_offset(kQuery * kMaxGeoms + p, 1);  // A's support point along d
+    gp.query_b[p] = gp.qpi[b];
+    gp.qoff[b][gp.qpi[b]++] = dpll_genmesh::wit_offset(kQuery * kMaxGeoms + p, 0);  // B's along -d
+  }
+  gp.max_N = kHullDirs;
+  for (int g = 0; g < kMaxGeoms; ++g)
+    if (gp.qpi[g] * batch > gp.max_N) gp.max_N = gp.qpi[g] * batch;
+  MeshPlan block;
+  plan_network_block<T>(block, gp.max_N);
+  gp.net_bytes = block.net_bytes;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t per_item = (size_t)dpll_genmesh::wit_per_item();
+  gp.off_W = take(sizeof(T) * per_item * batch);
+  gp.off_RB = take(sizeof(T) * per_item * batch);
+  gp.off_PD = take(sizeof(double) * 3 * kMaxPairs * batch);
+  gp.off_rows = take((size_t)dpll_genmesh::workspace_bytes(m, batch));
+  gp.off_surf = take(sizeof(T) * 3 * kHullDirs);
+  for (int g = 0; g < kMaxGeoms; ++g) {
+    gp.off_hull[g] = take(gp.qpi[g] ? sizeof(T) * 3 * kHullDirs : 0);
+    gp.off_dirs[g] = take(sizeof(T) * 3 * gp.qpi[g] * batch);
+  }
+  gp.off_nets = off;
+  gp.total = off + gp.net_bytes * gp.n_mesh;
+  return gp;
+}
+
+// the buffer plan of network k for N queries, placed in the general layout
+template <typename T> MeshPlan genmesh_block(const GenMeshPlan& gp, long long N) {
+  MeshPlan pl;
+  std::memset(&pl, 0, sizeof(pl));
+  plan_network_block<T>(pl, N);
+  pl.net_bytes = gp.net_bytes;
+  pl.off_nets = gp.off_nets;
+  pl.n_nets = gp.n_mesh;
+  return pl;
+}
+
+template <typename T> IcnnWeights<T> genmesh_weights(const GenMeshPlan& gp, const dpll_mesh_params_t* mp, int g, char* ws) {
+  IcnnWeights<T> w{(const T*)mp[g].hidden_weight, (const T*)mp[g].input_weight0, (const T*)mp[g].input_weight1,
+                   (const T*)mp[g].output_weight, (const T*)mp[g].perturbations};
+  w.dirs = (const T*)(ws + gp.off_dirs[g]);
+  w.qpi = gp.qpi[g];
+  w.point_stride = dpll_genmesh::wit_per_item();
+  for (int j = 0; j < dpll_genmesh::kMaxQueries; ++j) w.qoff[j] = gp.qoff[g][j];
+  return w;
+}
+
+// once per parameter set: |W| in GEMM order and the vertex set of every network (its support points over the reference's
+// 296 surface directions: the mesh extract_mesh builds for fcl, geometry.py:343-358)
+template <typename T>
+int genmesh_hulls(const dpll_model* m, int dtype, const GenMeshPlan& gp, const dpll_mesh_params_t* mp, char* ws, hipStream_t stream) {
+  bool any_pair = false;
+  for (int p = 0; p < m->desc.n_pairs; ++p) any_pair = any_pair || m->desc.geom_kind[m->desc.pair_a[p]] == kGeomMesh;
+  if (any_pair)
+    if (int rc = dpll_genmesh::surface_directions(dtype, ws + gp.off_surf, stream)) return rc;
+  const MeshPlan p296 = genmesh_block<T>(gp, kHullDirs);
+  for (int k = 0; k < gp.n_mesh; ++k) {
+    const int g = gp.geom_of[k];
+    IcnnWeights<T> w = genmesh_weights<T>(gp, mp, g, ws);
+    w.dirs = (const T*)(ws + gp.off_surf);
+    w.qpi = 1;
+    w.point_stride = 3;
+    w.qoff[0] = 0;
+    if (any_pair) {
+      if (int rc = mesh_forward<T>(p296, k, w, ws, QuatSource<T>{nullptr, 0}, stream, false, true, (T*)(ws + gp.off_hull[g]))) return rc;
+    } else {  // no vertex set needed: the weights only
+      char* nb = p296.net(ws, k);
+      constexpr bool kMfmaPath = std::is_same<T, float>::value;
+      hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (T*)(nb + p296.off_A), (T*)(nb + p296.off_AT),
+                         (T*)(nb + p296.off_a), kMfmaPath ? (T*)(nb + p296.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + p296.off_ATf) : (T*)nullptr);
+      if (int rc = check_launch("icnn_prep_kernel")) return rc;
+    }
+  }
+  return 0;
+}
+
+// per state: the networks' queries (ground directions; GJK / EPA direction of the candidates between learned shapes) and
+// the support points at them, into the (slot, side) witness layout
+template <typename T>
+int genmesh_support(const dpll_model* m, int dtype, const GenMeshPlan& gp, const dpll_mesh_params_t* mp, char* ws, const void* state,
+                    long long ld, long long batch, hipStream_t stream, bool for_backward) {
+  dpll_genmesh::QueryPlan qp;
+  std::memset(&qp, 0, sizeof(qp));
+  for (int g = 0; g < kMaxGeoms; ++g) {
+    if (gp.net_of[g] < 0) continue;
+    qp.pert[g] = mp[g].perturbations;
+    qp.dirs[g] = ws + gp.off_dirs[g];
+    qp.hull[g] = ws + gp.off_hull[g];
+    qp.qpi[g] = gp.qpi[g];
+  }
+  for (int p = 0; p < kMaxPairs; ++p) { qp.query_a[p] = gp.query_a[p]; qp.query_b[p] = gp.query_b[p]; }
+  qp.pdirs = (double*)(ws + gp.off_PD);
+  if (int rc = dpll_genmesh::queries(m, dtype, qp, state, ld, batch, stream)) return rc;
+  for (int k = 0; k < gp.n_mesh; ++k) {
+    const int g = gp.geom_of[k];
+    const MeshPlan pl = genmesh_block<T>(gp, gp.qpi[g] * batch);
+    if (int rc = mesh_forward<T>(pl, k, genmesh_weights<T>(gp, mp, g, ws), ws, QuatSource<T>{nullptr, 0}, stream, for_backward, false,
+                                 (T*)(ws + gp.off_W)))
+      return rc;
+  }
+  return 0;
+}
+
+template <typename T>
+int launch_genmesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
+                        long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
+                        void* loss, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
+                        long long workspace_bytes, hipStream_t stream) {
+  const GenMeshPlan gp = genmesh_plan<T>(m, batch);
+  if (!workspace || (size_t)workspace_bytes < gp.total) return fail(-3, "dpll_contactnets_loss_mesh: workspace too small%s");
+  if (!grad && loss_total) return fail(-3, "dpll_contactnets_loss_mesh: loss_total requires grad%s");
+  char* ws = (char*)workspace;
+  const int want_grad = grad != nullptr;
+  if (int rc = genmesh_hulls<T>(m, dtype, gp, mp, ws, stream)) return rc;
+  if (int rc = genmesh_support<T>(m, dtype, gp, mp, ws, xp, ld_xp, batch, stream, want_grad != 0)) return rc;  // terms at the NEXT state
+  if (int rc = dpll_genmesh::loss_items(m, dtype, p, x, ld_x, xp, ld_xp, batch, weights, scale, loss, force, iters, ws + gp.off_rows,
+                                        want_grad, ws + gp.off_W, want_grad ? ws + gp.off_RB : nullptr,
+                                        (const double*)(ws + gp.off_PD), stream))
+    return rc;
+  if (!want_grad) return 0;
+  const int head = dpll_general::param_count(m);
+  for (int k = 0; k < gp.n_mesh; ++k) {
+    const int g = gp.geom_of[k];
+    const MeshPlan pl = genmesh_block<T>(gp, gp.qpi[g] * batch);
+    if (int rc = mesh_backward<T, 1>(pl, k, genmesh_weights<T>(gp, mp, g, ws), ws, QuatSource<T>{nullptr, 0},
+                                     (T*)grad + head + (size_t)k * kNetParams, (T*)nullptr, (T*)nullptr, stream,
+                                     (const T*)(ws + gp.off_RB)))
+      return rc;
+  }
+  return dpll_genmesh::finalize(m, dtype, batch, ws + gp.off_rows, grad, loss_total, stream);
+}
+
+template <typename T>
+int launch_genmesh_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x0,
+                            long long ld_x, long long batch, long long steps, void* traj, long long ld_item, long long ld_step,
+                            bool write_x0, void* workspace, long long workspace_bytes, hipStream_t stream) {
+  const GenMeshPlan gp = genmesh_plan<T>(m, batch);
+  if (!workspace || (size_t)workspace_bytes < gp.total) return fail(-3, "dpll_step_mesh / dpll_simulate_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  const int nx = 13 + 2 * m->desc.n_joints;
+  if (int rc = genmesh_hulls<T>(m, dtype, gp, mp, ws, stream)) return rc;
+  T* out = (T*)traj;
+  if (write_x0) {  // traj[:, 0] = x0
+    if (hipMemcpy2DAsync(out, sizeof(T) * ld_item, x0, sizeof(T) * ld_x, sizeof(T) * nx, (size_t)batch, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+      return fail(-5, "dpll_simulate_mesh: copy of the initial states failed%s");
+    out += ld_step;
+  }
+  const T* state = (const T*)x0;
+  long long ld = ld_x;
+  for (long long s = 0; s < steps; ++s) {
+    if (int rc = genmesh_support<T>(m, dtype, gp, mp, ws, state, ld, batch, stream, false)) return rc;
+    if (int rc = dpll_genmesh::step_items(m, dtype, p, state, ld, batch, out, ld_item, ws + gp.off_W, (const double*)(ws + gp.off_PD), stream))
+      return rc;
+    state = out;
+    ld = ld_item;
+    out += ld_step;
+  }
+  return 0;
+}
+
+template <typename T>
+int launch_genmesh_terms(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
+                         long long ld_x, long long batch, void* Dm, void* M, void* J, void* phi, void* a, void* workspace,
+                         long long workspace_bytes, hipStream_t stream) {
+  const GenMeshPlan gp = genmesh_plan<T>(m, batch);
+  if (!workspace || (size_t)workspace_bytes < gp.total) return fail(-3, "dpll_terms_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  if (int rc = genmesh_hulls<T>(m, dtype, gp, mp, ws, stream)) return rc;
+  if (int rc = genmesh_support<T>(m, dtype, gp, mp, ws, x, ld_x, batch, stream, false)) return rc;
+  return dpll_genmesh::terms_items(m, dtype, p, x, ld_x, batch, Dm, M, J, phi, a, ws + gp.off_W, (const double*)(ws + gp.off_PD), stream);
+}
+
+// support points of every contact SLOT: points (batch, 16, 3) -- slot 4 g + s = query s of geometry g, slot 12 + p = B's
+// support point of body-body candidate p; rows of slots that belong to no learned shape hold no information
+template <typename T>
+int launch_genmesh_support(const dpll_model* m, int dtype, const dpll_mesh_params_t* mp, const void* x, long long ld_x, long long batch,
+                           void* points, void* workspace, long long workspace_bytes, hipStream_t stream) {
+  const GenMeshPlan gp = genmesh_plan<T>(m, batch);
+  if (!workspace || (size_t)workspace_bytes < gp.total) return fail(-3, "dpll_mesh_support_points: workspace too small%s");
+  char* ws = (char*)workspace;
+  if (int rc = genmesh_hulls<T>(m, dtype, gp, mp, ws, stream)) return rc;
+  if (int rc = genmesh_support<T>(m, dtype, gp, mp, ws, x, ld_x, batch, stream, false)) return rc;
+  // (slot, side 0) of the slots of the geometries: element (item, slot, 0, :) -> points (item, slot, :)
+  const size_t per_item = (size_t)dpll_genmesh::wit_per_item();
+  if (hipMemcpy2DAsync(points, sizeof(T) * 3, ws + gp.off_W, sizeof(T) * 6, sizeof(T) * 3, (size_t)batch * (per_item / 6), hipMemcpyDeviceToDevice,
+                       stream) != hipSuccess)
+    return fail(-5, "dpll_mesh_support_points: copy failed%s");
+  return 0;
+}
+
 // `mp`: one dpll_mesh_params_t per body (n_joints + 1 of them)
 int check_mesh(const dpll_model* m, const dpll_mesh_params_t* mp, const char* who) {
-  if (m->desc.n_geoms > 0 || m->desc.n_joints > 1) return fail(-2, "%s: mesh geometry is implemented for the specialised builds (0 or 1 joints, one mesh per body)", who);
   if (!mp) return fail(-1, "%s: null mesh parameter pointer", who);
+  if (m->desc.n_geoms > 0) {  // general build: one entry per geometry, those of the learned shapes filled in
+    int n_mesh = 0;
+    for (int g = 0; g < m->desc.n_geoms; ++g) {
+      if (m->desc.geom_kind[g] != kGeomMesh) continue;
+      ++n_mesh;
+      if (!mp[g].hidden_weight || !mp[g].input_weight0 || !mp[g].input_weight1 || !mp[g].output_weight || !mp[g].perturbations)
+        return fail(-1, "%s: null mesh parameter pointer", who);
+    }
+    if (n_mesh == 0) return fail(-2, "%s: the model has no learned shape (DPLL_GEOM_MESH geometry)", who);
+    return 0;
+  }
+  if (m->desc.n_joints > 1) return fail(-2, "%s: the specialised mesh builds take 0 or 1 joints (describe the model with n_geoms > 0 for the general build)", who);
   for (int g = 0; g <= m->desc.n_joints; ++g)
     if (!mp[g].hidden_weight || !mp[g].input_weight0 || !mp[g].input_weight1 || !mp[g].output_weight || !mp[g].perturbations)
       return fail(-1, "%s: null mesh parameter pointer", who);
   return 0;
 }
+
+#define DPLL_GENMESH(FN, ...)                                                                \
+  do {                                                                                       \
+    if (model->desc.n_geoms > 0) {                                                           \
+      if (dtype == DPLL_F32) return FN<float>(__VA_ARGS__);                                  \
+      return FN<double>(__VA_ARGS__);                                                        \
+    }                                                                                        \
+  } while (0)
 
 #define DPLL_MESH_DISPATCH(FN, ...)                                                          \
   do {                                                                                       \
@@ -1090,6 +1371,8 @@ int check_mesh(const dpll_model* m, const dpll_mesh_params_t* mp, const char* wh
 
 int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long long batch, const char* who) {
   if (!m) return fail(-1, "%s: null model", who);
+  for (int g = 0; g < m->desc.n_geoms; ++g)
+    if (m->desc.geom_kind[g] == kGeomMesh) return fail(-2, "%s: the model has learned shapes: use the *_mesh entry point", who);
   if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "%s: dtype must be DPLL_F32 or DPLL_F64", who);
   if (!p || !p->theta || !p->friction || !p->lengths) return fail(-1, "%s: null parameter pointer", who);
   if (batch < 0) return fail(-1, "%s: negative batch", who);
@@ -1117,7 +1400,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 17; }
+int dpll_abi_version(void) { return 19; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1130,7 +1413,8 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       if (desc->parent[j] < 0 || desc->parent[j] > j) return fail(-1, "dpll_model_create: parent[j] must be a body listed before body j + 1%s");
     for (int g = 0; g < desc->n_geoms; ++g) {
       if (desc->geom_body[g] < 0 || desc->geom_body[g] > desc->n_joints) return fail(-1, "dpll_model_create: geom_body out of range%s");
-      if (desc->geom_kind[g] != DPLL_GEOM_BOX && desc->geom_kind[g] != DPLL_GEOM_SPHERE && desc->geom_kind[g] != DPLL_GEOM_POLYGON)
+      if (desc->geom_kind[g] != DPLL_GEOM_BOX && desc->geom_kind[g] != DPLL_GEOM_SPHERE && desc->geom_kind[g] != DPLL_GEOM_POLYGON &&
+          desc->geom_kind[g] != DPLL_GEOM_MESH)
         return fail(-1, "dpll_model_create: unknown geometry kind%s");
       // (top-4 of the vertex set, geometry.py:196: fewer than 4 vertices cannot answer a support query)
       if (desc->geom_kind[g] == DPLL_GEOM_POLYGON && (desc->geom_nverts[g] < 4 || desc->geom_nverts[g] > DPLL_MAX_POLYGON_VERTICES))
@@ -1141,6 +1425,9 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
       const int a = desc->pair_a[p], b = desc->pair_b[p];
       if (a < 0 || b < 0 || a >= desc->n_geoms || b >= desc->n_geoms || a == b) return fail(-1, "dpll_model_create: pair geometry out of range%s");
       if (desc->geom_body[a] == desc->geom_body[b]) return fail(-1, "dpll_model_create: a collision candidate joins geometries of two different bodies%s");
+      // (the reference collides a learned shape with another learned shape or the ground only, geometry.py:543-551)
+      if ((desc->geom_kind[a] == DPLL_GEOM_MESH) != (desc->geom_kind[b] == DPLL_GEOM_MESH))
+        return fail(-2, "dpll_model_create: a candidate with a learned shape (DPLL_GEOM_MESH) needs one on both sides%s");
     }
     if (desc->rotated & ~3) return fail(-1, "dpll_model_create: rotated holds bits 0 and 1 only%s");
     // a frame rotation is a proper rotation; identities where the flag says so
@@ -1260,6 +1547,29 @@ int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const 
                 nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, ar);
 }
 
+int dpll_contactnets_train_step(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                                int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                                double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
+                                dpll_ar_t* ar, const dpll_adam_t* adam, void* stream) {
+  if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_train_step")) return rc;
+  if (model->desc.n_geoms > 0)
+    return fail(-2, "dpll_contactnets_train_step: specialised builds (the general build: dpll_contactnets_loss + an optimizer of the caller's)%s");
+  if ((batch > 0 && (!x || !x_plus)) || !grad || !loss_total || !adam || !adam->params || !adam->exp_avg || !adam->exp_avg_sq || !adam->state)
+    return fail(-1, "dpll_contactnets_train_step: null argument%s");
+  if (batch == 0 && !ar) return fail(-1, "dpll_contactnets_train_step: empty batch%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_train_step: row stride smaller than n_x%s");
+  if ((const void*)adam->params != params->theta)
+    return fail(-1, "dpll_contactnets_train_step: adam.params must be the flat buffer params.theta points to ([theta | friction | lengths])%s");
+  if (!(adam->lr >= 0.0) || !(adam->beta1 >= 0.0 && adam->beta1 < 1.0) || !(adam->beta2 >= 0.0 && adam->beta2 < 1.0) || !(adam->eps >= 0.0) || !(adam->weight_decay >= 0.0))
+    return fail(-1, "dpll_contactnets_train_step: Adam hyper-parameters out of range%s");
+  if (ar && (dpll_param_count(model) + 1) * (dtype == DPLL_F64 ? 2 : 1) > dpll_arx::kMaxWords)
+    return fail(-1, "dpll_contactnets_train_step: gradient row too long for the one-shot exchange%s");
+  AdamArgs args{adam->params, adam->exp_avg, adam->exp_avg_sq, adam->state, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay};
+  DPLL_DISPATCH(launch_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total,
+                nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, ar, args);
+}
+
 int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
                                   int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, double scale,
                                   void* grad, void* workspace, int64_t workspace_bytes, void* stream, int32_t reps,
@@ -1315,12 +1625,20 @@ int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* par
 
 int dpll_mesh_param_count(const dpll_model_t* model) {
   if (!model) return -1;
+  if (model->desc.n_geoms > 0) {  // general build: [theta | friction | lengths | one network per learned shape, geometry order]
+    int n_mesh = 0;
+    for (int g = 0; g < model->desc.n_geoms; ++g) n_mesh += model->desc.geom_kind[g] == kGeomMesh;
+    return dpll_general::param_count(model) + n_mesh * kNetParams;
+  }
   const int nb = model->desc.n_joints + 1;
   return 10 * nb + 1 + nb + nb * kNetParams;  // [theta | friction | one network per body]
 }
 
 int64_t dpll_mesh_workspace_bytes(const dpll_model_t* model, int64_t batch, int dtype) {
-  if (!model || batch < 1 || model->desc.n_joints > 1 || model->desc.n_geoms > 0) return -1;
+  if (!model || batch < 1) return -1;
+  if (model->desc.n_geoms > 0)
+    return (int64_t)(dtype == DPLL_F64 ? genmesh_plan<double>(model, batch).total : genmesh_plan<float>(model, batch).total);
+  if (model->desc.n_joints > 1) return -1;
   if (model->desc.n_joints == 0) return (int64_t)(dtype == DPLL_F64 ? mesh_plan<double, 0>(batch).total : mesh_plan<float, 0>(batch).total);
   return (int64_t)(dtype == DPLL_F64 ? mesh_plan<double, 1>(batch).total : mesh_plan<float, 1>(batch).total);
 }
@@ -1344,6 +1662,8 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
   if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_contactnets_loss_mesh")) return rc;
   const int nx = dpll_n_x(model);
   if (batch < 1 || !x || !x_plus || ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss_mesh: bad state arguments%s");
+  DPLL_GENMESH(launch_genmesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total,
+               force, iters, workspace, workspace_bytes, (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
                      loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1396,6 +1716,8 @@ int dpll_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* pa
   if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_step_mesh")) return rc;
   const int nx = dpll_n_x(model);
   if (batch < 1 || !x || !x_next || ld_x < nx || ld_next < nx) return fail(-1, "dpll_step_mesh: bad state arguments%s");
+  DPLL_GENMESH(launch_genmesh_simulate, model, dtype, params, mesh, x, ld_x, batch, 1, x_next, ld_next, 0, false, workspace,
+               workspace_bytes, (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_step, model, dtype, params, mesh, x, ld_x, batch, x_next, ld_next, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }
@@ -1407,6 +1729,8 @@ int dpll_simulate_mesh(const dpll_model_t* model, int dtype, const dpll_params_t
   if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_simulate_mesh")) return rc;
   const int nx = dpll_n_x(model);
   if (batch < 1 || steps < 1 || !x0 || !traj || ld_x < nx) return fail(-1, "dpll_simulate_mesh: bad state arguments%s");
+  DPLL_GENMESH(launch_genmesh_simulate, model, dtype, params, mesh, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, true,
+               workspace, workspace_bytes, (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_simulate, model, dtype, params, mesh, x0, ld_x, batch, steps, traj, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }
@@ -1419,6 +1743,8 @@ int dpll_step_backward_mesh(const dpll_model_t* model, int dtype, const dpll_par
   const int nx = dpll_n_x(model);
   if (batch < 1 || !x || !grad_x_next || !grad || ld_x < nx || ld_g < nx || (grad_x && ld_gx < nx))
     return fail(-1, "dpll_step_backward_mesh: bad arguments%s");
+  if (model->desc.n_geoms > 0)
+    return fail(-2, "dpll_step_backward_mesh: not built for the general build with learned shapes (loss, step, simulate and terms are)%s");
   DPLL_MESH_DISPATCH(launch_mesh_step_backward, model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
                      workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1429,6 +1755,7 @@ int dpll_mesh_support_points(const dpll_model_t* model, int dtype, const dpll_me
   if (int rc = check_mesh_call(model, dtype, nullptr, mesh, "dpll_mesh_support_points")) return rc;
   if (batch < 1 || !x || !points || ld_x < (model->desc.n_joints == 0 ? 4 : dpll_n_x(model)))
     return fail(-1, "dpll_mesh_support_points: bad arguments%s");
+  DPLL_GENMESH(launch_genmesh_support, model, dtype, mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_support, model, mesh, x, ld_x, batch, points, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1438,6 +1765,8 @@ int dpll_terms_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* p
   if (!params) return fail(-1, "dpll_terms_mesh: null parameter pointer%s");
   if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_terms_mesh")) return rc;
   if (batch < 1 || !x || ld_x < dpll_n_x(model)) return fail(-1, "dpll_terms_mesh: bad state arguments%s");
+  DPLL_GENMESH(launch_genmesh_terms, model, dtype, params, mesh, x, ld_x, batch, delassus, M, J, phi, a, workspace, workspace_bytes,
+               (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_terms, model, params, mesh, x, ld_x, batch, delassus, M, J, phi, a, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }

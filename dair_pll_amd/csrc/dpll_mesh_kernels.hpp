@@ -71,18 +71,26 @@ __global__ __launch_bounds__(256) void icnn_prep_kernel(IcnnWeights<T> w, T* __r
 }
 
 // query directions of a tile of rows into LDS; state row of item i starts at x + i * ld, quaternion first
+// direction of query n: read from `dirs` when given, else from the item's quaternion and the perturbation row (4 per item)
 template <typename T>
-__device__ __forceinline__ void load_queries(const T* __restrict__ x, long long ld, const T* __restrict__ pert,
+__device__ __forceinline__ void query_direction(const T* __restrict__ x, long long ld, const IcnnWeights<T>& w, long long n, T (&q)[3]) {
+  if (w.dirs) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) q[i] = w.dirs[3 * n + i];
+    return;
+  }
+  T quat[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) quat[i] = x[(n >> 2) * ld + i];
+  icnn_query<T>(quat, w.pert + 3 * (n & 3), q);
+}
+template <typename T>
+__device__ __forceinline__ void load_queries(const T* __restrict__ x, long long ld, const IcnnWeights<T>& w,
                                              long long n0, long long N, T (*Qs)[3]) {
   if (threadIdx.x < kTileRows) {
     const long long n = n0 + threadIdx.x;
     T q[3] = {T(0), T(0), T(1)};
-    if (n < N) {
-      T quat[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) quat[i] = x[(n >> 2) * ld + i];
-      icnn_query<T>(quat, pert + 3 * (n & 3), q);
-    }
+    if (n < N) query_direction<T>(x, ld, w, n, q);
 #pragma unroll
     for (int i = 0; i < 3; ++i) Qs[threadIdx.x][i] = q[i];
   }
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(256) void icnn_fwd1_kernel(const T* __restrict__ x,
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kTileRows;
     __syncthreads();
-    load_queries<T>(x, ld, w.pert, n0, N, Qs);
+    load_queries<T>(x, ld, w, n0, N, Qs);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < kTileRows; ++r) Hs[j][r] = icnn_act(Qs[r][0] * wd0[0] + Qs[r][1] * wd0[1] + Qs[r][2] * wd0[2]);
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void icnn_fwd2_kernel(const T* __restrict__ x,
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kTileRows;
     __syncthreads();
-    load_queries<T>(x, ld, w.pert, n0, N, Qs);
+    load_queries<T>(x, ld, w, n0, N, Qs);
 #pragma unroll
     for (int r = 0; r < kTileRows; ++r) {
       const uint32_t word = (n0 + r < N) ? M1[(n0 + r) * kMaskWords + (j >> 5)] : 0u;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void icnn_fwd2_kernel(const T* __restrict__ x,
     __syncthreads();
     if (threadIdx.x < kTileRows * 3) {
       const int r = threadIdx.x / 3, i = threadIdx.x % 3;
-      if (n0 + r < N) P[icnn_point_index(n0 + r, w.point_stride) + i] = (Pp[0][r][i] + Pp[1][r][i]) + (Pp[2][r][i] + Pp[3][r][i]);
+      if (n0 + r < N) P[icnn_point_index(n0 + r, w) + i] = (Pp[0][r][i] + Pp[1][r][i]) + (Pp[2][r][i] + Pp[3][r][i]);
     }
   }
 }
@@ -198,10 +206,10 @@ __global__ __launch_bounds__(256) void icnn_bwd1_kernel(const T* __restrict__ x,
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kTileRows;
     __syncthreads();
-    load_queries<T>(x, ld, w.pert, n0, N, Qs);
+    load_queries<T>(x, ld, w, n0, N, Qs);
     if (threadIdx.x < kTileRows * 3) {
       const int r = threadIdx.x / 3, i = threadIdx.x % 3;
-      Rs[r][i] = (n0 + r < N) ? RB[icnn_point_index(n0 + r, w.point_stride) + i] : T(0);
+      Rs[r][i] = (n0 + r < N) ? RB[icnn_point_index(n0 + r, w) + i] : T(0);
     }
     __syncthreads();
 #pragma unroll
@@ -260,11 +268,9 @@ __global__ __launch_bounds__(256) void icnn_bwd2_kernel(const T* __restrict__ x,
       const long long n = c0 + q;
       T val[4] = {T(0), T(0), T(0), T(0)};
       if (n < n_end) {
-        T quat[4], qd[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) quat[i] = x[(n >> 2) * ld + i];
-        icnn_query<T>(quat, w.pert + 3 * (n & 3), qd);
-        const long long pn = icnn_point_index(n, w.point_stride);
+        T qd[3];
+        query_direction<T>(x, ld, w, n, qd);
+        const long long pn = icnn_point_index(n, w);
         const T r0 = RB[pn], r1 = RB[pn + 1], r2 = RB[pn + 2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -434,17 +440,12 @@ __device__ __forceinline__ void fill_operand_tile(float* __restrict__ base, long
 }
 
 // queries of a 32-row tile into LDS (threads 0..31)
-__device__ __forceinline__ void load_queries32(const float* __restrict__ x, long long ld, const float* __restrict__ pert,
+__device__ __forceinline__ void load_queries32(const float* __restrict__ x, long long ld, const IcnnWeights<float>& w,
                                                long long n0, long long N, float (*Qs)[3]) {
   if (threadIdx.x < kMfmaRows) {
     const long long n = n0 + threadIdx.x;
     float q[3] = {0.f, 0.f, 1.f};
-    if (n < N) {
-      float quat[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) quat[i] = x[(n >> 2) * ld + i];
-      icnn_query<float>(quat, pert + 3 * (n & 3), q);
-    }
+    if (n < N) query_direction<float>(x, ld, w, n, q);
 #pragma unroll
     for (int i = 0; i < 3; ++i) Qs[threadIdx.x][i] = q[i];
   }
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ 
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kMfmaRows;
     __syncthreads();
-    load_queries32(x, ld, w.pert, n0, N, Qs);
+    load_queries32(x, ld, w, n0, N, Qs);
     __syncthreads();
     {  // H0 tile: thread -> column c = t & 255, rows (t >> 8) * 16 ..
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kMfmaRows;
     __syncthreads();
-    load_queries32(x, ld, w.pert, n0, N, Qs);
+    load_queries32(x, ld, w, n0, N, Qs);
     {  // U1 tile
       const int c = threadIdx.x & 255, r0 = (threadIdx.x >> 8) * 16;
       const float ac = a[c];
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
         v += dpp_mov<kQuadXor2>(v);
         v += dpp_mov<kRowHalfMirror>(v);
         v += dpp_mov<kRowMirror>(v);
-        if (part == 0 && n0 + row < N) P[icnn_point_index(n0 + row, w.point_stride) + i] = v;
+        if (part == 0 && n0 + row < N) P[icnn_point_index(n0 + row, w) + i] = v;
       }
     }
   }
@@ -604,10 +605,10 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long n0 = tile * kMfmaRows;
     __syncthreads();
-    load_queries32(x, ld, w.pert, n0, N, Qs);
+    load_queries32(x, ld, w, n0, N, Qs);
     if (threadIdx.x >= 64 && threadIdx.x < 64 + kMfmaRows * 3) {
       const int t = threadIdx.x - 64, r = t / 3, i = t % 3;
-      Rs[r][i] = (n0 + r < N) ? RB[icnn_point_index(n0 + r, w.point_stride) + i] : 0.f;
+      Rs[r][i] = (n0 + r < N) ? RB[icnn_point_index(n0 + r, w) + i] : 0.f;
     }
     __syncthreads();
     {  // Vb tile

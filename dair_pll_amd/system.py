@@ -31,6 +31,10 @@ from .urdf import ModelSpec, check_supported, parse_urdf
 _DTYPES = {torch.float32: _capi.F32, torch.float64: _capi.F64}
 
 
+def _differs_from_identity(rotation) -> bool:
+    return any(abs(rotation[i][j] - (1.0 if i == j else 0.0)) > 1e-12 for i in range(3) for j in range(3))
+
+
 def _ptr(tensor: Optional[Tensor]) -> Optional[int]:
     return None if tensor is None else tensor.data_ptr()
 
@@ -122,6 +126,36 @@ class DeepSupportConvex(Module):
         self.network = HomogeneousICNN(scale, dtype, device)
         pert = torch.cat((torch.zeros((1, 3)), perturbation * (torch.rand((n_query - 1, 3)) - 0.5)))
         self.register_buffer('perturbations', pert.to(device=device, dtype=dtype), persistent=False)
+
+
+class FusedAdamState:
+    """Adam moments and step count of a system's flat parameter buffer for :meth:`MultibodyLearnableSystem.contactnets_train_step`
+    (the update of ``torch.optim.Adam`` without amsgrad, ``experiment.py:213-228``, applied by the finalize kernel)."""
+
+    def __init__(self, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg: Optional[Tensor] = None
+        self.exp_avg_sq: Optional[Tensor] = None
+        self.state: Optional[Tensor] = None  # (3,) float64: [steps taken, beta1^steps, beta2^steps]
+
+    @property
+    def step(self) -> Tensor:
+        return self.state[:1]
+
+    def bind(self, flat: Tensor) -> None:
+        if self.exp_avg is None or self.exp_avg.shape != flat.shape or self.exp_avg.device != flat.device or self.exp_avg.dtype != flat.dtype:
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+            self.state = torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64, device=flat.device)
+
+    def struct(self, flat: Tensor) -> '_capi.AdamState':
+        return _capi.AdamState(flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.state.data_ptr(), self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.weight_decay)
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        return {'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq, 'state': self.state}
+
+    def load_state_dict(self, state: Dict[str, Tensor]) -> None:
+        self.exp_avg, self.exp_avg_sq, self.state = state['exp_avg'].clone(), state['exp_avg_sq'].clone(), state['state'].clone()
 
 
 class LagrangianTerms(Module):
@@ -266,7 +300,8 @@ class MultibodyLearnableSystem(Module):
         n_b, slots, stride = self.spec.n_joints + 1, self._geom_slots(), self._geo_stride()
         out = [(terms.lagrangian_terms.inertial_parameters, 0), (terms.contact_terms.friction_params, 10 * n_b)]
         lengths0 = 10 * n_b + 1 + slots
-        end = lengths0
+        # (the general build always carries its lengths block; the specialised mesh builds have none)
+        end = lengths0 if self.spec.is_fast() else lengths0 + stride * slots
         for g, geometry in enumerate(list(terms.contact_terms.geometries)[1:]):
             if isinstance(geometry, (Box, Sphere, Polygon)):
                 param = geometry.length_params if isinstance(geometry, Box) else (
@@ -293,15 +328,22 @@ class MultibodyLearnableSystem(Module):
         return [g for g in self.multibody_terms.contact_terms.geometries if isinstance(g, DeepSupportConvex)]
 
     def _mesh_struct(self, flat: Tensor):
-        """``dpll_mesh_params_t[n_bodies]``: one network per body, its weights at ``head + g * 67,328`` of the flat buffer"""
+        """``dpll_mesh_params_t[]``: the specialised builds take one entry per body (one network each), the general build
+        one per geometry slot (entries of geometries that are not learned shapes stay null); network k's weights sit at
+        ``head + k * 67,328`` of the flat buffer."""
         base, size, width = flat.data_ptr(), flat.element_size(), ICNN_WIDTH
-        n_b = self.spec.n_joints + 1
         per_net = width * width + 7 * width
-        meshes = self._meshes()
-        array = (_capi.MeshParams * len(meshes))()
+        geometries = list(self.multibody_terms.contact_terms.geometries)[1:]
+        fast = self.spec.is_fast()
+        head = self._layout()[1] - per_net * len(self._meshes())
+        array = (_capi.MeshParams * (len(geometries) if fast else _capi.MAX_GEOMS))()
         self._pert_keepalive = []
-        for g, mesh in enumerate(meshes):
-            off = 10 * n_b + 1 + n_b + g * per_net
+        k = 0
+        for g, mesh in enumerate(geometries):
+            if not isinstance(mesh, DeepSupportConvex):
+                continue
+            off = head + k * per_net
+            k += 1
             pert = mesh.perturbations
             if pert.dtype != flat.dtype or pert.device != flat.device or not pert.is_contiguous():
                 mesh.perturbations = pert = pert.to(device=flat.device, dtype=flat.dtype).contiguous()
@@ -486,6 +528,36 @@ class MultibodyLearnableSystem(Module):
                 param.grad = piece
         return total
 
+    def contactnets_train_step(self, x: Tensor, x_plus: Tensor, adam: 'FusedAdamState') -> Tensor:
+        """One whole training step -- the mean loss of the batch, its gradients, the gradient exchange when a process group
+        is bound (peer transport) and the Adam update of every parameter, in place -- in the loss launch and ONE more
+        kernel (``dpll_contactnets_train_step``; ``experiment.py:332-363``).  Returns the mean loss (one-element device
+        tensor); ``.grad`` of every parameter holds the gradient the update used.  Box geometry, cube / elbow topology."""
+        if not self.spec.is_fast() or self._mesh() is not None:
+            raise NotImplementedError('the fused training step serves the specialised box builds; use contactnets_loss_and_grad + an optimizer')
+        lib = _capi.library()
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        denom = self.global_batch if self.global_batch > 0 else xf.shape[0] * self.grad_world
+        flat = self._packed()
+        if self._flat_grad is None or self._flat_grad.device != xf.device:
+            self._alloc_grad_buffer(flat.numel(), xf.device)
+        ws_bytes = lib.dpll_workspace_bytes(self._model(), xf.shape[0])
+        if self._workspace is None or self._workspace.numel() < ws_bytes or self._workspace.device != xf.device:
+            self._workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=xf.device)
+        adam.bind(flat)
+        params = self._params_struct(flat)
+        state = adam.struct(flat)
+        _capi.check(lib.dpll_contactnets_train_step(
+            self._model(), _DTYPES[self.dtype], ctypes.byref(params), _ptr(xf), xf.stride(0), _ptr(xpf), xpf.stride(0), xf.shape[0],
+            None, 1.0 / denom, _ptr(self._flat_grad), _ptr(self._loss_total), _ptr(self._workspace), ws_bytes, self._fused_ar,
+            ctypes.byref(state), self._stream()))
+        self._grad_reduced = self._fused_ar is not None
+        for param, piece in zip(self._param_list(), self._split_flat(self._flat_grad)):
+            if param.grad is None or param.grad.data_ptr() != piece.data_ptr():
+                param.grad = piece
+        return self._loss_total
+
     def support_points(self, x: Tensor) -> Tensor:
         """``DeepSupportConvex.get_vertices`` for the ground-contact direction of every state:
         ``(*, n_x) -> (*, 4 n_bodies, 3)`` support points in the frames of their bodies (mesh systems only)."""
@@ -497,11 +569,15 @@ class MultibodyLearnableSystem(Module):
         flat = self._packed()
         workspace = self._mesh_workspace(xf.shape[0], xf.device)
         mesh = self._mesh_struct(flat)
-        k = 4 * len(self._meshes())
-        points = torch.empty((xf.shape[0], k, 3), dtype=self.dtype, device=xf.device)
+        k = 4 * len(self._meshes()) if self.spec.is_fast() else 4 * _capi.GEN_SLOTS  # (general build: every contact slot)
+        points = torch.zeros((xf.shape[0], k, 3), dtype=self.dtype, device=xf.device)
         _capi.check(lib.dpll_mesh_support_points(self._model(), _DTYPES[self.dtype], mesh, _ptr(xf),
                                                  xf.stride(0), xf.shape[0], _ptr(points), _ptr(workspace),
                                                  workspace.numel(), self._stream()))
+        if not self.spec.is_fast():  # keep the four ground queries of every learned shape, in geometry order
+            rows = [4 * g + s for g, (_, geom) in enumerate(self.spec.geoms()) if geom.kind == 'mesh' for s in range(4)]
+            points = points[:, rows]
+            k = len(rows)
         return points.reshape(batch_shape + (k, 3))
 
     def profile_loss_kernels(self, x: Tensor, x_plus: Tensor, reps: int = 100) -> Tuple[float, float]:
@@ -717,7 +793,11 @@ class MultibodyLearnableSystem(Module):
             body = self.spec.bodies[index]
             geometry = self.multibody_terms.contact_terms.geometries[g + 1]
             if isinstance(geometry, DeepSupportConvex):
-                def support(directions: np.ndarray) -> np.ndarray:
+                if _differs_from_identity(self.spec.geoms()[g][1].rotation):
+                    raise NotImplementedError('mesh extraction of a learned shape whose collision <origin> carries an rpy')
+                k_mesh = sum(1 for _, other in self.spec.geoms()[:g] if other.kind == 'mesh')  # rows of support_points
+
+                def support(directions: np.ndarray, geometry=geometry, k_mesh=k_mesh) -> np.ndarray:
                     # the HIP kernels evaluate the network (dpll_mesh_support_points): a state whose rotation takes
                     # the direction to -e_z makes the kernel's first query (perturbation row 0 = 0) that direction
                     param = geometry.network.output_weight
@@ -732,7 +812,7 @@ class MultibodyLearnableSystem(Module):
                     x[:, :4] = quat
                     with torch.no_grad():  # joint angles zero: every body has the base's rotation
                         points = self.support_points(x.to(device=param.device, dtype=param.dtype))
-                    return points[:, 4 * g, :].double().cpu().numpy()
+                    return points[:, 4 * k_mesh, :].double().cpu().numpy()
                 meshes[body.name] = export.extract_mesh(support)
         return meshes
 

@@ -68,17 +68,24 @@ class ContactNetsTrainer:
     (``lr=1e-3``, ``weight_decay`` as in ``examples/contactnets_simple.py:78-86``)."""
 
     def __init__(self, system, lr: float = 1e-3, weight_decay: float = 0.0, batch_size: int = 4096,
-                 seed: int = 0, loss: str = 'contactnets', use_graph: bool = False) -> None:
+                 seed: int = 0, loss: str = 'contactnets', use_graph: bool = False, fused_adam: bool = False) -> None:
         """``use_graph``: one training step (packing the parameters, fused loss + gradients, gradient exchange, Adam)
         is captured once as a hipGraph and replayed per full batch -- the step is a dozen launch-bound small
-        kernels, most of them the optimizer's."""
+        kernels, most of them the optimizer's.  ``fused_adam`` (box geometry, cube / elbow topology): the Adam update is
+        done by the finalize kernel of the loss launch (``dpll_contactnets_train_step``): a training step is two
+        launches; ``optimizer`` is then a :class:`FusedAdamState`."""
         assert loss in ('contactnets', 'prediction')  # MultibodyLosses of drake_experiment.py:47-52
         self.loss = loss
         self.system = system
         self.batch_size = batch_size
         self.use_graph = use_graph and loss == 'contactnets'
-        self.optimizer = torch.optim.Adam(system.parameters(), lr=lr, weight_decay=weight_decay,
-                                          capturable=self.use_graph)
+        self.fused_adam = fused_adam and loss == 'contactnets'
+        if self.fused_adam:
+            from .system import FusedAdamState
+            self.optimizer = FusedAdamState(lr=lr, weight_decay=weight_decay)
+        else:
+            self.optimizer = torch.optim.Adam(system.parameters(), lr=lr, weight_decay=weight_decay,
+                                              capturable=self.use_graph)
         self._graph = None
         self._static = None
         self.generator = torch.Generator().manual_seed(seed)
@@ -86,7 +93,8 @@ class ContactNetsTrainer:
         self.reducer: Optional[GradientAllReduce] = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 torch.distributed.get_world_size() > 1:
-            self.reducer = GradientAllReduce(system)
+            # (the fused update rides in the finalize kernel, and so must the exchange: the peer transport)
+            self.reducer = GradientAllReduce(system, transport='peer' if self.fused_adam else 'auto')
 
     def train_epoch(self, x: Tensor, x_plus: Tensor) -> float:
         """One pass over the (device-resident) pairs in shuffled mini-batches; returns the mean of the
@@ -115,11 +123,7 @@ class ContactNetsTrainer:
                 continue
             # a ragged tail batch may leave some ranks an empty shard: they launch a zero row and still take part in
             # the exchange (dpll_contactnets_loss accepts batch = 0 together with a gradient buffer)
-            total = self.system.contactnets_loss_and_grad(x[idx], x_plus[idx])
-            if self.reducer is not None:
-                self.reducer.all_reduce_mean()
-            self.optimizer.step()
-            losses.append(total.clone())
+            losses.append(self._step_body(x[idx], x_plus[idx]).clone())
         if self.reducer is not None:
             self.reducer.check_healthy()  # once per epoch: a timed-out exchange must not train on silently
         return torch.stack(losses).mean().item()
@@ -133,6 +137,8 @@ class ContactNetsTrainer:
         return hi - lo
 
     def _step_body(self, x: Tensor, x_plus: Tensor) -> Tensor:
+        if self.fused_adam:
+            return self.system.contactnets_train_step(x, x_plus, self.optimizer)
         total = self.system.contactnets_loss_and_grad(x, x_plus)
         if self.reducer is not None:
             self.reducer.all_reduce_mean()
@@ -152,8 +158,13 @@ class ContactNetsTrainer:
             # the state an eager warm-up changes (parameters, Adam moments and step count) is restored afterwards,
             # so that captured training is step for step the eager training
             params = [p.detach().clone() for p in self.system.parameters()]
-            saved_state = {id(p): {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
-                           for p, st in self.optimizer.state.items()}
+            if self.fused_adam:
+                self.optimizer.bind(self.system._packed())
+                fused_saved = {n: v.clone() for n, v in self.optimizer.state_dict().items()}
+                saved_state = {}
+            else:
+                saved_state = {id(p): {n: v.clone() for n, v in st.items() if torch.is_tensor(v)}
+                               for p, st in self.optimizer.state.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -167,7 +178,10 @@ class ContactNetsTrainer:
                     p.copy_(saved)
                 # optimizer state back to what it was before the warm-up (moments of earlier eager steps, a loaded
                 # checkpoint, or zeros when no step had been taken), IN PLACE: the graph holds these tensors' addresses
-                for k, st in self.optimizer.state.items():
+                if self.fused_adam:
+                    for n, v in self.optimizer.state_dict().items():
+                        v.copy_(fused_saved[n])
+                for k, st in ({} if self.fused_adam else self.optimizer.state).items():
                     for n, v in st.items():
                         if torch.is_tensor(v):
                             before = saved_state.get(id(k), {}).get(n)

@@ -5,8 +5,8 @@ The reference obtains the same facts from Drake's parser and symbolic plant
 mass / centre of mass / central inertia, the joint tree, collision geometry with
 ``drake:mu_static``, and a ground half-space with friction 1.0 added to every plant
 (``drake_utils.py:280-288``).  The kernels support one floating-base tree of up to three revolute or prismatic
-joints with up to three box / sphere / polygon collision geometries on any of its bodies (or a learned mesh on every
-body of a cube / elbow), all of it touching only the ground (the elbow's links are collision filtered,
+joints with up to three box / sphere / polygon / learned-mesh collision geometries on any of its bodies, touching the
+ground and -- up to four candidate pairs -- each other (the elbow's links are collision filtered,
 ``assets/contactnets_elbow.urdf``).  The cube and elbow systems of the reference's ContactNets example
 -- a serial chain with exactly one box per body -- run on builds specialised for them
 (:meth:`ModelSpec.is_fast`).
@@ -113,7 +113,9 @@ class ModelSpec:
     def is_fast(self) -> bool:
         """the cube / elbow topology the specialised builds are written for: a serial chain of at most one joint with
         exactly one box (or mesh) per body, no frame turned against its parent's"""
-        return (self.n_joints <= 1 and not self.rotated() and all(b.joint_kind == 'revolute' for b in self.bodies) and all(len(b.geoms) == 1 and b.geoms[0].kind in ('box', 'mesh') for b in self.bodies)
+        kinds = {geom.kind for _, geom in self.geoms()}
+        return (self.n_joints <= 1 and not self.rotated() and all(b.joint_kind == 'revolute' for b in self.bodies)
+                and all(len(b.geoms) == 1 for b in self.bodies) and kinds in ({'box'}, {'mesh'})
                 and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0) and not self.pairs)
 
     def friction_init(self) -> List[float]:
@@ -298,8 +300,9 @@ def check_supported(spec: ModelSpec) -> None:
     if len(spec.pairs) > MAX_PAIRS:
         raise NotImplementedError(f'at most {MAX_PAIRS} body-body collision candidates (exclude the others with a '
                                   'drake:collision_filter_group)')
-    if any(geom.kind == 'mesh' for _, geom in geoms):  # (is_fast: no joint or collision frame is rotated, either)
-        if not (spec.is_fast() and all(geom.kind == 'mesh' for _, geom in geoms)):
-            raise NotImplementedError('mesh (DeepSupportConvex) geometry: a serial chain of at most one joint with exactly '
-                                      'one mesh on every body and no body-body candidates (contactnets_cube_mesh.urdf, '
-                                      'contactnets_elbow_mesh.urdf)')
+    # a learned shape (DeepSupportConvex) collides with the ground or with another learned shape: the reference's
+    # GeometryCollider.collide has no case for a mesh against a box / sphere / polygon (TypeError, geometry.py:543-551)
+    for a, b in spec.pairs:
+        if (geoms[a][1].kind == 'mesh') != (geoms[b][1].kind == 'mesh'):
+            raise NotImplementedError('a body-body candidate between a mesh (DeepSupportConvex) and another kind of geometry: '
+                                      'the reference has no collider for it either (exclude it with a drake:collision_filter_group)')

@@ -47,7 +47,9 @@ enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSIC
 #define DPLL_MAX_POLYGON_VERTICES 8
 #define DPLL_GEOM_BLOCK (3 * DPLL_MAX_POLYGON_VERTICES) /* numbers per geometry in the general build's `lengths` block */
 
-enum dpll_geom_kind { DPLL_GEOM_BOX = 0, DPLL_GEOM_SPHERE = 1, DPLL_GEOM_POLYGON = 2 };
+/* DPLL_GEOM_MESH: a learned convex shape (DeepSupportConvex, geometry.py:255-364) of the GENERAL build: its network's
+ * parameters travel in the dpll_mesh_params_t array of the *_mesh entry points; its block of `lengths` is padding */
+enum dpll_geom_kind { DPLL_GEOM_BOX = 0, DPLL_GEOM_SPHERE = 1, DPLL_GEOM_POLYGON = 2, DPLL_GEOM_MESH = 3 };
 /* a prismatic joint moves its body along joint_axis by the joint coordinate (metres); its velocity column is the axis */
 enum dpll_joint_kind { DPLL_JOINT_REVOLUTE = 0, DPLL_JOINT_PRISMATIC = 1 };
 
@@ -280,6 +282,27 @@ int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const 
                                     int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
                                     double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                     dpll_ar_t* ar, void* stream);
+
+/* ---- one training step in two launches: the loss launch, and a finalize kernel that -- after summing the rows, chaining
+ * them to the parameters and (ar != NULL) exchanging [loss | gradients] with the other ranks -- applies Adam to the
+ * parameters in place (experiment.py:332-363 with the optimizer of :213-228: torch.optim.Adam without amsgrad; weight_decay
+ * is added to the gradient as torch does).  The specialised builds (cube / elbow, box geometry).  All pointers are device
+ * pointers of the call's dtype except `state`: three doubles [steps taken, beta1^steps, beta2^steps], {0, 1, 1} before the
+ * first step, advanced by the call (the bias corrections need no pow on the device and the step count survives graph replay).  `params` MUST be the flat buffer dpll_params_t.theta points to, laid out [theta | friction | lengths]
+ * (dpll_param_count entries): the next call then reads the updated parameters.  grad receives the (reduced) gradient the
+ * update used, loss_total the (reduced) weighted loss. */
+typedef struct dpll_adam {
+  void* params;
+  void* exp_avg;
+  void* exp_avg_sq;
+  double* state;
+  double lr, beta1, beta2, eps, weight_decay;
+} dpll_adam_t;
+
+int dpll_contactnets_train_step(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
+                                int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                                double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
+                                dpll_ar_t* ar, const dpll_adam_t* adam, void* stream);
 
 #ifdef __cplusplus
 }

@@ -254,3 +254,118 @@ def test_two_learned_shapes_export(golden, tmp_path):
     for body, name in zip(spec.bodies, ('elbow_1', 'elbow_2')):
         assert np.allclose(np.array(body.geoms[0].vertices), meshes[name][0], atol=0, rtol=1e-15)
         assert body.geoms[0].origin == ([0.0, 0.0, 0.0] if name == 'elbow_1' else [0.035, 0.0, 0.0])
+
+
+# ---- the reference's own body-body case: two learned shapes (GeometryCollider.collide_mesh_mesh, geometry.py:585-643) --------
+CLASP = 'clasp_mesh_literal'
+
+
+def build_general(g, dtype):
+    from dair_pll_amd import MultibodyLearnableSystem
+    system = MultibodyLearnableSystem({'model': os.path.join(ASSET_DIR, 'clasp_mesh.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+    assert not system.spec.is_fast() and system.spec.pairs == [(0, 1)]
+    system.load_state_dict({name: torch.tensor(g['param/' + name]) for name, _ in system.named_parameters()})
+    for index, geometry in enumerate(system.multibody_terms.contact_terms.geometries):
+        if index > 0:
+            geometry.perturbations = torch.tensor(g[f'param/{GEOM}{index}.perturbations'], dtype=dtype, device='cuda:0')
+    return system
+
+
+def clasp_oracle(g):
+    meshes = {}
+    for index in (1, 2):
+        meshes[index] = {'perturbations': torch.tensor(g[f'param/{GEOM}{index}.perturbations'])}
+        for key in ('hidden_weights.0', 'input_weights.0', 'input_weights.1', 'output_weight'):
+            meshes[index][key] = torch.tensor(g[f'param/{GEOM}{index}.network.{key}'])
+    system = O.OracleSystem(os.path.join(ASSET_DIR, 'clasp_mesh.urdf'), float(g['dt']), mesh_params=meshes)
+    system.theta = torch.tensor(g['param/multibody_terms.lagrangian_terms.inertial_parameters'])
+    system.friction = torch.tensor(g['param/multibody_terms.contact_terms.friction_params'])
+    return system
+
+
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+def test_two_learned_shapes_against_the_reference_run(golden, dtype):
+    """assets/clasp_mesh.urdf: a DeepSupportConvex on the base and on the tip of a two-joint arm, the pair a collision
+    candidate -- the fixture was recorded from the reference's unmodified DeepSupportConvex / collide_mesh_mesh /
+    extract_mesh (fcl's direction: the oracle's exact search).  On the device: vertex sets through the ICNN kernels, the
+    direction by GJK / EPA in LDS, the witnesses by the networks at +-d.  Loss, every gradient incl. both networks'
+    weights, step, rollout, terms."""
+    g = golden(CLASP)
+    system = build_general(g, dtype)
+    f64 = dtype == torch.float64
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    u = torch.zeros((x.shape[0], 0), device='cuda:0')
+    loss = system.contactnets_loss(x, u, xp)
+    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4)
+    loss.mean().backward()
+    for name, param in system.named_parameters():
+        ref = g['grad/' + name]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= (1e-9 if f64 else 2e-3) * max(np.abs(ref).max(), 1e-12 if not f64 else 1.0), (name, err, np.abs(ref).max())
+    system.zero_grad()
+    total = system.contactnets_loss_and_grad(x, xp)
+    assert abs(total.item() - float(g['loss_mean'])) < (1e-12 if f64 else 1e-6)
+    for name, param in system.named_parameters():
+        ref = g['grad/' + name]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= (1e-9 if f64 else 2e-3) * max(np.abs(ref).max(), 1e-12 if not f64 else 1.0), (name, err)
+    # dynamics
+    tol = (1e-10 if f64 else 1e-4) * max(1.0, np.abs(g['dynamics/x_next']).max())
+    assert np.abs(system.step(x).detach().cpu().double().numpy() - g['dynamics/x_next']).max() < tol
+    rows = g['simulate/rows']
+    traj, _ = system.simulate(x[rows].unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), int(g['simulate/steps']))
+    assert np.abs(traj.detach().cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4) * max(1.0, np.abs(g['simulate/traj']).max())
+    # terms: signed distances and Jacobian rows per geometry (order-free inside a geometry: Q3), the pair's row as it is
+    q, v = system.space.q_v(xp)
+    D, M, J, phi, a = system.multibody_terms(q, v, u)
+    k = system.spec.n_contacts
+    assert k == 9 and phi.shape == (x.shape[0], 9) and J.shape == (x.shape[0], 27, 8)
+    tight = 1e-9 if f64 else 2e-4
+    assert np.abs(M.cpu().double().numpy() - g['terms/M']).max() < (1e-12 if f64 else 1e-5) * max(1.0, np.abs(g['terms/M']).max())
+    phi_np, ref_phi = phi.cpu().double().numpy(), g['terms/phi']
+    for lo in (0, 4):
+        assert np.abs(np.sort(phi_np[:, lo:lo + 4], -1) - np.sort(ref_phi[:, lo:lo + 4], -1)).max() < tight
+    assert np.abs(phi_np[:, 8] - ref_phi[:, 8]).max() < tight
+    J_np = J.cpu().double().numpy()
+    assert np.abs(J_np[:, 8] - g['terms/J'][:, 8]).max() < tight * max(1.0, np.abs(g['terms/J']).max())  # the pair's normal row
+
+
+def test_two_learned_shapes_on_random_states_against_the_oracle(golden):
+    """states the fixture does not hold: the arm folded INTO the base (overlapping shapes: the EPA branch) and around
+    touching, networks perturbed; float64 kernels against the oracle (hull of the Minkowski difference)."""
+    g = golden(CLASP)
+    system = build_general(g, torch.float64)
+    oracle = clasp_oracle(g)
+    gen = torch.Generator().manual_seed(11)
+    n = 48
+    quat = torch.randn((n, 4), generator=gen, dtype=torch.float64)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    pos = torch.cat((0.05 * torch.randn((n, 2), generator=gen, dtype=torch.float64), 0.08 + 0.05 * torch.rand((n, 1), generator=gen, dtype=torch.float64)), -1)
+    # joint angles around the configurations of the fixture (where the pair is about to meet), spread so that a good part overlaps
+    base = torch.tensor(g['x'][:, 7:9])
+    joints = base[torch.randint(0, base.shape[0], (n,), generator=gen)] + 0.25 * torch.randn((n, 2), generator=gen, dtype=torch.float64)
+    vel = torch.cat((2.0 * torch.randn((n, 3), generator=gen, dtype=torch.float64), 0.3 * torch.randn((n, 3), generator=gen, dtype=torch.float64),
+                     2.0 * torch.randn((n, 2), generator=gen, dtype=torch.float64)), -1)
+    xs = torch.cat((quat, pos, joints, vel), -1)
+    with torch.no_grad():
+        phi_ref, _ = oracle.contact_terms(xs[:, :9])
+        x_next_ref = oracle.step(xs)
+    assert (phi_ref[:, 8] < 0).sum() >= 5 and (phi_ref[:, 8] > 0).sum() >= 5  # both branches of the search
+    xd = xs.cuda()
+    q, v = system.space.q_v(xd)
+    phi = system.multibody_terms(q, v, torch.zeros((n, 0), device='cuda:0'))[3].cpu()
+    assert (phi[:, 8] - phi_ref[:, 8]).abs().max() < 1e-9
+    x_next = system.step(xd).cpu()
+    assert (x_next - x_next_ref).abs().max() < 1e-8 * max(1.0, x_next_ref.abs().max().item())
+    oracle.requires_grad_()
+    loss_ref = oracle.contactnets_loss(xs, x_next_ref.detach())
+    loss_ref.mean().backward()
+    loss = system.contactnets_loss(xd, torch.zeros((n, 0), device='cuda:0'), x_next_ref.detach().cuda())
+    assert (loss.detach().cpu() - loss_ref.detach()).abs().max() < 1e-9
+    loss.mean().backward()
+    ref_named = oracle.named_parameters()
+    for name, param in system.named_parameters():
+        ref = ref_named[name].grad
+        err = (param.grad.cpu() - ref).abs().max().item()
+        assert err <= 1e-8 * max(ref.abs().max().item(), 1e-3), (name, err)

@@ -228,3 +228,57 @@ def test_training_a_model_with_a_prismatic_joint_and_turned_frames(use_graph):
     assert np.isfinite(log.epoch_losses).all() and log.epoch_losses[-1] < 0.8 * log.epoch_losses[0]
     assert (geometries[2].length_params.detach().abs() - true_box.abs()).abs().sum() < (start_box.abs() - true_box.abs()).abs().sum()
     assert abs(abs(geometries[3].length_param.item()) - true_radius) < abs(start_radius - true_radius)
+
+
+@pytest.mark.parametrize('model', ['cube', 'elbow'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_fused_adam_step_is_torch_adam(model, dtype):
+    """dpll_contactnets_train_step: the finalize kernel of the loss launch applies Adam in place.  Forty steps with
+    weight decay against torch.optim.Adam (experiment.py:213-228) fed by contactnets_loss_and_grad, eagerly and as a
+    replayed hipGraph: same parameters, same moments, same step count."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.trainer import ContactNetsTrainer
+    g = np.load(os.path.join(GOLDEN_DIR, 'cube_box_4096.npz' if model == 'cube' else 'elbow_box_4096.npz'))
+    x = torch.tensor(g['x'][:2048], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'][:2048], dtype=dtype, device='cuda:0')
+
+    def make():
+        system = MultibodyLearnableSystem({model: os.path.join(ASSET_DIR, model + '.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+        with torch.no_grad():
+            system.multibody_terms.contact_terms.geometries[1].length_params.mul_(1.2)
+            system.multibody_terms.contact_terms.friction_params[1] = 0.5
+        return system
+
+    ref, eager, graphed = make(), make(), make()
+    optimizer = torch.optim.Adam(ref.parameters(), lr=2e-3, weight_decay=1e-3)
+    t_eager = ContactNetsTrainer(eager, lr=2e-3, weight_decay=1e-3, batch_size=512, seed=3, fused_adam=True)
+    t_graph = ContactNetsTrainer(graphed, lr=2e-3, weight_decay=1e-3, batch_size=512, seed=3, fused_adam=True, use_graph=True)
+    order_gen = torch.Generator().manual_seed(3)
+    for epoch in range(10):
+        order = torch.randperm(x.shape[0], generator=order_gen).to(x.device)  # the trainer's own shuffle, replayed for the reference
+        for start in range(0, x.shape[0], 512):
+            idx = order[start:start + 512]
+            ref.contactnets_loss_and_grad(x[idx], xp[idx])
+            optimizer.step()
+        loss_eager = t_eager.train_epoch(x, xp)
+        loss_graph = t_graph.train_epoch(x, xp)
+        assert abs(loss_eager - loss_graph) <= 1e-6 * max(1.0, abs(loss_eager))
+    tol = 2e-5 if dtype == torch.float32 else 1e-10
+    for (name, p_ref), (_, p_eager), (_, p_graph) in zip(ref.named_parameters(), eager.named_parameters(), graphed.named_parameters()):
+        scale = max(1.0, p_ref.abs().max().item())
+        assert (p_ref - p_eager).abs().max().item() <= tol * scale, (name, (p_ref - p_eager).abs().max().item())
+        assert (p_eager - p_graph).abs().max().item() <= tol * scale, name
+        assert (p_ref - make().get_parameter(name)).abs().max().item() > 1e-4  # (the parameters did move)
+    assert t_eager.optimizer.step.item() == 40.0 and t_graph.optimizer.step.item() == 40.0
+    state = optimizer.state[next(iter(ref.parameters()))]
+    n = state['exp_avg'].numel()
+    assert torch.allclose(t_eager.optimizer.exp_avg[:n].reshape(state['exp_avg'].shape), state['exp_avg'], rtol=1e-4, atol=1e-9)
+
+
+def test_fused_training_step_refuses_models_it_does_not_serve():
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.system import FusedAdamState
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, 'chain3.urdf')}, 0.0068, device='cuda:0')
+    x = torch.zeros((4, system.space.n_x), device='cuda:0')
+    with pytest.raises(NotImplementedError):
+        system.contactnets_train_step(x, x, FusedAdamState())

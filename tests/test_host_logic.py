@@ -324,3 +324,36 @@ def test_general_models_are_described_for_the_general_build():
     bad = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     bad.rotated = 1  # turned frames are the general build's
     assert lib.dpll_model_create(ctypes.byref(bad), ctypes.byref(handle)) != 0 and b'general build' in lib.dpll_last_error()
+
+
+def test_learned_shapes_on_a_general_tree_are_described_for_the_general_build():
+    """assets/clasp_mesh.urdf: two DeepSupportConvex geometries on a two-joint arm whose pair is a collision candidate -- the
+    reference's own body-body case (geometry.py:543-546).  Geometry kind DPLL_GEOM_MESH, the networks behind the general
+    build's [theta | friction | lengths] head, the *_mesh entry points only."""
+    lib = _capi.library()
+    spec = parse_urdf(os.path.join(ASSET_DIR, 'clasp_mesh.urdf'))
+    assert not spec.is_fast() and spec.pairs == [(0, 1)] and spec.n_contacts == 9
+    desc = _capi.make_desc(spec, 0.0068)
+    assert desc.n_geoms == 2 and list(desc.geom_kind) == [3, 3, 0] and list(desc.geom_body) == [0, 2, 0] and desc.n_pairs == 1
+    handle = ctypes.c_void_p()
+    assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
+    head = 10 * 3 + 1 + _capi.GEN_SLOTS + _capi.GEN_SLOTS * _capi.GEOM_BLOCK
+    per_net = 256 * 256 + 7 * 256
+    assert lib.dpll_param_count(handle) == head and lib.dpll_mesh_param_count(handle) == head + 2 * per_net
+    assert lib.dpll_mesh_workspace_bytes(handle, 4096, _capi.F32) > 0 and lib.dpll_mesh_workspace_bytes(handle, 64, _capi.F64) > 0
+    # the plain entry points refuse the model before touching anything
+    params = _capi.Params(8, 8, 8)
+    rc = lib.dpll_contactnets_loss(handle, _capi.F64, ctypes.byref(params), 8, 17, 8, 17, 4, None, 1.0, None, None, None, None, None, None, 0, None)
+    assert rc == -2 and b'_mesh' in lib.dpll_last_error()
+    # a candidate between a learned shape and a box has no collider in the reference either (TypeError, geometry.py:547-551)
+    desc.geom_kind[1] = 0
+    assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(ctypes.c_void_p())) == -2
+    system = MultibodyLearnableSystem({'clasp_mesh': os.path.join(ASSET_DIR, 'clasp_mesh.urdf')}, 0.0068, device='cpu', dtype=torch.float64)
+    names = [name for name, _ in system.named_parameters()]
+    assert 'multibody_terms.contact_terms.geometries.2.network.hidden_weights.0' in names and len(names) == 2 + 2 * 4
+    layout, total = system._layout()
+    assert total == head + 2 * per_net and [offset for _, offset in layout][:3] == [0, 30, head]
+    flat = system._packed()
+    mesh = system._mesh_struct(flat)
+    assert len(mesh) == _capi.MAX_GEOMS and mesh[2].hidden_weight is None
+    assert mesh[1].hidden_weight == flat.data_ptr() + (head + per_net) * flat.element_size()

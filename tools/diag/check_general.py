@@ -6,9 +6,13 @@ sys.path.insert(0, os.getcwd())
 from dair_pll_amd import MultibodyLearnableSystem, _capi
 if os.environ.get('DPLL_LIB'):
     _capi.LIB_PATH = os.path.abspath(os.environ['DPLL_LIB'])
-for name in ('chain3', 'vee', 'gripper', 'mace', 'crank', 'slider', 'ballcube', 'grasp', 'clasp', 'pincer'):
+    if os.environ.get('DPLL_BISECT_ABI'):  # bisect builds of an older source whose struct layouts are the current ones (ABI 17 -> 18 added a geometry kind only)
+        import ctypes
+        _capi.ABI_VERSION = ctypes.CDLL(_capi.LIB_PATH).dpll_abi_version()
+names = os.environ.get('DPLL_MODELS', 'chain3 vee gripper mace crank slider ballcube grasp clasp pincer').split()
+for name in names:
     g = np.load(f'tests/golden/{name}_literal.npz')
-    for dtype in (torch.float32, torch.float64):
+    for dtype in ((torch.float64,) if os.environ.get('DPLL_F64_ONLY') else (torch.float32, torch.float64)):
         s = MultibodyLearnableSystem({name: f'assets/{name}.urdf'}, float(g['dt']), dtype=dtype, device='cuda:0')
         s.load_state_dict({k: torch.tensor(g['param/' + k]) for k, _ in s.named_parameters()})
         x = torch.tensor(g['x'], dtype=dtype, device='cuda:0'); xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
