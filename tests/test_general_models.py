@@ -234,7 +234,8 @@ def test_gpu_loss_gradients_dynamics(golden, name, dtype):
     k = system.spec.n_contacts
     assert force.shape == (x.shape[0], 3 * k) and iters.max().item() < 100
     f = force.cpu().double().numpy()
-    assert (np.linalg.norm(f[:, k:].reshape(-1, k, 2), axis=-1) <= f[:, :k] + 1e-6).all()
+    # (the float kernels project in float: feasible to a few ulp of the force itself)
+    assert (np.linalg.norm(f[:, k:].reshape(-1, k, 2), axis=-1) <= f[:, :k] * (1.0 + (0.0 if f64 else 1e-5)) + 1e-6).all()
     # dynamics
     tol = (1e-10 if f64 else 1e-4) * max(1.0, np.abs(g['dynamics/x_next']).max())  # (joint rates reach 10 rad/s where a pair closes)
     q, v = system.space.q_v(x)
