@@ -32,6 +32,17 @@ def slice_pairs(trajectories: Iterable[Tensor]) -> Tuple[Tensor, Tensor]:
     return torch.cat(xs), torch.cat(xps)
 
 
+def load_tosses(path: str) -> List[Tensor]:
+    """The trajectories of a toss data set stored as one array file (``states`` (sum T, n_x), ``lengths`` (n,)): the layout
+    ``assets/contactnets_cube_tosses.npz`` keeps the reference's 550 real cube tosses in (``assets/contactnets_cube/N.pt``
+    there, ``file_utils.py``: one ``(T, 13)`` tensor per toss)."""
+    import numpy as np
+    data = np.load(path)
+    states, lengths = torch.tensor(data['states']), data['lengths']
+    assert int(lengths.sum()) == states.shape[0]
+    return list(torch.split(states, [int(n) for n in lengths]))
+
+
 def slice_windows(trajectories: Iterable[Tensor], t_prediction: int) -> Tuple[Tensor, Tensor]:
     """The same slicing with a prediction horizon (``dataset_management.py:43-59`` with ``t_skip=0,
     t_history=1``): ``x_past (S, 1, n_x)`` and ``x_future (S, t_prediction, n_x)`` for every start index

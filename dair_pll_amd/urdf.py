@@ -66,6 +66,9 @@ class ModelSpec:
     # no joint connects and no collision filter group excludes (what Drake's GetCollisionCandidates keeps beyond the
     # ground pairs, drake_utils.py:178-184), the pair ordered by geometry type as the reference orders it
     pairs: List[Tuple[int, int]] = field(default_factory=list)
+    # links folded into another by a `fixed` joint: name -> name of the link that stands for it (collision filter groups
+    # may still name them)
+    welded: dict = field(default_factory=dict)
 
     @property
     def n_joints(self) -> int:
@@ -226,15 +229,18 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
     joints = []
     children = set()
     for joint in root.findall('joint'):
-        if joint.get('type') not in ('continuous', 'revolute', 'prismatic'):  # (limits are not modelled, as in the reference)
+        if joint.get('type') not in ('continuous', 'revolute', 'prismatic', 'fixed'):  # (limits are not modelled, as in the reference)
             raise NotImplementedError(f'joint type {joint.get("type")!r} is not supported')
         j_origin = joint.find('origin')
         axis = _vec(joint.find('axis').get('xyz')) if joint.find('axis') is not None else [1.0, 0.0, 0.0]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((joint.find('parent').get('link'), joint.find('child').get('link'),
                        _vec(j_origin.get('xyz') if j_origin is not None else None), [a / norm for a in axis],
-                       _rotation(j_origin), 'prismatic' if joint.get('type') == 'prismatic' else 'revolute'))
+                       _rotation(j_origin), joint.get('type') if joint.get('type') in ('prismatic', 'fixed') else 'revolute'))
         children.add(joints[-1][1])
+    welded = {}
+    joints = _weld_fixed_joints(by_name, order, joints, welded)
+    children = {child for _, child, *_ in joints}
     roots = [name for name in order if name not in children]
     if len(roots) != 1:
         raise ValueError('expected exactly one root link per URDF (dair_pll/drake_utils.py:309-335)')
@@ -251,9 +257,63 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
                 chain.append(child)
     if len(chain) != len(order):
         raise ValueError('disconnected links')
-    spec = ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain])
+    spec = ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain], welded=welded)
     spec.pairs = _collision_candidates(root, spec)
     return spec
+
+
+def _weld_fixed_joints(by_name, order, joints, welded):
+    """A `fixed` joint welds its child to its parent: the two links are ONE rigid body.  Drake keeps a welded link as a
+    body of its own (with inertial parameters of its own: the reference would learn them separately,
+    multibody_terms.py:161-207); the kernels' bodies are the links that move against each other, so here the child is folded
+    into its parent at parse time -- mass, centre of mass and central inertia combined (parallel axes), its collision
+    geometries and the joints hanging off it re-expressed in the parent's frame -- and the parent's learnable inertia stands
+    for both (a documented deviation of the parameter tree, not of the dynamics).  Returns the remaining joints."""
+    def central(body):
+        ixx, iyy, izz, ixy, ixz, iyz = body.inertia_cm
+        return [[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]
+
+    def shifted(inertia, mass, offset):  # inertia about a point displaced by `offset` from the centre of mass
+        d2 = sum(o * o for o in offset)
+        return [[inertia[i][j] + mass * ((d2 if i == j else 0.0) - offset[i] * offset[j]) for j in range(3)] for i in range(3)]
+
+    pending = [j for j in joints if j[5] == 'fixed']
+    joints = [j for j in joints if j[5] != 'fixed']
+    while pending:
+        # innermost first: a weld whose child carries no further weld
+        pick = next(j for j in pending if not any(other[0] == j[1] for other in pending))
+        pending.remove(pick)
+        parent_name, child_name, origin, _, rotation, _ = pick
+        parent, child = by_name[parent_name], by_name[child_name]
+        com_child = [origin[i] + sum(rotation[i][k] * child.com[k] for k in range(3)) for i in range(3)]
+        inertia_child = _matmul(_matmul(rotation, central(child)), _transpose(rotation))
+        mass = parent.mass + child.mass
+        com = [(parent.mass * parent.com[i] + child.mass * com_child[i]) / mass for i in range(3)]
+        total = [[a + b for a, b in zip(ra, rb)] for ra, rb in zip(
+            shifted(central(parent), parent.mass, [com[i] - parent.com[i] for i in range(3)]),
+            shifted(inertia_child, child.mass, [com[i] - com_child[i] for i in range(3)]))]
+        parent.mass, parent.com = mass, com
+        parent.inertia_cm = [total[0][0], total[1][1], total[2][2], total[0][1], total[0][2], total[1][2]]
+        for geom in child.geoms:
+            geom.origin = [origin[i] + sum(rotation[i][k] * geom.origin[k] for k in range(3)) for i in range(3)]
+            geom.rotation = _matmul(rotation, geom.rotation)
+            parent.geoms.append(geom)
+        moved = []
+        for j_parent, j_child, j_origin, j_axis, j_rotation, j_kind in joints + pending:
+            if j_parent == child_name:  # a joint that hung off the welded link now hangs off its parent
+                j_origin = [origin[i] + sum(rotation[i][k] * j_origin[k] for k in range(3)) for i in range(3)]
+                j_rotation = _matmul(rotation, j_rotation)
+                j_parent = parent_name
+            moved.append((j_parent, j_child, j_origin, j_axis, j_rotation, j_kind))
+        joints = [j for j in moved if j[5] != 'fixed']
+        pending = [j for j in moved if j[5] == 'fixed']
+        order.remove(child_name)
+        del by_name[child_name]
+        welded[child_name] = parent_name
+        for name, target in list(welded.items()):
+            if target == child_name:
+                welded[name] = parent_name
+    return joints
 
 
 def _collision_candidates(root, spec: ModelSpec) -> List[Tuple[int, int]]:
@@ -261,6 +321,7 @@ def _collision_candidates(root, spec: ModelSpec) -> List[Tuple[int, int]]:
     ``drake:collision_filter_group`` lists under ``drake:ignored_collision_filter_group``
     (``assets/contactnets_elbow.urdf:74-78`` of the reference)."""
     index = {body.name: i for i, body in enumerate(spec.bodies)}
+    index.update({name: index[target] for name, target in spec.welded.items()})
     groups, ignores = {}, []
     for element in root:
         if element.tag.endswith('collision_filter_group'):

@@ -466,6 +466,22 @@ def record_slice_fixture(name: str = 'cube_trajectories_0_2') -> None:
     print(f'{name}: {x.shape[0]} pairs, {out["window3/x_past"].shape[0]} windows of 3')
 
 
+def record_cube_tosses(name: str = 'contactnets_cube_tosses') -> None:
+    """The reference's whole cube-toss data set (assets/contactnets_cube/{0..549}.pt: 550 real tosses, (T, 13) float64
+    states, T in [85, 139]; SURVEY section 2 row 22 -- data, not code) as ONE array file under assets/: the states of all
+    trajectories one after the other plus their lengths.  `trainer.load_tosses` cuts it back into trajectories; the f1 demo
+    (examples/contactnets_cube.py) and bench.py's training configuration run on its 57,812 (x, x+) pairs."""
+    states, lengths = [], []
+    for index in range(550):
+        trajectory = torch.load(os.path.join(ASSETS, 'contactnets_cube', f'{index}.pt')).numpy()
+        assert trajectory.ndim == 2 and trajectory.shape[1] == 13 and trajectory.dtype == np.float64
+        states.append(trajectory)
+        lengths.append(trajectory.shape[0])
+    np.savez_compressed(os.path.join(REPO, 'assets', name + '.npz'), states=np.concatenate(states), lengths=np.array(lengths, dtype=np.int32),
+                        dt=np.float64(DT))
+    print(f'{name}: {len(lengths)} trajectories, {sum(lengths)} states, {sum(lengths) - len(lengths)} pairs')
+
+
 def record_dynamics_gradients(name: str = 'dynamics_gradients') -> None:
     """gradients THROUGH the reference's own ``forward_dynamics`` / ``VelocityIntegrator.step`` /
     ``Integrator.simulate`` (multibody_learnable_system.py:293-304, experiment.py:292-320) by torch autograd, with

@@ -357,3 +357,68 @@ def test_learned_shapes_on_a_general_tree_are_described_for_the_general_build():
     mesh = system._mesh_struct(flat)
     assert len(mesh) == _capi.MAX_GEOMS and mesh[2].hidden_weight is None
     assert mesh[1].hidden_weight == flat.data_ptr() + (head + per_net) * flat.element_size()
+
+
+def test_whole_toss_data_set_is_the_references():
+    """assets/contactnets_cube_tosses.npz: 550 tosses, 58,362 states, 57,812 pairs; its first three
+    trajectories are the raw files the slice fixture was recorded from, and slice_pairs of them gives the reference's pairs"""
+    from dair_pll_amd.trainer import load_tosses, slice_pairs
+    tosses = load_tosses(os.path.join(ASSET_DIR, 'contactnets_cube_tosses.npz'))
+    assert len(tosses) == 550 and sum(t.shape[0] for t in tosses) == 58362 and all(t.shape[1] == 13 and t.dtype == torch.float64 for t in tosses)
+    assert min(t.shape[0] for t in tosses) == 85 and max(t.shape[0] for t in tosses) == 139
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_trajectories_0_2.npz'))
+    for index in range(3):
+        assert np.array_equal(tosses[index].numpy(), g[f'trajectory/{index}'])
+    x, xp = slice_pairs(tosses)
+    assert x.shape == (57812, 13)
+    n = g['x'].shape[0]
+    assert np.array_equal(x[:n].numpy(), g['x']) and np.array_equal(xp[:n].numpy(), g['x_plus'])
+    # the 4096-pair benchmark fixture is a subset of these pairs
+    bench = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_4096.npz'))
+    rows = {row.tobytes() for row in x.numpy()}
+    assert all(row.tobytes() in rows for row in bench['x'][:64])
+
+
+def test_fixed_joints_weld_links_into_one_body(tmp_path):
+    """a `fixed` joint folds its child into its parent at parse time: composite mass / centre of mass /
+    central inertia by parallel axes, the child's collision geometry and the joint hanging off it re-expressed in the
+    parent's frame, collision filter groups that name the welded link still resolve"""
+    urdf = """<?xml version="1.0"?>
+<robot name="welded" xmlns:drake="https://drake.mit.edu/">
+  <link name="base"><inertial><origin xyz="0.01 0 0"/><mass value="0.3"/><inertia ixx="2e-4" iyy="3e-4" izz="4e-4" ixy="1e-5" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0 0 0"/><geometry><box size="0.1 0.06 0.04"/></geometry><drake:proximity_properties><drake:mu_static value="0.3"/></drake:proximity_properties></collision></link>
+  <link name="bracket"><inertial><origin xyz="0 0.02 0.01"/><mass value="0.1"/><inertia ixx="5e-5" iyy="2e-5" izz="6e-5" ixy="0" ixz="1e-6" iyz="0"/></inertial>
+    <collision><origin xyz="0.01 0 0" rpy="0 0 0.3"/><geometry><sphere radius="0.02"/></geometry><drake:proximity_properties><drake:mu_static value="0.2"/></drake:proximity_properties></collision></link>
+  <link name="arm"><inertial><origin xyz="0.03 0 0"/><mass value="0.05"/><inertia ixx="1e-5" iyy="2e-5" izz="2e-5" ixy="0" ixz="0" iyz="0"/></inertial>
+    <collision><origin xyz="0.03 0 0"/><geometry><box size="0.06 0.02 0.02"/></geometry><drake:proximity_properties><drake:mu_static value="0.25"/></drake:proximity_properties></collision></link>
+  <joint name="weld" type="fixed"><parent link="base"/><child link="bracket"/><origin xyz="0.05 0.01 0.02" rpy="0.2 -0.1 0.4"/></joint>
+  <joint name="hinge" type="continuous"><parent link="bracket"/><child link="arm"/><origin xyz="0 0.03 0" rpy="0 0 0"/><axis xyz="0 1 0"/></joint>
+  <drake:collision_filter_group name="g"><drake:member link="bracket"/><drake:member link="arm"/><drake:ignored_collision_filter_group name="g"/></drake:collision_filter_group>
+</robot>"""
+    path = tmp_path / 'welded.urdf'
+    path.write_text(urdf)
+    spec = parse_urdf(str(path))
+    assert [b.name for b in spec.bodies] == ['base', 'arm'] and spec.n_joints == 1 and spec.welded == {'bracket': 'base'}
+    from dair_pll_amd.urdf import _rotation
+    import xml.etree.ElementTree as ET
+    R = np.array(_rotation(ET.fromstring('<origin rpy="0.2 -0.1 0.4"/>')))
+    o = np.array([0.05, 0.01, 0.02])
+    m_a, c_a, I_a = 0.3, np.array([0.01, 0, 0]), np.array([[2e-4, 1e-5, 0], [1e-5, 3e-4, 0], [0, 0, 4e-4]])
+    m_b, c_b, I_b = 0.1, o + R @ np.array([0, 0.02, 0.01]), R @ np.array([[5e-5, 0, 1e-6], [0, 2e-5, 0], [1e-6, 0, 6e-5]]) @ R.T
+    m = m_a + m_b
+    c = (m_a * c_a + m_b * c_b) / m
+    shift = lambda I, mass, d: I + mass * (d @ d * np.eye(3) - np.outer(d, d))
+    I = shift(I_a, m_a, c - c_a) + shift(I_b, m_b, c - c_b)
+    base = spec.bodies[0]
+    assert abs(base.mass - m) < 1e-15 and np.abs(np.array(base.com) - c).max() < 1e-15
+    ixx, iyy, izz, ixy, ixz, iyz = base.inertia_cm
+    assert np.abs(np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]) - I).max() < 1e-16
+    # the bracket's sphere now sits on the base, the hinge hangs off the base
+    assert [g.kind for g in base.geoms] == ['box', 'sphere']
+    assert np.abs(np.array(base.geoms[1].origin) - (o + R @ np.array([0.01, 0, 0]))).max() < 1e-15
+    assert np.abs(np.array(spec.bodies[1].joint_origin) - (o + R @ np.array([0, 0.03, 0]))).max() < 1e-15
+    assert np.abs(np.array(spec.bodies[1].joint_rotation) - R).max() < 1e-15 and spec.bodies[1].parent == 0
+    # arm is the child of the body the bracket became: no candidate between them; the filter group resolved the welded name
+    assert spec.pairs == []
+    system = MultibodyLearnableSystem({'welded': str(path)}, 0.0068, device='cpu')
+    assert system.space.n_x == 15 and system.multibody_terms.lagrangian_terms.inertial_parameters.shape == (2, 10)
