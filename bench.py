@@ -192,7 +192,7 @@ class Timer:
         return 'eager' + (f' (hipGraph capture failed: {self.capture_error})' if self.capture_error else '')
 
 
-def loss_roofline(system, workload, dtype, batch, x, xp):
+def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
     if workload in ('elbow_mesh', 'clasp', 'slider', 'clasp_mesh'):
@@ -205,6 +205,8 @@ def loss_roofline(system, workload, dtype, batch, x, xp):
         dominant = max(gemms, key=gemms.get)
         flops = 2.0 * (4 * batch) * 256 * 256
         tflops = flops / (gemms[dominant] * 1e-3) / 1e12
+        # (split-bf16 forms: still priced against the f32 matrix rate -- the algorithmic work is the f32 GEMM; the bf16
+        # cores do 3 or 6 products per f32 product, which is how the fraction can pass the f32 form's ceiling)
         peak = MFMA_F32_PEAK_TFLOPS if dtype == 'f32' else VALU_F64_PEAK_TFLOPS
         return {'bound': 'mfma', 'achieved': tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tflops / peak,
                 'traffic': None, 'kernel': dominant, 'kernel_ms': gemms[dominant],
@@ -248,11 +250,13 @@ def build_system(workload, dtype_name, dt, device):
     return MultibodyLearnableSystem({workload: os.path.join(REPO, 'assets', URDF[workload])}, dt, dtype=dtype, device=str(device))
 
 
-def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device, use_graph=True, steps_per_graph=50):
+def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device, use_graph=True, steps_per_graph=50, mesh_gemm=0):
     """one single-GPU configuration of the loss path: value, step time, roofline"""
     dtype = torch.float32 if dtype_name == 'f32' else torch.float64
     x_np, xp_np, dt = load_pairs(batch, 0, workload)
     system = build_system(workload, dtype_name, dt, device)
+    if mesh_gemm:  # the ICNN GEMMs on the bf16 matrix cores, operands split into bf16 planes (csrc/dpll_mesh_bf16.hpp)
+        system.set_solver(mesh_gemm=mesh_gemm)
     x, xp = torch.tensor(x_np, dtype=dtype, device=device), torch.tensor(xp_np, dtype=dtype, device=device)
     step = lambda: system.contactnets_loss_and_grad(x, xp)
     for _ in range(3):
@@ -260,7 +264,7 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
     torch.cuda.synchronize()
     timer = Timer(step, steps, warmup, use_graph, steps_per_graph, torch.cuda.synchronize, lambda t: t)
     elapsed, times = timer.measure(repeats)
-    roof = loss_roofline(system, workload, dtype_name, batch, x, xp)
+    roof = loss_roofline(system, workload, dtype_name, batch, x, xp, mesh_gemm)
     if roof is None:  # whole-step roofline (an upper bound on every kernel's time, so a lower bound on its fraction)
         step_ms = elapsed / steps * 1e3
         if workload == 'elbow_mesh':  # 2 networks x 4 GEMMs of (4 batch) x 256 x 256 (per link)
@@ -275,6 +279,8 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
             gbs = bytes_per_step(workload, dtype_name) * batch / (step_ms * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                     'kernel': 'gen_loss_kernel + row fold + finalize (general build: one lane per contact slot)', 'kernel_ms': step_ms}
+    if mesh_gemm:
+        workload = f'{workload} (ICNN GEMMs: bf16 matrix cores, operands split into {mesh_gemm} bf16 planes)'
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
             'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
@@ -561,6 +567,10 @@ def main() -> None:
                     configs.append(run_simulate_config(w, d, b, h, 5, device))
                 except Exception as exc:  # noqa: BLE001
                     configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
+            try:
+                configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=2))
+            except Exception as exc:  # noqa: BLE001
+                configs.append({'workload': 'mesh (bf16 planes)', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
             for fused in (False, True):
                 try:
                     configs.append(run_train_config('f32', 4096, 400, device, fused))

@@ -44,7 +44,7 @@ class SolverOpts(ctypes.Structure):
                 ('ls_tol', c_double), ('n_stages', c_int32), ('stage_max_iter', c_int32), ('stage_factor', c_double),
                 ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('fast_ls', c_int32),
                 ('warm_start', c_int32), ('wide', c_int32), ('loss_stage_factor', c_double), ('loss_n_stages', c_int32),
-                ('f64_refine', c_int32)]
+                ('f64_refine', c_int32), ('mesh_gemm', c_int32), ('reserved_', c_int32)]
 
 
 class Params(ctypes.Structure):

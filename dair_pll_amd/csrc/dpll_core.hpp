@@ -893,6 +893,10 @@ struct SolverOpts {
   int loss_n_stages;
   // double-precision solves: 1 = float iterations refined in double (sap_solve), 0 = every iteration in double
   int f64_refine;
+  // float mesh pipeline: form of the ICNN GEMM kernels -- 0 = v_mfma_f32_32x32x2_f32 (exact f32; default), 2 / 3 = the bf16
+  // matrix cores on operands split into 2 / 3 bf16 planes (csrc/dpll_mesh_bf16.hpp)
+  int mesh_gemm;
+  int reserved_;
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag

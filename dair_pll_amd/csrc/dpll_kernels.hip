@@ -74,6 +74,7 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
 #include "dpll_genmesh.hpp"
 #include "dpll_gjk.hpp"
 #include "dpll_mesh_kernels.hpp"
+#include "dpll_mesh_bf16.hpp"
 namespace {
 
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
@@ -605,6 +606,7 @@ SolverOpts default_opts(int dtype, int n_joints = 0, bool general = false) {
   o.loss_n_stages = (!general && n_joints == 1) ? 5 : 0;
   o.loss_stage_factor = 2.5;
   o.f64_refine = 1;
+  o.mesh_gemm = 0;
   return o;
 }
 
@@ -801,7 +803,7 @@ struct MeshPlan {
   long long N, n_tiles;
   int n_nets, loss_blocks, gemm_blocks, b1_blocks, n_slabs, row_stride;
   // one block of buffers per network (offsets relative to the block): the backward of a network needs its own forward
-  size_t off_A, off_AT, off_Af, off_ATf, off_a, off_M1, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
+  size_t off_A, off_AT, off_Af, off_ATf, off_Ab, off_ATb, off_a, off_M1, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
   // shared: support points / their adjoints of all networks (batch, 4 n_nets, 3), the loss kernel's rows + chain matrix,
   // the bodies' world quaternions (batch, n_nets, 4; only for n_nets > 1)
   size_t off_P, off_RB, off_rows, off_bq, off_nets, total;
@@ -826,6 +828,8 @@ template <typename T> void plan_network_block(MeshPlan& pl, long long N) {
   pl.off_AT = take(sizeof(T) * kW * kW);
   pl.off_Af = take(kMfma ? sizeof(T) * kW * kW : 0);   // the same two matrices in the MFMA kernels' fragment order
   pl.off_ATf = take(kMfma ? sizeof(T) * kW * kW : 0);
+  pl.off_Ab = take(kMfma ? 2 * 3 * kW * kW : 0);       // ... and as up to three bf16 planes (dpll_mesh_bf16.hpp)
+  pl.off_ATb = take(kMfma ? 2 * 3 * kW * kW : 0);
   pl.off_a = take(sizeof(T) * kW);
   pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
   pl.off_U0 = take(sizeof(T) * kW * pl.N);
@@ -913,6 +917,10 @@ int mesh_body_quats(const dpll_model* m, const MeshPlan& pl, char* ws, const T* 
   return check_launch("mesh_body_quat_kernel");
 }
 
+// which form of the float GEMM kernels a call uses: 0 = v_mfma_f32_32x32x2_f32 (exact f32, the default), 2 / 3 = bf16 matrix
+// cores on operands split into 2 / 3 bf16 planes (dpll_solver_opts_t.mesh_gemm); set by the C entry points
+thread_local int t_mesh_gemm = 0;
+
 // forward half of network g: prep + the two forward GEMMs -> its support points (and M1, U0 for the backward half)
 template <typename T>
 int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, hipStream_t stream,
@@ -922,17 +930,40 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
   // (`points`: where this launch's support points go when it is not the shared (batch, 4 n_nets, 3) array)
   T* P = points ? points : (T*)(ws + pl.off_P) + 12 * g;
   constexpr bool kMfmaPath = std::is_same<T, float>::value;
-  if (prep)  // (|W| in GEMM order: only the weights enter, so the steps of a rollout after the first skip it)
+  bool split_prep = false;  // (|W| in GEMM order: only the weights enter, so the steps of a rollout after the first skip it)
+  if constexpr (std::is_same<T, float>::value) {
+    split_prep = t_mesh_gemm != 0;  // the bf16 forms read their own planes (and |wout|): nothing of the f32 layouts
+    if (prep && t_mesh_gemm == 2)
+      hipLaunchKernelGGL((icnn_prep_bf16_kernel<2>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + pl.off_Ab), (__bf16*)(nb + pl.off_ATb), (float*)a);
+    if (prep && t_mesh_gemm == 3)
+      hipLaunchKernelGGL((icnn_prep_bf16_kernel<3>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + pl.off_Ab), (__bf16*)(nb + pl.off_ATb), (float*)a);
+  }
+  if (prep && !split_prep)
     hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
                        kMfmaPath ? (T*)(nb + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + pl.off_ATf) : (T*)nullptr);
   mesh_mark(stream);
   if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
-                       (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1));
-    mesh_mark(stream);
-    hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
-                       (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
-                       (float*)P, for_backward ? (float*)(nb + pl.off_U1) : (float*)nullptr);
+    float* U1t = for_backward ? (float*)(nb + pl.off_U1) : (float*)nullptr;
+#define DPLL_FWD_BF16(PL_)                                                                                                         \
+    do {                                                                                                                          \
+      hipLaunchKernelGGL((icnn_fwd1_bf16<PL_>), dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,                   \
+                         (const __bf16*)(nb + pl.off_Ab), (uint32_t*)(nb + pl.off_M1));                                           \
+      mesh_mark(stream);                                                                                                          \
+      hipLaunchKernelGGL((icnn_fwd2_bf16<PL_>), dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,                   \
+                         (const __bf16*)(nb + pl.off_ATb), (const float*)a, (const uint32_t*)(nb + pl.off_M1),                    \
+                         (float*)(nb + pl.off_U0), (float*)P);                                                                    \
+    } while (0)
+    if (t_mesh_gemm == 2) DPLL_FWD_BF16(2);
+    else if (t_mesh_gemm == 3) DPLL_FWD_BF16(3);
+    else {
+      hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
+                         (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1));
+      mesh_mark(stream);
+      hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
+                         (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
+                         (float*)P, U1t);
+    }
+#undef DPLL_FWD_BF16
   } else {
     hipLaunchKernelGGL((icnn_fwd1_kernel<T>), dim3(pl.gemm_blocks), dim3(256), 0, stream, q.ptr, q.ld, pl.N, w, (const T*)A,
                        (uint32_t*)(nb + pl.off_M1));
@@ -952,13 +983,28 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
   char* nb = pl.net(ws, g);
   const T* RB = adjoints ? adjoints : (const T*)(ws + pl.off_RB) + 12 * g;
   if constexpr (std::is_same<T, float>::value) {
-    hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
-                       (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
-                       (const float*)(nb + pl.off_U0), (const float*)RB, (double*)(nb + pl.off_b1),
-                       (float*)(nb + pl.off_Vb));
-    mesh_mark(stream);
-    hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
-                       (const float*)(nb + pl.off_Vb), (const float*)(nb + pl.off_U1), (float*)(nb + pl.off_slabs));
+#define DPLL_BWD_BF16(PL_)                                                                                                         \
+    do {                                                                                                                          \
+      hipLaunchKernelGGL((icnn_bwd1_bf16<PL_>), dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,       \
+                         (const __bf16*)(nb + pl.off_Ab), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),       \
+                         (const float*)(nb + pl.off_U0), (const float*)RB, (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb));  \
+      mesh_mark(stream);                                                                                                          \
+      hipLaunchKernelGGL((icnn_bwd2_bf16<PL_>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,                           \
+                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),        \
+                         (float*)(nb + pl.off_slabs));                                                                            \
+    } while (0)
+    if (t_mesh_gemm == 2) DPLL_BWD_BF16(2);
+    else if (t_mesh_gemm == 3) DPLL_BWD_BF16(3);
+    else {
+      hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
+                         (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
+                         (const float*)(nb + pl.off_U0), (const float*)RB, (double*)(nb + pl.off_b1),
+                         (float*)(nb + pl.off_Vb));
+      mesh_mark(stream);
+      hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
+                         (const float*)(nb + pl.off_Vb), (const float*)(nb + pl.off_U1), (float*)(nb + pl.off_slabs));
+    }
+#undef DPLL_BWD_BF16
   } else {
     hipLaunchKernelGGL((icnn_bwd1_kernel<T>), dim3(pl.b1_blocks), dim3(256), 0, stream, (const T*)q.ptr, q.ld, pl.N, w,
                        (const T*)(nb + pl.off_A), (const T*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
@@ -1210,6 +1256,12 @@ int genmesh_hulls(const dpll_model* m, int dtype, const GenMeshPlan& gp, const d
       constexpr bool kMfmaPath = std::is_same<T, float>::value;
       hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (T*)(nb + p296.off_A), (T*)(nb + p296.off_AT),
                          (T*)(nb + p296.off_a), kMfmaPath ? (T*)(nb + p296.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + p296.off_ATf) : (T*)nullptr);
+      if constexpr (kMfmaPath) {
+        if (t_mesh_gemm == 2)
+          hipLaunchKernelGGL((icnn_prep_bf16_kernel<2>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + p296.off_Ab), (__bf16*)(nb + p296.off_ATb), (float*)(nb + p296.off_a));
+        if (t_mesh_gemm == 3)
+          hipLaunchKernelGGL((icnn_prep_bf16_kernel<3>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + p296.off_Ab), (__bf16*)(nb + p296.off_ATb), (float*)(nb + p296.off_a));
+      }
       if (int rc = check_launch("icnn_prep_kernel")) return rc;
     }
   }
@@ -1477,6 +1529,8 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
   if (opts->max_iter < 1 || opts->max_ls < 1 || opts->n_stages < 1 || opts->stage_max_iter < 1 || opts->stage_max_ls < 1 || !(opts->stage_factor >= 1.0))
     return fail(-1, "dpll_model_set_solver: iteration limits must be >= 1%s");
   if (opts->wide < -1 || opts->wide > 1) return fail(-1, "dpll_model_set_solver: wide must be -1, 0 or 1%s");
+  if (opts->mesh_gemm != 0 && opts->mesh_gemm != 2 && opts->mesh_gemm != 3)
+    return fail(-1, "dpll_model_set_solver: mesh_gemm must be 0 (f32 MFMA), 2 or 3 (bf16 planes)%s");
   if (opts->loss_n_stages < 0 || (opts->loss_n_stages > 0 && !(opts->loss_stage_factor >= 1.0)))
     return fail(-1, "dpll_model_set_solver: loss_n_stages >= 0 and, when set, loss_stage_factor >= 1%s");
   std::memcpy(&model->opts[dtype], opts, sizeof(SolverOpts));
@@ -1649,6 +1703,7 @@ int check_mesh_call(const dpll_model_t* model, int dtype, const dpll_params_t* p
   if (!model) return fail(-1, "%s: null model", who);
   if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "%s: bad dtype", who);
   if (params && (!params->theta || !params->friction)) return fail(-1, "%s: null parameter pointer", who);
+  t_mesh_gemm = dtype == DPLL_F32 ? model->opts[DPLL_F32].mesh_gemm : 0;  // (the float64 path has no matrix-core form)
   return check_mesh(model, mesh, who);
 }
 }  // namespace

@@ -311,6 +311,16 @@ __device__ __forceinline__ void reduce_strided4(const S* __restrict__ base, long
   // summands first, first + 16, ... < n of 4 consecutive columns; unrolled by 4 so that 4 vector loads are in flight
   struct alignas(4 * sizeof(S)) V4 { S v[4]; };
   int s = first;
+  // eight vector loads in flight (the 256 partial rows of icnn_bwd1 are 16 summands per thread: two round trips, not four)
+  for (; s + 7 * kRedGroups < n; s += 8 * kRedGroups) {
+    V4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const V4*)(base + (long long)(s + u * kRedGroups) * stride);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[i] += ((double(v[0].v[i]) + double(v[1].v[i])) + (double(v[2].v[i]) + double(v[3].v[i]))) +
+                ((double(v[4].v[i]) + double(v[5].v[i])) + (double(v[6].v[i]) + double(v[7].v[i])));
+  }
   for (; s + 3 * kRedGroups < n; s += 4 * kRedGroups) {
     const V4 a = *(const V4*)(base + (long long)s * stride);
     const V4 b = *(const V4*)(base + (long long)(s + kRedGroups) * stride);
@@ -350,10 +360,20 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
     const int col0 = c0 < 3 * kW ? 4 * kW + c0 : (c0 < 6 * kW ? kW + (c0 - 3 * kW) : c0 - 6 * kW);
     reduce_strided4<double>(b1 + col0 + 4 * cg, (long long)kB1Cols, b1_blocks, sg, acc);
   } else if (grad_head && cg < 8) {  // head: up to 32 columns of the loss kernel's rows = 8 column groups (scalar loads: odd strides)
-    for (int r = sg; r < n_rows; r += kRedGroups)
+    // (clamped addresses, eight rows' loads in flight, the values masked afterwards: a 256-row launch is two round trips)
+    for (int r0 = sg; r0 < n_rows; r0 += 8 * kRedGroups) {
+      double v[8][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (4 * cg + i < kCols) acc[i] += rows[(long long)r * row_stride + 4 * cg + i];
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u * kRedGroups < n_rows ? r0 + u * kRedGroups : n_rows - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[u][i] = rows[(long long)r * row_stride + (4 * cg + i < kCols ? 4 * cg + i : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += (r0 + u * kRedGroups < n_rows && 4 * cg + i < kCols) ? v[u][i] : 0.0;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) red[sg][4 * cg + i] = acc[i];

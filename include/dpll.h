@@ -110,6 +110,9 @@ typedef struct dpll_solver_opts {
   double loss_stage_factor; /* continuation schedule of the loss solve (eps 1e-3) when it differs from the dynamics solve's */
   int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves */
   int32_t f64_refine;       /* DPLL_F64 solves: 1 = float iterations refined in double to `tol` (default), 0 = all double */
+  int32_t mesh_gemm;        /* DPLL_F32 mesh pipeline, ICNN GEMMs: 0 = f32 MFMA (exact f32, default), 2 / 3 = bf16 matrix cores on
+                               operands split into 2 / 3 bf16 planes (3: f32-grade accuracy, 2: 2^-16 per product) */
+  int32_t reserved_;
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;

@@ -369,3 +369,47 @@ def test_two_learned_shapes_on_random_states_against_the_oracle(golden):
         ref = ref_named[name].grad
         err = (param.grad.cpu() - ref).abs().max().item()
         assert err <= 1e-8 * max(ref.abs().max().item(), 1e-3), (name, err)
+
+
+@pytest.mark.parametrize('case', CASES + [CLASP])
+@pytest.mark.parametrize('mode', [2, 3])
+def test_split_bf16_gemm_forms_meet_the_float32_tolerances(golden, case, mode):
+    """dpll_solver_opts_t.mesh_gemm: the ICNN GEMMs on the bf16 matrix cores with the operands split into 2 planes (three
+    products per k-step, "bf16 x 3") or 3 planes (six products, f32-grade) -- csrc/dpll_mesh_bf16.hpp.  The float32
+    tolerances of the default (exact f32 MFMA) kernels hold for both against the reference-run fixtures."""
+    g = golden(case)
+    system = build_general(g, torch.float32) if case == CLASP else build(g, torch.float32)
+    system.set_solver(mesh_gemm=mode)
+    x = torch.tensor(g['x'], dtype=torch.float32, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=torch.float32, device='cuda:0')
+    loss = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp)
+    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < 1e-4
+    loss.mean().backward()
+    for name, param in system.named_parameters():
+        ref = g['grad/' + name]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= 2e-3 * max(np.abs(ref).max(), 1e-12), (name, err, np.abs(ref).max())
+    tol = 1e-4 * max(1.0, np.abs(g['dynamics/x_next']).max())
+    assert np.abs(system.step(x).detach().cpu().double().numpy() - g['dynamics/x_next']).max() < tol
+
+
+def test_split_bf16_gemm_forms_on_the_benchmark_batch(golden):
+    """4096 pairs: support points that land on another vertex of the learned shape (a LeakyReLU mask flipped) and the loss /
+    gradient differences against the float64 kernels, for the three GEMM forms (the numbers of DESIGN.md 5a)"""
+    g = golden('cube_mesh_literal')
+    big = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'cube_box_4096.npz'))
+    x64, xp64 = torch.tensor(big['x'], device='cuda:0'), torch.tensor(big['x_plus'], device='cuda:0')
+    s64 = build(g, torch.float64)
+    p64 = s64.support_points(xp64).cpu().numpy()
+    t64 = s64.contactnets_loss_and_grad(x64, xp64).item()
+    g64 = {n: p.grad.cpu().numpy().copy() for n, p in s64.named_parameters()}
+    for mode, flips_allowed, grad_tol in ((0, 2e-4, 2e-5), (3, 2e-4, 2e-5), (2, 1e-3, 5e-4)):
+        s32 = build(g, torch.float32)
+        if mode:
+            s32.set_solver(mesh_gemm=mode)
+        p32 = s32.support_points(xp64.float()).cpu().double().numpy()
+        assert (np.abs(p64 - p32).max(-1) > 1e-5).mean() <= flips_allowed, mode
+        t32 = s32.contactnets_loss_and_grad(x64.float(), xp64.float()).item()
+        assert abs(t64 - t32) < 1e-6 * max(1.0, abs(t64)), mode
+        for n, p in s32.named_parameters():
+            assert np.abs(p.grad.cpu().double().numpy() - g64[n]).max() <= grad_tol * max(np.abs(g64[n]).max(), 1e-12), (mode, n)
