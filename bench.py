@@ -382,6 +382,8 @@ def main() -> None:
     parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
     parser.add_argument('--workload', choices=['cube', 'elbow', 'mesh'], default='cube',
                         help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]; mesh = configs[3]')
+    parser.add_argument('--mesh-gemm', type=int, choices=[0, 2, 3], default=0,
+                        help='mesh workload: form of the ICNN GEMM kernels (0 = f32 MFMA, 2 / 3 = bf16 matrix cores on 2 / 3 bf16 planes)')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     parser.add_argument('--steps-per-graph', type=int, default=50,
                         help='steps captured per hipGraph (amortises the ~10 us replay floor); the timed region '
@@ -447,6 +449,8 @@ def main() -> None:
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     x_np, xp_np, dt = load_pairs(args.batch, seed=rank, workload=args.workload)
     system = build_system(args.workload, args.dtype, dt, device)
+    if args.mesh_gemm and args.workload == 'mesh':
+        system.set_solver(mesh_gemm=args.mesh_gemm)
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
 
@@ -520,7 +524,7 @@ def main() -> None:
             dist.destroy_process_group()
         raise SystemExit(1)
 
-    roof = loss_roofline(system, args.workload, args.dtype, args.batch, x, xp)
+    roof = loss_roofline(system, args.workload, args.dtype, args.batch, x, xp, args.mesh_gemm)
     total = system.contactnets_loss_and_grad(x, xp)
     if reducer is not None:
         total = reducer.all_reduce_mean()[:1]

@@ -2210,13 +2210,14 @@ template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class M
 DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
                                 const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3] = nullptr,
-                                const T (*pair_dir)[3] = nullptr);
+                                const T (*pair_dir)[3] = nullptr, const T (*witness_a)[3] = nullptr);
 
 template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class MD, int GP>
 DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x,
                                 int first_contact, const T* xbar_next, LossGrad<T, NJ, NG, GP>& grad,
                                 const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr,
-                                T (*xbar)[13 + 2 * NJ] = nullptr) {
+                                T (*xbar)[13 + 2 * NJ] = nullptr, const MeshPairIn<T, TA, KPL>* mesh_in = nullptr,
+                                T (*rbar_a_out)[3] = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kDynamicsEps), ieps = fast_rcp(eps);
   const T* q = x;
@@ -2234,10 +2235,10 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
   T mu[KPL], qc[KPL][3];
   const T idt = T(1) / dt;
   TA pdirs[kMaxPairs][3];
-  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs);
+  const bool have_dirs = pair_find_directions<T, TA, Lanes, NJ>(md, dp, kinA, pdirs, mesh_in ? mesh_in->dirs : nullptr);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
     compute_contact<T, TA, NJ>(md, dp, t.kin, kinA, first_contact + c, cg[c], witness ? witness[c] : nullptr,
-                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c));
+                               pair_dir_of<TA>(have_dirs, pdirs, first_contact + c), mesh_in ? mesh_in->wit_a[c] : nullptr);
     Jc[c] = cg[c].J;
     mu[c] = cg[c].mu;
     T jv[3];
@@ -2297,7 +2298,8 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
         }
       }
     }
-    step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar, witness, pdir);
+    step_state_adjoint<T, TA, NJ, KPL, Lanes>(md, dp, x, first_contact, xbar_next, y, vn, sv, lam, *xbar, witness, pdir,
+                                              mesh_in ? mesh_in->wit_a : nullptr);
   }
   // ---- per-contact pieces: kappa_c, friction and witness gradients; s' = s - sum_c J_c^T kappa_c ---
   T jtk[NV];
@@ -2321,6 +2323,9 @@ DPLL_HD void step_item_backward(const MD& md, const Derived<T, NJ, NG>& dp, cons
     witness_adjoint<T, NJ>(t.kin, cg[c], ag, lam, nak, vn, -kap[2] * idt, rbar, rbar_a);
     if (rbar_out) {
       DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_out[c][i] = rbar[i];
+    }
+    if (rbar_a_out) {
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) rbar_a_out[c][i] = rbar_a[i];
     }
     add_geometry_grad(cg[c], gmu, rbar, rbar_a, grad);
   }
@@ -2361,7 +2366,7 @@ template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class M
 DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, const T* x, int first_contact,
                                 const T* xbar_next, const TA (&y)[6 + NJ], const T (&vn)[6 + NJ], const T (&sv)[6 + NJ],
                                 const T (&lam)[6 + NJ], T (&xbar)[13 + 2 * NJ], const T (*witness)[3],
-                                const T (*pair_dir)[3]) {
+                                const T (*pair_dir)[3], const T (*witness_a)[3]) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ, NX = NQ + NV;
   using S = DualT<TA>;
   Derived<S, NJ, NG> dps;
@@ -2406,9 +2411,12 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
     S phic = S(TA(0));
     DPLL_UNROLL for (int c = 0; c < KPL; ++c) {
       ContactGeom<S, NJ, MD::kGeneral> cg;
-      S wit[3] = {S(TA(0)), S(TA(0)), S(TA(0))};
+      S wit[3] = {S(TA(0)), S(TA(0)), S(TA(0))}, wit_a[3] = {S(TA(0)), S(TA(0)), S(TA(0))};
       if (witness) {
         DPLL_UNROLL for (int i = 0; i < 3; ++i) wit[i] = S(TA(witness[c][i]));
+      }
+      if (witness_a) {
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) wit_a[i] = S(TA(witness_a[c][i]));
       }
       S pd[3] = {S(TA(0)), S(TA(0)), S(TA(1))};
       const int pp = first_contact + c - kQuery * kMaxGeoms;
@@ -2416,7 +2424,8 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
       if (is_pair) {
         DPLL_UNROLL for (int i = 0; i < 3; ++i) pd[i] = S(TA(pair_dir[pp][i]));
       }
-      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg, witness ? wit : nullptr, is_pair ? pd : nullptr);
+      compute_contact<S, S, NJ>(md, dps, t.kin, kin, first_contact + c, cg, witness ? wit : nullptr, is_pair ? pd : nullptr,
+                                witness_a ? wit_a : nullptr);
       S jy[3], jv[3], jl[3];
       cjac_apply<S, S, NJ>(cg.J, ys, jy);
       cjac_apply<S, S, NJ>(cg.J, vm, jv);

@@ -62,7 +62,7 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
     return dpll_fail(-3, "dpll_step_backward: workspace too small%s");
   hipLaunchKernelGGL((gen_step_backward_kernel<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, general_desc(m), m->opts[DPLL_F64],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch,
-                     (double*)workspace, (T*)grad_x, ld_gx);
+                     (double*)workspace, (T*)grad_x, ld_gx, (const T*)nullptr, (T*)nullptr, (const double*)nullptr);
   if (int rc = dpll_check_launch("gen_step_backward_kernel")) return rc;
   return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)nullptr, stream);
 }

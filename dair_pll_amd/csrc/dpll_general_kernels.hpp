@@ -209,13 +209,14 @@ __global__ __launch_bounds__(kWave) void gen_simulate_kernel(GeneralDesc md, Sol
 }
 
 // backward of one step: parameter gradient and state adjoint (double arithmetic, as in the specialised builds)
-template <typename T, int NJ>
+template <typename T, int NJ, bool MESH = false>
 __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                                   const T* __restrict__ friction, const T* __restrict__ lengths,
                                                                   const T* __restrict__ x, long long ld_x,
                                                                   const T* __restrict__ gx, long long ld_g, long long batch,
                                                                   double* __restrict__ partials, T* __restrict__ xbar_out,
-                                                                  long long ld_xb) {
+                                                                  long long ld_xb, const T* __restrict__ wit, T* __restrict__ rbar,
+                                                                  const double* __restrict__ pdirs) {
   using D = GD<T, NJ>;
   using C = double;
   const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
@@ -244,7 +245,29 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = C(x[it * ld_x + i]); gr[i] = valid ? C(gx[it * ld_g + i]) : C(0); xb[i] = C(0); }
     // (an idle group's seed is zero, so what it adds to the sums below is zero)
-    step_item_backward<C, C, NJ, 1, GenLanes>(md, dp, opt, xr, cidx, gr, acc, nullptr, nullptr, &xb);
+    if constexpr (MESH) {
+      C wt[1][3], rb[1][3] = {{C(0), C(0), C(0)}}, rba[1][3] = {{C(0), C(0), C(0)}};
+      MeshPairIn<C, C, 1> in;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        wt[0][i] = C(wit[it * kWitPerItem + (cidx * 2 + 0) * 3 + i]);
+        in.wit_a[0][i] = C(wit[it * kWitPerItem + (cidx * 2 + 1) * 3 + i]);
+      }
+#pragma unroll
+      for (int p = 0; p < kMaxPairs; ++p)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) in.dirs[p][i] = pdirs[(it * kMaxPairs + p) * 3 + i];
+      step_item_backward<C, C, NJ, 1, GenLanes>(md, dp, opt, xr, cidx, gr, acc, wt, rb, &xb, &in, rba);
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          rbar[it * kWitPerItem + (cidx * 2 + 0) * 3 + i] = T(rb[0][i]);
+          rbar[it * kWitPerItem + (cidx * 2 + 1) * 3 + i] = T(rba[0][i]);
+        }
+      }
+    } else {
+      step_item_backward<C, C, NJ, 1, GenLanes>(md, dp, opt, xr, cidx, gr, acc, nullptr, nullptr, &xb);
+    }
     if (xbar_out && valid && cidx == 0) {
 #pragma unroll
       for (int i = 0; i < D::NX; ++i) xbar_out[it * ld_xb + i] = T(xb[i]);

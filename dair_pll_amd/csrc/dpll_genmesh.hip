@@ -210,6 +210,16 @@ int launch_step_items(const dpll_model* m, int dtype, const dpll_params_t* p, co
   return dpll_check_launch("gen_simulate_kernel (mesh)");
 }
 template <typename T, int NJ>
+int launch_step_backward_items(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, const void* gx, long long ld_g,
+                               long long batch, void* rows_ws, void* grad_x, long long ld_gx, const void* wit, void* rbar,
+                               const double* pdirs, hipStream_t stream) {
+  const int rows = row_blocks(batch);
+  hipLaunchKernelGGL((gen_step_backward_kernel<T, NJ, true>), dim3(rows + 1), dim3(kWave), 0, stream, general_desc(m), m->opts[DPLL_F64],
+                     (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch,
+                     (double*)rows_ws, (T*)grad_x, ld_gx, (const T*)wit, (T*)rbar, pdirs);
+  return dpll_check_launch("gen_step_backward_kernel (mesh)");
+}
+template <typename T, int NJ>
 int launch_terms_items(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm, void* M,
                        void* J, void* phi, void* a, const void* wit, const double* pdirs, hipStream_t stream) {
   if (!J) return dpll_fail(-1, "dpll_terms_mesh (general build): the J output is required%s");
@@ -276,6 +286,12 @@ int finalize(const dpll_model* m, int dtype, long long batch, void* rows, void* 
 int step_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* x_next,
                long long ld_next, const void* wit, const double* pdirs, hipStream_t stream) {
   DPLL_GENMESH_DISPATCH(launch_step_items, m, dtype, p, x, ld_x, batch, x_next, ld_next, wit, pdirs, stream);
+}
+
+int step_backward_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* gx,
+                        long long ld_g, long long batch, void* rows, void* grad_x, long long ld_gx, const void* wit, void* rbar,
+                        const double* pdirs, hipStream_t stream) {
+  DPLL_GENMESH_DISPATCH(launch_step_backward_items, m, p, x, ld_x, gx, ld_g, batch, rows, grad_x, ld_gx, wit, rbar, pdirs, stream);
 }
 
 int terms_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm,

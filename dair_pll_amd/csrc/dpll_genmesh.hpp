@@ -44,6 +44,10 @@ int loss_items(const dpll_model* m, int dtype, const dpll_params_t* p, const voi
 int finalize(const dpll_model* m, int dtype, long long batch, void* rows, void* grad, void* loss_total, hipStream_t stream);
 int step_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* x_next,
                long long ld_next, const void* wit, const double* pdirs, hipStream_t stream);
+// backward of one step (parameter rows + state adjoint + witness adjoints); finalize() chains the rows afterwards
+int step_backward_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* gx,
+                        long long ld_g, long long batch, void* rows, void* grad_x, long long ld_gx, const void* wit, void* rbar,
+                        const double* pdirs, hipStream_t stream);
 int terms_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm,
                 void* M, void* J, void* phi, void* a, const void* wit, const double* pdirs, hipStream_t stream);
 }  // namespace dpll_genmesh

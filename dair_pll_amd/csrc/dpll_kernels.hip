@@ -1324,6 +1324,32 @@ int launch_genmesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, 
   return dpll_genmesh::finalize(m, dtype, batch, ws + gp.off_rows, grad, loss_total, stream);
 }
 
+// backward of dpll_step_mesh for a general model with learned shapes: support points at x, the step's backward (rows for the
+// head of the gradient, the state adjoint, the witness adjoints), then the networks' backward kernels
+template <typename T>
+int launch_genmesh_step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
+                                 long long ld_x, const void* gx, long long ld_g, long long batch, void* grad, void* grad_x, long long ld_gx,
+                                 void* workspace, long long workspace_bytes, hipStream_t stream) {
+  const GenMeshPlan gp = genmesh_plan<T>(m, batch);
+  if (!workspace || (size_t)workspace_bytes < gp.total) return fail(-3, "dpll_step_backward_mesh: workspace too small%s");
+  char* ws = (char*)workspace;
+  if (int rc = genmesh_hulls<T>(m, dtype, gp, mp, ws, stream)) return rc;
+  if (int rc = genmesh_support<T>(m, dtype, gp, mp, ws, x, ld_x, batch, stream, true)) return rc;
+  if (int rc = dpll_genmesh::step_backward_items(m, dtype, p, x, ld_x, gx, ld_g, batch, ws + gp.off_rows, grad_x, ld_gx, ws + gp.off_W,
+                                                 ws + gp.off_RB, (const double*)(ws + gp.off_PD), stream))
+    return rc;
+  const int head = dpll_general::param_count(m);
+  for (int k = 0; k < gp.n_mesh; ++k) {
+    const int g = gp.geom_of[k];
+    const MeshPlan pl = genmesh_block<T>(gp, gp.qpi[g] * batch);
+    if (int rc = mesh_backward<T, 1>(pl, k, genmesh_weights<T>(gp, mp, g, ws), ws, QuatSource<T>{nullptr, 0},
+                                     (T*)grad + head + (size_t)k * kNetParams, (T*)nullptr, (T*)nullptr, stream,
+                                     (const T*)(ws + gp.off_RB)))
+      return rc;
+  }
+  return dpll_genmesh::finalize(m, dtype, batch, ws + gp.off_rows, grad, nullptr, stream);
+}
+
 template <typename T>
 int launch_genmesh_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x0,
                             long long ld_x, long long batch, long long steps, void* traj, long long ld_item, long long ld_step,
@@ -1798,8 +1824,8 @@ int dpll_step_backward_mesh(const dpll_model_t* model, int dtype, const dpll_par
   const int nx = dpll_n_x(model);
   if (batch < 1 || !x || !grad_x_next || !grad || ld_x < nx || ld_g < nx || (grad_x && ld_gx < nx))
     return fail(-1, "dpll_step_backward_mesh: bad arguments%s");
-  if (model->desc.n_geoms > 0)
-    return fail(-2, "dpll_step_backward_mesh: not built for the general build with learned shapes (loss, step, simulate and terms are)%s");
+  DPLL_GENMESH(launch_genmesh_step_backward, model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx, workspace,
+               workspace_bytes, (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_step_backward, model, dtype, params, mesh, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx,
                      workspace, workspace_bytes, (hipStream_t)stream);
 }

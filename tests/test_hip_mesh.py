@@ -413,3 +413,31 @@ def test_split_bf16_gemm_forms_on_the_benchmark_batch(golden):
         assert abs(t64 - t32) < 1e-6 * max(1.0, abs(t64)), mode
         for n, p in s32.named_parameters():
             assert np.abs(p.grad.cpu().double().numpy() - g64[n]).max() <= grad_tol * max(np.abs(g64[n]).max(), 1e-12), (mode, n)
+
+
+def test_two_learned_shapes_rollout_gradients_against_oracle_autograd(golden):
+    """dpll_step_backward_mesh of the general build: the gradient of a 2-step rollout with respect to every parameter (both
+    networks' weights included) and to the initial state, against torch autograd through the oracle (differentiable cone
+    solve; the candidate's direction a constant, as in the reference); state gradients on the unit-quaternion tangent (Q2)"""
+    g = golden(CLASP)
+    system = build_general(g, torch.float64)
+    oracle = clasp_oracle(g).requires_grad_()
+    rows = np.linspace(0, g['x'].shape[0] - 1, 16).astype(int)
+    x_np = g['x'][rows]
+    w = torch.rand((len(rows), 2, x_np.shape[1]), generator=torch.Generator().manual_seed(5), dtype=torch.float64) - 0.5
+    x_ref = torch.tensor(x_np).requires_grad_(True)
+    traj_ref = oracle.simulate(x_ref, 2)
+    (traj_ref[:, 1:] * w).sum().backward()
+    x = torch.tensor(x_np, device='cuda:0').requires_grad_(True)
+    traj, _ = system.simulate(x.unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), 2)
+    assert (traj.detach().cpu() - traj_ref.detach()).abs().max() < 1e-9
+    (traj[:, 1:] * w.cuda()).sum().backward()
+    ref_named = oracle.named_parameters()
+    for name, param in system.named_parameters():
+        ref = ref_named[name].grad.numpy()
+        err = np.abs(param.grad.cpu().numpy() - ref).max()
+        assert err <= 1e-7 * max(np.abs(ref).max(), 1e-3), (name, err, np.abs(ref).max())
+    diff = (x.grad.cpu() - x_ref.grad).numpy()
+    q = x_np[:, :4] / np.linalg.norm(x_np[:, :4], axis=-1, keepdims=True)
+    diff[:, :4] -= (diff[:, :4] * q).sum(-1, keepdims=True) * q
+    assert np.abs(diff).max() <= 1e-7 * x_ref.grad.abs().max().item()
