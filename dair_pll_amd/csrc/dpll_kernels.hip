@@ -835,7 +835,7 @@ template <typename T> void plan_network_block(MeshPlan& pl, long long N) {
   pl.off_U0 = take(sizeof(T) * kW * pl.N);
   // MFMA path: Vb (icnn_bwd1) and U1 (icnn_fwd2) as operand tiles for icnn_bwd2, whole 32-row tiles
   pl.off_Vb = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
-  pl.off_U1 = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
+  pl.off_U1 = take(0);  // (round 2 kept U1 operand tiles here)
   pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
   pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
   pl.net_bytes = off;
@@ -943,7 +943,8 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
                        kMfmaPath ? (T*)(nb + pl.off_Af) : (T*)nullptr, kMfmaPath ? (T*)(nb + pl.off_ATf) : (T*)nullptr);
   mesh_mark(stream);
   if constexpr (std::is_same<T, float>::value) {
-    float* U1t = for_backward ? (float*)(nb + pl.off_U1) : (float*)nullptr;
+    float* U1t = nullptr;  // (U1 is rebuilt from the mask words by the weight-gradient GEMM: nothing of it is stored)
+    (void)for_backward;
 #define DPLL_FWD_BF16(PL_)                                                                                                         \
     do {                                                                                                                          \
       hipLaunchKernelGGL((icnn_fwd1_bf16<PL_>), dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,                   \
@@ -1001,8 +1002,9 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
                          (const float*)(nb + pl.off_U0), (const float*)RB, (double*)(nb + pl.off_b1),
                          (float*)(nb + pl.off_Vb));
       mesh_mark(stream);
-      hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.n_tiles,
-                         (const float*)(nb + pl.off_Vb), (const float*)(nb + pl.off_U1), (float*)(nb + pl.off_slabs));
+      hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
+                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
+                         (float*)(nb + pl.off_slabs));
     }
 #undef DPLL_BWD_BF16
   } else {

@@ -676,38 +676,47 @@ __global__ __launch_bounds__(512) void icnn_bwd1_mfma(const float* __restrict__ 
   }
 }
 
-// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j] as a plain split-K GEMM on the operand tiles that icnn_bwd1_mfma (Vb) and
-// icnn_fwd2_mfma (U1) left behind.  Grid (4 = k-half x j-half, n_slabs): a block owns a 128 x 128 piece over its slab
-// of row tiles; wave v the k-tile v >> 1 and the two j-tiles 2 (v & 1), 2 (v & 1) + 1 of the piece (two accumulator
-// sets).  Per row tile the block copies 4 + 4 operand tiles (32 KB) global -> registers -> LDS, double buffered:
-// the next tile's loads are in flight during this tile's 32 MFMAs per wave, one barrier per tile.  Per MFMA a wave
-// issues 3/8 LDS reads (ds_read_b128) and almost no VALU, which is what the f32 MFMA pipe needs to stay busy
-// (PMC on the previous forms: 14 VALU instructions per MFMA, MFMA busy 43 %).
+// d|Wh|[k][j] = sum_n Vb[n][k] U1[n][j] as a split-K GEMM.  Grid (4 = k-half x j-half, n_slabs): a block owns a 128 x 128
+// piece over its slab of row tiles; wave v the k-tile v >> 1 and the two j-tiles 2 (v & 1), 2 (v & 1) + 1 of the piece (two
+// accumulator sets).  Vb comes as the operand tiles icnn_bwd1_mfma left behind (global -> registers -> LDS, double buffered:
+// the next tile's loads are in flight during this tile's 32 MFMAs per wave, one barrier per tile).  U1 = |wout| (mask ? 1 :
+// 1/2) has two values per column, so it is NOT stored (round 2 wrote and re-read 16 MB of U1 operand tiles per call): a lane
+// rebuilds its B elements from the tile's mask words in LDS -- a broadcast read, a shift and a select per MFMA, well inside
+// the 16 issue slots an f32 MFMA leaves.
 constexpr int kB2Pieces = 4;
-__global__ __launch_bounds__(512) void icnn_bwd2_mfma(long long n_tiles, const float* __restrict__ VbT,
-                                                      const float* __restrict__ U1T, float* __restrict__ slabs) {
-  __shared__ f32x4 Ls[2][8][256];  // [buffer][0..3: Vb k-tiles, 4..7: U1 j-tiles][4 KB operand tile]
+__global__ __launch_bounds__(512) void icnn_bwd2_mfma(long long N, const float* __restrict__ VbT, const uint32_t* __restrict__ M1,
+                                                      const float* __restrict__ a, float* __restrict__ slabs) {
+  __shared__ f32x4 Ls[2][4][256];  // [buffer][Vb k-tile of the piece][4 KB operand tile]
+  __shared__ uint32_t Ms[2][kMfmaRows][4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   const int kq = blockIdx.x & 1, jq = blockIdx.x >> 1;
   const int ktl = wv >> 1, jtl = 2 * (wv & 1);
+  const long long n_tiles = (N + kMfmaRows - 1) / kMfmaRows;
   const long long per = (n_tiles + gridDim.y - 1) / gridDim.y;
   const long long t_begin = (long long)blockIdx.y * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
+  const float a0 = a[128 * jq + 32 * jtl + l31], a1 = a[128 * jq + 32 * (jtl + 1) + l31];
+  const float h0 = a0 * float(kIcnnSlope), h1 = a1 * float(kIcnnSlope);
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-  // copy assignment: float4 number threadIdx.x + 512 m of the chunk's 2048 (slot = number >> 8, index = number & 255)
-  f32x4 stage[4];
+  // copy assignment: float4 number threadIdx.x + 512 m of the chunk's 1024 (slot = number >> 8, index = number & 255)
+  f32x4 stage[2];
+  uint32_t mstage = 0u;
   auto fetch = [&](long long t) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < 2; ++m) {
       const int slot = 2 * m + (threadIdx.x >> 8), idx = threadIdx.x & 255;
-      const float* src = slot < 4 ? VbT + (t * 8 + 4 * kq + slot) * 1024 : U1T + (t * 8 + 4 * jq + (slot - 4)) * 1024;
-      stage[m] = ((const f32x4*)src)[idx];
+      stage[m] = ((const f32x4*)(VbT + (t * 8 + 4 * kq + slot) * 1024))[idx];
+    }
+    if (threadIdx.x < kMfmaRows * 4) {
+      const long long n = t * kMfmaRows + (threadIdx.x >> 2);
+      mstage = n < N ? M1[n * kMaskWords + 4 * jq + (threadIdx.x & 3)] : 0u;
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) Ls[buf][2 * m + (threadIdx.x >> 8)][threadIdx.x & 255] = stage[m];
+    for (int m = 0; m < 2; ++m) Ls[buf][2 * m + (threadIdx.x >> 8)][threadIdx.x & 255] = stage[m];
+    if (threadIdx.x < kMfmaRows * 4) Ms[buf][threadIdx.x >> 2][threadIdx.x & 3] = mstage;
   };
   if (t_begin < t_end) { fetch(t_begin); commit(0); }
   __syncthreads();
@@ -715,14 +724,21 @@ __global__ __launch_bounds__(512) void icnn_bwd2_mfma(long long n_tiles, const f
     const int cur = (int)((t - t_begin) & 1);
     const bool more = t + 1 < t_end;
     if (more) fetch(t + 1);
+    // this lane's B elements of the tile's 16 MFMA steps, all rebuilt before the first MFMA (row of step i: 2 i + half)
+    float b0[16], b1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t w0 = Ms[cur][2 * i + half][jtl], w1 = Ms[cur][2 * i + half][jtl + 1];
+      b0[i] = ((w0 >> l31) & 1u) ? a0 : h0;
+      b1[i] = ((w1 >> l31) & 1u) ? a1 : h1;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int idx = (q * 32 + l31) * 2 + half;
-      const f32x4 a4 = Ls[cur][ktl][idx], b0 = Ls[cur][4 + jtl][idx], b1 = Ls[cur][5 + jtl][idx];
+      const f32x4 a4 = Ls[cur][ktl][(q * 32 + l31) * 2 + half];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b0[e], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b1[e], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b0[4 * q + e], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b1[4 * q + e], acc1, 0, 0, 0);
       }
     }
     if (more) commit(cur ^ 1);
