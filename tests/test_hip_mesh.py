@@ -441,3 +441,42 @@ def test_two_learned_shapes_rollout_gradients_against_oracle_autograd(golden):
     q = x_np[:, :4] / np.linalg.norm(x_np[:, :4], axis=-1, keepdims=True)
     diff[:, :4] -= (diff[:, :4] * q).sum(-1, keepdims=True) * q
     assert np.abs(diff).max() <= 1e-7 * x_ref.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('case', ['cube_mesh_literal', CLASP])
+def test_mesh_workspace_is_exactly_what_the_library_asks_for(golden, case):
+    """dpll_mesh_workspace_bytes: the mesh pipelines (specialised and general build) run inside EXACTLY that many bytes -- guard
+    bands of canaries on both sides stay intact over ragged batch sizes, one byte less is refused -- and ragged batches give
+    the per-item losses of the full batch"""
+    import ctypes
+    from dair_pll_amd import _capi
+    g = golden(case)
+    lib = _capi.library()
+    for dtype in (torch.float32, torch.float64):
+        system = build_general(g, dtype) if case == CLASP else build(g, dtype)
+        code = _capi.F64 if dtype == torch.float64 else _capi.F32
+        flat = system._packed()
+        params, mesh = system._params_struct(flat), system._mesh_struct(flat)
+        x_all = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+        xp_all = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+        full = system.contactnets_loss(x_all, torch.zeros((x_all.shape[0], 0), device='cuda:0'), xp_all).detach()
+        for batch in (1, 3, 33, x_all.shape[0]):
+            x, xp = x_all[:batch].contiguous(), xp_all[:batch].contiguous()
+            need = lib.dpll_mesh_workspace_bytes(system._model(), batch, code)
+            assert need > 0
+            guard = 4096
+            arena = torch.full((need + 2 * guard,), 0xA5, dtype=torch.uint8, device='cuda:0')
+            ws = arena[guard:guard + need]
+            loss = torch.zeros(batch, dtype=dtype, device='cuda:0')
+            grad = torch.zeros(flat.numel(), dtype=dtype, device='cuda:0')
+            total = torch.zeros(1, dtype=dtype, device='cuda:0')
+            args = [system._model(), code, ctypes.byref(params), mesh, x.data_ptr(), x.stride(0), xp.data_ptr(), xp.stride(0), batch, None,
+                    1.0 / batch, loss.data_ptr(), grad.data_ptr(), total.data_ptr(), None, None, ws.data_ptr()]
+            _capi.check(lib.dpll_contactnets_loss_mesh(*args, need, system._stream()))
+            torch.cuda.synchronize()
+            assert (arena[:guard] == 0xA5).all() and (arena[guard + need:] == 0xA5).all(), (case, dtype, batch)
+            assert torch.isfinite(grad).all()
+            assert (loss - full[:batch]).abs().max().item() <= (1e-12 if dtype == torch.float64 else 1e-6)
+            assert abs(total.item() - loss.double().mean().item()) <= (1e-12 if dtype == torch.float64 else 1e-6)
+            assert lib.dpll_contactnets_loss_mesh(*args, need - 1, system._stream()) != 0
+        assert lib.dpll_mesh_workspace_bytes(system._model(), 0, code) == -1
