@@ -20,7 +20,7 @@ GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 19  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 20  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,7 +44,8 @@ class SolverOpts(ctypes.Structure):
                 ('ls_tol', c_double), ('n_stages', c_int32), ('stage_max_iter', c_int32), ('stage_factor', c_double),
                 ('stage_tol', c_double), ('stage_ls_tol', c_double), ('stage_max_ls', c_int32), ('fast_ls', c_int32),
                 ('warm_start', c_int32), ('wide', c_int32), ('loss_stage_factor', c_double), ('loss_n_stages', c_int32),
-                ('f64_refine', c_int32), ('mesh_gemm', c_int32), ('reserved_', c_int32)]
+                ('f64_refine', c_int32), ('mesh_gemm', c_int32), ('portfolio', c_int32),
+                ('race_stages', c_int32 * 3), ('race_flags', c_int32 * 3), ('race_factor', c_double * 3)]
 
 
 class Params(ctypes.Structure):

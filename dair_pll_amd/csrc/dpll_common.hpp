@@ -42,9 +42,21 @@ constexpr int kQuadXor2 = 0x4E;       // quad_perm [2,3,0,1]
 constexpr int kRowHalfMirror = 0x141; // lane i <-> 7 - i inside each 8 lanes
 constexpr int kRowMirror = 0x140;     // lane i <-> 15 - i inside each 16 lanes
 
-template <int G> struct GpuLanes {
+// P: racing copies of every item (SolverOpts::portfolio): an item owns G * P consecutive lanes, copy v the lanes
+// [v G, (v + 1) G) of them; sums and searches stay inside a copy's G lanes
+template <int G, int P = 1> struct GpuLanes {
   static_assert(G == 1 || G == 4 || G == 8 || G == 16, "lanes per item: one per contact slot (4, 8 or 16), or 1 (wide build)");
+  static_assert(P == 1 || ((P == 2 || P == 4) && G >= 4 && G * P <= 16), "racing copies share a 16-lane DPP row with their item");
   static constexpr int kGroup = G;
+  static constexpr int kVariants = P;
+  static __device__ __forceinline__ int variant() { return (int)((threadIdx.x / G) & (P - 1)); }
+  // OR over the copies of an item of a value that is uniform inside each copy
+  static __device__ __forceinline__ int item_or(int x) {
+    if (P == 1) return x;
+    if (G == 4) x |= dpp_mov<kRowHalfMirror>(x);          // lanes i <-> 7 - i: the other quad of the 8
+    if (G * P == 16) x |= dpp_mov<kRowMirror>(x);          // the other half of the row
+    return x;
+  }
   template <typename T> static __device__ __forceinline__ T group_sum(T x) {
     if (G == 1) return x;
     x += dpp_mov<kQuadXor1>(x);
@@ -65,7 +77,7 @@ template <int G> struct GpuLanes {
   // item in LDS, the specialised builds the caller's registers.  The per-item stride is padded so that the four groups of
   // a wave, which read the same member in one instruction, fall on different LDS banks.
   template <class Store> static __device__ __forceinline__ Store& item_store(Store& local) {
-    if constexpr (G == 16) {
+    if constexpr (G == 16 && P == 1) {
       struct Padded { Store s; char pad[(sizeof(Store) % 256 < 64 ? 64 : 0) + 8]; };
       __shared__ Padded items[kWave / G];
       return items[(threadIdx.x & (kWave - 1)) / G].s;
@@ -256,12 +268,15 @@ template <int G, typename T> __device__ __forceinline__ T wave_sum_to_lane63(T x
   return x;  // the total over the groups in lane 63; other lanes hold partial sums
 }
 
-template <typename T, int NJ, int G = Dims<T, NJ>::G, int NG = NJ + 1, int GP = 3>
+// WAVES > 1: a workgroup of several waves still writes ONE row -- every wave leaves its sum in LDS, the first PIOTA threads
+// add them up in wave order (fixed order: bitwise reproducible)
+template <typename T, int NJ, int G = Dims<T, NJ>::G, int NG = NJ + 1, int GP = 3, int WAVES = 1>
 __device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG, GP>& acc, double loss_acc, double* __restrict__ partials) {
   using D = Dims<T, NJ, NG, GP>;
   using Lanes = GpuLanes<G>;
   double* dst = partials + (long long)blockIdx.x * D::PI;
-  const bool writer = threadIdx.x == kWave - 1;
+  const bool writer = (threadIdx.x & (kWave - 1)) == kWave - 1;
+  static_assert(WAVES == 1 || GP == 3, "multi-wave workgroups: the specialised builds");
   if constexpr (GP > 3) {
     // wide rows (the general build): element by element, nothing kept live
     const double l = wave_sum_to_lane63<G>(Lanes::group_sum(loss_acc));
@@ -299,7 +314,20 @@ __device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG, GP>& ac
     for (int i = 0; i < GP; ++i)
       row[1 + kIota * D::NB + NG + GP * g + i] = double(wave_sum_to_lane63<G>(Lanes::group_sum(acc.g_len[g][i])));
   }
-  if (writer) {
+  if constexpr (WAVES > 1) {
+    __shared__ double wave_rows[WAVES][D::PIOTA];
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < D::PIOTA; ++i) wave_rows[threadIdx.x / kWave][i] = row[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < D::PIOTA) {
+      double v = wave_rows[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) v += wave_rows[w][threadIdx.x];
+      dst[threadIdx.x] = v;
+    }
+  } else if (writer) {
 #pragma unroll
     for (int i = 0; i < D::PIOTA; ++i) dst[i] = row[i];
   }

@@ -896,7 +896,11 @@ struct SolverOpts {
   // float mesh pipeline: form of the ICNN GEMM kernels -- 0 = v_mfma_f32_32x32x2_f32 (exact f32; default), 2 / 3 = the bf16
   // matrix cores on operands split into 2 / 3 bf16 planes (csrc/dpll_mesh_bf16.hpp)
   int mesh_gemm;
-  int reserved_;
+  // racing schedules (dpll.h): copies of an item's lane group with other continuation schedules; 0 = by batch size, 1 = off
+  int portfolio;
+  int race_stages[3];
+  int race_flags[3];  // 1 = warm start, 2 = full Newton steps only (no line search)
+  double race_factor[3];
 };
 
 // in-place-free Cholesky that only keeps what the solves need: strictly-lower L and 1 / diag
@@ -981,17 +985,43 @@ DPLL_HD void sap_advance(const JT (&Jc)[KPL], const T (&mu)[KPL], const SapPoint
 template <typename T, typename TA, int NJ, int KPL, class Lanes, class JT>
 DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const T (&mu)[KPL],
                        const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3],
-                       const T (&y0)[6 + NJ], bool use_y0) {
+                       const T (&y0)[6 + NJ], bool use_y0, bool race = false, bool* winner = nullptr) {
   constexpr int NV = 6 + NJ;
   // float storage with a wider accumulation type: iterate on increments, all in float (sap_advance)
   constexpr bool kIncremental = DPLL_INCREMENTAL && sizeof(T) < sizeof(TA);
   const T tol2 = T(opt.tol * opt.tol), stol2 = T(opt.stall_tol * opt.stall_tol), ls_tol = T(opt.ls_tol);
-  const T stage_tol2 = T(opt.stage_tol * opt.stage_tol), inv_factor = T(1.0 / opt.stage_factor);
-  const int last_stage = opt.n_stages - 1;
+  const T stage_tol2 = T(opt.stage_tol * opt.stage_tol);
+  // Racing schedules (SolverOpts::portfolio): the lane group of an item exists Lanes::kVariants times in the wave; copy 0
+  // runs the caller's continuation schedule, the others the schedules of opt.race_*.  The copies solve the same problem
+  // to the same tolerance in lock step (no extra time per iteration); the item is finished when any copy is.
+  int n_stages = opt.n_stages;
+  T factor = T(opt.stage_factor), inv_factor = T(1.0 / opt.stage_factor);
+  // a racing copy may run without the line search (cheaper: a rejected step makes the whole wave run the fall-back code): it
+  // is then not globally convergent, which costs nothing -- copy 0 is, and a copy only counts once it has met the
+  // stopping rule with finite numbers (the objective is strictly convex: whoever meets it is at the same minimiser)
+  bool full_steps = false;
+  if constexpr (Lanes::kVariants > 1) {
+    if (race) {
+      const int vr = Lanes::variant();
+      DPLL_UNROLL for (int k = 1; k < Lanes::kVariants && k <= 3; ++k) {
+        n_stages = vr == k ? opt.race_stages[k - 1] : n_stages;
+        factor = vr == k ? T(opt.race_factor[k - 1]) : factor;
+        inv_factor = vr == k ? T(1) / T(opt.race_factor[k - 1]) : inv_factor;
+        use_y0 = vr == k ? (opt.race_flags[k - 1] & 1) != 0 : use_y0;
+        full_steps = vr == k ? (opt.race_flags[k - 1] & 2) != 0 : full_steps;
+      }
+    }
+  }
+  const int last_stage = n_stages - 1;
   T eps_c = eps;  // regularisation of the current stage (per item: items advance independently)
-  for (int s = 0; s < last_stage; ++s) eps_c *= T(opt.stage_factor);
+  if constexpr (Lanes::kVariants > 1) {
+    DPLL_UNROLL for (int s = 0; s < 8; ++s) eps_c *= s < last_stage ? factor : T(1);  // (per lane: no divergent loop)
+  } else {
+    for (int s = 0; s < last_stage; ++s) eps_c *= factor;
+  }
   int stage = 0, it_stage = 0;
   bool active = true;
+  bool finished = false;  // this copy met the stopping rule itself (racing: it may also end because another copy did)
   int iters = 0;
   DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = use_y0 ? TA(y0[i]) : TA(0);
   // every lane of the group starts its share of the Hessian from M / group size (a power of two, so exact): the
@@ -1076,7 +1106,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     DPLL_UNROLL for (int i = 0; i < NV; ++i) first1 += (trial.My[i] - ieps * trial.jtg[i]) * d[i];
     // alpha = 1 stands when the slope there is small enough, and also -- while the search is capped at one probe --
     // when l is still descending at 1 (the capped search would stop at its lower bracket, alpha = 1)
-    const bool reject = moving && !(tabs(first1) <= slope_tol) && (first1 > T(0) || ls_cap > 1);
+    const bool reject = moving && !full_steps && !(tabs(first1) <= slope_tol) && (first1 > T(0) || ls_cap > 1);
     DPLL_PHASE(3);
     const bool fell_back = Lanes::wave_any(reject);
     if (fell_back) {
@@ -1169,7 +1199,21 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     iters = active ? it + 1 : iters;
     const bool stage_done = converged || stalled || (!final_stage && it_stage + 1 >= opt.stage_max_iter);
     const bool advance = active && !final_stage && stage_done && !force_free;
-    active = active && !((final_stage && stage_done) || force_free);
+    const bool ends = (final_stage && stage_done) || force_free;
+    bool sound = true;
+    if constexpr (Lanes::kVariants > 1) {
+      // racing copies other than the first: only a decrement that is a number and under the tolerance counts (copy 0
+      // keeps the rule above, which also ends a solve that stalled or went to NaN -- the invalid-solve mask's business)
+      const T limit = tol2 * scale2;
+      sound = Lanes::variant() == 0 || (final_stage && dec2 <= limit) || (force_free && dec2 <= T(0));
+    }
+    finished = finished || (active && ends && sound);
+    active = active && !ends;
+    if constexpr (Lanes::kVariants > 1) {
+      // (evaluated by every lane, outside any short-circuit: a cross-lane read of a lane that skipped it returns zero)
+      const int any_finished = Lanes::item_or(finished ? 1 : 0);
+      active = active && any_finished == 0;
+    }
     stage = advance ? stage + 1 : stage;
     eps_c = advance ? eps_c * inv_factor : eps_c;
     it_stage = advance ? 0 : it_stage + 1;
@@ -1193,6 +1237,14 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
   const T ieps = fast_rcp(eps);
   DPLL_UNROLL for (int c = 0; c < KPL; ++c)
     DPLL_UNROLL for (int r = 0; r < 3; ++r) f[c][r] = (in_b ? pb.pr[c].g[r] : pa.pr[c].g[r]) * ieps;
+  if constexpr (Lanes::kVariants > 1) {
+    // the finished copy with the lowest index supplies the item's outputs (none finished: max_iter ran out, copy 0 does)
+    const int done_bits = Lanes::item_or(finished ? (1 << Lanes::variant()) : 0);
+    const int first = done_bits == 0 ? 0 : __builtin_ctz(done_bits);
+    if (winner) *winner = Lanes::variant() == first;
+  } else {
+    if (winner) *winner = true;
+  }
   return iters;
 }
 
@@ -1214,10 +1266,10 @@ template <typename T, int NJ> DPLL_HD void cjac_to_float(const CJac<T, NJ, true>
 template <typename T, typename TA, int NJ, int KPL, class Lanes, bool DENSE>
 DPLL_HD int sap_solve(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ, DENSE> (&Jc)[KPL], const T (&mu)[KPL],
                       const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3],
-                      const T (&y0)[6 + NJ], bool use_y0) {
+                      const T (&y0)[6 + NJ], bool use_y0, bool race = false, bool* winner = nullptr) {
   constexpr int NV = 6 + NJ;
   if constexpr (DPLL_MIXED_F64 && sizeof(T) == 8 && sizeof(TA) == 8) {
-    if (opt.f64_refine == 0) return sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, opt, y, f, y0, use_y0);
+    if (opt.f64_refine == 0) return sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, opt, y, f, y0, use_y0, race, winner);
     float Mf[NV][NV], muf[KPL], qcf[KPL][3], ff[KPL][3], y0f[NV];
     CJac<float, NJ, DENSE> Jf[KPL];
     DPLL_UNROLL for (int i = 0; i < NV; ++i) {
@@ -1233,14 +1285,16 @@ DPLL_HD int sap_solve(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ, DENSE> (&J
     coarse.tol = 1e-6;
     coarse.stall_tol = 1e-5;
     double yc[NV];
-    const int it_coarse = sap_newton<float, double, NJ, KPL, Lanes>(Mf, Jf, muf, qcf, float(eps), coarse, yc, ff, y0f, use_y0);
+    // (racing copies: the float phase races the schedules; every copy then refines ITS point with the same one-stage
+    // schedule and the item is finished when the first of them -- the float phase's winner, typically -- has converged)
+    const int it_coarse = sap_newton<float, double, NJ, KPL, Lanes>(Mf, Jf, muf, qcf, float(eps), coarse, yc, ff, y0f, use_y0, race);
     SolverOpts fine = opt;
     fine.n_stages = 1;
     T start[NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i) start[i] = T(yc[i]);
-    return it_coarse + sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, fine, y, f, start, true);
+    return it_coarse + sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, fine, y, f, start, true, false, winner);
   } else {
-    return sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, opt, y, f, y0, use_y0);
+    return sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, opt, y, f, y0, use_y0, race, winner);
   }
 }
 
@@ -1382,6 +1436,9 @@ constexpr double kPairTie = 1e-12;   // support values (metres) closer than this
 // host/one-lane implementation of the lane-group primitives
 struct OneLane {
   static constexpr int kGroup = 1;  // lanes that share one item
+  static constexpr int kVariants = 1;  // racing copies of an item (SolverOpts::portfolio): the device builds only
+  static DPLL_HD int variant() { return 0; }
+  static DPLL_HD int item_or(int x) { return x; }
   template <typename T> static DPLL_HD T group_sum(T x) { return x; }
   static DPLL_HD bool group_any(bool x) { return x; }
   static DPLL_HD bool wave_any(bool x) { return x; }
@@ -1983,7 +2040,7 @@ template <typename T, typename TA, int NJ, int KPL, class Lanes, int NG, class M
 DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts& opt, const T* x, const T* xp,
                     int first_contact, T weight, bool want_grad, LossGrad<T, NJ, NG, GP>& grad, T (&force)[KPL][3],
                     int& iters, const T (*witness)[3] = nullptr, T (*rbar_out)[3] = nullptr,
-                    const MeshPairIn<T, TA, KPL>* mesh_in = nullptr, T (*rbar_a_out)[3] = nullptr) {
+                    const MeshPairIn<T, TA, KPL>* mesh_in = nullptr, T (*rbar_a_out)[3] = nullptr, bool* winner_out = nullptr) {
   constexpr int NB = NJ + 1, NV = 6 + NJ, NQ = 7 + NJ;
   const T dt = T(md.dt), eps = T(kLossEps);
   const T* v = x + NQ;
@@ -2028,13 +2085,18 @@ DPLL_HD T loss_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverOpts
     loss_opt.n_stages = opt.loss_n_stages;
     loss_opt.stage_factor = opt.loss_stage_factor;
   }
-  iters = sap_solve<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, loss_opt, y, force, dv, opt.warm_start != 0);
+  bool winner = true;  // racing copies of the item (SolverOpts::portfolio): the copy whose result counts
+  iters = sap_solve<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, loss_opt, y, force, dv, opt.warm_start != 0, true, &winner);
+  if (winner_out) *winner_out = winner;
   DPLL_CORE_STAMP(5);
   // invalid-solve mask (multibody_learnable_system.py:186-192)
   bool bad = false;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c)
     DPLL_UNROLL for (int r = 0; r < 3; ++r) bad = bad || bad_number(force[c][r]) || tabs(force[c][r]) > T(kInvalidForce);
   bad = Lanes::group_any(bad);
+  // (a copy that lost the race contributes nothing: its gradient terms are masked like an invalid solve's; the kernel
+  // takes loss, forces and iteration count from the winner's lanes)
+  if constexpr (Lanes::kVariants > 1) bad = bad || !winner;
   DPLL_UNROLL for (int c = 0; c < KPL; ++c)
     DPLL_UNROLL for (int r = 0; r < 3; ++r) force[c][r] = bad ? T(0) : force[c][r];
   // g = J^T f, w = M^-1 g

@@ -83,8 +83,14 @@ namespace {
 // DENSE: built for two waves per SIMD (<= 256 registers, a few spills) -- for launches with more waves than SIMDs, where
 // a second resident wave fills the issue slots a lone wave leaves empty (65,536 pairs: 800 -> 944 M steps/s); the
 // headline launch (256 waves) keeps the roomier one-wave build (it is 1 % faster there).
-template <typename T, int NJ, bool MESH = false, bool DENSE = false>
-__global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+constexpr int kRaceWaves = 4;  // waves per workgroup of the racing build
+// RACE: copies of every item's lane group that run other continuation schedules of the cone solve in lock step
+// (SolverOpts::portfolio, dpll_core.hpp sap_newton): for launches that would leave SIMDs idle.  An item owns G * RACE
+// lanes; the copy that converged first supplies the item's loss, forces, iteration count and gradient terms.
+// The racing build runs workgroups of four waves (one per SIMD of a CU) that share one partial row, so that the finalize
+// kernel sums as many rows as without the copies.
+template <typename T, int NJ, bool MESH = false, bool DENSE = false, int RACE = 1>
+__global__ __launch_bounds__(RACE > 1 ? kRaceWaves * kWave : kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
                                                      const T* __restrict__ x, long long ld_x,
                                                      const T* __restrict__ xp, long long ld_xp, long long batch,
@@ -93,19 +99,21 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
                                                      double* __restrict__ partials, int want_grad,
                                                      const T* __restrict__ witness, T* __restrict__ rbar_out) {
   using D = Dims<T, NJ>;
-  using Lanes = GpuLanes<D::G>;
+  using Lanes = GpuLanes<D::G, RACE>;
+  static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
+  constexpr int kItems = (RACE > 1 ? kRaceWaves : 1) * D::IPW / RACE;  // items per workgroup
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
-  const int slot = lane / D::G;
+  const int slot = lane / (D::G * RACE);
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
-    if (want_grad) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
     return;
   }
   DPLL_STAMP(0);
   // the first item's state rows are requested before the parameter math so that their memory latency hides behind it
-  const long long stride = (long long)item_blocks * D::IPW;
-  long long base = (long long)blockIdx.x * D::IPW;
+  const long long stride = (long long)item_blocks * kItems;
+  long long base = (long long)blockIdx.x * kItems;
   long long item = base + slot;
   bool valid = item < batch;
   long long it = valid ? item : batch - 1;  // idle groups shadow the last item: keeps every lane live for DPP
@@ -134,7 +142,10 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
         for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
       }
     } else {
-      L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it);
+      bool winner = true;
+      L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, nullptr,
+                                                            nullptr, nullptr, nullptr, &winner);
+      if constexpr (RACE > 1) valid = valid && winner;  // the other copies write nothing and add nothing to the row
     }
     if (valid) {
       if (cidx == 0) {
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
         row[D::K + 2 * cidx + 1] = f[0][1];
       }
     }
-    loss_acc += (cidx == 0) ? double(w) * double(L) : 0.0;
+    loss_acc += (cidx == 0 && (RACE == 1 || valid)) ? double(w) * double(L) : 0.0;
 #ifdef DPLL_STAMPS
     {
       const int mx = __builtin_amdgcn_readfirstlane(n_it);  // not the max, just a sample; max below
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
   }
   if (!want_grad) return;
-  store_iota_row<T, NJ>(acc, loss_acc, partials);
+  store_iota_row<T, NJ, D::G, NJ + 1, 3, (RACE > 1 ? kRaceWaves : 1)>(acc, loss_acc, partials);
   DPLL_STAMP(3);
 }
 
@@ -607,15 +618,44 @@ SolverOpts default_opts(int dtype, int n_joints = 0, bool general = false) {
   o.loss_stage_factor = 2.5;
   o.f64_refine = 1;
   o.mesh_gemm = 0;
+  // racing copies of the loss solve (launches of <= 4096 cube pairs: 4 copies; <= 4096 elbow pairs: 2): the schedules that,
+  // together with the one above, had the lowest worst case on the 4096-pair batches of the real tosses
+  // (tools/diag/race_schedules.py; all cold starts on full Newton steps).  Cube, 4 copies: 14 -> 11 iterations for the
+  // slowest item (mean 7.0 -> 4.7); elbow, 2 copies: 18 -> 17
+  o.portfolio = 0;
+  if (n_joints == 1 && !general) {
+    o.race_stages[0] = 3; o.race_factor[0] = 10.0; o.race_flags[0] = 2;
+    o.race_stages[1] = 1; o.race_factor[1] = 1.0; o.race_flags[1] = 2;
+    o.race_stages[2] = 2; o.race_factor[2] = 5.0; o.race_flags[2] = 2;
+  } else {
+    o.race_stages[0] = 1; o.race_factor[0] = 1.0; o.race_flags[0] = 2;
+    o.race_stages[1] = 2; o.race_factor[1] = 30.0; o.race_flags[1] = 2;
+    o.race_stages[2] = 5; o.race_factor[2] = 2.0; o.race_flags[2] = 2;
+  }
   return o;
 }
 
-template <typename T, int NJ> int loss_blocks(long long batch) {
-  using D = Dims<T, NJ>;
-  long long blocks = (batch + D::IPW - 1) / D::IPW;
+// item workgroups (= partial rows) of a launch whose waves hold `ipw` items each
+inline int blocks_for(long long batch, int ipw) {
+  long long blocks = (batch + ipw - 1) / ipw;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
+}
+template <typename T, int NJ> int loss_blocks(long long batch, int copies = 1) {
+  return blocks_for(batch, copies > 1 ? kRaceWaves * Dims<T, NJ>::IPW / copies : Dims<T, NJ>::IPW);
+}
+
+// Racing copies per item of the loss launch (dpll_solver_opts_t::portfolio): the most that were asked for (0: four) that
+// keep an item inside a 16-lane row and the launch within one wave per SIMD -- the copies use SIMDs that would idle,
+// they never make a wave wait for a SIMD.
+inline int race_copies(int requested, int lanes_per_item, long long batch) {
+  int p = requested == 0 ? 4 : requested;
+  if (batch < 1) return 1;
+  while (p > 1 && (lanes_per_item * p > 16 || (long long)kRaceWaves * blocks_for(batch, kRaceWaves * kWave / (lanes_per_item * p)) > kSimds))
+    p >>= 1;
+  if (requested == 0 && p < 4) p = 1;  // measured: two copies buy one iteration of fourteen (cube) or none (elbow)
+  return p;
 }
 
 }  // namespace
@@ -630,7 +670,8 @@ template <typename T, int NJ>
 int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
                        long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* force,
                        int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
-  const int blocks = loss_blocks<T, NJ>(batch);
+  const int copies = race_copies(m->opts[dtype].portfolio, Dims<T, NJ>::G, batch);
+  const int blocks = loss_blocks<T, NJ>(batch, copies);
   // wide build (one lane per item): from 65,536 pairs, where it has a wave for every SIMD.  Measured, lane-per-contact
   // builds vs wide, M steps/s: cube f32 16,384 pairs 524 vs 398, 32,768 level, 65,536 934 vs 1340, 262,144 1221 vs 1723;
   // at 65,536: cube f64 423 vs 684, elbow f32 293 vs 476 (0.5-1.4 KB of scratch spills and still ahead); elbow f64
@@ -658,8 +699,18 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
-  else
+  else if (copies == 1)
     hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
+  else if (copies == 2)
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 2>), dim3(blocks + 1), dim3(kRaceWaves * kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
+  else if constexpr (Dims<T, NJ>::G * 4 <= 16)
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4>), dim3(blocks + 1), dim3(kRaceWaves * kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
@@ -672,7 +723,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                 void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
                 hipStream_t stream, const dpll_ar* ar = nullptr, AdamArgs adam = AdamArgs{}) {
   using D = Dims<T, NJ>;
-  const int blocks = loss_blocks<T, NJ>(batch);
+  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, D::G, batch));
   const int want_grad = grad != nullptr;
   if (want_grad) {
     if (!workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
@@ -704,7 +755,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
                  long long ld_xp, long long batch, double scale, void* grad, void* workspace, long long workspace_bytes,
                  hipStream_t stream, int reps, float* ms_loss, float* ms_finalize) {
   using D = Dims<T, NJ>;
-  const int blocks = loss_blocks<T, NJ>(batch);
+  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, D::G, batch));
   if (!grad || !workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
     return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
   // two passes, two events each (an event between every pair of kernels costs several microseconds of its own):
@@ -1480,7 +1531,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 19; }
+int dpll_abi_version(void) { return 20; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1559,6 +1610,12 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
   if (opts->wide < -1 || opts->wide > 1) return fail(-1, "dpll_model_set_solver: wide must be -1, 0 or 1%s");
   if (opts->mesh_gemm != 0 && opts->mesh_gemm != 2 && opts->mesh_gemm != 3)
     return fail(-1, "dpll_model_set_solver: mesh_gemm must be 0 (f32 MFMA), 2 or 3 (bf16 planes)%s");
+  if (opts->portfolio != 0 && opts->portfolio != 1 && opts->portfolio != 2 && opts->portfolio != 4)
+    return fail(-1, "dpll_model_set_solver: portfolio must be 0 (by batch size), 1 (off), 2 or 4%s");
+  for (int k = 0; k < 3; ++k)
+    if (opts->race_stages[k] < 1 || opts->race_stages[k] > 8 || !(opts->race_factor[k] >= 1.0) || (opts->race_flags[k] & ~3))
+      return fail(-1, "dpll_model_set_solver: racing schedules need 1 <= race_stages <= 8, race_factor >= 1, race_flags in 0..3%s");
+  if (opts->n_stages > 8 && opts->portfolio != 1) return fail(-1, "dpll_model_set_solver: n_stages > 8 needs portfolio = 1%s");
   if (opts->loss_n_stages < 0 || (opts->loss_n_stages > 0 && !(opts->loss_stage_factor >= 1.0)))
     return fail(-1, "dpll_model_set_solver: loss_n_stages >= 0 and, when set, loss_stage_factor >= 1%s");
   std::memcpy(&model->opts[dtype], opts, sizeof(SolverOpts));
@@ -1587,10 +1644,8 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (!model || batch < 0) return -1;
   if (model->desc.n_geoms > 0) return dpll_general::workspace_bytes(model, batch);
   const int nb = model->desc.n_joints + 1;
-  int64_t ipw = kWave / (kQuery * nb);
-  int64_t blocks = (batch + ipw - 1) / ipw;
-  if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
-  if (blocks < 1) blocks = 1;
+  // (the racing build of the loss launch runs four-wave workgroups: never more rows than the one-wave launches)
+  const int64_t blocks = blocks_for(batch, kWave / (kQuery * nb));
   const int64_t pi = 1 + 10 * nb + (nb + 1) + 3 * nb;
   const int64_t chain = 100 * nb + (nb + 1) * nb + 3 * nb;  // the rows-to-parameters matrix behind the rows
   return (blocks * pi + chain) * (int64_t)sizeof(double);

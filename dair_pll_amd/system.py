@@ -423,6 +423,8 @@ class MultibodyLearnableSystem(Module):
         code = _DTYPES[self.dtype]
         _capi.check(lib.dpll_model_get_solver(self._model(), code, ctypes.byref(opts)))
         for key, value in kwargs.items():
+            if isinstance(value, (tuple, list)):  # (the racing schedules: three entries each)
+                value = type(getattr(opts, key))(*value)
             setattr(opts, key, value)
         _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
 

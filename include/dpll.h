@@ -112,7 +112,17 @@ typedef struct dpll_solver_opts {
   int32_t f64_refine;       /* DPLL_F64 solves: 1 = float iterations refined in double to `tol` (default), 0 = all double */
   int32_t mesh_gemm;        /* DPLL_F32 mesh pipeline, ICNN GEMMs: 0 = f32 MFMA (exact f32, default), 2 / 3 = bf16 matrix cores on
                                operands split into 2 / 3 bf16 planes (3: f32-grade accuracy, 2: 2^-16 per product) */
-  int32_t reserved_;
+  /* Racing continuation schedules (loss solve, lane-per-contact builds): a launch that leaves SIMDs idle gives every item
+   * `portfolio` copies of its lane group; copy 0 runs the schedule above, copy v >= 1 runs (race_stages[v-1],
+   * race_factor[v-1]) with race_flags[v-1] (1 = warm start, 2 = full Newton steps only: no line search, so none of its
+   * steps sends the wave through the fall-back code); the item is finished when ANY copy has met `tol` (copies >= 1: with
+   * finite numbers) and the finished copy with the lowest index supplies every output -- deterministic, and in iterations
+   * never behind the schedule above alone.
+   * 0 = chosen from the batch size (as many copies as keep the launch within one wave per SIMD), 1 = off, 2, 4. */
+  int32_t portfolio;
+  int32_t race_stages[3];
+  int32_t race_flags[3];
+  double race_factor[3];
 } dpll_solver_opts_t;
 
 typedef struct dpll_model dpll_model_t;

@@ -42,10 +42,10 @@ def default_opts(dtype) -> SolverOpts:
     if np.dtype(dtype) == np.float64:
         return SolverOpts(max_iter=100, max_ls=50, tol=1e-13, stall_tol=1e-10, ls_tol=0.9, n_stages=6, stage_max_iter=3,
                           stage_factor=3.0, stage_tol=0.3, stage_ls_tol=0.9, stage_max_ls=50, fast_ls=1, warm_start=0, wide=-1,
-                          loss_stage_factor=2.5, loss_n_stages=0, f64_refine=1, mesh_gemm=0, reserved_=0)
+                          loss_stage_factor=2.5, loss_n_stages=0, f64_refine=1, mesh_gemm=0, portfolio=1)
     return SolverOpts(max_iter=60, max_ls=30, tol=1e-6, stall_tol=1e-5, ls_tol=0.9, n_stages=6, stage_max_iter=3,
                       stage_factor=3.0, stage_tol=0.3, stage_ls_tol=0.9, stage_max_ls=50, fast_ls=1, warm_start=0, wide=-1,
-                          loss_stage_factor=2.5, loss_n_stages=0, f64_refine=1, mesh_gemm=0, reserved_=0)
+                          loss_stage_factor=2.5, loss_n_stages=0, f64_refine=1, mesh_gemm=0, portfolio=1)
 
 
 def n_geom_slots(desc: ModelDesc) -> int:

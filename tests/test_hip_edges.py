@@ -164,7 +164,7 @@ def test_wide_and_lane_per_contact_builds_agree(urdf, case, dtype):
     xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
     out = {}
     for wide in ('0', '1'):
-        system.set_solver(wide=int(wide))
+        system.set_solver(wide=int(wide), portfolio=1)  # (like for like: no racing copies in the lane-per-contact build)
         loss, force, iters = system.contact_forces(x, xp)
         system.contactnets_loss_and_grad(x, xp)
         out[wide] = (loss.clone(), force.clone(), iters.clone(), system.grad_buffer().clone())
@@ -174,6 +174,58 @@ def test_wide_and_lane_per_contact_builds_agree(urdf, case, dtype):
     assert (out['0'][2] - out['1'][2]).abs().max() <= 1
     assert (out['0'][3] - out['1'][3]).abs().max() <= (1e-9 if dtype == torch.float64 else 2e-3) * out['0'][3].abs().max()
     assert np.abs(out['1'][0].cpu().double().numpy() - g['loss']).max() < (1e-10 if dtype == torch.float64 else 1e-4)
+
+
+@pytest.mark.parametrize('urdf,case,copies', [('cube.urdf', 'cube_box_4096', 4), ('cube.urdf', 'cube_box_4096', 2),
+                                              ('elbow.urdf', 'elbow_box_4096', 2)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
+    """``dpll_solver_opts_t.portfolio``: every item's lane group exists 2 or 4 times in its wave and the copies run other
+    continuation schedules of the cone solve in lock step; the item stops when the first copy has converged and that copy
+    supplies loss, forces, iteration count and gradient terms.  Against the launch without copies on the 4096
+    reference-run pairs: the same losses, forces and batch gradient to the solver's tolerance, no item needs more
+    iterations than before and the slowest needs fewer, forces inside their cones, the launch bitwise reproducible; the
+    default (0) picks four copies for a launch of <= 4096 cube pairs and none beyond."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    g = np.load(os.path.join(GOLDEN_DIR, case + '.npz'))
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, urdf)}, float(g['dt']), dtype=dtype, device='cuda:0')
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+
+    def launch(portfolio, rows=4096):
+        system.set_solver(portfolio=portfolio)
+        loss, force, iters = system.contact_forces(x[:rows], xp[:rows])
+        total = system.contactnets_loss_and_grad(x[:rows], xp[:rows]).clone()
+        return loss.clone(), force.clone(), iters.clone(), system.grad_buffer().clone(), total
+
+    alone, raced, again = launch(1), launch(copies), launch(copies)
+    for a, b in zip(raced, again):
+        assert torch.equal(a, b)
+    f64 = dtype == torch.float64
+    assert (raced[0] - alone[0]).abs().max().item() <= (1e-11 if f64 else 5e-6)
+    assert np.abs(raced[0].cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4)
+    assert (raced[1] - alone[1]).abs().max() <= (1e-8 if f64 else 2e-3) * max(1.0, alone[1].abs().max().item())
+    assert (raced[3] - alone[3]).abs().max() <= (1e-9 if f64 else 2e-3) * alone[3].abs().max()
+    assert abs(raced[4].item() - alone[4].item()) <= (1e-12 if f64 else 1e-7)
+    assert (raced[2] <= alone[2]).all()  # copy 0 IS the schedule of the launch without copies
+    if copies == 4:
+        assert raced[2].max().item() <= alone[2].max().item() - 2, (raced[2].max().item(), alone[2].max().item())
+        assert raced[2].float().mean().item() < 0.8 * alone[2].float().mean().item()
+    k = system.spec.n_contacts
+    fn, ft = raced[1][:, :k], raced[1][:, k:].reshape(-1, k, 2)
+    assert (ft.norm(dim=-1) <= fn * (1 + 1e-5) + 1e-7).all() and (fn >= 0).all()
+    if copies == 4:  # the default: four copies up to 4096 pairs, none beyond (a launch with more waves than SIMDs gains nothing)
+        auto = launch(0)
+        for a, b in zip(raced, auto):
+            assert torch.equal(a, b)
+        ragged, ragged_alone = launch(0, rows=4001), launch(1, rows=4001)
+        assert (ragged[0] - ragged_alone[0]).abs().max().item() <= (1e-11 if f64 else 5e-6) and (ragged[2] <= ragged_alone[2]).all()
+        xb, xpb = torch.cat([x, x[:1]]), torch.cat([xp, xp[:1]])
+        system.set_solver(portfolio=0)
+        _, _, it_auto = system.contact_forces(xb, xpb)
+        system.set_solver(portfolio=1)
+        _, _, it_one = system.contact_forces(xb, xpb)
+        assert torch.equal(it_auto, it_one)
 
 
 def test_full_size_65536_float64_wide_build():

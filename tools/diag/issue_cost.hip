@@ -2,6 +2,7 @@
 //   hipcc -O3 --offload-arch=gfx950 -o issue_cost issue_cost.hip && ./issue_cost
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 template <int MODE> __global__ void cost(float* out, unsigned long long* cycles, int iters) {
   float a[16]; double d[16];
   for (int i = 0; i < 16; ++i) { a[i] = threadIdx.x * 1e-3f + i + 1.f; d[i] = threadIdx.x * 1e-3 + i + 1.0; }
@@ -28,32 +29,34 @@ template <int MODE> __global__ void cost(float* out, unsigned long long* cycles,
   out[blockIdx.x * 64 + threadIdx.x] = s;
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
-int main() {
-  float* out; unsigned long long* cyc; unsigned long long h[256];
-  (void)hipMalloc(&out, 256 * 64 * 4); (void)hipMalloc(&cyc, 256 * 8);
+int main(int argc, char** argv) {
+  const int grid = argc > 1 ? atoi(argv[1]) : 256;  // one-wave workgroups: 256 = one per CU, 1024 = one per SIMD
+
+  float* out; unsigned long long* cyc; static unsigned long long h[8192];
+  (void)hipMalloc(&out, 8192 * 64 * 4); (void)hipMalloc(&cyc, 8192 * 8);
   const int iters = 2048;
   const char* names[11] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add", "v_add_f32_dpp (row_half_mirror)", "v_add_f32_dpp (row_shr:1)", "ds_swizzle_b32 + v_add_f32", "ds_bpermute_b32 + v_add_f32"};
   const int per[11] = {1, 1, 1, 2, 3, 1, 4, 1, 1, 2, 2};
   for (int mode = 0; mode < 11; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       switch (mode) {
-        case 0: hipLaunchKernelGGL(cost<0>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 1: hipLaunchKernelGGL(cost<1>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 2: hipLaunchKernelGGL(cost<2>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 3: hipLaunchKernelGGL(cost<3>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 4: hipLaunchKernelGGL(cost<4>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 5: hipLaunchKernelGGL(cost<5>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 6: hipLaunchKernelGGL(cost<6>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 7: hipLaunchKernelGGL(cost<7>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 8: hipLaunchKernelGGL(cost<8>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        case 9: hipLaunchKernelGGL(cost<9>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
-        default: hipLaunchKernelGGL(cost<10>, dim3(256), dim3(64), 0, 0, out, cyc, iters); break;
+        case 0: hipLaunchKernelGGL(cost<0>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 1: hipLaunchKernelGGL(cost<1>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 2: hipLaunchKernelGGL(cost<2>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 3: hipLaunchKernelGGL(cost<3>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 4: hipLaunchKernelGGL(cost<4>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 5: hipLaunchKernelGGL(cost<5>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 6: hipLaunchKernelGGL(cost<6>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 7: hipLaunchKernelGGL(cost<7>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 8: hipLaunchKernelGGL(cost<8>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 9: hipLaunchKernelGGL(cost<9>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        default: hipLaunchKernelGGL(cost<10>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
       }
       (void)hipDeviceSynchronize();
     }
-    (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
-    double mean = 0; for (int i = 0; i < 256; ++i) mean += (double)h[i]; mean /= 256;
-    printf("%-44s %.2f cycles per group of %d instruction(s) (16 independent chains)\n", names[mode], mean / iters / 16, per[mode]);
+    (void)hipMemcpy(h, cyc, grid * 8, hipMemcpyDeviceToHost);
+    double mean = 0, mx = 0; for (int i = 0; i < grid; ++i) { mean += (double)h[i]; mx = h[i] > mx ? (double)h[i] : mx; } mean /= grid;
+    printf("grid %d  %-44s %.2f (slowest wave %.2f) cycles per group of %d instruction(s) (16 independent chains)\n", grid, names[mode], mean / iters / 16, mx / iters / 16, per[mode]);
   }
   return 0;
 }

@@ -15,6 +15,7 @@ dtype = torch.float64 if 'f64' in sys.argv else torch.float32
 g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_4096.npz'))
 s = MultibodyLearnableSystem({'cube': os.path.join(REPO, 'assets', 'cube.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
 x = torch.tensor(g['x'], dtype=dtype, device='cuda:0'); xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+s.set_solver(portfolio=int(os.environ.get('DPLL_PORTFOLIO', '1')))
 for _ in range(5): s.contactnets_loss_and_grad(x, xp)
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
@@ -37,7 +38,7 @@ for label, idx in (('slowest', order[-1]), ('median', order[len(order) // 2]), (
     print(label, 'wave', idx, 'total', total[idx], 'max newton iters in wave', its[idx], dict(zip(names, seg[idx])))
 print('mean per segment', dict(zip(names, seg.mean(0).round(0))), 'mean total', total.mean())
 print('newton ticks per iteration (slowest wave)', seg[order[-1], 2] / max(1, its[order[-1]]))
-print('launch skew: last start', t[:, 0].max() - t[:, 0].min(), 'last end', t[:, 3].max() - t[:, 0].min())
+print('launch skew: last start', t[:, 0].max() - t[:, 0].min(), 'last end', t[:, 3].max() - t[:, 0].min(), 'start quantiles', np.quantile(t[:, 0] - t[:, 0].min(), [0.25, 0.5, 0.75, 0.9, 1.0]))
 
 pn = ['grad+hessian+reduce', 'cholesky+solve', 'decrement+tests', 'state at y+d', 'fallback search', 'update+stage-logic']
 w = order[-1]
