@@ -985,7 +985,7 @@ DPLL_HD void sap_advance(const JT (&Jc)[KPL], const T (&mu)[KPL], const SapPoint
 template <typename T, typename TA, int NJ, int KPL, class Lanes, class JT>
 DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const T (&mu)[KPL],
                        const T (&qc)[KPL][3], T eps, const SolverOpts& opt, TA (&y)[6 + NJ], T (&f)[KPL][3],
-                       const T (&y0)[6 + NJ], bool use_y0, bool race = false, bool* winner = nullptr) {
+                       const T (&y0)[6 + NJ], bool use_y0, bool race = false, bool* winner = nullptr, bool participate = true) {
   constexpr int NV = 6 + NJ;
   // float storage with a wider accumulation type: iterate on increments, all in float (sap_advance)
   constexpr bool kIncremental = DPLL_INCREMENTAL && sizeof(T) < sizeof(TA);
@@ -1020,7 +1020,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     for (int s = 0; s < last_stage; ++s) eps_c *= factor;
   }
   int stage = 0, it_stage = 0;
-  bool active = true;
+  bool active = participate;  // (racing copies: the refinement phase of a double solve runs the float phase's winner only)
   bool finished = false;  // this copy met the stopping rule itself (racing: it may also end because another copy did)
   int iters = 0;
   DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = use_y0 ? TA(y0[i]) : TA(0);
@@ -1240,7 +1240,8 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
   if constexpr (Lanes::kVariants > 1) {
     // the finished copy with the lowest index supplies the item's outputs (none finished: max_iter ran out, copy 0 does)
     const int done_bits = Lanes::item_or(finished ? (1 << Lanes::variant()) : 0);
-    const int first = done_bits == 0 ? 0 : __builtin_ctz(done_bits);
+    const int part_bits = Lanes::item_or(participate ? (1 << Lanes::variant()) : 0);
+    const int first = __builtin_ctz((done_bits != 0 ? done_bits : part_bits) | (1 << Lanes::kVariants));
     if (winner) *winner = Lanes::variant() == first;
   } else {
     if (winner) *winner = true;
@@ -1285,14 +1286,15 @@ DPLL_HD int sap_solve(const T (&M)[6 + NJ][6 + NJ], const CJac<T, NJ, DENSE> (&J
     coarse.tol = 1e-6;
     coarse.stall_tol = 1e-5;
     double yc[NV];
-    // (racing copies: the float phase races the schedules; every copy then refines ITS point with the same one-stage
-    // schedule and the item is finished when the first of them -- the float phase's winner, typically -- has converged)
-    const int it_coarse = sap_newton<float, double, NJ, KPL, Lanes>(Mf, Jf, muf, qcf, float(eps), coarse, yc, ff, y0f, use_y0, race);
+    // (racing copies: the float phase races the schedules, its winner alone is refined in double -- the other copies hold
+    // points that are not converged and would only send the wave through the line search's fall-back code)
+    bool coarse_winner = true;
+    const int it_coarse = sap_newton<float, double, NJ, KPL, Lanes>(Mf, Jf, muf, qcf, float(eps), coarse, yc, ff, y0f, use_y0, race, &coarse_winner);
     SolverOpts fine = opt;
     fine.n_stages = 1;
     T start[NV];
     DPLL_UNROLL for (int i = 0; i < NV; ++i) start[i] = T(yc[i]);
-    return it_coarse + sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, fine, y, f, start, true, false, winner);
+    return it_coarse + sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, fine, y, f, start, true, false, winner, coarse_winner);
   } else {
     return sap_newton<T, TA, NJ, KPL, Lanes>(M, Jc, mu, qc, eps, opt, y, f, y0, use_y0, race, winner);
   }
