@@ -57,6 +57,15 @@ template <int G, int P = 1> struct GpuLanes {
     if (G * P == 16) x |= dpp_mov<kRowMirror>(x);          // the other half of the row
     return x;
   }
+  // the value one copy of the item holds (`mine` true in exactly one copy, the value uniform inside a copy), in every copy:
+  // a sum in which the other copies enter as zero
+  template <typename T> static __device__ __forceinline__ T item_pick(bool mine, T x) {
+    if (P == 1) return x;
+    x = mine ? x : T(0);
+    if (G == 4) x += dpp_mov<kRowHalfMirror>(x);
+    if (G * P == 16) x += dpp_mov<kRowMirror>(x);
+    return x;
+  }
   template <typename T> static __device__ __forceinline__ T group_sum(T x) {
     if (G == 1) return x;
     x += dpp_mov<kQuadXor1>(x);

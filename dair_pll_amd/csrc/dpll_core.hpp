@@ -810,7 +810,9 @@ template <typename T> struct Proj {
 };
 template <typename T> DPLL_HD void lorentz_project(const T (&z)[3], Proj<T>& p) {
   const T r2 = z[0] * z[0] + z[1] * z[1];
-  const bool pos = r2 > T(0);
+  // (a tangential part whose square is not a normal number counts as none: v_rsq_f32 returns inf for a denormal input and
+  // r = r2 * inf poisons the solve -- a cube that has come to rest in a long rollout gets there, |z_t| ~ 1e-20)
+  const bool pos = r2 > T(sizeof(T) == 4 ? 1e-34 : 1e-300);
   const T ir = pos ? fast_rsqrt(r2) : T(0);
   const T r = r2 * ir;
   const T n = z[2];
@@ -1441,6 +1443,7 @@ struct OneLane {
   static constexpr int kVariants = 1;  // racing copies of an item (SolverOpts::portfolio): the device builds only
   static DPLL_HD int variant() { return 0; }
   static DPLL_HD int item_or(int x) { return x; }
+  template <typename T> static DPLL_HD T item_pick(bool, T x) { return x; }
   template <typename T> static DPLL_HD T group_sum(T x) { return x; }
   static DPLL_HD bool group_any(bool x) { return x; }
   static DPLL_HD bool wave_any(bool x) { return x; }
@@ -2229,7 +2232,14 @@ DPLL_HD void step_item(const MD& md, const Derived<T, NJ, NG>& dp, const SolverO
     qc[c][2] = jv[2] + cg.phi * idt;
   }
   TA y[NV];
-  iters = sap_solve<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, impulse, vm, false);
+  bool winner = true;
+  iters = sap_solve<T, TA, NJ, KPL, Lanes>(t.M, Jc, mu, qc, eps, opt, y, impulse, vm, false, true, &winner);
+  if constexpr (Lanes::kVariants > 1) {
+    // racing copies (rollouts of a batch that leaves SIMDs idle): every copy goes on from the winner's velocity change, so
+    // the copies of an item hold the same state at every step (`impulse` stays each copy's own: the rollout does not use it)
+    DPLL_UNROLL for (int i = 0; i < NV; ++i) y[i] = Lanes::item_pick(winner, y[i]);
+    iters = Lanes::item_pick(winner, iters);
+  }
   // v+ = v- + M^-1 J^T impulse = v- + y*: the primal optimum IS that velocity change (M y* = J^T f), and
   // taking it from y instead of re-solving with the projected impulse avoids amplifying the impulse's
   // rounding error by |J|^2 / (eps M).

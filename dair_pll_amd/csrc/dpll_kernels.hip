@@ -350,7 +350,9 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
 }
 
 // ---- simulation: `steps` VelocityIntegrator steps per item, trajectory written as it goes ---------
-template <typename T, int NJ, bool MESH = false>
+// RACE: racing copies of every item (as in the loss kernel): a rollout's wave pays, at every step, for its slowest item --
+// with four copies it holds 4 items instead of 16 and an item needs the fewest iterations of its copies
+template <typename T, int NJ, bool MESH = false, int RACE = 1>
 __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
                                                          const T* __restrict__ x0, long long ld_x, long long batch,
@@ -358,14 +360,16 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
                                                          long long ld_step, int write_x0, int* __restrict__ iters,
                                                          const T* __restrict__ witness) {
   using D = Dims<T, NJ>;
-  using Lanes = GpuLanes<D::G>;
+  using Lanes = GpuLanes<D::G, RACE>;
+  static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
+  constexpr int kItems = D::IPW / RACE;  // items per wave
   const int lane = threadIdx.x;
-  const int cidx = lane % D::G;
-  const int slot = lane / D::G;
+  const int cidx = lane % (D::G * RACE);  // (0: the lane that writes the item's rows)
+  const int slot = lane / (D::G * RACE);
   Derived<T, NJ> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
-  const long long stride = (long long)gridDim.x * D::IPW;
-  for (long long base = (long long)blockIdx.x * D::IPW; base < batch; base += stride) {
+  const long long stride = (long long)gridDim.x * kItems;
+  for (long long base = (long long)blockIdx.x * kItems; base < batch; base += stride) {
     const long long item = base + slot;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
         for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
         step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it, wit);
       } else {
-        step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx, xn, imp, n_it);
+        step_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, cidx % D::G, xn, imp, n_it);
       }
       total += n_it;
 #pragma unroll
@@ -646,15 +650,18 @@ template <typename T, int NJ> int loss_blocks(long long batch, int copies = 1) {
   return blocks_for(batch, copies > 1 ? kRaceWaves * Dims<T, NJ>::IPW / copies : Dims<T, NJ>::IPW);
 }
 
-// Racing copies per item of the loss launch (dpll_solver_opts_t::portfolio): the most that were asked for (0: four) that
-// keep an item inside a 16-lane row and the launch within one wave per SIMD -- the copies use SIMDs that would idle,
-// they never make a wave wait for a SIMD.
-inline int race_copies(int requested, int lanes_per_item, long long batch) {
-  int p = requested == 0 ? 4 : requested;
+// Racing copies per item (dpll_solver_opts_t::portfolio): what was asked for -- 0: `preferred`, the number measured best for
+// the launch in question -- reduced until an item stays inside a 16-lane row and the launch within one wave per SIMD (the
+// copies use SIMDs that would idle, they never make a wave wait for one).  A default that cannot have its preferred
+// number runs without copies: fewer copies buy too little (cube loss: two copies save one iteration of fourteen).
+// More active SIMDs also cost clock: the same kernel runs ~25 % slower per iteration with a wave on every SIMD than
+// with a wave per CU (in-kernel cycle counts do not change, times do), which is why the float rollouts prefer two copies.
+inline int race_copies(int requested, int lanes_per_item, long long batch, int preferred = 4) {
+  int p = requested == 0 ? preferred : requested;
   if (batch < 1) return 1;
   while (p > 1 && (lanes_per_item * p > 16 || (long long)kRaceWaves * blocks_for(batch, kRaceWaves * kWave / (lanes_per_item * p)) > kSimds))
     p >>= 1;
-  if (requested == 0 && p < 4) p = 1;  // measured: two copies buy one iteration of fourteen (cube) or none (elbow)
+  if (requested == 0 && p < preferred) p = 1;
   return p;
 }
 
@@ -801,11 +808,24 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   using D = Dims<T, NJ>;
   long long blocks = (batch + D::IPW - 1) / D::IPW;
   if (blocks > 8192) blocks = 8192;
+  // racing copies (the loss launch's rule: four per item while the launch stays within one wave per SIMD)
+  // (measured, 4096 cube rollouts of 80 steps, us per step with 1 / 2 / 4 copies: f32 13.3 / 11.2 / 14.9, f64 19.6 / 18.2 / 16.6;
+  // elbow f32 18.6 / 18.2: the elbow runs without)
+  const int copies = (witness || NJ > 0 && m->opts[dtype].portfolio == 0) ? 1 : race_copies(m->opts[dtype].portfolio, D::G, batch, sizeof(T) == 4 ? 2 : 4);
   if (witness)
     hipLaunchKernelGGL((simulate_kernel<T, NJ, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
                        (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)witness);
-  else
+  else if (copies == 2)
+    hipLaunchKernelGGL((simulate_kernel<T, NJ, false, 2>), dim3((int)((batch + D::IPW / 2 - 1) / (D::IPW / 2))), dim3(kWave), 0, stream,
+                       m->desc, m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x,
+                       batch, steps, (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
+  else if (copies == 4) {
+    if constexpr (D::G * 4 <= 16)
+      hipLaunchKernelGGL((simulate_kernel<T, NJ, false, 4>), dim3((int)((batch + D::IPW / 4 - 1) / (D::IPW / 4))), dim3(kWave), 0, stream,
+                         m->desc, m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x,
+                         batch, steps, (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
+  } else
     hipLaunchKernelGGL((simulate_kernel<T, NJ, false>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
                        (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);

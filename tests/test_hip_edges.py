@@ -228,6 +228,39 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
         assert torch.equal(it_auto, it_one)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_long_rollouts_come_to_rest_and_racing_copies_follow_the_same_path(dtype):
+    """80-step fused rollouts of the 4096 toss states: most cubes come to rest, where the tangential cone residual
+    underflows (|z_t|^2 is a float denormal: v_rsq_f32 answers inf and, before round 3, 384 of the 4096 float
+    trajectories ended in NaN on the device and none on the host) -- every state stays finite, the cubes stay on the
+    ground plane.  The rollout kernel's racing copies (``portfolio``: 2 per item in float, 4 in double by default) take
+    every step from the winning copy's velocity: over 8 steps the trajectories agree with the launch without copies to
+    the solver's tolerance, launches are bitwise reproducible."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    g = np.load(os.path.join(GOLDEN_DIR, 'cube_box_4096.npz'))
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, 'cube.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+    x0 = torch.tensor(g['x'], dtype=dtype, device='cuda:0').unsqueeze(-2)
+    carry = torch.zeros((4096, 1), device='cuda:0')
+    half = float(system.multibody_terms.contact_terms.geometries[1].length_params.detach().abs().min())
+    with torch.no_grad():
+        for copies in (1, 0):
+            system.set_solver(portfolio=copies)
+            traj, _ = system.simulate(x0, carry, 80)
+            assert torch.isfinite(traj).all(), (copies, int((~torch.isfinite(traj)).any(-1).any(-1).sum()))
+            assert (traj[:, -1, 6] > half - 2e-3).all()               # nobody fell through the ground
+            assert (traj[:, -1, :4].norm(dim=-1) - 1).abs().max() < 1e-2  # (quaternions are not re-normalised: drift only)
+            assert (traj[:, -1, 7:].abs().max(-1).values < 1e-3).float().mean() > 0.5  # most have come to rest
+        short = {}
+        for copies in (1, 2, 4):
+            system.set_solver(portfolio=copies)
+            short[copies], _ = system.simulate(x0, carry, 8)
+            again, _ = system.simulate(x0, carry, 8)
+            assert torch.equal(short[copies], again)
+        tol = 1e-9 if dtype == torch.float64 else 5e-4
+        for copies in (2, 4):
+            assert (short[copies] - short[1]).abs().max().item() < tol, (copies, (short[copies] - short[1]).abs().max().item())
+
+
 def test_full_size_65536_float64_wide_build():
     """BASELINE configs[4], fp64 leg at its per-launch size: 65,536 pairs (the one-lane-per-item build, 1024 waves)
     drawn with replacement from the 4096 reference-run pairs -- every item's loss equals the reference-run value of the

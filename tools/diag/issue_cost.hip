@@ -3,10 +3,22 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+// MODE 11 / 12: the same v_fma_f32 stream as MODE 0 but as 32 KB / 8 KB of straight-line code per loop trip (the Newton loop's shape:
+// long unrolled bodies that do not fit the wave's instruction buffer), to see what the waves of a CU cost each other in
+// instruction fetch
 template <int MODE> __global__ void cost(float* out, unsigned long long* cycles, int iters) {
   float a[16]; double d[16];
   for (int i = 0; i < 16; ++i) { a[i] = threadIdx.x * 1e-3f + i + 1.f; d[i] = threadIdx.x * 1e-3 + i + 1.0; }
   unsigned long long t0 = __builtin_readcyclecounter();
+  if (MODE >= 11) {
+    constexpr int kBody = MODE == 11 ? 256 : 64;  // x 16 instructions x 8 bytes
+    for (int it = 0; it < iters / kBody; ++it) {
+#pragma unroll
+      for (int r = 0; r < kBody; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = __builtin_fmaf(a[i], 1.0001f + 1e-6f * (r + 1), 1e-3f);
+    }
+  } else
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -35,9 +47,9 @@ int main(int argc, char** argv) {
   float* out; unsigned long long* cyc; static unsigned long long h[8192];
   (void)hipMalloc(&out, 8192 * 64 * 4); (void)hipMalloc(&cyc, 8192 * 8);
   const int iters = 2048;
-  const char* names[11] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add", "v_add_f32_dpp (row_half_mirror)", "v_add_f32_dpp (row_shr:1)", "ds_swizzle_b32 + v_add_f32", "ds_bpermute_b32 + v_add_f32"};
-  const int per[11] = {1, 1, 1, 2, 3, 1, 4, 1, 1, 2, 2};
-  for (int mode = 0; mode < 11; ++mode) {
+  const char* names[13] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add", "v_add_f32_dpp (row_half_mirror)", "v_add_f32_dpp (row_shr:1)", "ds_swizzle_b32 + v_add_f32", "ds_bpermute_b32 + v_add_f32", "v_fma_f32, 32 KB straight-line body", "v_fma_f32, 8 KB straight-line body"};
+  const int per[13] = {1, 1, 1, 2, 3, 1, 4, 1, 1, 2, 2, 1, 1};
+  for (int mode = 0; mode < 13; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       switch (mode) {
         case 0: hipLaunchKernelGGL(cost<0>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
@@ -50,6 +62,8 @@ int main(int argc, char** argv) {
         case 7: hipLaunchKernelGGL(cost<7>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
         case 8: hipLaunchKernelGGL(cost<8>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
         case 9: hipLaunchKernelGGL(cost<9>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 11: hipLaunchKernelGGL(cost<11>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
+        case 12: hipLaunchKernelGGL(cost<12>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
         default: hipLaunchKernelGGL(cost<10>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
       }
       (void)hipDeviceSynchronize();
