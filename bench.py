@@ -283,7 +283,7 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
         workload = f'{workload} (ICNN GEMMs: bf16 matrix cores, operands split into {mesh_gemm} bf16 planes)'
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
-            'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
+            'racing_copies': system.racing_copies(batch), 'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
             'roofline': {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel') if k in roof}}
 
 
@@ -319,7 +319,7 @@ def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device):
     achieved = alg / (ms * 1e-3) / 1e9
     return {'workload': f'simulate ({workload}, {horizon} steps per launch)', 'dtype': dtype_name, 'batch': batch,
             'value': batch * horizon / (ms * 1e-3), 'unit': 'trajectory-steps/s (forward only)', 'ms_per_step': ms / horizon,
-            'kernel_ms': ms, 'launch': 'one simulate_kernel launch per rollout',
+            'kernel_ms': ms, 'launch': 'one simulate_kernel launch per rollout', 'racing_copies': system.racing_copies(batch, rollout=True),
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'kernel': 'simulate_kernel'}}
 
@@ -545,6 +545,7 @@ def main() -> None:
             'data': DATA[args.workload],
             'config': {'workload': f'{names[args.workload]}, batch={args.batch} per GPU, fwd+bwd contactnets_loss',
                        'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'launch': timer.launch,
+                       'racing_copies': system.racing_copies(args.batch),
                        'timing': f'median of {len(times)} repeats of the {args.steps}-step timed region '
                                  f'({sum(times):.2f} s measured in total)',
                        'repeats': len(times), 'repeat_ms': [round(t * 1e3, 5) for t in times[:5]],

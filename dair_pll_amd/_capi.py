@@ -148,6 +148,8 @@ def library() -> ctypes.CDLL:
         getattr(lib, name).argtypes = [c_void_p]
     lib.dpll_workspace_bytes.argtypes = [c_void_p, c_int64]
     lib.dpll_workspace_bytes.restype = c_int64
+    lib.dpll_racing_copies.argtypes = [c_void_p, c_int, c_int64, c_int]
+    lib.dpll_racing_copies.restype = c_int
     lib.dpll_contactnets_loss.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64,
                                           c_int64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_void_p]
@@ -206,7 +208,7 @@ def check(status: int) -> None:
 
 EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_model_destroy',
                     'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
-                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_step_backward', 'dpll_simulate',
+                    'dpll_param_count', 'dpll_workspace_bytes', 'dpll_racing_copies', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_step_backward', 'dpll_simulate',
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
                     'dpll_profile_contactnets_loss_mesh',
                     'dpll_step_mesh', 'dpll_simulate_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',

@@ -811,7 +811,7 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   // racing copies (the loss launch's rule: four per item while the launch stays within one wave per SIMD)
   // (measured, 4096 cube rollouts of 80 steps, us per step with 1 / 2 / 4 copies: f32 13.3 / 11.2 / 14.9, f64 19.6 / 18.2 / 16.6;
   // elbow f32 18.6 / 18.2: the elbow runs without)
-  const int copies = (witness || NJ > 0 && m->opts[dtype].portfolio == 0) ? 1 : race_copies(m->opts[dtype].portfolio, D::G, batch, sizeof(T) == 4 ? 2 : 4);
+  const int copies = witness ? 1 : dpll_racing_copies(m, dtype, batch, 1);
   if (witness)
     hipLaunchKernelGGL((simulate_kernel<T, NJ, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
@@ -1669,6 +1669,15 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   const int64_t pi = 1 + 10 * nb + (nb + 1) + 3 * nb;
   const int64_t chain = 100 * nb + (nb + 1) * nb + 3 * nb;  // the rows-to-parameters matrix behind the rows
   return (blocks * pi + chain) * (int64_t)sizeof(double);
+}
+
+int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what) {
+  if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || (what != 0 && what != 1)) return -1;
+  if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return 1;
+  const int lanes = kQuery * (model->desc.n_joints + 1);
+  const int asked = model->opts[dtype].portfolio;
+  if (what == 0) return race_copies(asked, lanes, batch);
+  return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, lanes, batch, dtype == DPLL_F32 ? 2 : 4);
 }
 
 int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,

@@ -416,6 +416,12 @@ class MultibodyLearnableSystem(Module):
             _capi._lib.dpll_model_destroy(handle)
             self._handle = None
 
+    def racing_copies(self, batch: int, rollout: bool = False) -> int:
+        """Racing copies per item (``dpll_solver_opts_t.portfolio``) of a loss (or rollout) launch of ``batch`` items."""
+        if self._mesh() is not None:  # (learned shapes: the support points come from the ICNN kernels, no copies)
+            return 1
+        return int(_capi.library().dpll_racing_copies(self._model(), _DTYPES[self.dtype], batch, 1 if rollout else 0))
+
     def set_solver(self, **kwargs) -> None:
         """Override ``max_iter / max_ls / tol / stall_tol / ls_tol`` for this system's dtype."""
         lib = _capi.library()

@@ -157,6 +157,11 @@ int dpll_param_count(const dpll_model_t* model);  /* layout [theta | friction | 
 /* bytes of scratch dpll_contactnets_loss needs for a batch of `batch` items (gradient partial sums) */
 int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch);
 
+/* Racing copies per item (dpll_solver_opts_t.portfolio) that a launch of `batch` items would run with the model's current
+ * solver settings: what = 0 the loss launch (dpll_contactnets_loss and its variants), 1 the rollout / step launch
+ * (dpll_simulate, dpll_step).  1 = no copies (always: general build, learned shapes).  -1 on a bad argument. */
+int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what);
+
 /* ContactNets loss of `batch` transitions (x -> x_plus), forward and backward in one pass.
  *   x, x_plus   (batch, n_x), row strides ld_x / ld_xp elements
  *   weights     optional (batch,) upstream gradient d(total)/d(loss_i); the effective weight of item i is

@@ -198,6 +198,9 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
         total = system.contactnets_loss_and_grad(x[:rows], xp[:rows]).clone()
         return loss.clone(), force.clone(), iters.clone(), system.grad_buffer().clone(), total
 
+    if urdf == 'elbow.urdf':  # eight lanes per item: room for two copies, which buy nothing -- the default runs without
+        system.set_solver(portfolio=0)
+        assert system.racing_copies(4096) == 1 and system.racing_copies(4096, rollout=True) == 1
     alone, raced, again = launch(1), launch(copies), launch(copies)
     for a, b in zip(raced, again):
         assert torch.equal(a, b)
@@ -222,6 +225,8 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
         assert (ragged[0] - ragged_alone[0]).abs().max().item() <= (1e-11 if f64 else 5e-6) and (ragged[2] <= ragged_alone[2]).all()
         xb, xpb = torch.cat([x, x[:1]]), torch.cat([xp, xp[:1]])
         system.set_solver(portfolio=0)
+        assert system.racing_copies(4096) == 4 and system.racing_copies(4097) == 1 and system.racing_copies(1) == 4
+        assert system.racing_copies(4096, rollout=True) == (4 if f64 else 2) and system.racing_copies(16384, rollout=True) == 1
         _, _, it_auto = system.contact_forces(xb, xpb)
         system.set_solver(portfolio=1)
         _, _, it_one = system.contact_forces(xb, xpb)
