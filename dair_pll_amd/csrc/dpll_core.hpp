@@ -44,11 +44,6 @@
 
 #define DPLL_UNROLL _Pragma("unroll")
 #if defined(__clang__)
-#define DPLL_UNINITIALIZED [[clang::uninitialized]]  // opt a local out of -ftrivial-auto-var-init
-#else
-#define DPLL_UNINITIALIZED
-#endif
-#if defined(__clang__)
 #define DPLL_NOUNROLL _Pragma("clang loop unroll(disable)")
 #else
 #define DPLL_NOUNROLL _Pragma("GCC unroll 1")
@@ -1529,9 +1524,7 @@ DPLL_HD_CALL void pair_direction(const S (*a)[3], int na, int kind_a, const S (*
   best.sep = S(-3.0e38);
   best.d[0] = S(0); best.d[1] = S(0); best.d[2] = S(1);
   best.k = 0x7fffffff;
-  // (the general translation unit zero-initialises locals, csrc/Makefile: not these 2 x 292 bytes of tables per lane --
-  // pair_features writes every entry that is read)
-  DPLL_UNINITIALIZED PairFeatures fa, fb;
+  PairFeatures fa, fb;  // (every entry below the n_* counts is written by pair_features; nothing beyond them is read)
   pair_features(kind_a, na, fa);
   pair_features(kind_b, nb, fb);
   const int n_vv = na * nb, n_veb = na * fb.n_edges, n_vea = nb * fa.n_edges, n_ta = fa.n_tris, n_tb = fb.n_tris;

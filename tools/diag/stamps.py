@@ -15,7 +15,7 @@ dtype = torch.float64 if 'f64' in sys.argv else torch.float32
 g = np.load(os.path.join(REPO, 'tests', 'golden', 'cube_box_4096.npz'))
 s = MultibodyLearnableSystem({'cube': os.path.join(REPO, 'assets', 'cube.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
 x = torch.tensor(g['x'], dtype=dtype, device='cuda:0'); xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
-s.set_solver(portfolio=int(os.environ.get('DPLL_PORTFOLIO', '1')))
+s.set_solver(portfolio=int(os.environ.get('DPLL_PORTFOLIO', '0')))
 for _ in range(5): s.contactnets_loss_and_grad(x, xp)
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
