@@ -56,6 +56,8 @@ json.dump(old, open(os.path.join(DST, f'{TAG}_hbm_traffic.json'), 'w'), indent=1
 with open(os.path.join(SRC, 'stamps.txt')) as f:
     text = [l for l in f.read().splitlines() if 'amdgpu.ids' not in l]
 with open(os.path.join(DST, f'{TAG}_loss_kernel_stamps.txt'), 'w') as f:
-    f.write('tools/diag/stamps.py, f32, B=4096 (256 one-wave workgroups, 16 items per wave); units: shader cycles (s_memtime); '
-            'the stamped build runs ~10 % slower than the shipped one\n' + re.sub(r'np\.(?:int64|float64)\(([^)]*)\)', r'\1', '\n'.join(text)) + '\n')
+    f.write('tools/diag/stamps.py, f32, B=4096, the shipping launch: racing build, 256 four-wave workgroups of 16 items (a wave: 4 items x '
+            '4 copies x 4 contact lanes); the stamps are those of wave 0 of every workgroup, its reduce+store segment includes the wait '
+            'for the other three waves at the barrier before the shared partial row; units: s_memtime ticks; the stamped build runs '
+            '~10 % slower than the shipped one\n' + re.sub(r'np\.(?:int64|float64)\(([^)]*)\)', r'\1', '\n'.join(text)) + '\n')
 print(json.dumps(old, indent=1)); print(open(os.path.join(DST, f'{TAG}_loss_kernel_pmc.csv')).read())
