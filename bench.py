@@ -230,7 +230,8 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
                 with open(path.replace('hbm_traffic.json', 'loss_kernel_pmc.csv')) as handle:
                     counters = {row.split(',')[0]: float(row.split(',')[1]) for row in handle.read().splitlines()[1:]}
                 props = torch.cuda.get_device_properties(torch.cuda.current_device())
-                simds, hz = 4 * props.multi_processor_count, props.clock_rate * 1e3
+                # (clock_rate in kHz where this torch build reports it; else the 2.4 GHz peak engine clock of the part)
+                simds, hz = 4 * props.multi_processor_count, (getattr(props, 'clock_rate', 0) or 2.4e6) * 1e3
                 valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * hz * simds)
     except (OSError, KeyError, ValueError, IndexError, TypeError, AttributeError):
         pass
