@@ -288,6 +288,28 @@ def test_long_rollouts_of_every_model_family_stay_finite(name, urdf, representat
     assert traj.abs().max().item() < 1e3
 
 
+def test_racing_copies_on_other_samples_of_the_toss_data():
+    """The racing schedules were picked on the benchmark batch; on five other 4096-pair samples of the reference's 57,812
+    cube-toss pairs (``assets/contactnets_cube_tosses.npz``) the launch with copies returns the same losses (1e-6), no item
+    needs more iterations than without, the mean falls by a quarter or more and the slowest item never gets slower
+    (measured: 16/15/14/15/16 -> 12/13/11/12/16 iterations)."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.trainer import load_tosses, slice_pairs
+    path = os.path.join(ASSET_DIR, 'contactnets_cube_tosses.npz')
+    x_all, xp_all = slice_pairs(load_tosses(path))
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, 'cube.urdf')}, float(np.load(path)['dt']), dtype=torch.float32, device='cuda:0')
+    for seed in range(1, 6):
+        pick = torch.randperm(x_all.shape[0], generator=torch.Generator().manual_seed(seed))[:4096]
+        x, xp = x_all[pick].float().cuda(), xp_all[pick].float().cuda()
+        system.set_solver(portfolio=1)
+        loss_1, _, iters_1 = system.contact_forces(x, xp)
+        system.set_solver(portfolio=0)
+        loss_4, _, iters_4 = system.contact_forces(x, xp)
+        assert (loss_4 - loss_1).abs().max().item() < 1e-6
+        assert (iters_4 <= iters_1).all()
+        assert iters_4.float().mean().item() < 0.75 * iters_1.float().mean().item()
+
+
 def test_full_size_65536_float64_wide_build():
     """BASELINE configs[4], fp64 leg at its per-launch size: 65,536 pairs (the one-lane-per-item build, 1024 waves)
     drawn with replacement from the 4096 reference-run pairs -- every item's loss equals the reference-run value of the
