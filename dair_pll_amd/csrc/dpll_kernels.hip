@@ -84,6 +84,13 @@ namespace {
 // a second resident wave fills the issue slots a lone wave leaves empty (65,536 pairs: 800 -> 944 M steps/s); the
 // headline launch (256 waves) keeps the roomier one-wave build (it is 1 % faster there).
 constexpr int kRaceWaves = 4;  // waves per workgroup of the racing build
+// A racing launch has a wave for EVERY SIMD, and the dispatcher does not spread them: a float kernel of <= 256 registers fits
+// twice on a SIMD, waves get doubled up while other SIMDs idle, and a doubled wave runs at ~2/3 speed (measured with the
+// rollout kernel, 188 VGPRs: 256 / 512 / 1024 / 2048 one-wave workgroups of identical work take 13.1 / 13.4 / 20.1 / 20.2 us
+// per step; the double build, 334 VGPRs, 19.4 / 19.8 / 19.7 / 37.8; an LDS reservation that caps a CU at four workgroups
+// does not help: the doubling is inside the CU).  Touching accumulation register a127 makes the wave's allocation (vector +
+// accumulation registers share one file of 512) exceed half the file, so a SIMD holds exactly one such wave.
+__device__ __forceinline__ void claim_whole_simd() { asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127"); }
 // RACE: copies of every item's lane group that run other continuation schedules of the cone solve in lock step
 // (SolverOpts::portfolio, dpll_core.hpp sap_newton): for launches that would leave SIMDs idle.  An item owns G * RACE
 // lanes; the copy that converged first supplies the item's loss, forces, iteration count and gradient terms.
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(RACE > 1 ? kRaceWaves * kWave : kWave, DENSE ? 2 : 
   using Lanes = GpuLanes<D::G, RACE>;
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
   constexpr int kItems = (RACE > 1 ? kRaceWaves : 1) * D::IPW / RACE;  // items per workgroup
+  if constexpr (!DENSE) claim_whole_simd();  // (this build serves the launches of at most one wave per SIMD)
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
   const int slot = lane / (D::G * RACE);
@@ -352,7 +360,8 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
 // ---- simulation: `steps` VelocityIntegrator steps per item, trajectory written as it goes ---------
 // RACE: racing copies of every item (as in the loss kernel): a rollout's wave pays, at every step, for its slowest item --
 // with four copies it holds 4 items instead of 16 and an item needs the fewest iterations of its copies
-template <typename T, int NJ, bool MESH = false, int RACE = 1>
+// SOLO: for launches of at most one wave per SIMD (claim_whole_simd)
+template <typename T, int NJ, bool MESH = false, int RACE = 1, bool SOLO = (RACE > 1)>
 __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
                                                          const T* __restrict__ x0, long long ld_x, long long batch,
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
   using Lanes = GpuLanes<D::G, RACE>;
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
   constexpr int kItems = D::IPW / RACE;  // items per wave
+  if constexpr (SOLO) claim_whole_simd();
   const int lane = threadIdx.x;
   const int cidx = lane % (D::G * RACE);  // (0: the lane that writes the item's rows)
   const int slot = lane / (D::G * RACE);
@@ -656,8 +666,6 @@ template <typename T, int NJ> int loss_blocks(long long batch, int copies = 1) {
 // the launch in question -- reduced until an item stays inside a 16-lane row and the launch within one wave per SIMD (the
 // copies use SIMDs that would idle, they never make a wave wait for one).  A default that cannot have its preferred
 // number runs without copies: fewer copies buy too little (cube loss: two copies save one iteration of fourteen).
-// More active SIMDs also cost clock: the same kernel runs ~25 % slower per iteration with a wave on every SIMD than
-// with a wave per CU (in-kernel cycle counts do not change, times do), which is why the float rollouts prefer two copies.
 inline int race_copies(int requested, int lanes_per_item, long long batch, int preferred = 4) {
   int p = requested == 0 ? preferred : requested;
   if (batch < 1) return 1;
@@ -811,8 +819,8 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   long long blocks = (batch + D::IPW - 1) / D::IPW;
   if (blocks > 8192) blocks = 8192;
   // racing copies (the loss launch's rule: four per item while the launch stays within one wave per SIMD)
-  // (measured, 4096 cube rollouts of 80 steps, us per step with 1 / 2 / 4 copies: f32 13.3 / 11.2 / 14.9, f64 19.6 / 18.2 / 16.6;
-  // elbow f32 18.6 / 18.2: the elbow runs without)
+  // (measured, 4096 cube rollouts of 80 steps, us per step with 1 / 2 / 4 copies: f32 13.1 / 11.4 / 10.4, f64 19.6 / 18.2 / 16.6;
+  // elbow f32 18.6 / 18.2: the elbow runs without.  Before the waves claimed their SIMDs, four float copies took 14.8)
   const int copies = witness ? 1 : dpll_racing_copies(m, dtype, batch, 1);
   if (witness)
     hipLaunchKernelGGL((simulate_kernel<T, NJ, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
@@ -827,7 +835,11 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
       hipLaunchKernelGGL((simulate_kernel<T, NJ, false, 4>), dim3((int)((batch + D::IPW / 4 - 1) / (D::IPW / 4))), dim3(kWave), 0, stream,
                          m->desc, m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x,
                          batch, steps, (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
-  } else
+  } else if (blocks <= kSimds)
+    hipLaunchKernelGGL((simulate_kernel<T, NJ, false, 1, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
+                       (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
+  else
     hipLaunchKernelGGL((simulate_kernel<T, NJ, false>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
                        (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
@@ -1679,7 +1691,7 @@ int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int 
   const int lanes = kQuery * (model->desc.n_joints + 1);
   const int asked = model->opts[dtype].portfolio;
   if (what == 0) return race_copies(asked, lanes, batch);
-  return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, lanes, batch, dtype == DPLL_F32 ? 2 : 4);
+  return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, lanes, batch);
 }
 
 int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,

@@ -226,7 +226,7 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
         xb, xpb = torch.cat([x, x[:1]]), torch.cat([xp, xp[:1]])
         system.set_solver(portfolio=0)
         assert system.racing_copies(4096) == 4 and system.racing_copies(4097) == 1 and system.racing_copies(1) == 4
-        assert system.racing_copies(4096, rollout=True) == (4 if f64 else 2) and system.racing_copies(16384, rollout=True) == 1
+        assert system.racing_copies(4096, rollout=True) == 4 and system.racing_copies(16384, rollout=True) == 1
         _, _, it_auto = system.contact_forces(xb, xpb)
         system.set_solver(portfolio=1)
         _, _, it_one = system.contact_forces(xb, xpb)
@@ -238,7 +238,7 @@ def test_long_rollouts_come_to_rest_and_racing_copies_follow_the_same_path(dtype
     """80-step fused rollouts of the 4096 toss states: most cubes come to rest, where the tangential cone residual
     underflows (|z_t|^2 is a float denormal: v_rsq_f32 answers inf and, before round 3, 384 of the 4096 float
     trajectories ended in NaN on the device and none on the host) -- every state stays finite, the cubes stay on the
-    ground plane.  The rollout kernel's racing copies (``portfolio``: 2 per item in float, 4 in double by default) take
+    ground plane.  The rollout kernel's racing copies (``portfolio``: 4 per item by default) take
     every step from the winning copy's velocity: over 8 steps the trajectories agree with the launch without copies to
     the solver's tolerance, launches are bitwise reproducible."""
     from dair_pll_amd import MultibodyLearnableSystem

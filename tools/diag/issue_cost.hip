@@ -46,11 +46,14 @@ int main(int argc, char** argv) {
 
   float* out; unsigned long long* cyc; static unsigned long long h[8192];
   (void)hipMalloc(&out, 8192 * 64 * 4); (void)hipMalloc(&cyc, 8192 * 8);
-  const int iters = 2048;
+  const int iters = argc > 2 ? atoi(argv[2]) : 2048;  // (long runs: what the part's clock does under the load, see `wall`)
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const char* names[13] = {"v_fma_f32", "v_fma_f64", "v_add_f64", "v_rsq_f32 + v_add_f32", "cvt f32->f64 + v_add_f64 + cvt f64->f32", "v_add_f32_dpp (quad_perm)", "v_cmp + v_cndmask + mul + add", "v_add_f32_dpp (row_half_mirror)", "v_add_f32_dpp (row_shr:1)", "ds_swizzle_b32 + v_add_f32", "ds_bpermute_b32 + v_add_f32", "v_fma_f32, 32 KB straight-line body", "v_fma_f32, 8 KB straight-line body"};
   const int per[13] = {1, 1, 1, 2, 3, 1, 4, 1, 1, 2, 2, 1, 1};
   for (int mode = 0; mode < 13; ++mode) {
+    float wall_ms = 0.f;
     for (int rep = 0; rep < 2; ++rep) {
+      (void)hipEventRecord(e0, 0);
       switch (mode) {
         case 0: hipLaunchKernelGGL(cost<0>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
         case 1: hipLaunchKernelGGL(cost<1>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
@@ -66,11 +69,13 @@ int main(int argc, char** argv) {
         case 12: hipLaunchKernelGGL(cost<12>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
         default: hipLaunchKernelGGL(cost<10>, dim3(grid), dim3(64), 0, 0, out, cyc, iters); break;
       }
+      (void)hipEventRecord(e1, 0);
       (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&wall_ms, e0, e1);
     }
     (void)hipMemcpy(h, cyc, grid * 8, hipMemcpyDeviceToHost);
     double mean = 0, mx = 0; for (int i = 0; i < grid; ++i) { mean += (double)h[i]; mx = h[i] > mx ? (double)h[i] : mx; } mean /= grid;
-    printf("grid %d  %-44s %.2f (slowest wave %.2f) cycles per group of %d instruction(s) (16 independent chains)\n", grid, names[mode], mean / iters / 16, mx / iters / 16, per[mode]);
+    printf("grid %d  %-44s %.2f (slowest wave %.2f) cycles per group of %d instruction(s) (16 independent chains); wall %.3f ns per group (kernel %.3f ms)\n", grid, names[mode], mean / iters / 16, mx / iters / 16, per[mode], wall_ms * 1e6 / iters / 16, wall_ms);
   }
   return 0;
 }
