@@ -1678,8 +1678,11 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (!model || batch < 0) return -1;
   if (model->desc.n_geoms > 0) return dpll_general::workspace_bytes(model, batch);
   const int nb = model->desc.n_joints + 1;
-  // (the racing build of the loss launch runs four-wave workgroups: never more rows than the one-wave launches)
-  const int64_t blocks = blocks_for(batch, kWave / (kQuery * nb));
+  // (the racing build of the loss launch: kRaceWaves-wave workgroups of kRaceWaves * 16 / copies items)
+  const int lanes = kQuery * nb, copies = race_copies(0, lanes, batch);
+  const int64_t plain = blocks_for(batch, kWave / lanes);
+  const int64_t raced = copies > 1 ? blocks_for(batch, kRaceWaves * kWave / (lanes * copies)) : 0;
+  const int64_t blocks = plain > raced ? plain : raced;
   const int64_t pi = 1 + 10 * nb + (nb + 1) + 3 * nb;
   const int64_t chain = 100 * nb + (nb + 1) * nb + 3 * nb;  // the rows-to-parameters matrix behind the rows
   return (blocks * pi + chain) * (int64_t)sizeof(double);
