@@ -96,8 +96,10 @@ __device__ __forceinline__ void claim_whole_simd() { asm volatile("v_accvgpr_wri
 // lanes; the copy that converged first supplies the item's loss, forces, iteration count and gradient terms.
 // The racing build runs workgroups of four waves (one per SIMD of a CU) that share one partial row, so that the finalize
 // kernel sums as many rows as without the copies.
-template <typename T, int NJ, bool MESH = false, bool DENSE = false, int RACE = 1>
-__global__ __launch_bounds__(RACE > 1 ? kRaceWaves * kWave : kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+// WAVES: waves per workgroup; the waves of a workgroup share ONE partial row (the racing build always; the plain builds from
+// 512 waves per launch, so that the finalize kernel never sums more than 512 rows)
+template <typename T, int NJ, bool MESH = false, bool DENSE = false, int RACE = 1, int WAVES = (RACE > 1 ? kRaceWaves : 1)>
+__global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
                                                      const T* __restrict__ x, long long ld_x,
                                                      const T* __restrict__ xp, long long ld_xp, long long batch,
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(RACE > 1 ? kRaceWaves * kWave : kWave, DENSE ? 2 : 
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<D::G, RACE>;
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
-  constexpr int kItems = (RACE > 1 ? kRaceWaves : 1) * D::IPW / RACE;  // items per workgroup
+  constexpr int kItems = WAVES * D::IPW / RACE;  // items per workgroup
   if constexpr (!DENSE) claim_whole_simd();  // (this build serves the launches of at most one wave per SIMD)
   const int lane = threadIdx.x;
   const int cidx = lane % D::G;
@@ -187,16 +189,16 @@ __global__ __launch_bounds__(RACE > 1 ? kRaceWaves * kWave : kWave, DENSE ? 2 : 
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
   }
   if (!want_grad) return;
-  store_iota_row<T, NJ, D::G, NJ + 1, 3, (RACE > 1 ? kRaceWaves : 1)>(acc, loss_acc, partials);
+  store_iota_row<T, NJ, D::G, NJ + 1, 3, WAVES>(acc, loss_acc, partials);
   DPLL_STAMP(3);
 }
 
 // Wide build: ONE lane per item, all of its contacts in that lane (the core templates with KPL = K, as the host build
 // runs them).  No cross-lane sums inside the solver (a DPP add costs 9.5 cycles against 4 for plain arithmetic, DESIGN
 // section 4) and 64 items per wave instead of 16, at the price of a ~2x longer serial chain per iteration: for launches
-// far beyond one wave per SIMD only (launch_loss picks it from 65,536 pairs of the one-body model).
-template <typename T, int NJ>
-__global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+// far beyond one wave per SIMD only (launch_loss_kernel picks it beyond 32,768 pairs).
+template <typename T, int NJ, int WAVES = 1>
+__global__ __launch_bounds__(WAVES * kWave) void loss_kernel_wide(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                           const T* __restrict__ friction, const T* __restrict__ lengths,
                                                           const T* __restrict__ x, long long ld_x,
                                                           const T* __restrict__ xp, long long ld_xp, long long batch,
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOp
   const int lane = threadIdx.x;
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
-    if (want_grad) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
     return;
   }
   Derived<T, NJ> dp;
@@ -216,8 +218,8 @@ __global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOp
   LossGrad<T, NJ> acc;
   zero_grad(acc);
   double loss_acc = 0.0;
-  const long long stride = (long long)item_blocks * kWave;
-  for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
+  const long long stride = (long long)item_blocks * (WAVES * kWave);
+  for (long long base = (long long)blockIdx.x * (WAVES * kWave); base < batch; base += stride) {
     const long long item = base + lane;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kWave) void loss_kernel_wide(ModelDesc md, SolverOp
     loss_acc += double(w) * double(L);
   }
   if (!want_grad) return;
-  store_iota_row<T, NJ, 1>(acc, loss_acc, partials);
+  store_iota_row<T, NJ, 1, NJ + 1, 3, WAVES>(acc, loss_acc, partials);
 }
 
 // sums the per-wave rows in a fixed order (bitwise reproducible) and converts to the parameter dtype.
@@ -689,13 +691,13 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
   const int copies = race_copies(m->opts[dtype].portfolio, Dims<T, NJ>::G, batch);
   const int blocks = loss_blocks<T, NJ>(batch, copies);
-  // wide build (one lane per item): from 65,536 pairs, where it has a wave for every SIMD.  Measured, lane-per-contact
-  // builds vs wide, M steps/s: cube f32 16,384 pairs 524 vs 398, 32,768 level, 65,536 934 vs 1340, 262,144 1221 vs 1723;
-  // at 65,536: cube f64 423 vs 684, elbow f32 293 vs 476 (0.5-1.4 KB of scratch spills and still ahead); elbow f64
-  // 118 vs 85 (3.2 KB of spills): that one stays on the lane-per-contact builds
+  // wide build (one lane per item): beyond 32,768 pairs.  Measured (round 3, waves that claim their SIMD, shared partial rows),
+  // loss + finalize in us, lane-per-contact builds vs wide: cube f32 16,384 pairs 22.2 vs 34.8, 32,768 32.0 vs 34.9, 49,152
+  // 41.3 vs 34.8, 65,536 55.6 vs 35.2; cube f64 32,768 63.5 vs 70.7, 49,152 81.6 vs 73.2; elbow f32 32,768 112.6 vs 122.1,
+  // 49,152 163.7 vs 132.1; elbow f64 stays on the lane-per-contact builds (65,536: 118 vs 85 M steps/s, 3.2 KB of spills)
   // dpll_solver_opts_t::wide overrides the choice (tests compare the builds on the same inputs)
   const int wide_opt = m->opts[dtype].wide;
-  const bool wide = wide_opt >= 0 ? wide_opt == 1 : (batch >= 65536 && !(std::is_same<T, double>::value && NJ == 1));
+  const bool wide = wide_opt >= 0 ? wide_opt == 1 : (batch > 32768 && !(std::is_same<T, double>::value && NJ == 1));
   int rows = blocks;
   if (batch == 0) {  // an empty shard: no item workgroups, only the one that writes the chain matrix; zero partial rows
     hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
@@ -704,19 +706,38 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        want_grad, (const T*)nullptr, (T*)nullptr);
     return 0;
   }
+  // from 512 waves per launch the workgroups are four waves that share a partial row: the finalize kernel's time follows the
+  // number of rows (256 rows 3.0 us, 1024 rows 5.5, 2048 rows 8.7)
+  constexpr int kShare = 4;
   if (wide) {
     long long wb = (batch + kWave - 1) / kWave;
-    rows = (int)(wb > kMaxLossBlocks ? kMaxLossBlocks : wb);
-    hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad);
-  } else if (blocks > kSimds)  // more waves than SIMDs: the two-waves-per-SIMD build
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, true>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+    if (wb > kMaxLossBlocks) wb = kMaxLossBlocks;
+    if (wb >= 512) {
+      rows = (int)((wb + kShare - 1) / kShare);
+      hipLaunchKernelGGL((loss_kernel_wide<T, NJ, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
+                         (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                         ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                         want_grad);
+    } else {
+      rows = (int)wb;
+      hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                         (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                         ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                         want_grad);
+    }
+  } else if (blocks > kSimds) {  // more waves than SIMDs: the two-waves-per-SIMD build
+    rows = (blocks + kShare - 1) / kShare;
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, true, 1, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
-  else if (copies == 1)
+  } else if (copies == 1 && blocks >= 512) {
+    rows = (blocks + kShare - 1) / kShare;
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 1, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
+  } else if (copies == 1)
     hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,

@@ -150,6 +150,54 @@ def test_wide_build_matches_chunks_with_weights():
     assert (whole - chunks).abs().max() <= 1e-5 * chunks.abs().max()
 
 
+@pytest.mark.parametrize('urdf,n', [('cube.urdf', 8001), ('cube.urdf', 16384), ('cube.urdf', 20001), ('cube.urdf', 40001),
+                                    ('elbow.urdf', 8192), ('elbow.urdf', 9001), ('elbow.urdf', 33001)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_every_launch_shape_matches_chunks_of_4096(urdf, n, dtype):
+    """The builds between the headline size and the wide build -- one wave per SIMD with claimed SIMDs (up to 1024 waves),
+    four-wave workgroups sharing a partial row (from 512 waves), two waves per SIMD (beyond 1024), the wide build (beyond
+    32,768 pairs) -- on ragged sizes: batch mean and every gradient equal those of the same pairs launched in chunks of
+    4096, the launch is bitwise reproducible and stays inside ``dpll_workspace_bytes`` (canaries)."""
+    import ctypes
+    from dair_pll_amd import MultibodyLearnableSystem, _capi
+    case = 'cube_box_4096' if urdf == 'cube.urdf' else 'elbow_box_4096'
+    g = np.load(os.path.join(GOLDEN_DIR, case + '.npz'))
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, urdf)}, float(g['dt']), dtype=dtype, device='cuda:0')
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    pick = torch.randint(0, 4096, (n,), device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(n))
+    xb, xpb = x[pick].contiguous(), xp[pick].contiguous()
+    lib = _capi.library()
+    flat = system._packed()
+    params = system._params_struct(flat)
+    code = _capi.F64 if dtype == torch.float64 else _capi.F32
+    need = lib.dpll_workspace_bytes(system._model(), n)
+    n_params = lib.dpll_param_count(system._model())
+    guard = 4096
+    arena = torch.full((need + 2 * guard,), 0x5A, dtype=torch.uint8, device='cuda:0')
+    out = []
+    for _ in range(2):
+        grad = torch.zeros(n_params, dtype=dtype, device='cuda:0')
+        total = torch.zeros(1, dtype=dtype, device='cuda:0')
+        _capi.check(lib.dpll_contactnets_loss(system._model(), code, ctypes.byref(params), xb.data_ptr(), xb.stride(0), xpb.data_ptr(),
+                                              xpb.stride(0), n, None, 1.0 / n, None, grad.data_ptr(), total.data_ptr(), None, None,
+                                              arena[guard:].data_ptr(), need, system._stream()))
+        torch.cuda.synchronize()
+        out.append((grad, total))
+    assert (arena[:guard] == 0x5A).all() and (arena[guard + need:] == 0x5A).all()
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    chunk_grad = torch.zeros(n_params, dtype=torch.float64, device='cuda:0')
+    chunk_total = 0.0
+    for i in range(0, n, 4096):
+        m = min(4096, n - i)
+        t = system.contactnets_loss_and_grad(xb[i:i + m], xpb[i:i + m])
+        chunk_grad += system.grad_buffer().double().reshape(-1)[1:1 + n_params] * m / n  # ([mean loss | gradients])
+        chunk_total += t.item() * m / n
+    tol = 1e-10 if dtype == torch.float64 else 2e-5
+    assert abs(out[0][1].item() - chunk_total) <= tol * max(1.0, abs(chunk_total))
+    assert (out[0][0].double() - chunk_grad).abs().max() <= (1e-9 if dtype == torch.float64 else 1e-4) * chunk_grad.abs().max()
+
+
 @pytest.mark.parametrize('urdf,case,dtype', [('cube.urdf', 'cube_box_literal', torch.float64),
                                              ('elbow.urdf', 'elbow_box_literal', torch.float32),
                                              ('elbow.urdf', 'elbow_box_literal', torch.float64)])
