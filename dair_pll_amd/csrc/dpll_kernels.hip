@@ -421,6 +421,53 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
   }
 }
 
+// Wide build of the rollout kernel: ONE lane per trajectory, all of its contacts in that lane (as loss_kernel_wide): for
+// launches far beyond one wave per SIMD, where the lane-per-contact build needs several rounds of waves.
+template <typename T, int NJ, bool SOLO = false>
+__global__ __launch_bounds__(kWave) void simulate_kernel_wide(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
+                                                              const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                              const T* __restrict__ x0, long long ld_x, long long batch,
+                                                              long long steps, T* __restrict__ out, long long ld_item,
+                                                              long long ld_step, int write_x0, int* __restrict__ iters) {
+  using D = Dims<T, NJ>;
+  using Lanes = GpuLanes<1>;
+  if constexpr (SOLO) claim_whole_simd();
+  Derived<T, NJ> dp;
+  derive_params<T, NJ>(md, theta, friction, lengths, dp);
+  const long long stride = (long long)gridDim.x * kWave;
+  for (long long base = (long long)blockIdx.x * kWave; base < batch; base += stride) {
+    const long long item = base + threadIdx.x;
+    const bool valid = item < batch;
+    const long long it = valid ? item : batch - 1;
+    T xr[D::NX];
+#pragma unroll
+    for (int i = 0; i < D::NX; ++i) xr[i] = x0[it * ld_x + i];
+    T* dst = out + it * ld_item;
+    if (write_x0) {
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) dst[i] = xr[i];
+      }
+      dst += ld_step;
+    }
+    int total = 0;
+    for (long long s = 0; s < steps; ++s) {
+      T xn[D::NX], imp[D::K][3];
+      int n_it = 0;
+      step_item<T, typename Acc<T>::type, NJ, D::K, Lanes>(md, dp, opt, xr, 0, xn, imp, n_it);
+      total += n_it;
+#pragma unroll
+      for (int i = 0; i < D::NX; ++i) xr[i] = xn[i];
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < D::NX; ++i) dst[i] = xr[i];
+      }
+      dst += ld_step;
+    }
+    if (iters && valid) iters[it] = total;
+  }
+}
+
 // ---- adjoint of one simulation step with respect to the parameters (state = data) -----------------------
 // STATE: also the adjoint of the input state (n_x forward-mode passes of the terms, core step_state_adjoint)
 // MESH: witnesses from the ICNN kernels in, their adjoint r_bar out (as in the loss kernel)
@@ -843,6 +890,9 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   // (measured, 4096 cube rollouts of 80 steps, us per step with 1 / 2 / 4 copies: f32 13.1 / 11.4 / 10.4, f64 19.6 / 18.2 / 16.6;
   // elbow f32 18.6 / 18.2: the elbow runs without.  Before the waves claimed their SIMDs, four float copies took 14.8)
   const int copies = witness ? 1 : dpll_racing_copies(m, dtype, batch, 1);
+  // wide build: the loss launch's rule (dpll_solver_opts_t::wide overrides)
+  const int wide_opt = m->opts[dtype].wide;
+  const bool sim_wide = !witness && (wide_opt >= 0 ? wide_opt == 1 : (batch > 32768 && !(std::is_same<T, double>::value && NJ == 1)));
   if (witness)
     hipLaunchKernelGGL((simulate_kernel<T, NJ, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
@@ -856,6 +906,17 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
       hipLaunchKernelGGL((simulate_kernel<T, NJ, false, 4>), dim3((int)((batch + D::IPW / 4 - 1) / (D::IPW / 4))), dim3(kWave), 0, stream,
                          m->desc, m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x,
                          batch, steps, (T*)out, ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr);
+  } else if (sim_wide) {
+    long long wb = (batch + kWave - 1) / kWave;
+    if (wb > 8192) wb = 8192;
+    if (wb <= kSimds)
+      hipLaunchKernelGGL((simulate_kernel_wide<T, NJ, true>), dim3((int)wb), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                         (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
+                         (T*)out, ld_item, ld_step, write_x0, (int*)iters);
+    else
+      hipLaunchKernelGGL((simulate_kernel_wide<T, NJ>), dim3((int)wb), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
+                         (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,
+                         (T*)out, ld_item, ld_step, write_x0, (int*)iters);
   } else if (blocks <= kSimds)
     hipLaunchKernelGGL((simulate_kernel<T, NJ, false, 1, true>), dim3((int)blocks), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps,

@@ -336,6 +336,32 @@ def test_long_rollouts_of_every_model_family_stay_finite(name, urdf, representat
     assert traj.abs().max().item() < 1e3
 
 
+@pytest.mark.parametrize('urdf,dtype', [('cube.urdf', torch.float32), ('cube.urdf', torch.float64), ('elbow.urdf', torch.float32)])
+def test_wide_rollout_build_matches_lane_per_contact(urdf, dtype):
+    """``dpll_simulate`` beyond 32,768 trajectories runs one lane per trajectory (``simulate_kernel_wide``): on a ragged
+    40,001-trajectory launch its 6-step rollouts equal the lane-per-contact build's to the solver's tolerance, the default
+    picks it (bitwise the forced build's result), launches are reproducible."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    case = 'cube_box_4096' if urdf == 'cube.urdf' else 'elbow_box_4096'
+    g = np.load(os.path.join(GOLDEN_DIR, case + '.npz'))
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, urdf)}, float(g['dt']), dtype=dtype, device='cuda:0')
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    n = 40001
+    pick = torch.randint(0, 4096, (n,), device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(3))
+    x0 = x[pick].unsqueeze(-2)
+    carry = torch.zeros((n, 1), device='cuda:0')
+    out = {}
+    with torch.no_grad():
+        for wide in (0, 1, -1):
+            system.set_solver(wide=wide)
+            out[wide], _ = system.simulate(x0, carry, 6)
+        again, _ = system.simulate(x0, carry, 6)
+    assert torch.isfinite(out[1]).all()
+    assert torch.equal(out[-1], out[1]) and torch.equal(again, out[1])
+    tol = 1e-10 if dtype == torch.float64 else 5e-4
+    assert (out[0] - out[1]).abs().max().item() < tol, (out[0] - out[1]).abs().max().item()
+
+
 def test_racing_copies_on_other_samples_of_the_toss_data():
     """The racing schedules were picked on the benchmark batch; on five other 4096-pair samples of the reference's 57,812
     cube-toss pairs (``assets/contactnets_cube_tosses.npz``) the launch with copies returns the same losses (1e-6), no item
