@@ -257,20 +257,20 @@ static_assert(kMaxLossBlocks <= 2048, "finalize_kernel sums at most two passes o
 
 // rows rowg, rowg + 32, ... of one column, all loads issued before the first add (fixed summation order).  The loads
 // are unconditional (clamped addresses, the value masked afterwards): no branch per load, all of them in flight at once.
-template <int LOADS>
+template <int LOADS, int GROUPS = 32>
 __device__ __forceinline__ double finalize_column(const double* __restrict__ partials, int n_rows, int stride, int width, int col, int rowg,
                                                   int row0 = 0) {
   double v[LOADS];
   const int c = col < width ? col : width - 1;
 #pragma unroll
   for (int i = 0; i < LOADS; ++i) {
-    const int r = row0 + rowg + 32 * i;
+    const int r = row0 + rowg + GROUPS * i;
     const int rc = r < n_rows ? r : (n_rows > 0 ? n_rows - 1 : 0);  // n_rows = 0 (empty shard): reads the chain area, masked below
     v[i] = partials[(long long)rc * stride + c];
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < LOADS; ++i) s += (col < width && row0 + rowg + 32 * i < n_rows) ? v[i] : 0.0;
+  for (int i = 0; i < LOADS; ++i) s += (col < width && row0 + rowg + GROUPS * i < n_rows) ? v[i] : 0.0;
   return s;
 }
 
@@ -288,19 +288,21 @@ struct AdamArgs {
   double lr, beta1, beta2, eps, weight_decay;
 };
 
-template <typename T, int NJ, bool FUSED = false>
-__global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double* __restrict__ partials, int n_rows,
+// GROUPS: row groups = waves / 2 of the one workgroup (32: 1024 threads; 8: 256 threads, for launches of <= 256 rows)
+template <typename T, int NJ, bool FUSED = false, int GROUPS = 32>
+__global__ __launch_bounds__(GROUPS * 32) void finalize_kernel(const double* __restrict__ partials, int n_rows,
                                                                     T* __restrict__ grad, T* __restrict__ loss_total,
                                                                     dpll_arx::Peers peers, int rank, int world,
                                                                     uint32_t* __restrict__ seq_ptr, uint32_t* __restrict__ err,
                                                                     AdamArgs adam) {
   using D = Dims<T, NJ>;
   static_assert(D::PI <= 32, "partial row must fit 32 columns");
-  __shared__ double red[32][33];
+  __shared__ double red[GROUPS][33];
   __shared__ double tot[32];
   const int col = threadIdx.x & 31, rowg = threadIdx.x >> 5;
   // uniform branch (n_rows is a kernel argument): the headline grid has 256 rows = 8 per thread
-  const double s = n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
+  const double s = GROUPS == 8 ? finalize_column<32, 8>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
+                   : n_rows <= 256 ? finalize_column<8>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
                    : n_rows <= 512 ? finalize_column<16>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
                    : n_rows <= 1024 ? finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg)
                                     : finalize_column<32>(partials, n_rows, D::PI, D::PIOTA, col, rowg) +
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const double
   if (threadIdx.x < 32) {
     double t = 0.0;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) t += red[r][col];
+    for (int r = 0; r < GROUPS; ++r) t += red[r][col];
     tot[threadIdx.x] = t;
   }
   __syncthreads();
@@ -824,6 +826,10 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
       hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
                          rows, (T*)grad,
                          (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1, adam);
+    else if (rows <= 256)
+      hipLaunchKernelGGL((finalize_kernel<T, NJ, false, 8>), dim3(1), dim3(256), 0, stream, (const double*)workspace,
+                         rows, (T*)grad,
+                         (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, adam);
     else
       hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
                          rows, (T*)grad,
