@@ -822,7 +822,13 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                                              want_grad, stream);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
-    if (ar)
+    // (<= 256 rows: the 256-thread build, with or without the exchange -- the two sum the rows in the same order, so a
+    // separate exchange after the launch gives bitwise the row of the fused one)
+    if (ar && rows <= 256)
+      hipLaunchKernelGGL((finalize_kernel<T, NJ, true, 8>), dim3(1), dim3(256), 0, stream, (const double*)workspace,
+                         rows, (T*)grad,
+                         (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1, adam);
+    else if (ar)
       hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
                          rows, (T*)grad,
                          (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1, adam);
