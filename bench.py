@@ -214,7 +214,8 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
                 'pipeline_gemm_tflops': 4 * flops / (sum(gemms.values()) * 1e-3) / 1e12,
                 'note': 'v_mfma_f32_32x32x2_f32 (exact f32); peak = dense f32 matrix rate of MI355X_MICROARCH.md'
                         if dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
-    ms_loss, ms_fin = system.profile_loss_kernels(x, xp, reps=200)
+    passes = [system.profile_loss_kernels(x, xp, reps=200) for _ in range(3)]  # (HIP events on the launch stream, 200 launches each)
+    ms_loss, ms_fin = sorted(p[0] for p in passes)[1], sorted(p[1] for p in passes)[1]
     achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
     traffic = valu_frac = source = lib_match = None
     path = newest_profile('hbm_traffic.json')

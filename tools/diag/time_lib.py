@@ -35,3 +35,11 @@ for _ in range(5):
     best = min(best, (time.perf_counter() - t0) / 1000 * 1e6)
 print(f'{os.path.basename(sys.argv[1])}: loss kernel {min(a for a, _ in ts) * 1e3:.2f} us, finalize {min(b for _, b in ts) * 1e3:.2f} us, '
       f'step (graph) {best:.2f} us, err {err:.1e}, iters max {iters.max().item()}', flush=True)
+# the same kernel timing again, right after ~0.5 s of back-to-back graph replays (what bench.py's roofline object sees)
+import time as _t
+t_end = _t.perf_counter() + 0.5
+while _t.perf_counter() < t_end:
+    graph.replay()
+torch.cuda.synchronize()
+ts2 = [s.profile_loss_kernels(x, xp, reps=200) for _ in range(3)]
+print(f'   after 0.5 s of sustained replays: loss kernel {min(a for a, _ in ts2) * 1e3:.2f} us, finalize {min(b for _, b in ts2) * 1e3:.2f} us', flush=True)
