@@ -110,6 +110,52 @@ def test_library_exports_every_declared_symbol():
     assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) != 0
 
 
+def test_racing_copies_and_solver_settings_through_the_c_abi():
+    """``dpll_racing_copies`` (no device work: the launch shape is host logic): four copies for launches of at most 4096 cube
+    pairs / trajectories, none beyond (a wave per SIMD is the limit), none for the elbow unless asked for (two fit its row),
+    none for the general build; ``dpll_model_set_solver`` refuses copies or racing schedules it cannot run, and the workspace
+    a loss launch needs never grows with the copies."""
+    from dair_pll_amd import _capi
+    from dair_pll_amd.urdf import parse_urdf
+    lib = _capi.library()
+    handles = {}
+    for name in ('cube', 'elbow', 'gripper'):
+        handle = ctypes.c_void_p()
+        desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, name + '.urdf')), 0.0068, 'reference_literal')
+        assert lib.dpll_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
+        handles[name] = handle
+    for dtype in (_capi.F32, _capi.F64):
+        assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 0) for b in (1, 4096, 4097, 65536)] == [4, 4, 1, 1]
+        assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 1) for b in (1, 4096, 4097)] == [4, 4, 1]
+        assert lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 0) == 1 and lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 1) == 1
+        assert lib.dpll_racing_copies(handles['gripper'], dtype, 512, 0) == 1
+    assert lib.dpll_racing_copies(handles['cube'], 7, 4096, 0) == -1 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 2) == -1
+    opts = _capi.SolverOpts()
+    assert lib.dpll_model_get_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
+    assert opts.portfolio == 0 and list(opts.race_flags) == [2, 2, 2]
+    opts.portfolio = 2
+    assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
+    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 2 and lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4097, 0) == 1
+    opts.portfolio = 4  # (eight lanes per item: four copies do not fit a 16-lane row -- the launch falls back to two)
+    assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
+    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 2
+    for field, value in (('portfolio', 3), ('portfolio', -1)):
+        bad = _capi.SolverOpts.from_buffer_copy(opts)
+        setattr(bad, field, value)
+        assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) != 0 and b'portfolio' in lib.dpll_last_error()
+    bad = _capi.SolverOpts.from_buffer_copy(opts)
+    bad.race_stages[1] = 9
+    assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) != 0 and b'race_stages' in lib.dpll_last_error()
+    bad = _capi.SolverOpts.from_buffer_copy(opts)
+    bad.race_factor[0] = 0.5
+    assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) != 0
+    # rows of the racing launch: four-wave workgroups of 16 items -- as many rows as the launch without copies writes
+    cube_ws = lib.dpll_workspace_bytes(handles['cube'], 4096)
+    assert cube_ws == (256 * 16 + 100 + 2 + 3) * 8
+    for handle in handles.values():
+        lib.dpll_model_destroy(handle)
+
+
 def test_integrator_generic_path_matches_space_euler_step():
     """VelocityIntegrator with a user callback (no GPU): q+ = q (+) v+ dt, trajectory layout."""
     space = FloatingBaseSpace(1)
