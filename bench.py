@@ -563,7 +563,7 @@ def main() -> None:
             # the other BASELINE.json configurations, same process, after the headline (about a minute in total)
             configs = []
             for w, d, b, k in (('elbow', 'f32', 4096, 1000), ('elbow', 'f64', 4096, 500), ('mesh', 'f32', 4096, 200),
-                               ('cube', 'f64', 4096, 1000), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100),
+                               ('cube', 'f64', 4096, 1000), ('cube', 'f32', 16384, 400), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100),
                                ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50), ('slider', 'f32', 4096, 50), ('clasp_mesh', 'f32', 4096, 20)):
                 try:
                     configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
