@@ -98,7 +98,9 @@ __device__ __forceinline__ void claim_whole_simd() { asm volatile("v_accvgpr_wri
 // kernel sums as many rows as without the copies.
 // WAVES: waves per workgroup; the waves of a workgroup share ONE partial row (the racing build always; the plain builds from
 // 512 waves per launch, so that the finalize kernel never sums more than 512 rows)
-template <typename T, int NJ, bool MESH = false, bool DENSE = false, int RACE = 1, int WAVES = (RACE > 1 ? kRaceWaves : 1)>
+// KPL: contacts per lane (1; 2 for the elbow's four-copy racing build: 8 contacts on 4 lanes leave its 16-lane row room for
+// four copies)
+template <typename T, int NJ, bool MESH = false, bool DENSE = false, int RACE = 1, int WAVES = (RACE > 1 ? kRaceWaves : 1), int KPL = 1>
 __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
                                                      const T* __restrict__ x, long long ld_x,
@@ -108,13 +110,15 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
                                                      double* __restrict__ partials, int want_grad,
                                                      const T* __restrict__ witness, T* __restrict__ rbar_out) {
   using D = Dims<T, NJ>;
-  using Lanes = GpuLanes<D::G, RACE>;
+  constexpr int G = D::K / KPL;  // lanes of one copy of an item
+  using Lanes = GpuLanes<G, RACE>;
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
-  constexpr int kItems = WAVES * D::IPW / RACE;  // items per workgroup
+  static_assert(KPL == 1 || !MESH, "several contacts per lane: box geometry");
+  constexpr int kItems = WAVES * (kWave / G) / RACE;  // items per workgroup
   if constexpr (!DENSE) claim_whole_simd();  // (this build serves the launches of at most one wave per SIMD)
   const int lane = threadIdx.x;
-  const int cidx = lane % D::G;
-  const int slot = lane / (D::G * RACE);
+  const int cidx = lane % G;
+  const int slot = lane / (G * RACE);
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
     if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
   double loss_acc = 0.0;
   while (true) {
     const T w = valid ? T(scale) * (weights ? weights[it] : T(1)) : T(0);
-    T f[1][3];
+    T f[KPL][3];
     int n_it = 0;
     DPLL_STAMP(1);
     // mesh geometry: this contact's support point comes from the ICNN kernels; its adjoint goes back to them
@@ -146,15 +150,16 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
     if constexpr (MESH) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
-      L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, wit, rb);
+      if constexpr (KPL == 1)
+        L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, wit, rb);
       if (rbar_out && valid) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
       }
     } else {
       bool winner = true;
-      L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, nullptr,
-                                                            nullptr, nullptr, nullptr, &winner);
+      L = loss_item<T, typename Acc<T>::type, NJ, KPL, Lanes>(md, dp, opt, xr, xpr, cidx * KPL, w, want_grad != 0, acc, f, n_it, nullptr,
+                                                              nullptr, nullptr, nullptr, &winner);
       if constexpr (RACE > 1) valid = valid && winner;  // the other copies write nothing and add nothing to the row
     }
     if (valid) {
@@ -164,9 +169,13 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
       }
       if (force) {
         T* row = force + it * (3 * D::K);
-        row[cidx] = f[0][2];
-        row[D::K + 2 * cidx] = f[0][0];
-        row[D::K + 2 * cidx + 1] = f[0][1];
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+          const int contact = cidx * KPL + c;
+          row[contact] = f[c][2];
+          row[D::K + 2 * contact] = f[c][0];
+          row[D::K + 2 * contact + 1] = f[c][1];
+        }
       }
     }
     loss_acc += (cidx == 0 && (RACE == 1 || valid)) ? double(w) * double(L) : 0.0;
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
   }
   if (!want_grad) return;
-  store_iota_row<T, NJ, D::G, NJ + 1, 3, WAVES>(acc, loss_acc, partials);
+  store_iota_row<T, NJ, G, NJ + 1, 3, WAVES>(acc, loss_acc, partials);
   DPLL_STAMP(3);
 }
 
@@ -688,12 +697,13 @@ SolverOpts default_opts(int dtype, int n_joints = 0, bool general = false) {
   // among them (tools/diag/race_schedules.py and its multi-sample search; all cold starts on full Newton steps): slowest
   // item 14 / 16 / 15 / 14 / 15 / 16 / 13 / 14 -> 11 / 11 / 11 / 11 / 11 / 12 / 11 / 12 iterations, mean 7.0 -> 4.7.  (The
   // first table -- picked on the benchmark batch alone: 1, 2 x 30, 5 x 2 -- left 12 / 13 / 16 on three of the others.)
-  // The elbow's entries are used only when copies are asked for explicitly (two fit its 16-lane row: 18 -> 17)
+  // The elbow: four copies on its two-contacts-per-lane build (float: 18 -> 13 iterations on the 4096-pair batch; the copies are
+  // the best pure-Newton triple of tools/diag/race_schedules.py elbow_box_4096 4)
   o.portfolio = 0;
   if (n_joints == 1 && !general) {
-    o.race_stages[0] = 3; o.race_factor[0] = 10.0; o.race_flags[0] = 2;
-    o.race_stages[1] = 1; o.race_factor[1] = 1.0; o.race_flags[1] = 2;
-    o.race_stages[2] = 2; o.race_factor[2] = 5.0; o.race_flags[2] = 2;
+    o.race_stages[0] = 2; o.race_factor[0] = 5.0; o.race_flags[0] = 2;
+    o.race_stages[1] = 5; o.race_factor[1] = 2.0; o.race_flags[1] = 2;
+    o.race_stages[2] = 8; o.race_factor[2] = 2.0; o.race_flags[2] = 2;
   } else {
     o.race_stages[0] = 1; o.race_factor[0] = 1.0; o.race_flags[0] = 2;
     o.race_stages[1] = 2; o.race_factor[1] = 100.0; o.race_flags[1] = 2;
@@ -709,8 +719,15 @@ inline int blocks_for(long long batch, int ipw) {
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
-template <typename T, int NJ> int loss_blocks(long long batch, int copies = 1) {
-  return blocks_for(batch, copies > 1 ? kRaceWaves * Dims<T, NJ>::IPW / copies : Dims<T, NJ>::IPW);
+// lanes of one copy of an item in the loss launch: one per contact, except the elbow's four-copy racing build (two contacts
+// per lane, so that four copies fit the item's 16-lane row)
+// (measured, elbow 4096 pairs, loss kernel us with 1 / 2 / 4 copies: f32 33.2 / 31.5 / 30.0 -- slowest item 18 / 17 / 13 iterations at
+// +20 % per iteration for the second contact in the lane --, f64 52.5 / 57.1 / 63.3: the default races the float elbow only)
+template <typename T, int NJ> constexpr int race_lanes(int copies_asked) {
+  return (NJ == 1 && (copies_asked == 4 || (copies_asked == 0 && sizeof(T) == 4))) ? 4 : kQuery * (NJ + 1);
+}
+template <typename T, int NJ> int loss_blocks(long long batch, int copies = 1, int lanes = Dims<T, NJ>::G) {
+  return blocks_for(batch, copies > 1 ? kRaceWaves * kWave / (lanes * copies) : Dims<T, NJ>::IPW);
 }
 
 // Racing copies per item (dpll_solver_opts_t::portfolio): what was asked for -- 0: `preferred`, the number measured best for
@@ -738,8 +755,9 @@ template <typename T, int NJ>
 int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
                        long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* force,
                        int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
-  const int copies = race_copies(m->opts[dtype].portfolio, Dims<T, NJ>::G, batch);
-  const int blocks = loss_blocks<T, NJ>(batch, copies);
+  const int lanes = race_lanes<T, NJ>(m->opts[dtype].portfolio);
+  const int copies = race_copies(m->opts[dtype].portfolio, lanes, batch);
+  const int blocks = loss_blocks<T, NJ>(batch, copies, lanes);
   // wide build (one lane per item): beyond 32,768 pairs.  Measured (round 3, waves that claim their SIMD, shared partial rows),
   // loss + finalize in us, lane-per-contact builds vs wide: cube f32 16,384 pairs 22.2 vs 34.8, 32,768 32.0 vs 34.9, 49,152
   // 41.3 vs 34.8, 65,536 55.6 vs 35.2; cube f64 32,768 63.5 vs 70.7, 49,152 81.6 vs 73.2; elbow f32 32,768 112.6 vs 122.1,
@@ -801,6 +819,11 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
+  else  // the elbow: two contacts per lane
+    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4, kRaceWaves, 2>), dim3(blocks + 1), dim3(kRaceWaves * kWave), 0, stream, m->desc,
+                       m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
+                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
+                       want_grad, (const T*)nullptr, (T*)nullptr);
   return rows;
 }
 
@@ -810,7 +833,8 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                 void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
                 hipStream_t stream, const dpll_ar* ar = nullptr, AdamArgs adam = AdamArgs{}) {
   using D = Dims<T, NJ>;
-  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, D::G, batch));
+  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, race_lanes<T, NJ>(m->opts[dtype].portfolio), batch),
+                                        race_lanes<T, NJ>(m->opts[dtype].portfolio));
   const int want_grad = grad != nullptr;
   if (want_grad) {
     if (!workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
@@ -852,7 +876,8 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
                  long long ld_xp, long long batch, double scale, void* grad, void* workspace, long long workspace_bytes,
                  hipStream_t stream, int reps, float* ms_loss, float* ms_finalize) {
   using D = Dims<T, NJ>;
-  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, D::G, batch));
+  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, race_lanes<T, NJ>(m->opts[dtype].portfolio), batch),
+                                        race_lanes<T, NJ>(m->opts[dtype].portfolio));
   if (!grad || !workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
     return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
   // two passes, two events each (an event between every pair of kernels costs several microseconds of its own):
@@ -1785,8 +1810,10 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
 int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what) {
   if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || (what != 0 && what != 1)) return -1;
   if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return 1;
-  const int lanes = kQuery * (model->desc.n_joints + 1);
   const int asked = model->opts[dtype].portfolio;
+  int lanes = kQuery * (model->desc.n_joints + 1);
+  // (the elbow's two-contacts-per-lane racing build: when four copies are asked for, and by default in float)
+  if (what == 0 && model->desc.n_joints == 1 && (asked == 4 || (asked == 0 && dtype == DPLL_F32))) lanes = 4;
   if (what == 0) return race_copies(asked, lanes, batch);
   return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, lanes, batch);
 }

@@ -225,7 +225,7 @@ def test_wide_and_lane_per_contact_builds_agree(urdf, case, dtype):
 
 
 @pytest.mark.parametrize('urdf,case,copies', [('cube.urdf', 'cube_box_4096', 4), ('cube.urdf', 'cube_box_4096', 2),
-                                              ('elbow.urdf', 'elbow_box_4096', 2)])
+                                              ('elbow.urdf', 'elbow_box_4096', 2), ('elbow.urdf', 'elbow_box_4096', 4)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
     """``dpll_solver_opts_t.portfolio``: every item's lane group exists 2 or 4 times in its wave and the copies run other
@@ -246,9 +246,9 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
         total = system.contactnets_loss_and_grad(x[:rows], xp[:rows]).clone()
         return loss.clone(), force.clone(), iters.clone(), system.grad_buffer().clone(), total
 
-    if urdf == 'elbow.urdf':  # eight lanes per item: room for two copies, which buy nothing -- the default runs without
+    if urdf == 'elbow.urdf':  # eight lanes per item: two copies fit, or four on the build with two contacts per lane (float default)
         system.set_solver(portfolio=0)
-        assert system.racing_copies(4096) == 1 and system.racing_copies(4096, rollout=True) == 1
+        assert system.racing_copies(4096) == (1 if dtype == torch.float64 else 4) and system.racing_copies(4096, rollout=True) == 1
     alone, raced, again = launch(1), launch(copies), launch(copies)
     for a, b in zip(raced, again):
         assert torch.equal(a, b)
@@ -258,14 +258,19 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
     assert (raced[1] - alone[1]).abs().max() <= (1e-8 if f64 else 2e-3) * max(1.0, alone[1].abs().max().item())
     assert (raced[3] - alone[3]).abs().max() <= (1e-9 if f64 else 2e-3) * alone[3].abs().max()
     assert abs(raced[4].item() - alone[4].item()) <= (1e-12 if f64 else 1e-7)
-    assert (raced[2] <= alone[2]).all()  # copy 0 IS the schedule of the launch without copies
-    if copies == 4:
+    if urdf == 'elbow.urdf' and copies == 4:
+        # (two contacts per lane: the contact sums are taken in another order, so copy 0 is the launch without copies only to
+        # rounding -- an item may need one iteration more; the slowest needs several fewer)
+        assert (raced[2] <= alone[2] + 1).all() and raced[2].max().item() <= alone[2].max().item() - 3
+    else:
+        assert (raced[2] <= alone[2]).all()  # copy 0 IS the schedule of the launch without copies
+    if copies == 4 and urdf == 'cube.urdf':
         assert raced[2].max().item() <= alone[2].max().item() - 2, (raced[2].max().item(), alone[2].max().item())
         assert raced[2].float().mean().item() < 0.8 * alone[2].float().mean().item()
     k = system.spec.n_contacts
     fn, ft = raced[1][:, :k], raced[1][:, k:].reshape(-1, k, 2)
     assert (ft.norm(dim=-1) <= fn * (1 + 1e-5) + 1e-7).all() and (fn >= 0).all()
-    if copies == 4:  # the default: four copies up to 4096 pairs, none beyond (a launch with more waves than SIMDs gains nothing)
+    if copies == 4 and urdf == 'cube.urdf':  # the default: four copies up to 4096 pairs, none beyond (a launch with more waves than SIMDs gains nothing)
         auto = launch(0)
         for a, b in zip(raced, auto):
             assert torch.equal(a, b)

@@ -127,7 +127,8 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
     for dtype in (_capi.F32, _capi.F64):
         assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 0) for b in (1, 4096, 4097, 65536)] == [4, 4, 1, 1]
         assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 1) for b in (1, 4096, 4097)] == [4, 4, 1]
-        assert lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 0) == 1 and lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 1) == 1
+        assert lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 0) == (4 if dtype == _capi.F32 else 1)  # (two contacts per lane)
+        assert lib.dpll_racing_copies(handles['elbow'], dtype, 4097, 0) == 1 and lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 1) == 1
         assert lib.dpll_racing_copies(handles['gripper'], dtype, 512, 0) == 1
     assert lib.dpll_racing_copies(handles['cube'], 7, 4096, 0) == -1 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 2) == -1
     opts = _capi.SolverOpts()
@@ -135,10 +136,10 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
     assert opts.portfolio == 0 and list(opts.race_flags) == [2, 2, 2]
     opts.portfolio = 2
     assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
-    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 2 and lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4097, 0) == 1
-    opts.portfolio = 4  # (eight lanes per item: four copies do not fit a 16-lane row -- the launch falls back to two)
+    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 2 and lib.dpll_racing_copies(handles['elbow'], _capi.F32, 8192, 0) == 1
+    opts.portfolio = 4  # (the loss launch: the build with two contacts per lane; a rollout has no such build and falls back to two)
     assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
-    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 2
+    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 4 and lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 1) == 2
     for field, value in (('portfolio', 3), ('portfolio', -1)):
         bad = _capi.SolverOpts.from_buffer_copy(opts)
         setattr(bad, field, value)
