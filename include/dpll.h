@@ -118,7 +118,8 @@ typedef struct dpll_solver_opts {
    * steps sends the wave through the fall-back code); the item is finished when ANY copy has met `tol` (copies >= 1: with
    * finite numbers) and the finished copy with the lowest index supplies every output -- deterministic, and in iterations
    * never behind the schedule above alone.
-   * 0 = chosen from the batch size (as many copies as keep the launch within one wave per SIMD), 1 = off, 2, 4. */
+   * 0 = chosen from the model and the batch size (four copies where they fit a 16-lane row -- cube; float elbow, on a build
+   * with two contacts per lane -- and keep the launch within one wave per SIMD, else none), 1 = off, 2, 4. */
   int32_t portfolio;
   int32_t race_stages[3];
   int32_t race_flags[3];
