@@ -723,9 +723,10 @@ inline int blocks_for(long long batch, int ipw) {
 // per lane, so that four copies fit the item's 16-lane row)
 // (measured, elbow 4096 pairs, loss kernel us with 1 / 2 / 4 copies: f32 33.2 / 31.5 / 30.0 -- slowest item 18 / 17 / 13 iterations at
 // +20 % per iteration for the second contact in the lane --, f64 52.5 / 57.1 / 63.3: the default races the float elbow only)
-template <typename T, int NJ> constexpr int race_lanes(int copies_asked) {
-  return (NJ == 1 && (copies_asked == 4 || (copies_asked == 0 && sizeof(T) == 4))) ? 4 : kQuery * (NJ + 1);
+inline int race_lanes_of(int n_joints, bool is_float, int copies_asked) {  // (the one rule: launchers and dpll_racing_copies)
+  return (n_joints == 1 && (copies_asked == 4 || (copies_asked == 0 && is_float))) ? 4 : kQuery * (n_joints + 1);
 }
+template <typename T, int NJ> int race_lanes(int copies_asked) { return race_lanes_of(NJ, sizeof(T) == 4, copies_asked); }
 template <typename T, int NJ> int loss_blocks(long long batch, int copies = 1, int lanes = Dims<T, NJ>::G) {
   return blocks_for(batch, copies > 1 ? kRaceWaves * kWave / (lanes * copies) : Dims<T, NJ>::IPW);
 }
@@ -1811,11 +1812,9 @@ int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int 
   if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || (what != 0 && what != 1)) return -1;
   if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return 1;
   const int asked = model->opts[dtype].portfolio;
-  int lanes = kQuery * (model->desc.n_joints + 1);
-  // (the elbow's two-contacts-per-lane racing build: when four copies are asked for, and by default in float)
-  if (what == 0 && model->desc.n_joints == 1 && (asked == 4 || (asked == 0 && dtype == DPLL_F32))) lanes = 4;
-  if (what == 0) return race_copies(asked, lanes, batch);
-  return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, lanes, batch);
+  if (what == 0) return race_copies(asked, race_lanes_of(model->desc.n_joints, dtype == DPLL_F32, asked), batch);
+  // rollouts: one lane per contact always; the elbow's gain nothing from two copies, so its default is none
+  return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, kQuery * (model->desc.n_joints + 1), batch);
 }
 
 int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
