@@ -88,9 +88,14 @@ constexpr int kRaceWaves = 4;  // waves per workgroup of the racing build
 // twice on a SIMD, waves get doubled up while other SIMDs idle, and a doubled wave runs at ~2/3 speed (measured with the
 // rollout kernel, 188 VGPRs: 256 / 512 / 1024 / 2048 one-wave workgroups of identical work take 13.1 / 13.4 / 20.1 / 20.2 us
 // per step; the double build, 334 VGPRs, 19.4 / 19.8 / 19.7 / 37.8; an LDS reservation that caps a CU at four workgroups
-// does not help: the doubling is inside the CU).  Touching accumulation register a127 makes the wave's allocation (vector +
-// accumulation registers share one file of 512) exceed half the file, so a SIMD holds exactly one such wave.
-__device__ __forceinline__ void claim_whole_simd() { asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127"); }
+// does not help: the doubling is inside the CU).  Touching accumulation register a95 makes the wave's allocation (vector +
+// accumulation registers share one file of 512) exceed half the file for every float kernel here (>= 183 vector registers),
+// so a SIMD holds exactly one such wave; it leaves 416 vector registers to the kernel.  The double kernels allocate more than
+// half the file by themselves and do not claim (a claim of 128 accumulation registers cost the double elbow kernel, 512
+// vector registers, 6 %: 48.7 -> 51.6 us).
+template <typename T> __device__ __forceinline__ void claim_whole_simd() {
+  if constexpr (sizeof(T) == 4) asm volatile("v_accvgpr_write_b32 a95, 0" ::: "a95");
+}
 // RACE: copies of every item's lane group that run other continuation schedules of the cone solve in lock step
 // (SolverOpts::portfolio, dpll_core.hpp sap_newton): for launches that would leave SIMDs idle.  An item owns G * RACE
 // lanes; the copy that converged first supplies the item's loss, forces, iteration count and gradient terms.
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
   static_assert(KPL == 1 || !MESH, "several contacts per lane: box geometry");
   constexpr int kItems = WAVES * (kWave / G) / RACE;  // items per workgroup
-  if constexpr (!DENSE) claim_whole_simd();  // (this build serves the launches of at most one wave per SIMD)
+  if constexpr (!DENSE) claim_whole_simd<T>();  // (this build serves the launches of at most one wave per SIMD)
   const int lane = threadIdx.x;
   const int cidx = lane % G;
   const int slot = lane / (G * RACE);
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(kWave) void simulate_kernel(ModelDesc md, SolverOpt
   using Lanes = GpuLanes<D::G, RACE>;
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
   constexpr int kItems = D::IPW / RACE;  // items per wave
-  if constexpr (SOLO) claim_whole_simd();
+  if constexpr (SOLO) claim_whole_simd<T>();
   const int lane = threadIdx.x;
   const int cidx = lane % (D::G * RACE);  // (0: the lane that writes the item's rows)
   const int slot = lane / (D::G * RACE);
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(kWave) void simulate_kernel_wide(ModelDesc md, Solv
                                                               long long ld_step, int write_x0, int* __restrict__ iters) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<1>;
-  if constexpr (SOLO) claim_whole_simd();
+  if constexpr (SOLO) claim_whole_simd<T>();
   Derived<T, NJ> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
   const long long stride = (long long)gridDim.x * kWave;
@@ -774,7 +779,7 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        want_grad, (const T*)nullptr, (T*)nullptr);
     return 0;
   }
-  // from 512 waves per launch the workgroups are four waves that share a partial row: the finalize kernel's time follows the
+  // beyond 512 waves per launch the workgroups are four waves that share a partial row: the finalize kernel's time follows the
   // number of rows (256 rows 3.0 us, 1024 rows 5.5, 2048 rows 8.7)
   constexpr int kShare = 4;
   if (wide) {
@@ -799,7 +804,8 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
                        ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
                        want_grad, (const T*)nullptr, (T*)nullptr);
-  } else if (copies == 1 && blocks >= 512) {
+  } else if (copies == 1 && blocks > 512) {  // (at 512 waves the one-wave workgroups spread over all CUs, two each: the double
+                                             // elbow kernel, 512 registers and spills, lost 6 % when packed four to a CU)
     rows = (blocks + kShare - 1) / kShare;
     hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 1, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
