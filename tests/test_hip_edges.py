@@ -279,7 +279,7 @@ def test_racing_copies_of_the_loss_solve(urdf, case, copies, dtype):
         xb, xpb = torch.cat([x, x[:1]]), torch.cat([xp, xp[:1]])
         system.set_solver(portfolio=0)
         assert system.racing_copies(4096) == 4 and system.racing_copies(4097) == 1 and system.racing_copies(1) == 4
-        assert system.racing_copies(4096, rollout=True) == 4 and system.racing_copies(16384, rollout=True) == 1
+        assert system.racing_copies(4096, rollout=True) == 4 and system.racing_copies(8192, rollout=True) == 2 and system.racing_copies(16384, rollout=True) == 1
         _, _, it_auto = system.contact_forces(xb, xpb)
         system.set_solver(portfolio=1)
         _, _, it_one = system.contact_forces(xb, xpb)

@@ -126,7 +126,7 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
         handles[name] = handle
     for dtype in (_capi.F32, _capi.F64):
         assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 0) for b in (1, 4096, 4097, 65536)] == [4, 4, 1, 1]
-        assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 1) for b in (1, 4096, 4097)] == [4, 4, 1]
+        assert [lib.dpll_racing_copies(handles['cube'], dtype, b, 1) for b in (1, 4096, 4097, 8192, 8193)] == [4, 4, 2, 2, 1]  # (rollouts gain from two as well)
         assert lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 0) == (4 if dtype == _capi.F32 else 1)  # (two contacts per lane)
         assert lib.dpll_racing_copies(handles['elbow'], dtype, 4097, 0) == 1 and lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 1) == 1
         assert lib.dpll_racing_copies(handles['gripper'], dtype, 512, 0) == 1
