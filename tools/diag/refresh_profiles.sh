@@ -32,7 +32,6 @@ python3 tools/diag/time_general.py > $O/general_times.txt 2>&1
 # keep what profiles/ is made of: the stats summaries, the counter tables, the tail of the headline trace
 head -1 $O/stats/run_kernel_trace.csv > $O/stats/trace_tail.csv; tail -40 $O/stats/run_kernel_trace.csv >> $O/stats/trace_tail.csv
 find $O -name 'run_kernel_trace.csv' -delete
-find $O -name '*.csv' -size +20M -delete
 find $O -name '*_agent_info.csv' -delete
 # the summaries profiles/ keeps are made here (the raw counter tables are tens of MB: over gpurun's 64 MiB return limit)
 for f in general_times.txt pmc_mesh.txt; do cp $O/$f gpurun_out/r03_profiles_$f 2>/dev/null; done
