@@ -404,6 +404,13 @@ def main() -> None:
     parser.add_argument('--launch-check', action='store_true',
                         help='testing aid for the N > 1 launcher: the ranks rendezvous, count themselves with one all-reduce of '
                              'the backend and rank 0 prints a JSON line; no GPU is touched')
+    parser.add_argument('--rehearse', action='store_true',
+                        help='N = 1 only: run the N > 1 code path on one GPU -- a world-size-1 process group of --backend (nccl = RCCL: '
+                             'communicator set-up, the all-reduce of [loss, gradients] inside hipGraph capture and replay, the barrier / '
+                             'max-over-ranks fences) -- so that the first multi-GPU run is not the first execution of that path')
+    parser.add_argument('--ref-value', type=float, default=None,
+                        help='N > 1: the N = 1 value (trajectory-steps/s) to set this run against; config.weak_scaling_vs_ref = value / '
+                             '(N * ref).  Default: the newest profiles/rNN_bench_line.json of the same workload, dtype and batch')
     parser.add_argument('--min-timed-s', type=float, default=0.5,
                         help='the timed region (exactly --steps steps) is repeated until at least this much time has been '
                              'measured in total (and at least --repeats times); the median region is reported')
@@ -434,12 +441,19 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.rehearse
     host_staged = False
     dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1 and 'MASTER_PORT' not in os.environ:  # the rehearsal without a launcher: a rendezvous of one
+            import socket
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
         else:
@@ -559,6 +573,25 @@ def main() -> None:
             line['config']['rccl_ranks'] = rccl_ranks
             line['config']['collective_alt'] = alt
             line['config']['collective_alt_ms'] = alt.get('ms_per_step') if alt else None
+            if args.rehearse and world == 1:
+                line['config']['rehearsal'] = f'world-size-1 {args.backend} process group: the N > 1 code path on one GPU'
+            # informational (the driver forms the scaling curve from the per-N values itself): this run against an N = 1 value
+            ref, ref_source = args.ref_value, '--ref-value'
+            if ref is None:
+                try:
+                    path = newest_profile('bench_line.json')
+                    with open(path) as handle:
+                        cached = json.load(handle)
+                    same = (cached.get('n_gpus') == 1 and cached.get('dtype') == args.dtype and args.workload == 'cube'
+                            and cached.get('config', {}).get('per_gpu_batch') == args.batch and 'cube' in cached.get('config', {}).get('workload', ''))
+                    if same:
+                        ref, ref_source = float(cached['value']), os.path.relpath(path, REPO)
+                except (OSError, KeyError, ValueError, TypeError):
+                    ref = None
+            if ref:
+                line['config']['weak_scaling_vs_ref'] = {
+                    'ref_value_n1': ref, 'ref_source': ref_source, 'efficiency': line['value'] / (world * ref),
+                    'efficiency_alt': (alt['value'] / (world * ref)) if alt and alt.get('value') else None}
         if world == 1 and not args.no_configs and args.workload == 'cube' and args.batch == 4096:
             # the other BASELINE.json configurations, same process, after the headline (about a minute in total)
             configs = []

@@ -83,6 +83,10 @@ static_assert(kMaxPairs <= 4, "the pairs share the kQuery contact slots of one g
 constexpr int kJointRevolute = 0, kJointPrismatic = 1;
 constexpr int kQuery = 4;       // witness points per convex geometry (geometry.py:47-48)
 constexpr int kIota = 10;       // per-body inertial vector [m, h = m c (3), I_o (xx,yy,zz,xy,xz,yz)]
+// continuation stages a build with racing copies can start from: its starting regularisation eps * factor^(stages - 1) is
+// formed by a loop unrolled this many times (no divergent loop per lane); dpll_model_set_solver refuses longer schedules --
+// n_stages, loss_n_stages, race_stages -- unless the copies are switched off (portfolio = 1)
+constexpr int kRaceMaxStages = 8;
 
 #ifndef DPLL_PRISMATIC  // (diagnostic builds define it to 0: every joint a hinge at compile time)
 #define DPLL_PRISMATIC 1
@@ -1012,7 +1016,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
   const int last_stage = n_stages - 1;
   T eps_c = eps;  // regularisation of the current stage (per item: items advance independently)
   if constexpr (Lanes::kVariants > 1) {
-    DPLL_UNROLL for (int s = 0; s < 8; ++s) eps_c *= s < last_stage ? factor : T(1);  // (per lane: no divergent loop)
+    DPLL_UNROLL for (int s = 0; s < kRaceMaxStages; ++s) eps_c *= s < last_stage ? factor : T(1);  // (per lane: no divergent loop)
   } else {
     for (int s = 0; s < last_stage; ++s) eps_c *= factor;
   }

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
   static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
   static_assert(KPL == 1 || !MESH, "several contacts per lane: box geometry");
   constexpr int kItems = WAVES * (kWave / G) / RACE;  // items per workgroup
-  if constexpr (!DENSE) claim_whole_simd<T>();  // (this build serves the launches of at most one wave per SIMD)
+  if constexpr (!DENSE) claim_whole_simd<T>();  // (this build serves the launches of at most one wave per SIMD: the launchers
+                                                // send anything bigger to the DENSE build -- box and mesh geometry alike)
   const int lane = threadIdx.x;
   const int cidx = lane % G;
   const int slot = lane / (G * RACE);
@@ -355,7 +356,12 @@ __global__ __launch_bounds__(GROUPS * 32) void finalize_kernel(const double* __r
       grad[threadIdx.x - 1] = value;
     }
   }
-  if (adam.params) {  // (uniform: a kernel argument)
+  // A timed-out exchange hands back NaN rows by design (dpll_allreduce.hpp) and sets the error word: the update is then
+  // skipped altogether -- parameters, both moments and the step count keep the values of the previous step, so the abort the
+  // trainer raises when it next looks at the word (every 16 steps) finds nothing that has to be undone.
+  bool exchange_ok = true;
+  if constexpr (FUSED) exchange_ok = err == nullptr || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  if (adam.params && exchange_ok) {  // (uniform: kernel arguments and one word every thread reads alike)
     const double steps = adam.state[0] + 1.0, pow1 = adam.state[1] * adam.beta1, pow2 = adam.state[2] * adam.beta2;
     __syncthreads();  // every thread has read the state before thread 0 advances it
     if (threadIdx.x == 0) { adam.state[0] = steps; adam.state[1] = pow1; adam.state[2] = pow2; }
@@ -749,6 +755,25 @@ inline int race_copies(int requested, int lanes_per_item, long long batch, int p
   return p;
 }
 
+// The shape of a loss launch with racing copies: lanes of one copy of an item, copies per item.  The two-contacts-per-lane
+// build (the elbow: 4 lanes per copy) exists with FOUR copies only, so when the launch cannot have four (a batch beyond one
+// wave per SIMD) the shape is decided again on the one-contact-per-lane build -- lanes first and copies second used to leave
+// a two-copy launch sized for workgroups of twice its items (correct through the grid-stride loop, half the workgroups).
+struct RaceShape { int lanes, copies; };
+inline RaceShape race_shape(int n_joints, bool is_float, int asked, long long batch) {
+  const int full = kQuery * (n_joints + 1);
+  RaceShape r{race_lanes_of(n_joints, is_float, asked), 1};
+  r.copies = race_copies(asked, r.lanes, batch);
+  if (r.lanes < full && r.copies != 4) {
+    r.lanes = full;
+    r.copies = race_copies(asked, full, batch);
+  }
+  return r;
+}
+template <typename T, int NJ> RaceShape race_shape(const dpll_model* m, int dtype, long long batch) {
+  return race_shape(NJ, sizeof(T) == 4, m->opts[dtype].portfolio, batch);
+}
+
 }  // namespace
 
 int dpll_fail(int code, const char* fmt, const char* detail) { return fail(code, fmt, detail); }
@@ -756,14 +781,20 @@ int dpll_check_launch(const char* what) { return check_launch(what); }
 
 namespace {
 
-// Picks the build of the loss kernel for this launch and launches it; returns the number of partial rows written.
-template <typename T, int NJ>
-int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
-                       long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* force,
-                       int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
-  const int lanes = race_lanes<T, NJ>(m->opts[dtype].portfolio);
-  const int copies = race_copies(m->opts[dtype].portfolio, lanes, batch);
-  const int blocks = loss_blocks<T, NJ>(batch, copies, lanes);
+// Which build of the loss kernel a launch of `batch` pairs runs and with what grid: decided in ONE place, for the launcher,
+// the workspace check, the profiling utility and dpll_racing_copies (what a caller / a test may ask about a launch).
+enum LossBuild { kLossEmpty, kLossWide, kLossWideShared, kLossDense, kLossPlainShared, kLossPlain, kLossRace2, kLossRace4, kLossRace4Kpl2 };
+struct LossPlan {
+  LossBuild build;
+  int lanes, copies;  // lanes of one copy of an item, racing copies per item
+  int blocks;         // item workgroups of the one-wave plain launch (the workspace is sized for these rows)
+  int rows;           // item workgroups of THIS launch = partial rows written (the grid is rows + 1: the chain-matrix workgroup)
+  int threads;        // per workgroup
+};
+template <typename T, int NJ> LossPlan plan_loss(const dpll_model* m, int dtype, long long batch) {
+  const RaceShape shape = race_shape<T, NJ>(m, dtype, batch);
+  LossPlan pl{kLossPlain, shape.lanes, shape.copies, loss_blocks<T, NJ>(batch, shape.copies, shape.lanes), 0, kWave};
+  pl.rows = pl.blocks;
   // wide build (one lane per item): beyond 32,768 pairs.  Measured (round 3, waves that claim their SIMD, shared partial rows),
   // loss + finalize in us, lane-per-contact builds vs wide: cube f32 16,384 pairs 22.2 vs 34.8, 32,768 32.0 vs 34.9, 49,152
   // 41.3 vs 34.8, 65,536 55.6 vs 35.2; cube f64 32,768 63.5 vs 70.7, 49,152 81.6 vs 73.2; elbow f32 32,768 112.6 vs 122.1,
@@ -771,67 +802,95 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
   // dpll_solver_opts_t::wide overrides the choice (tests compare the builds on the same inputs)
   const int wide_opt = m->opts[dtype].wide;
   const bool wide = wide_opt >= 0 ? wide_opt == 1 : (batch > 32768 && !(std::is_same<T, double>::value && NJ == 1));
-  int rows = blocks;
-  if (batch == 0) {  // an empty shard: no item workgroups, only the one that writes the chain matrix; zero partial rows
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-    return 0;
-  }
   // beyond 512 waves per launch the workgroups are four waves that share a partial row: the finalize kernel's time follows the
   // number of rows (256 rows 3.0 us, 1024 rows 5.5, 2048 rows 8.7)
   constexpr int kShare = 4;
-  if (wide) {
+  if (batch == 0) {  // an empty shard: no item workgroups, only the one that writes the chain matrix; zero partial rows
+    pl.build = kLossEmpty; pl.rows = 0;
+  } else if (wide) {
     long long wb = (batch + kWave - 1) / kWave;
     if (wb > kMaxLossBlocks) wb = kMaxLossBlocks;
-    if (wb >= 512) {
-      rows = (int)((wb + kShare - 1) / kShare);
-      hipLaunchKernelGGL((loss_kernel_wide<T, NJ, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
-                         (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                         ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                         want_grad);
-    } else {
-      rows = (int)wb;
-      hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                         (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                         ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                         want_grad);
-    }
-  } else if (blocks > kSimds) {  // more waves than SIMDs: the two-waves-per-SIMD build
-    rows = (blocks + kShare - 1) / kShare;
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, true, 1, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-  } else if (copies == 1 && blocks > 512) {  // (at 512 waves the one-wave workgroups spread over all CUs, two each: the double
-                                             // elbow kernel, 512 registers and spills, lost 6 % when packed four to a CU)
-    rows = (blocks + kShare - 1) / kShare;
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 1, kShare>), dim3(rows + 1), dim3(kShare * kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-  } else if (copies == 1)
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), dim3(blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-  else if (copies == 2)
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 2>), dim3(blocks + 1), dim3(kRaceWaves * kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-  else if constexpr (Dims<T, NJ>::G * 4 <= 16)
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4>), dim3(blocks + 1), dim3(kRaceWaves * kWave), 0, stream, m->desc, m->opts[dtype],
-                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-  else  // the elbow: two contacts per lane
-    hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4, kRaceWaves, 2>), dim3(blocks + 1), dim3(kRaceWaves * kWave), 0, stream, m->desc,
-                       m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp,
-                       ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace,
-                       want_grad, (const T*)nullptr, (T*)nullptr);
-  return rows;
+    if (wb >= 512) { pl.build = kLossWideShared; pl.rows = (int)((wb + kShare - 1) / kShare); pl.threads = kShare * kWave; }
+    else { pl.build = kLossWide; pl.rows = (int)wb; }
+  } else if (pl.blocks > kSimds) {  // more waves than SIMDs: the two-waves-per-SIMD build
+    pl.build = kLossDense; pl.rows = (pl.blocks + kShare - 1) / kShare; pl.threads = kShare * kWave;
+  } else if (pl.copies == 1 && pl.blocks > 512) {  // (at 512 waves the one-wave workgroups spread over all CUs, two each: the double
+                                                   // elbow kernel, 512 registers and spills, lost 6 % when packed four to a CU)
+    pl.build = kLossPlainShared; pl.rows = (pl.blocks + kShare - 1) / kShare; pl.threads = kShare * kWave;
+  } else if (pl.copies == 1) {
+    pl.build = kLossPlain;
+  } else {
+    pl.threads = kRaceWaves * kWave;
+    pl.build = pl.copies == 2 ? kLossRace2 : (pl.lanes * 4 <= 16 && pl.lanes == Dims<T, NJ>::G ? kLossRace4 : kLossRace4Kpl2);
+  }
+  return pl;
+}
+
+// launches the build plan_loss picked; returns the number of partial rows written
+template <typename T, int NJ>
+int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
+                       long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* force,
+                       int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
+  const LossPlan pl = plan_loss<T, NJ>(m, dtype, batch);
+  constexpr int kShare = 4;
+#define DPLL_LOSS_ARGS m->desc, m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, \
+                       (const T*)xp, ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad
+  const dim3 grid(pl.rows + 1), block(pl.threads);
+  switch (pl.build) {
+    case kLossEmpty:
+    case kLossPlain:
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      break;
+    case kLossWideShared:
+      hipLaunchKernelGGL((loss_kernel_wide<T, NJ, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS);
+      break;
+    case kLossWide:
+      hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), grid, block, 0, stream, DPLL_LOSS_ARGS);
+      break;
+    case kLossDense:
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, true, 1, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      break;
+    case kLossPlainShared:
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 1, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      break;
+    case kLossRace2:
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 2>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      break;
+    case kLossRace4:
+      if constexpr (Dims<T, NJ>::G * 4 <= 16)
+        hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      break;
+    case kLossRace4Kpl2:  // the elbow: two contacts per lane
+      if constexpr (Dims<T, NJ>::G == 8)
+        hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4, kRaceWaves, 2>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr,
+                           (T*)nullptr);
+      break;
+  }
+#undef DPLL_LOSS_ARGS
+  return pl.rows;
+}
+
+// the finalize kernel behind a loss launch of `rows` partial rows (<= 256 rows: the 256-thread build, with or without the
+// exchange -- the two sum the rows in the same order, so a separate exchange after the launch gives bitwise the row of the
+// fused one); the ONE rule for the launcher and the profiling utility
+template <typename T, int NJ>
+void launch_finalize(const void* workspace, int rows, void* grad, void* loss_total, const dpll_ar* ar, const AdamArgs& adam, hipStream_t stream) {
+  const dpll_arx::Peers peers = ar ? ar->peers : dpll_arx::Peers{};
+  const int rank = ar ? ar->rank : 0, world = ar ? ar->world : 1;
+  uint32_t* seq = ar ? ar->state : (uint32_t*)nullptr;
+  uint32_t* err = ar ? ar->state + 1 : (uint32_t*)nullptr;
+  if (ar && rows <= 256)
+    hipLaunchKernelGGL((finalize_kernel<T, NJ, true, 8>), dim3(1), dim3(256), 0, stream, (const double*)workspace, rows, (T*)grad, (T*)loss_total,
+                       peers, rank, world, seq, err, adam);
+  else if (ar)
+    hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, rows, (T*)grad,
+                       (T*)loss_total, peers, rank, world, seq, err, adam);
+  else if (rows <= 256)
+    hipLaunchKernelGGL((finalize_kernel<T, NJ, false, 8>), dim3(1), dim3(256), 0, stream, (const double*)workspace, rows, (T*)grad, (T*)loss_total,
+                       peers, rank, world, seq, err, adam);
+  else
+    hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace, rows, (T*)grad,
+                       (T*)loss_total, peers, rank, world, seq, err, adam);
 }
 
 template <typename T, int NJ>
@@ -840,8 +899,8 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                 void* loss_total, void* force, int32_t* iters, void* workspace, long long workspace_bytes,
                 hipStream_t stream, const dpll_ar* ar = nullptr, AdamArgs adam = AdamArgs{}) {
   using D = Dims<T, NJ>;
-  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, race_lanes<T, NJ>(m->opts[dtype].portfolio), batch),
-                                        race_lanes<T, NJ>(m->opts[dtype].portfolio));
+  const RaceShape shape = race_shape<T, NJ>(m, dtype, batch);
+  const int blocks = loss_blocks<T, NJ>(batch, shape.copies, shape.lanes);
   const int want_grad = grad != nullptr;
   if (want_grad) {
     if (!workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
@@ -853,24 +912,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                                              want_grad, stream);
   if (int rc = check_launch("loss_kernel")) return rc;
   if (want_grad) {
-    // (<= 256 rows: the 256-thread build, with or without the exchange -- the two sum the rows in the same order, so a
-    // separate exchange after the launch gives bitwise the row of the fused one)
-    if (ar && rows <= 256)
-      hipLaunchKernelGGL((finalize_kernel<T, NJ, true, 8>), dim3(1), dim3(256), 0, stream, (const double*)workspace,
-                         rows, (T*)grad,
-                         (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1, adam);
-    else if (ar)
-      hipLaunchKernelGGL((finalize_kernel<T, NJ, true>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         rows, (T*)grad,
-                         (T*)loss_total, ar->peers, ar->rank, ar->world, ar->state, ar->state + 1, adam);
-    else if (rows <= 256)
-      hipLaunchKernelGGL((finalize_kernel<T, NJ, false, 8>), dim3(1), dim3(256), 0, stream, (const double*)workspace,
-                         rows, (T*)grad,
-                         (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, adam);
-    else
-      hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         rows, (T*)grad,
-                         (T*)loss_total, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, adam);
+    launch_finalize<T, NJ>(workspace, rows, grad, loss_total, ar, adam, stream);
     if (int rc = check_launch("finalize_kernel")) return rc;
   }
   return 0;
@@ -883,8 +925,8 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
                  long long ld_xp, long long batch, double scale, void* grad, void* workspace, long long workspace_bytes,
                  hipStream_t stream, int reps, float* ms_loss, float* ms_finalize) {
   using D = Dims<T, NJ>;
-  const int blocks = loss_blocks<T, NJ>(batch, race_copies(m->opts[dtype].portfolio, race_lanes<T, NJ>(m->opts[dtype].portfolio), batch),
-                                        race_lanes<T, NJ>(m->opts[dtype].portfolio));
+  const RaceShape shape = race_shape<T, NJ>(m, dtype, batch);
+  const int blocks = loss_blocks<T, NJ>(batch, shape.copies, shape.lanes);
   if (!grad || !workspace || workspace_bytes < ((long long)blocks * D::PI + D::CHAIN) * (long long)sizeof(double))
     return fail(-3, "dpll_profile_contactnets_loss: grad and workspace are required%s");
   // two passes, two events each (an event between every pair of kernels costs several microseconds of its own):
@@ -905,8 +947,7 @@ int profile_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const v
     ok = ok && hipEventRecord(ev[1], stream) == hipSuccess && hipEventRecord(ev[2], stream) == hipSuccess;
     for (int r = 0; r < reps; ++r) {
       launch_loss_only();
-      hipLaunchKernelGGL((finalize_kernel<T, NJ, false>), dim3(1), dim3(kFinalizeThreads), 0, stream, (const double*)workspace,
-                         rows, (T*)grad, (T*)nullptr, dpll_arx::Peers{}, 0, 1, (uint32_t*)nullptr, (uint32_t*)nullptr, AdamArgs{});
+      launch_finalize<T, NJ>(workspace, rows, grad, nullptr, nullptr, AdamArgs{}, stream);  // (the build launch_loss ships for these rows)
     }
     ok = ok && hipEventRecord(ev[3], stream) == hipSuccess;
     rc = check_launch("profile launches");
@@ -1272,10 +1313,21 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   const int want_grad = grad != nullptr;
   // terms live at the NEXT state
   if (int rc = mesh_forward_all<T, NJ>(m, pl, mp, ws, (const T*)xp, ld_xp, batch, stream, want_grad != 0)) return rc;
-  hipLaunchKernelGGL((loss_kernel<T, NJ, true>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype],
-                     (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,
-                     batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),
-                     want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr);
+  // (the float build claims its SIMD, which serves launches of at most one wave per SIMD; beyond -- more than 16,384 cube or
+  // 8192 elbow pairs -- the float launch runs the build for two waves per SIMD, as the box path does; the double kernels
+  // allocate more than half the register file by themselves and never claim)
+#define DPLL_MESH_LOSS(DENSE_)                                                                                                   \
+  hipLaunchKernelGGL((loss_kernel<T, NJ, true, DENSE_>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype], \
+                     (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,         \
+                     batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),              \
+                     want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr)
+  if constexpr (std::is_same<T, float>::value) {
+    if (pl.loss_blocks > kSimds) DPLL_MESH_LOSS(true);
+    else DPLL_MESH_LOSS(false);
+  } else {
+    DPLL_MESH_LOSS(false);
+  }
+#undef DPLL_MESH_LOSS
   mesh_mark(stream);
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
@@ -1773,11 +1825,16 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
   if (opts->portfolio != 0 && opts->portfolio != 1 && opts->portfolio != 2 && opts->portfolio != 4)
     return fail(-1, "dpll_model_set_solver: portfolio must be 0 (by batch size), 1 (off), 2 or 4%s");
   for (int k = 0; k < 3; ++k)
-    if (opts->race_stages[k] < 1 || opts->race_stages[k] > 8 || !(opts->race_factor[k] >= 1.0) || (opts->race_flags[k] & ~3))
+    if (opts->race_stages[k] < 1 || opts->race_stages[k] > kRaceMaxStages || !(opts->race_factor[k] >= 1.0) || (opts->race_flags[k] & ~3))
       return fail(-1, "dpll_model_set_solver: racing schedules need 1 <= race_stages <= 8, race_factor >= 1, race_flags in 0..3%s");
-  if (opts->n_stages > 8 && opts->portfolio != 1) return fail(-1, "dpll_model_set_solver: n_stages > 8 needs portfolio = 1%s");
+  // (the builds with racing copies form the starting regularisation with a loop of kRaceMaxStages steps, sap_newton: a longer
+  // schedule -- of the dynamics solve or of the loss solve, whose schedule loss_item copies into n_stages -- would start too low
+  // and END below the reference's eps)
+  if (opts->n_stages > kRaceMaxStages && opts->portfolio != 1) return fail(-1, "dpll_model_set_solver: n_stages > 8 needs portfolio = 1%s");
   if (opts->loss_n_stages < 0 || (opts->loss_n_stages > 0 && !(opts->loss_stage_factor >= 1.0)))
     return fail(-1, "dpll_model_set_solver: loss_n_stages >= 0 and, when set, loss_stage_factor >= 1%s");
+  if (opts->loss_n_stages > kRaceMaxStages && opts->portfolio != 1)
+    return fail(-1, "dpll_model_set_solver: loss_n_stages > 8 needs portfolio = 1%s");
   std::memcpy(&model->opts[dtype], opts, sizeof(SolverOpts));
   return 0;
 }
@@ -1815,10 +1872,17 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
 }
 
 int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what) {
-  if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || (what != 0 && what != 1)) return -1;
+  if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || what < 0 || what > 3) return -1;
+  if (what >= 2) {  // the shape of the loss launch: 2 = item workgroups (= partial rows), 3 = lanes of one copy of an item
+    if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return -1;
+    LossPlan pl;
+    if (dtype == DPLL_F32) pl = model->desc.n_joints == 0 ? plan_loss<float, 0>(model, dtype, batch) : plan_loss<float, 1>(model, dtype, batch);
+    else pl = model->desc.n_joints == 0 ? plan_loss<double, 0>(model, dtype, batch) : plan_loss<double, 1>(model, dtype, batch);
+    return what == 2 ? pl.rows : (pl.build == kLossWide || pl.build == kLossWideShared ? 1 : pl.lanes);
+  }
   if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return 1;
   const int asked = model->opts[dtype].portfolio;
-  if (what == 0) return race_copies(asked, race_lanes_of(model->desc.n_joints, dtype == DPLL_F32, asked), batch);
+  if (what == 0) return race_shape(model->desc.n_joints, dtype == DPLL_F32, asked, batch).copies;
   // rollouts: one lane per contact always; the elbow's gain nothing from two copies, so its default is none; the cube's gain
   // from two as well (4096 trajectories, us per step with 1 / 2 / 4 copies: 13.1 / 11.4 / 10.4), so 4097 .. 8192 run with two
   return (model->desc.n_joints > 0 && asked == 0) ? 1 : race_copies(asked, kQuery * (model->desc.n_joints + 1), batch, 4, true);

@@ -99,6 +99,9 @@ class ContactNetsTrainer:
                                               capturable=self.use_graph)
         self._graph = None
         self._static = None
+        # how the steps reached the device: `enqueued` = training steps whose kernels this process enqueued one by one
+        # (eager batches, the warm-up and the capture of a graph), `replayed` = steps that were one hipGraph replay
+        self.step_counts = {'enqueued': 0, 'replayed': 0}
         self.generator = torch.Generator().manual_seed(seed)
         self.health_every = 16  # steps between looks at the peer exchange's error word (each look synchronises)
         self.reducer: Optional[GradientAllReduce] = None
@@ -148,6 +151,7 @@ class ContactNetsTrainer:
         return hi - lo
 
     def _step_body(self, x: Tensor, x_plus: Tensor) -> Tensor:
+        self.step_counts['enqueued'] += 1
         if self.fused_adam:
             return self.system.contactnets_train_step(x, x_plus, self.optimizer)
         total = self.system.contactnets_loss_and_grad(x, x_plus)
@@ -205,6 +209,7 @@ class ContactNetsTrainer:
         torch.index_select(x, 0, idx, out=xs)
         torch.index_select(x_plus, 0, idx, out=xps)
         self._graph.replay()
+        self.step_counts['replayed'] += 1
         return total.clone()
 
     def _train_epoch_prediction(self, x_past: Tensor, x_future: Tensor) -> float:

@@ -108,7 +108,7 @@ typedef struct dpll_solver_opts {
   int32_t warm_start;     /* loss solve starts from the observed velocity jump dv instead of 0 */
   int32_t wide;           /* loss-kernel build: -1 = by batch size, 0 = one lane per contact, 1 = one lane per item */
   double loss_stage_factor; /* continuation schedule of the loss solve (eps 1e-3) when it differs from the dynamics solve's */
-  int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves */
+  int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves; like n_stages at most 8 unless portfolio = 1 */
   int32_t f64_refine;       /* DPLL_F64 solves: 1 = float iterations refined in double to `tol` (default), 0 = all double */
   int32_t mesh_gemm;        /* DPLL_F32 mesh pipeline, ICNN GEMMs: 0 = f32 MFMA (exact f32, default), 2 / 3 = bf16 matrix cores on
                                operands split into 2 / 3 bf16 planes (3: f32-grade accuracy, 2: 2^-16 per product) */
@@ -160,7 +160,9 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch);
 
 /* Racing copies per item (dpll_solver_opts_t.portfolio) that a launch of `batch` items would run with the model's current
  * solver settings: what = 0 the loss launch (dpll_contactnets_loss and its variants), 1 the rollout / step launch
- * (dpll_simulate, dpll_step).  1 = no copies (always: general build, learned shapes).  -1 on a bad argument. */
+ * (dpll_simulate, dpll_step).  1 = no copies (always: general build, learned shapes).  -1 on a bad argument.
+ * The SHAPE of the loss launch (specialised builds only, else -1): what = 2 its item workgroups (= partial rows; the grid has
+ * one more, which writes the chain matrix), what = 3 the lanes of one copy of an item (1: the wide build). */
 int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what);
 
 /* ContactNets loss of `batch` transitions (x -> x_plus), forward and backward in one pass.

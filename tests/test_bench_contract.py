@@ -85,3 +85,43 @@ def test_bare_two_rank_bench_on_one_device():
     assert 'all-reduce' in line['config']['collective'] and 'gloo' in line['config']['collective']  # the backend's collective is the reported route
     assert line['value'] == pytest.approx(8192 * 20 / (line['ms_per_step'] * 20 / 1e3), rel=1e-4)
     assert 'cpu_baseline' not in line and 'configs' not in line
+
+
+def test_eight_rank_launch_check_on_cpu():
+    """the command the driver's scaling tier ends with -- `python bench.py --gpus 8` -- as far as it goes without GPUs: the
+    launcher starts eight ranks, they rendezvous on 127.0.0.1 and count themselves with one all-reduce (gloo), rank 0
+    prints the one line (the 8-rank launch must not see its first execution on the 8-GPU node)"""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--single-device', '--backend', 'gloo', '--launch-check'],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')]
+    assert lines == [{'launch_check': True, 'n_gpus': 8, 'rccl_ranks': 8, 'backend': 'gloo'}]
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_inside_graph_capture_on_one_gpu():
+    """Dress rehearsal of the multi-GPU step on ONE GPU: a world-size-1 `nccl` (= RCCL) process group
+    on cuda:0, bench.py's own timed(reducer) with the collective transport -- communicator set-up, the all-reduce of
+    [loss | gradients] captured in the step's hipGraph and replayed, barrier + max-over-ranks fences.  Capture must have
+    worked, or the line must say that the launches were eager and why (never a silent fall-back)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--rehearse', '--steps', '20', '--warmup', '5',
+                          '--min-timed-s', '0.05', '--no-configs', '--no-cpu-baseline', '--ref-value', '2.0e8'],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1
+    line = lines[0]
+    assert REQUIRED <= set(line) and line['n_gpus'] == 1 and line['value'] > 0
+    config = line['config']
+    assert config['rccl_ranks'] == 1 and 'nccl all-reduce' in config['collective'] and 'rehearsal' in config
+    launch = config['launch']
+    print('rehearsal launch:', launch, '| ms_per_step', line['ms_per_step'])
+    assert launch.startswith('hipGraph replay') or 'hipGraph capture failed' in launch, launch
+    # the same loss as without the process group (a SUM over one rank), and the efficiency figure against the given N = 1 value
+    assert config['mean_loss'] == pytest.approx(3.555887e-04, rel=1e-4)
+    eff = config['weak_scaling_vs_ref']
+    assert eff['ref_source'] == '--ref-value' and eff['efficiency'] == pytest.approx(line['value'] / 2.0e8, rel=1e-4)

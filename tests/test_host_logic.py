@@ -130,7 +130,13 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
         assert lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 0) == (4 if dtype == _capi.F32 else 1)  # (two contacts per lane)
         assert lib.dpll_racing_copies(handles['elbow'], dtype, 4097, 0) == 1 and lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 1) == 1
         assert lib.dpll_racing_copies(handles['gripper'], dtype, 512, 0) == 1
-    assert lib.dpll_racing_copies(handles['cube'], 7, 4096, 0) == -1 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 2) == -1
+    assert lib.dpll_racing_copies(handles['cube'], 7, 4096, 0) == -1 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 4) == -1
+    # the shape of the loss launch (what = 2: item workgroups, 3: lanes per copy): the racing launch writes as many rows as the
+    # plain one; the wide build (one lane per item) in four-wave workgroups from 512 waves on
+    assert [lib.dpll_racing_copies(handles['cube'], _capi.F32, b, 2) for b in (4096, 4097, 16384, 65536)] == [256, 257, 256, 256]
+    assert [lib.dpll_racing_copies(handles['cube'], _capi.F32, b, 3) for b in (4096, 4097, 65536)] == [4, 4, 1]
+    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 3) == 4 and lib.dpll_racing_copies(handles['elbow'], _capi.F64, 4096, 3) == 8
+    assert lib.dpll_racing_copies(handles['gripper'], _capi.F32, 4096, 2) == -1
     opts = _capi.SolverOpts()
     assert lib.dpll_model_get_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
     assert opts.portfolio == 0 and list(opts.race_flags) == [2, 2, 2]
@@ -140,6 +146,14 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
     opts.portfolio = 4  # (the loss launch: the build with two contacts per lane; a rollout has no such build and falls back to two)
     assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
     assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 0) == 4 and lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 1) == 2
+    # ... and when the batch is too big for four copies the launch goes back to one contact per lane BEFORE its grid is sized
+    # (lanes were picked first, and a two-copy launch got the grid of workgroups twice its size)
+    for batch in (4097, 6000, 8192):
+        copies, lanes, rows = (lib.dpll_racing_copies(handles['elbow'], _capi.F32, batch, what) for what in (0, 3, 2))
+        assert lanes == 8 and copies in (1, 2)
+        items_per_group = 4 * 64 // (lanes * copies) if copies > 1 else 64 // lanes
+        groups = -(-batch // items_per_group)
+        assert rows == (groups if copies > 1 or groups <= 512 else -(-groups // 4)), (batch, copies, rows)
     for field, value in (('portfolio', 3), ('portfolio', -1)):
         bad = _capi.SolverOpts.from_buffer_copy(opts)
         setattr(bad, field, value)
@@ -147,6 +161,17 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
     bad = _capi.SolverOpts.from_buffer_copy(opts)
     bad.race_stages[1] = 9
     assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) != 0 and b'race_stages' in lib.dpll_last_error()
+    # schedules longer than the racing builds' unrolled start loop (8 stages): refused for either solve unless copies are off
+    for field in ('n_stages', 'loss_n_stages'):
+        bad = _capi.SolverOpts.from_buffer_copy(opts)
+        setattr(bad, field, 9)
+        bad.loss_stage_factor = 2.0
+        for portfolio in (0, 2, 4):
+            bad.portfolio = portfolio
+            assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) != 0 and field.encode() in lib.dpll_last_error()
+        bad.portfolio = 1
+        assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) == 0
+    assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(opts)) == 0
     bad = _capi.SolverOpts.from_buffer_copy(opts)
     bad.race_factor[0] = 0.5
     assert lib.dpll_model_set_solver(handles['elbow'], _capi.F32, ctypes.byref(bad)) != 0
