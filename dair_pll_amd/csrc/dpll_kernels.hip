@@ -106,14 +106,18 @@ template <typename T> __device__ __forceinline__ void claim_whole_simd() {
 // KPL: contacts per lane (1; 2 for the elbow's four-copy racing build: 8 contacts on 4 lanes leave its 16-lane row room for
 // four copies)
 template <typename T, int NJ, bool MESH = false, bool DENSE = false, int RACE = 1, int WAVES = (RACE > 1 ? kRaceWaves : 1), int KPL = 1>
-__global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
-                                                     const T* __restrict__ friction, const T* __restrict__ lengths,
-                                                     const T* __restrict__ x, long long ld_x,
+__global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(const T* __restrict__ x, long long ld_x,
                                                      const T* __restrict__ xp, long long ld_xp, long long batch,
+                                                     const T* __restrict__ theta, const T* __restrict__ friction,
+                                                     const T* __restrict__ lengths,
                                                      const T* __restrict__ weights, double scale, T* __restrict__ loss,
                                                      T* __restrict__ force, int* __restrict__ iters,
                                                      double* __restrict__ partials, int want_grad,
-                                                     const T* __restrict__ witness, T* __restrict__ rbar_out) {
+                                                     const T* __restrict__ witness, T* __restrict__ rbar_out,
+                                                     ModelDesc md, SolverOpts opt) {
+  // (argument order: what the first loads of a wave need -- the state pointers, strides and the batch size -- comes first so that
+  // the kernel-argument preload of gfx950 (-amdgpu-kernarg-preload-count, csrc/Makefile) hands it over in SGPRs at wave start:
+  // the state rows are requested without waiting for a fetch of the argument segment; the two structs are fetched behind them)
   using D = Dims<T, NJ>;
   constexpr int G = D::K / KPL;  // lanes of one copy of an item
   using Lanes = GpuLanes<G, RACE>;
@@ -213,13 +217,13 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(Mode
 // section 4) and 64 items per wave instead of 16, at the price of a ~2x longer serial chain per iteration: for launches
 // far beyond one wave per SIMD only (launch_loss_kernel picks it beyond 32,768 pairs).
 template <typename T, int NJ, int WAVES = 1>
-__global__ __launch_bounds__(WAVES * kWave) void loss_kernel_wide(ModelDesc md, SolverOpts opt, const T* __restrict__ theta,
-                                                          const T* __restrict__ friction, const T* __restrict__ lengths,
-                                                          const T* __restrict__ x, long long ld_x,
+__global__ __launch_bounds__(WAVES * kWave) void loss_kernel_wide(const T* __restrict__ x, long long ld_x,
                                                           const T* __restrict__ xp, long long ld_xp, long long batch,
+                                                          const T* __restrict__ theta, const T* __restrict__ friction,
+                                                          const T* __restrict__ lengths,
                                                           const T* __restrict__ weights, double scale, T* __restrict__ loss,
                                                           T* __restrict__ force, int* __restrict__ iters,
-                                                          double* __restrict__ partials, int want_grad) {
+                                                          double* __restrict__ partials, int want_grad, ModelDesc md, SolverOpts opt) {
   using D = Dims<T, NJ>;
   using Lanes = GpuLanes<1>;
   const int lane = threadIdx.x;
@@ -833,37 +837,37 @@ int launch_loss_kernel(const dpll_model* m, int dtype, const dpll_params_t* p, c
                        int32_t* iters, void* workspace, int want_grad, hipStream_t stream) {
   const LossPlan pl = plan_loss<T, NJ>(m, dtype, batch);
   constexpr int kShare = 4;
-#define DPLL_LOSS_ARGS m->desc, m->opts[dtype], (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, \
-                       (const T*)xp, ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad
+#define DPLL_LOSS_ARGS (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, \
+                       (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad
   const dim3 grid(pl.rows + 1), block(pl.threads);
   switch (pl.build) {
     case kLossEmpty:
     case kLossPlain:
-      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr, m->desc, m->opts[dtype]);
       break;
     case kLossWideShared:
-      hipLaunchKernelGGL((loss_kernel_wide<T, NJ, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS);
+      hipLaunchKernelGGL((loss_kernel_wide<T, NJ, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, m->desc, m->opts[dtype]);
       break;
     case kLossWide:
-      hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), grid, block, 0, stream, DPLL_LOSS_ARGS);
+      hipLaunchKernelGGL((loss_kernel_wide<T, NJ>), grid, block, 0, stream, DPLL_LOSS_ARGS, m->desc, m->opts[dtype]);
       break;
     case kLossDense:
-      hipLaunchKernelGGL((loss_kernel<T, NJ, false, true, 1, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, true, 1, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr, m->desc, m->opts[dtype]);
       break;
     case kLossPlainShared:
-      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 1, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 1, kShare>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr, m->desc, m->opts[dtype]);
       break;
     case kLossRace2:
-      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 2>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+      hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 2>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr, m->desc, m->opts[dtype]);
       break;
     case kLossRace4:
       if constexpr (Dims<T, NJ>::G * 4 <= 16)
-        hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr);
+        hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr, (T*)nullptr, m->desc, m->opts[dtype]);
       break;
     case kLossRace4Kpl2:  // the elbow: two contacts per lane
       if constexpr (Dims<T, NJ>::G == 8)
         hipLaunchKernelGGL((loss_kernel<T, NJ, false, false, 4, kRaceWaves, 2>), grid, block, 0, stream, DPLL_LOSS_ARGS, (const T*)nullptr,
-                           (T*)nullptr);
+                           (T*)nullptr, m->desc, m->opts[dtype]);
       break;
   }
 #undef DPLL_LOSS_ARGS
@@ -1317,10 +1321,10 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   // 8192 elbow pairs -- the float launch runs the build for two waves per SIMD, as the box path does; the double kernels
   // allocate more than half the register file by themselves and never claim)
 #define DPLL_MESH_LOSS(DENSE_)                                                                                                   \
-  hipLaunchKernelGGL((loss_kernel<T, NJ, true, DENSE_>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, m->desc, m->opts[dtype], \
-                     (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)x, ld_x, (const T*)xp, ld_xp,         \
-                     batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),              \
-                     want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr)
+  hipLaunchKernelGGL((loss_kernel<T, NJ, true, DENSE_>), dim3(pl.loss_blocks + 1), dim3(kWave), 0, stream, (const T*)x, ld_x,     \
+                     (const T*)xp, ld_xp, batch, (const T*)p->theta, (const T*)p->friction, (const T*)nullptr,                    \
+                     (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),                     \
+                     want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr, m->desc, m->opts[dtype])
   if constexpr (std::is_same<T, float>::value) {
     if (pl.loss_blocks > kSimds) DPLL_MESH_LOSS(true);
     else DPLL_MESH_LOSS(false);

@@ -69,6 +69,9 @@ class ModelSpec:
     # links folded into another by a `fixed` joint: name -> name of the link that stands for it (collision filter groups
     # may still name them)
     welded: dict = field(default_factory=dict)
+    # the root link is welded to the world (a URDF whose root is a link named `world`: Drake welds it, and the reference gives
+    # the model a FixedBaseSpace, drake_utils.py:329-332): no base coordinates
+    fixed_base: bool = False
 
     @property
     def n_joints(self) -> int:
@@ -343,6 +346,99 @@ def _collision_candidates(root, spec: ModelSpec) -> List[Tuple[int, int]]:
                 continue
             pairs.append((gb, ga) if TYPE_ORDER[geom_a.kind] > TYPE_ORDER[geom_b.kind] else (ga, gb))
     return pairs
+
+
+# limits of the forest build (csrc/dpll_forest.hpp): several models per system, one wave per item, everything in LDS
+FOREST_MAX_BODIES = 16
+FOREST_MAX_GEOMS = 12
+FOREST_MAX_PAIRS = 16
+FOREST_MAX_CONTACTS = 64
+FOREST_MAX_V = 32
+
+
+@dataclass
+class SystemSpec:
+    """The models of one system -- ``init_urdfs: Dict[str, str]`` of the reference's constructor
+    (``multibody_learnable_system.py:51-54``), one floating-base (or fixed-base) tree each (``drake_utils.py:309-335``) -- in
+    dict order, with the body-body collision candidates of the whole plant: inside a model as :func:`_collision_candidates`
+    finds them, and every geometry of one model against every geometry of another (Drake filters nothing between models)."""
+    names: List[str]
+    models: List[ModelSpec]
+    pairs: List[Tuple[int, int]] = field(default_factory=list)
+
+    def bodies(self) -> List[BodySpec]:
+        return [body for spec in self.models for body in spec.bodies]
+
+    def geoms(self):
+        """``[(body index in the system, GeomSpec)]``: the order of ``friction_params[1:]`` and of the contact blocks"""
+        out, first = [], 0
+        for spec in self.models:
+            out += [(first + index, geom) for index, geom in spec.geoms()]
+            first += len(spec.bodies)
+        return out
+
+    @property
+    def n_q(self) -> int:
+        return sum((0 if spec.fixed_base else 7) + spec.n_joints for spec in self.models)
+
+    @property
+    def n_v(self) -> int:
+        return sum((0 if spec.fixed_base else 6) + spec.n_joints for spec in self.models)
+
+    @property
+    def n_contacts(self) -> int:
+        return sum(1 if geom.kind == 'sphere' else 4 for _, geom in self.geoms()) + len(self.pairs)
+
+    def friction_init(self) -> List[float]:
+        return [self.models[0].ground_mu] + [geom.mu for _, geom in self.geoms()]
+
+
+def build_system_spec(models) -> SystemSpec:
+    """``models``: ``{name: ModelSpec}`` in the order of the reference's ``init_urdfs``"""
+    names, specs = list(models.keys()), list(models.values())
+    system = SystemSpec(names, specs)
+    offsets, count = [], 0
+    for spec in specs:
+        offsets.append(count)
+        count += len(spec.geoms())
+    own = set()
+    for offset, spec in zip(offsets, specs):
+        own |= {(offset + a, offset + b) for a, b in spec.pairs}
+    model_of = [m for m, spec in enumerate(specs) for _ in spec.geoms()]
+    geoms = system.geoms()
+    pairs = []
+    for ga in range(len(geoms)):
+        for gb in range(ga + 1, len(geoms)):
+            swap = TYPE_ORDER[geoms[ga][1].kind] > TYPE_ORDER[geoms[gb][1].kind]
+            pair = (gb, ga) if swap else (ga, gb)
+            if model_of[ga] != model_of[gb] or pair in own:
+                pairs.append(pair)
+    system.pairs = pairs
+    return system
+
+
+def check_forest_supported(system: SystemSpec) -> None:
+    """What the forest build takes; anything else fails loudly at construction."""
+    geoms = system.geoms()
+    if len(system.bodies()) > FOREST_MAX_BODIES:
+        raise NotImplementedError(f'at most {FOREST_MAX_BODIES} bodies per system')
+    if not 1 <= len(geoms) <= FOREST_MAX_GEOMS:
+        raise NotImplementedError(f'between 1 and {FOREST_MAX_GEOMS} collision geometries per system')
+    if len(system.pairs) > FOREST_MAX_PAIRS:
+        raise NotImplementedError(f'at most {FOREST_MAX_PAIRS} body-body collision candidates (exclude the others with a '
+                                  'drake:collision_filter_group)')
+    if system.n_contacts > FOREST_MAX_CONTACTS or system.n_v > FOREST_MAX_V:
+        raise NotImplementedError(f'at most {FOREST_MAX_CONTACTS} contacts and {FOREST_MAX_V} velocities per system')
+    for spec in system.models:
+        for index, body in enumerate(spec.bodies):
+            if index > 0 and not 0 <= body.parent < index:
+                raise NotImplementedError('links must be listed after their parent')
+    for _, geom in geoms:
+        if geom.kind == 'mesh':
+            raise NotImplementedError('learned shapes (DeepSupportConvex) run on the general build: one model of at most '
+                                      f'{MAX_JOINTS} joints and {MAX_GEOMS} geometries')
+        if geom.kind == 'polygon' and not 4 <= len(geom.vertices) <= MAX_POLYGON_VERTICES:
+            raise NotImplementedError(f'a polygon has 4 to {MAX_POLYGON_VERTICES} vertices (support queries return 4 of them)')
 
 
 def check_supported(spec: ModelSpec) -> None:
