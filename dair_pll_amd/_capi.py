@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 from typing import Optional
 
-from .urdf import ModelSpec, _differs, _matmul, _matvec, _transpose, check_supported
+from .urdf import ModelSpec, _differs, _matmul, _matvec, _transpose, check_supported  # noqa: F401
 
 MAX_JOINTS = 3
 MAX_BODIES = 4
@@ -20,7 +20,7 @@ GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 20  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 21  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -173,6 +173,8 @@ def make_forest_desc(system_spec, dt: float, inertia_mode: str = 'reference_lite
                 desc.parent[b] = -1
                 desc.joint_kind[b] = JOINT_FIXED if fixed else JOINT_FLOATING
                 desc.q_index[b], desc.v_index[b], desc.depth[b] = q_off, v_off, 0
+                for axis in range(3):  # (a fixed base: where its root sits in the world)
+                    desc.joint_origin[b][axis] = spec.mount_origin[axis] if fixed else 0.0
             else:
                 desc.parent[b] = first + body.parent
                 desc.joint_kind[b] = JOINT_KINDS[body.joint_kind]
@@ -242,6 +244,7 @@ def library() -> ctypes.CDLL:
         raise DpllError(f'{LIB_PATH} has ABI version {lib.dpll_abi_version()}, this binding needs {ABI_VERSION}: rebuild it '
                         f'(`make -C {os.path.join(_HERE, "csrc")}`)')
     lib.dpll_model_create.argtypes = [POINTER(ModelDesc), POINTER(c_void_p)]
+    lib.dpll_forest_model_create.argtypes = [POINTER(ForestDesc), POINTER(c_void_p)]
     lib.dpll_model_destroy.argtypes = [c_void_p]
     lib.dpll_model_destroy.restype = None
     lib.dpll_model_set_solver.argtypes = [c_void_p, c_int, POINTER(SolverOpts)]
@@ -308,7 +311,7 @@ def check(status: int) -> None:
         raise DpllError(f'dpll call failed ({status}): {message.decode() if message else "?"}')
 
 
-EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_model_destroy',
+EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 'dpll_forest_model_create', 'dpll_model_destroy',
                     'dpll_model_set_solver', 'dpll_model_get_solver', 'dpll_n_x', 'dpll_n_contacts',
                     'dpll_param_count', 'dpll_workspace_bytes', 'dpll_racing_copies', 'dpll_contactnets_loss', 'dpll_profile_contactnets_loss', 'dpll_step', 'dpll_step_backward', 'dpll_simulate',
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',

@@ -353,9 +353,13 @@ struct dpll_ar {
   void* opened[dpll_arx::kMaxWorld];
 };
 
+namespace dpll_forest { struct ForestDesc; }
 struct dpll_model {
   dpll::ModelDesc desc;
   dpll::SolverOpts opts[2];
+  // a model of the forest build (csrc/dpll_forest.hip): its description on the host and, from the first launch on, on the device
+  dpll_forest::ForestDesc* forest = nullptr;
+  void* forest_dev = nullptr;
 };
 
 // error reporting shared by the translation units (defined in dpll_kernels.hip)

@@ -1,0 +1,504 @@
+// dpll_forest.hip -- the FOREST build on the device: one wave per item, an item's blocks in LDS with run-time sizes.
+//
+// For systems the register-resident builds do not take (dpll_kernels.hip: cube / elbow; dpll_general.hip: one model of up to
+// 3 joints, 3 geometries, 4 candidates): several models in one system (the reference's init_urdfs: Dict[str, str],
+// multibody_learnable_system.py:51-54, drake_utils.py:309-335), up to 16 bodies, 12 geometries, 16 body-body candidates, 64
+// contacts, 32 velocities.  The per-item program is csrc/dpll_forest.hpp -- the same source the host checker runs with a team
+// of one lane; here the team is a wavefront: lanes take bodies / contacts / matrix entries in strides, phases end at a
+// workgroup barrier (one wave per workgroup), sums over the team are DPP wave reductions, the direction search of a body-body
+// candidate spreads its candidate directions over the 64 lanes.  One kernel per dtype and entry point: no template ranges.
+// Gradients: every workgroup keeps ONE partial row in LDS across the items it loops over and writes it at the end; rows are
+// folded 64 at a time and the finalize kernel chains the sum to [theta | friction | lengths] (one thread per parameter).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "dpll_common.hpp"
+#include "dpll_forest.hpp"
+#include "dpll_forest_api.hpp"
+
+namespace {
+
+using namespace dpll_forest;
+
+static_assert(sizeof(ForestDesc) == sizeof(dpll_forest_desc_t), "ForestDesc must mirror dpll_forest_desc_t");
+static_assert(dpll_forest::kMaxBodies == DPLL_FOREST_MAX_BODIES && dpll_forest::kMaxGeoms == DPLL_FOREST_MAX_GEOMS &&
+                  dpll_forest::kMaxPairs == DPLL_FOREST_MAX_PAIRS && kMaxContacts == DPLL_FOREST_MAX_CONTACTS && kMaxV == DPLL_FOREST_MAX_V,
+              "limits");
+
+struct WaveLanes {  // the lane-group policy of dpll_core.hpp's direction search: the whole wave is one group
+  static constexpr int kGroup = kWave;
+  static constexpr int kVariants = 1;
+  static __device__ __forceinline__ int lane_in_group() { return (int)(threadIdx.x & (kWave - 1)); }
+  template <typename S> static __device__ __forceinline__ void group_best(S& value, int& index, S (&d)[3]) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const S ov = __shfl_xor(value, off);
+      const int oi = __shfl_xor(index, off);
+      const S o0 = __shfl_xor(d[0], off), o1 = __shfl_xor(d[1], off), o2 = __shfl_xor(d[2], off);
+      const bool take = ov > value || (ov == value && oi < index);
+      value = take ? ov : value;
+      index = take ? oi : index;
+      d[0] = take ? o0 : d[0]; d[1] = take ? o1 : d[1]; d[2] = take ? o2 : d[2];
+    }
+  }
+};
+struct WaveTeam {
+  static constexpr int kSize = kWave;
+  static __device__ __forceinline__ int rank() { return (int)threadIdx.x; }
+  static __device__ __forceinline__ void sync() { __syncthreads(); }
+  static __device__ __forceinline__ float sum(float x) { return wave_sum_of_groups<1>(x); }
+  static __device__ __forceinline__ double sum(double x) { return wave_sum_of_groups<1>(x); }
+  static __device__ __forceinline__ bool any(bool x) { return __any(x) != 0; }
+  using Lanes = WaveLanes;
+};
+
+// the description from device memory into LDS, by the whole wave
+__device__ __forceinline__ void fetch_desc(const ForestDesc* __restrict__ src, ForestDesc& dst) {
+  const int* s = reinterpret_cast<const int*>(src);
+  int* d = reinterpret_cast<int*>(&dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(ForestDesc) / 4); i += kWave) d[i] = s[i];
+  __syncthreads();
+}
+
+extern __shared__ __align__(16) char forest_smem[];
+
+// ---- ContactNets loss, forward + backward ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave) void forest_loss_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
+                                                            const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                            const T* __restrict__ x, long long ld_x, const T* __restrict__ xp, long long ld_xp,
+                                                            long long batch, const T* __restrict__ weights, double scale, T* __restrict__ loss,
+                                                            T* __restrict__ force, int* __restrict__ iters, double* __restrict__ partials,
+                                                            int want_grad, int row_stride) {
+  __shared__ ForestDesc fd;
+  fetch_desc(fdp, fd);
+  const int width = row_width(fd);
+  double* row = reinterpret_cast<double*>(forest_smem);
+  Arena<T, double> A;
+  A.carve(forest_smem + (((size_t)width * sizeof(double) + 15) & ~(size_t)15), fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  for (int e = threadIdx.x; e < width; e += kWave) row[e] = 0.0;
+  Forest<T, double, WaveTeam> prog(fd, A);
+  prog.derive(theta, friction, lengths);
+  const int K = fd.n_contacts;
+  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    const T w = T(scale) * (weights ? weights[item] : T(1));
+    int n_it = 0;
+    const T L = prog.loss(x + item * ld_x, xp + item * ld_xp, lengths, opt, w, want_grad != 0, row, n_it);
+    if (threadIdx.x == 0) {
+      if (loss) loss[item] = L;
+      if (iters) iters[item] = n_it;
+    }
+    if (force) {  // reference ordering: normals, then (t_x, t_y) per contact (multibody_terms.py:415-426)
+      T* dst = force + item * (3 * K);
+      for (int c = threadIdx.x; c < K; c += kWave) {
+        dst[c] = A.force[3 * c + 2];
+        dst[K + 2 * c] = A.force[3 * c];
+        dst[K + 2 * c + 1] = A.force[3 * c + 1];
+      }
+    }
+    __syncthreads();
+  }
+  if (!want_grad) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < width; e += kWave) partials[(long long)blockIdx.x * row_stride + e] = row[e];
+}
+
+// ---- rows -> parameters: blocks of kFold rows are summed first, the finalize kernel sums those and applies the chain ------------
+constexpr int kFold = 64;
+constexpr int kRowThreads = 512;  // one thread per column (a row has at most 1 + 160 + 12 + 16 + 288 = 477 entries)
+__global__ __launch_bounds__(kRowThreads) void forest_fold_kernel(const double* __restrict__ partials, int n_rows, int width, int row_stride,
+                                                                  double* __restrict__ folded) {
+  const int col = threadIdx.x;
+  if (col >= width) return;
+  const int r0 = (int)blockIdx.x * kFold, r1 = r0 + kFold < n_rows ? r0 + kFold : n_rows;
+  double s = 0.0;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partials[(long long)(r + u) * row_stride + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; r < r1; ++r) s += partials[(long long)r * row_stride + col];
+  folded[(long long)blockIdx.x * row_stride + col] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(kRowThreads) void forest_finalize_kernel(const ForestDesc* __restrict__ fdp, const T* __restrict__ theta,
+                                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                                      const double* __restrict__ folded, int n_rows, int row_stride,
+                                                                      T* __restrict__ grad, T* __restrict__ loss_total) {
+  __shared__ ForestDesc fd;
+  __shared__ double tot[kRowThreads];
+  {
+    const int* s = reinterpret_cast<const int*>(fdp);
+    int* d = reinterpret_cast<int*>(&fd);
+    for (int i = threadIdx.x; i < (int)(sizeof(ForestDesc) / 4); i += kRowThreads) d[i] = s[i];
+  }
+  __syncthreads();
+  const int width = row_width(fd), col = threadIdx.x;
+  double s = 0.0;
+  if (col < width)
+    for (int r = 0; r < n_rows; ++r) s += folded[(long long)r * row_stride + col];
+  tot[col] = s;
+  __syncthreads();
+  const int n_params = param_count(fd);
+  for (int k = threadIdx.x; k < n_params; k += kRowThreads) grad[k] = T(chain_param(fd, theta, friction, lengths, tot, k));
+  if (threadIdx.x == 0 && loss_total) *loss_total = T(tot[0]);
+}
+
+// ---- simulation: `steps` VelocityIntegrator steps per item, the current state in LDS ---------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave) void forest_simulate_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
+                                                                const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                                const T* __restrict__ x0, long long ld_x, long long batch, long long steps,
+                                                                T* __restrict__ out, long long ld_item, long long ld_step, int write_x0,
+                                                                int* __restrict__ iters) {
+  __shared__ ForestDesc fd;
+  fetch_desc(fdp, fd);
+  const int nx = fd.n_q + fd.n_v;
+  T* cur = reinterpret_cast<T*>(forest_smem);
+  T* nxt = cur + nx;
+  Arena<T, double> A;
+  A.carve(forest_smem + (((size_t)2 * nx * sizeof(T) + 15) & ~(size_t)15), fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  Forest<T, double, WaveTeam> prog(fd, A);
+  prog.derive(theta, friction, lengths);
+  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    for (int i = threadIdx.x; i < nx; i += kWave) cur[i] = x0[item * ld_x + i];
+    __syncthreads();
+    T* dst = out + item * ld_item;
+    if (write_x0) {
+      for (int i = threadIdx.x; i < nx; i += kWave) dst[i] = cur[i];
+      dst += ld_step;
+    }
+    int total = 0;
+    for (long long s = 0; s < steps; ++s) {
+      total += prog.step(cur, lengths, opt, nxt);
+      for (int i = threadIdx.x; i < nx; i += kWave) { const T v = nxt[i]; cur[i] = v; dst[i] = v; }
+      __syncthreads();
+      dst += ld_step;
+    }
+    if (iters && threadIdx.x == 0) iters[item] = total;
+  }
+}
+
+// ---- backward of one step: parameter rows and (STATE) the state adjoint; double arithmetic ------------------------------------------
+template <typename T, bool STATE>
+__global__ __launch_bounds__(kWave) void forest_step_backward_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
+                                                                     const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                                     const T* __restrict__ x, long long ld_x, const T* __restrict__ gx,
+                                                                     long long ld_g, long long batch, double* __restrict__ partials,
+                                                                     int row_stride, T* __restrict__ xbar_out, long long ld_xb) {
+  __shared__ ForestDesc fd;
+  fetch_desc(fdp, fd);
+  const int width = row_width(fd);
+  double* row = reinterpret_cast<double*>(forest_smem);
+  Arena<double, double> A;
+  Arena<DualT<double>, DualT<double>> B;
+  size_t off = ((size_t)width * sizeof(double) + 15) & ~(size_t)15;
+  off += A.carve(forest_smem + off, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  if (STATE) B.carve(forest_smem + off, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  else B.carve(nullptr, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  for (int e = threadIdx.x; e < width; e += kWave) row[e] = 0.0;
+  Forest<double, double, WaveTeam> prog(fd, A);
+  prog.derive(theta, friction, lengths);
+  ForestBackward<WaveTeam> back(fd, A, B);
+  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    back.run(x + item * ld_x, gx + item * ld_g, theta, friction, lengths, opt, row, STATE ? xbar_out + item * ld_xb : (T*)nullptr);
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < width; e += kWave) partials[(long long)blockIdx.x * row_stride + e] = row[e];
+}
+
+// ---- MultibodyTerms.forward (multibody_terms.py:584-609): D, M, J, phi, a --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave) void forest_terms_kernel(const ForestDesc* __restrict__ fdp, const T* __restrict__ theta,
+                                                             const T* __restrict__ friction, const T* __restrict__ lengths,
+                                                             const T* __restrict__ x, long long ld_x, long long batch, T* __restrict__ Dout,
+                                                             T* __restrict__ Mout, T* __restrict__ Jout, T* __restrict__ phiout,
+                                                             T* __restrict__ aout) {
+  __shared__ ForestDesc fd;
+  fetch_desc(fdp, fd);
+  Arena<T, double> A;
+  A.carve(forest_smem, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  Forest<T, double, WaveTeam> prog(fd, A);
+  prog.derive(theta, friction, lengths);
+  const int nv = fd.n_v, K = fd.n_contacts;
+  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    prog.load_state(x + item * ld_x);
+    prog.terms();
+    prog.contacts(lengths);
+    if (Mout)
+      for (int e = threadIdx.x; e < nv * nv; e += kWave) Mout[item * nv * nv + e] = A.M[e];
+    if (aout)
+      for (int e = threadIdx.x; e < nv; e += kWave) aout[item * nv + e] = A.a[e];
+    if (phiout)
+      for (int c = threadIdx.x; c < K; c += kWave) phiout[item * K + c] = A.ct[c].phi;
+    // rows of J in the reference order [normals | mu (t_x, t_y) per contact]: row r of contact c, scaled
+    auto jrow = [&](int r, int i) -> T {
+      const int c = r < K ? r : (r - K) / 2, comp = r < K ? 2 : (r - K) % 2;
+      const T scale = r < K ? T(1) : A.ct[c].mu;
+      return scale * A.J[((size_t)c * 3 + comp) * nv + i];
+    };
+    if (Jout)
+      for (int e = threadIdx.x; e < 3 * K * nv; e += kWave) Jout[item * 3 * K * nv + e] = jrow(e / nv, e % nv);
+    if (Dout) {
+      // D = J M^-1 J^T = Z Z^T with Z = (L^-1 J^T)^T: one forward substitution per row of J (a lane each), into the CJ block
+      T* Z = A.CJ;
+      for (int r = threadIdx.x; r < 3 * K; r += kWave)
+        for (int i = 0; i < nv; ++i) {
+          T s = jrow(r, i);
+          for (int p = 0; p < i; ++p) s -= A.LM[i * nv + p] * Z[(size_t)r * nv + p];
+          Z[(size_t)r * nv + i] = s * A.invdM[i];
+        }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 9 * K * K; e += kWave) {
+        const int r = e / (3 * K), c = e % (3 * K);
+        T s = T(0);
+        for (int i = 0; i < nv; ++i) s += Z[(size_t)r * nv + i] * Z[(size_t)c * nv + i];
+        Dout[item * 9 * K * K + e] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+const ForestDesc& host_desc(const dpll_model* m) { return *m->forest; }
+
+// the description's device copy, made at the first launch (never inside a stream capture: callers warm up eagerly)
+const ForestDesc* device_desc(const dpll_model* m) {
+  if (!m->forest_dev) {
+    void* dev = nullptr;
+    if (hipMalloc(&dev, sizeof(ForestDesc)) != hipSuccess) return nullptr;
+    if (hipMemcpy(dev, m->forest, sizeof(ForestDesc), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(dev);
+      return nullptr;
+    }
+    const_cast<dpll_model*>(m)->forest_dev = dev;
+  }
+  return static_cast<const ForestDesc*>(m->forest_dev);
+}
+
+int stride_of(const ForestDesc& fd) { return (row_width(fd) + 1) & ~1; }
+int grid_for(long long batch, size_t lds_bytes) {
+  // workgroups that can be resident at once (160 KB of LDS per CU, at most 8 one-wave workgroups per CU), capped at the batch
+  long long per_cu = (long long)((160 * 1024) / (lds_bytes + sizeof(ForestDesc) + 256));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  long long blocks = 256 * per_cu;
+  if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+  if (blocks > batch) blocks = batch;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+long long folded_rows(long long rows) { return (rows + kFold - 1) / kFold; }
+
+template <typename K> int allow_lds(K kernel, size_t bytes, const char* who) {
+  if (bytes + sizeof(ForestDesc) + 4096 > 160 * 1024) return dpll_fail(-2, "%s: the model needs more LDS per item than a CU has", who);
+  if (bytes > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return dpll_fail(-5, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", who);
+  return 0;
+}
+size_t round16(size_t n) { return (n + 15) & ~(size_t)15; }
+
+template <typename T>
+int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp,
+                long long batch, const void* weights, double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
+                void* workspace, long long ws_bytes, hipStream_t stream) {
+  const ForestDesc& fd = host_desc(m);
+  const ForestDesc* dev = device_desc(m);
+  if (!dev) return dpll_fail(-5, "dpll_contactnets_loss (forest build): could not place the model description on the device%s");
+  const int want_grad = grad != nullptr;
+  if (want_grad) {
+    if (!workspace || ws_bytes < dpll_forest_api::workspace_bytes(m, batch)) return dpll_fail(-3, "dpll_contactnets_loss: workspace too small%s");
+  } else if (loss_total) {
+    return dpll_fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
+  }
+  const size_t lds = round16((size_t)row_width(fd) * sizeof(double)) + arena_bytes<T, double>(fd);
+  if (int rc = allow_lds(forest_loss_kernel<T>, lds, "dpll_contactnets_loss")) return rc;
+  const int rows = batch > 0 ? grid_for(batch, lds) : 0;
+  const int stride = stride_of(fd);
+  if (rows > 0) {
+    hipLaunchKernelGGL((forest_loss_kernel<T>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[dtype], (const T*)p->theta, (const T*)p->friction,
+                       (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force,
+                       (int*)iters, (double*)workspace, want_grad, stride);
+    if (int rc = dpll_check_launch("forest_loss_kernel")) return rc;
+  }
+  if (!want_grad) return 0;
+  double* folded = (double*)workspace + (long long)grid_for(batch > 0 ? batch : 1, lds) * stride;
+  const int n_folded = (int)folded_rows(rows);
+  if (n_folded > 0) {
+    hipLaunchKernelGGL(forest_fold_kernel, dim3(n_folded), dim3(kRowThreads), 0, stream, (const double*)workspace, rows, row_width(fd), stride, folded);
+    if (int rc = dpll_check_launch("forest_fold_kernel")) return rc;
+  }
+  hipLaunchKernelGGL((forest_finalize_kernel<T>), dim3(1), dim3(kRowThreads), 0, stream, dev, (const T*)p->theta, (const T*)p->friction,
+                     (const T*)p->lengths, (const double*)folded, n_folded, stride, (T*)grad, (T*)loss_total);
+  return dpll_check_launch("forest_finalize_kernel");
+}
+
+template <typename T>
+int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch, long long steps,
+                    void* out, long long ld_item, long long ld_step, int write_x0, int32_t* iters, hipStream_t stream) {
+  const ForestDesc& fd = host_desc(m);
+  const ForestDesc* dev = device_desc(m);
+  if (!dev) return dpll_fail(-5, "dpll_simulate (forest build): could not place the model description on the device%s");
+  const size_t lds = round16((size_t)2 * (fd.n_q + fd.n_v) * sizeof(T)) + arena_bytes<T, double>(fd);
+  if (int rc = allow_lds(forest_simulate_kernel<T>, lds, "dpll_simulate")) return rc;
+  hipLaunchKernelGGL((forest_simulate_kernel<T>), dim3(grid_for(batch, lds)), dim3(kWave), lds, stream, dev, m->opts[dtype], (const T*)p->theta,
+                     (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps, (T*)out, ld_item, ld_step, write_x0, (int*)iters);
+  return dpll_check_launch("forest_simulate_kernel");
+}
+
+template <typename T>
+int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, const void* gx, long long ld_g, long long batch,
+                         void* grad, void* grad_x, long long ld_gx, void* workspace, long long ws_bytes, hipStream_t stream) {
+  const ForestDesc& fd = host_desc(m);
+  const ForestDesc* dev = device_desc(m);
+  if (!dev) return dpll_fail(-5, "dpll_step_backward (forest build): could not place the model description on the device%s");
+  if (!workspace || ws_bytes < dpll_forest_api::workspace_bytes(m, batch)) return dpll_fail(-3, "dpll_step_backward: workspace too small%s");
+  const size_t head = round16((size_t)row_width(fd) * sizeof(double));
+  const size_t lds = head + arena_bytes<double, double>(fd) + (grad_x ? arena_bytes<DualT<double>, DualT<double>>(fd) : 0);
+  if (grad_x) {
+    if (int rc = allow_lds(forest_step_backward_kernel<T, true>, lds, "dpll_step_backward")) return rc;
+  } else {
+    if (int rc = allow_lds(forest_step_backward_kernel<T, false>, lds, "dpll_step_backward")) return rc;
+  }
+  // (rows: never more than the loss launch of the same batch writes -- the workspace is sized for those)
+  const size_t loss_lds = round16((size_t)row_width(fd) * sizeof(double)) + arena_bytes<float, double>(fd);
+  int rows = grid_for(batch, lds);
+  const int cap = grid_for(batch, loss_lds);
+  if (rows > cap) rows = cap;
+  const int stride = stride_of(fd);
+  if (grad_x)
+    hipLaunchKernelGGL((forest_step_backward_kernel<T, true>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[DPLL_F64], (const T*)p->theta,
+                       (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch, (double*)workspace, stride,
+                       (T*)grad_x, ld_gx);
+  else
+    hipLaunchKernelGGL((forest_step_backward_kernel<T, false>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[DPLL_F64], (const T*)p->theta,
+                       (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch, (double*)workspace, stride,
+                       (T*)nullptr, 0LL);
+  if (int rc = dpll_check_launch("forest_step_backward_kernel")) return rc;
+  double* folded = (double*)workspace + (long long)cap * stride;
+  const int n_folded = (int)folded_rows(rows);
+  hipLaunchKernelGGL(forest_fold_kernel, dim3(n_folded), dim3(kRowThreads), 0, stream, (const double*)workspace, rows, row_width(fd), stride, folded);
+  if (int rc = dpll_check_launch("forest_fold_kernel")) return rc;
+  hipLaunchKernelGGL((forest_finalize_kernel<T>), dim3(1), dim3(kRowThreads), 0, stream, dev, (const T*)p->theta, (const T*)p->friction,
+                     (const T*)p->lengths, (const double*)folded, n_folded, stride, (T*)grad, (T*)nullptr);
+  return dpll_check_launch("forest_finalize_kernel");
+}
+
+template <typename T>
+int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm, void* M, void* J, void* phi,
+                 void* a, hipStream_t stream) {
+  const ForestDesc& fd = host_desc(m);
+  const ForestDesc* dev = device_desc(m);
+  if (!dev) return dpll_fail(-5, "dpll_terms (forest build): could not place the model description on the device%s");
+  const size_t lds = arena_bytes<T, double>(fd);
+  if (int rc = allow_lds(forest_terms_kernel<T>, lds, "dpll_terms")) return rc;
+  hipLaunchKernelGGL((forest_terms_kernel<T>), dim3(grid_for(batch, lds)), dim3(kWave), lds, stream, dev, (const T*)p->theta, (const T*)p->friction,
+                     (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J, (T*)phi, (T*)a);
+  return dpll_check_launch("forest_terms_kernel");
+}
+
+}  // namespace
+
+namespace dpll_forest_api {
+
+int check_desc(const dpll_forest_desc_t* d) {
+  if (d->n_bodies < 1 || d->n_bodies > dpll_forest::kMaxBodies) return dpll_fail(-2, "dpll_forest_model_create: 1 to 16 bodies%s");
+  if (d->n_geoms < 1 || d->n_geoms > dpll_forest::kMaxGeoms) return dpll_fail(-2, "dpll_forest_model_create: 1 to 12 collision geometries%s");
+  if (d->n_pairs < 0 || d->n_pairs > dpll_forest::kMaxPairs) return dpll_fail(-2, "dpll_forest_model_create: at most 16 body-body collision candidates%s");
+  if (d->n_contacts < 1 || d->n_contacts > kMaxContacts) return dpll_fail(-2, "dpll_forest_model_create: 1 to 64 contacts%s");
+  if (d->n_v < 1 || d->n_v > kMaxV) return dpll_fail(-2, "dpll_forest_model_create: 1 to 32 generalized velocities%s");
+  if (!(d->dt > 0.0)) return dpll_fail(-1, "dpll_forest_model_create: dt must be positive%s");
+  if (d->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && d->inertia_mode != DPLL_INERTIA_PHYSICAL)
+    return dpll_fail(-1, "dpll_forest_model_create: unknown inertia_mode%s");
+  if (d->rotated & ~3) return dpll_fail(-1, "dpll_forest_model_create: rotated holds bits 0 and 1 only%s");
+  int n_q = 0, n_v = 0, max_depth = 0;
+  for (int b = 0; b < d->n_bodies; ++b) {
+    const int kind = d->joint_kind[b], parent = d->parent[b];
+    if (kind != kJointRevolute && kind != kJointPrismatic && kind != kJointFloating && kind != kJointFixed)
+      return dpll_fail(-1, "dpll_forest_model_create: unknown joint kind%s");
+    const bool root = kind == kJointFloating || kind == kJointFixed;
+    if (root ? parent != -1 : (parent < 0 || parent >= b)) return dpll_fail(-1, "dpll_forest_model_create: a root has parent -1, any other body a parent listed before it%s");
+    if (d->depth[b] != (root ? 0 : d->depth[parent] + 1)) return dpll_fail(-1, "dpll_forest_model_create: depth[] must be the distance to the root%s");
+    max_depth = d->depth[b] > max_depth ? d->depth[b] : max_depth;
+    const int nq = kind == kJointFloating ? 7 : (kind == kJointFixed ? 0 : 1), nv = dofs_of(kind);
+    if (d->q_index[b] < 0 || d->q_index[b] + nq > d->n_q || d->v_index[b] < 0 || d->v_index[b] + nv > d->n_v)
+      return dpll_fail(-1, "dpll_forest_model_create: q_index / v_index out of range%s");
+    if (!root && d->v_index[b] <= d->v_index[parent]) return dpll_fail(-1, "dpll_forest_model_create: a body's velocities come after its parent's%s");
+    for (int i = 0; i < nv; ++i)
+      if (d->dof_body[d->v_index[b] + i] != b) return dpll_fail(-1, "dpll_forest_model_create: dof_body does not match v_index%s");
+    n_q += nq;
+    n_v += nv;
+  }
+  if (n_q != d->n_q || n_v != d->n_v || max_depth != d->max_depth) return dpll_fail(-1, "dpll_forest_model_create: n_q / n_v / max_depth do not match the bodies%s");
+  int contacts = 0;
+  for (int g = 0; g < d->n_geoms; ++g) {
+    if (d->geom_body[g] < 0 || d->geom_body[g] >= d->n_bodies) return dpll_fail(-1, "dpll_forest_model_create: geom_body out of range%s");
+    const int kind = d->geom_kind[g];
+    if (kind != DPLL_GEOM_BOX && kind != DPLL_GEOM_SPHERE && kind != DPLL_GEOM_POLYGON)
+      return dpll_fail(-2, "dpll_forest_model_create: boxes, spheres and polygons (learned shapes run on the general build)%s");
+    if (kind == DPLL_GEOM_POLYGON && (d->geom_nverts[g] < 4 || d->geom_nverts[g] > DPLL_MAX_POLYGON_VERTICES))
+      return dpll_fail(-2, "dpll_forest_model_create: a polygon has 4 to 8 vertices%s");
+    for (int s = 0; s < (kind == DPLL_GEOM_SPHERE ? 1 : 4); ++s, ++contacts)
+      if (contacts >= d->n_contacts || d->contact_geom[contacts] != g || d->contact_slot[contacts] != s)
+        return dpll_fail(-1, "dpll_forest_model_create: contacts must list every geometry's witnesses in order, then the candidates%s");
+  }
+  for (int p = 0; p < d->n_pairs; ++p, ++contacts) {
+    const int a = d->pair_a[p], b = d->pair_b[p];
+    if (a < 0 || b < 0 || a >= d->n_geoms || b >= d->n_geoms || a == b || d->geom_body[a] == d->geom_body[b])
+      return dpll_fail(-1, "dpll_forest_model_create: a candidate joins geometries of two different bodies%s");
+    if (contacts >= d->n_contacts || d->contact_geom[contacts] >= 0 || d->contact_slot[contacts] != p)
+      return dpll_fail(-1, "dpll_forest_model_create: contacts must list every geometry's witnesses in order, then the candidates%s");
+  }
+  if (contacts != d->n_contacts) return dpll_fail(-1, "dpll_forest_model_create: n_contacts does not match the geometries and candidates%s");
+  return 0;
+}
+
+int n_x(const dpll_model* m) { return m->forest->n_q + m->forest->n_v; }
+int n_contacts(const dpll_model* m) { return m->forest->n_contacts; }
+int param_count(const dpll_model* m) { return dpll_forest::param_count(*m->forest); }
+long long workspace_bytes(const dpll_model* m, long long batch) {
+  const ForestDesc& fd = *m->forest;
+  const size_t lds = round16((size_t)row_width(fd) * sizeof(double)) + arena_bytes<float, double>(fd);  // (the launch with the most rows)
+  const long long rows = grid_for(batch > 0 ? batch : 1, lds);
+  return (rows + folded_rows(rows)) * stride_of(fd) * (long long)sizeof(double);
+}
+void release(dpll_model* m) {
+  if (m->forest_dev) (void)hipFree(m->forest_dev);
+  m->forest_dev = nullptr;
+  delete m->forest;
+  m->forest = nullptr;
+}
+
+#define DPLL_FOREST_DISPATCH(FN, ...)                          \
+  do {                                                         \
+    if (dtype == DPLL_F32) return FN<float>(__VA_ARGS__);      \
+    return FN<double>(__VA_ARGS__);                            \
+  } while (0)
+
+int loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp, long long batch,
+         const void* weights, double scale, void* loss_out, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
+         long long ws_bytes, hipStream_t stream) {
+  DPLL_FOREST_DISPATCH(launch_loss, m, dtype, p, x, ld_x, xp, ld_xp, batch, weights, scale, loss_out, grad, loss_total, force, iters, workspace,
+                       ws_bytes, stream);
+}
+int simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch, long long steps, void* out,
+             long long ld_item, long long ld_step, int write_x0, int32_t* iters, hipStream_t stream) {
+  DPLL_FOREST_DISPATCH(launch_simulate, m, dtype, p, x0, ld_x, batch, steps, out, ld_item, ld_step, write_x0, iters, stream);
+}
+int step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* gx, long long ld_g,
+                  long long batch, void* grad, void* grad_x, long long ld_gx, void* workspace, long long ws_bytes, hipStream_t stream) {
+  DPLL_FOREST_DISPATCH(launch_step_backward, m, p, x, ld_x, gx, ld_g, batch, grad, grad_x, ld_gx, workspace, ws_bytes, stream);
+}
+int terms(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm, void* M, void* J,
+          void* phi, void* a, hipStream_t stream) {
+  DPLL_FOREST_DISPATCH(launch_terms, m, p, x, ld_x, batch, Dm, M, J, phi, a, stream);
+}
+
+}  // namespace dpll_forest_api

@@ -1197,6 +1197,220 @@ template <typename S, typename SA, class Team> struct Forest {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Backward of one simulation step (dpll_core.hpp step_item_backward + step_state_adjoint): the gradient of
+// sum(xbar_next . x_next) with respect to the parameters (added into `row`, iota space) and, when `xbar` is given, to the
+// state -- implicit differentiation of the cone solve's stationarity condition, the state part by forward-mode duals through
+// the same program (one pass per state component on a second arena).  Double arithmetic whatever the storage dtype.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class Team> struct ForestBackward {
+  using D = double;
+  using Du = DualT<double>;
+  const ForestDesc& fd;
+  Arena<D, D>& A;
+  Arena<Du, Du>& B;
+  DPLL_HD ForestBackward(const ForestDesc& fd_, Arena<D, D>& A_, Arena<Du, Du>& B_) : fd(fd_), A(A_), B(B_) {}
+
+  // sv, lam live in A.tmp2 / A.gv after this call; returns nothing (row / xbar are the outputs)
+  template <typename X, typename P>
+  DPLL_HD void run(const X* x, const X* xbar_next, const P* theta, const P* friction, const P* lengths, const SolverOpts& opt, double* row,
+                   X* xbar) {
+    Forest<D, D, Team> prog(fd, A);
+    const D dt = fd.dt, eps = kDynamicsEps, ieps = 1.0 / eps, idt = 1.0 / dt;
+    prog.step(x, lengths, opt, (X*)nullptr);  // leaves v- (A.vp), y* (A.y0), v+ (A.w), the contacts, M and its factor, a, V, AG
+    D* sv = A.tmp2;
+    D* lam = A.gv;
+    // seed: d/d v+ plus the pull-back of d/d q+ through q+ = q (+) v+ dt
+    for (int b = Team::rank(); b < A.nb; b += Team::kSize) {
+      const int kind = fd.joint_kind[b], qi = fd.q_index[b], vi = fd.v_index[b];
+      if (kind == kJointFloating) {
+        D qq[4], ob[4], rbar[3];
+        DPLL_UNROLL for (int i = 0; i < 4; ++i) { qq[i] = D(x[qi + i]); ob[i] = D(xbar_next[qi + i]); }
+        const D r[3] = {A.w[vi] * dt, A.w[vi + 1] * dt, A.w[vi + 2] * dt};
+        quat_exp_mul_adjoint<D>(qq, r, ob, rbar);
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) {
+          sv[vi + i] = D(xbar_next[A.nq + vi + i]) + dt * rbar[i];
+          sv[vi + 3 + i] = D(xbar_next[A.nq + vi + 3 + i]) + dt * D(xbar_next[qi + 4 + i]);
+        }
+      } else if (kind != kJointFixed) {
+        sv[vi] = D(xbar_next[A.nq + vi]) + dt * D(xbar_next[qi]);
+      }
+    }
+    // H lambda = s at the solution
+    for (int c = Team::rank(); c < A.K; c += Team::kSize) {
+      const ContactRec<D>& ct = A.ct[c];
+      D jy[3];
+      prog.jac_apply(c, A.y0, jy);
+      ConePoint<D>& cp = A.p0[c];
+      cp.zs[0] = -(ct.mu * jy[0] + ct.qc[0]) * ieps;
+      cp.zs[1] = -(ct.mu * jy[1] + ct.qc[1]) * ieps;
+      cp.zs[2] = -(jy[2] + ct.qc[2]) * ieps;
+      prog.project_point(cp);
+      const D tx = cp.that[0], ty = cp.that[1];
+      const D dP[6] = {cp.cp * ty * ty + cp.a * tx * tx, cp.cp * tx * tx + cp.a * ty * ty, cp.a, (cp.a - cp.cp) * tx * ty, cp.b * tx, cp.b * ty};
+      const D m1 = ct.mu * ieps, m2 = ct.mu * m1;
+      D* C = A.Cc + 6 * c;
+      C[0] = dP[0] * m2; C[1] = dP[1] * m2; C[2] = dP[2] * ieps; C[3] = dP[3] * m2; C[4] = dP[4] * m1; C[5] = dP[5] * m1;
+      // (the projection's own Jacobian entries, for kappa below)
+      D* keep = A.jd + 3 * c;  // not enough room for six: kappa is formed from C and the unscaled J lambda instead
+      (void)keep;
+    }
+    Team::sync();
+    for (int e = Team::rank(); e < A.K * A.nv; e += Team::kSize) {
+      const int c = e / A.nv, j = e % A.nv;
+      const D* Jrow = A.J + (size_t)c * 3 * A.nv;
+      const D* C = A.Cc + 6 * c;
+      const D j0 = Jrow[j], j1 = Jrow[A.nv + j], j2 = Jrow[2 * A.nv + j];
+      D* dst = A.CJ + (size_t)c * 3 * A.nv;
+      dst[j] = C[0] * j0 + C[3] * j1 + C[4] * j2;
+      dst[A.nv + j] = C[3] * j0 + C[1] * j1 + C[5] * j2;
+      dst[2 * A.nv + j] = C[4] * j0 + C[5] * j1 + C[2] * j2;
+    }
+    Team::sync();
+    for (int e = Team::rank(); e < A.nv * (A.nv + 1) / 2; e += Team::kSize) {
+      int i = 0;
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      const int j = e - i * (i + 1) / 2;
+      D h = A.M[i * A.nv + j];
+      for (int c = 0; c < A.K; ++c) {
+        const D* Jrow = A.J + (size_t)c * 3 * A.nv;
+        const D* CJ = A.CJ + (size_t)c * 3 * A.nv;
+        h += Jrow[i] * CJ[j] + Jrow[A.nv + i] * CJ[A.nv + j] + Jrow[2 * A.nv + i] * CJ[2 * A.nv + j];
+      }
+      A.H[i * A.nv + j] = h;
+    }
+    prog.cholesky(A.H, A.invd, A.nv, false);
+    prog.chol_solve(A.H, A.invd, sv, lam, A.tmp, A.nv);
+    if (xbar) state_adjoint(x, xbar_next, theta, friction, lengths, sv, lam, xbar);
+    // per-contact pieces: kappa_c = C_c (J_c lambda) (C carries D_mu and 1 / eps), friction and witness gradients
+    for (int c = Team::rank(); c < A.K; c += Team::kSize) {
+      ContactRec<D>& ct = A.ct[c];
+      D pl[3], pv[3];
+      prog.jac_apply(c, lam, pl);
+      prog.jac_apply(c, A.w, pv);
+      const D* C = A.Cc + 6 * c;
+      // ak = D_mu kappa = C (J lambda) with C = D_mu dP D_mu / eps
+      const D ak[3] = {C[0] * pl[0] + C[3] * pl[1] + C[4] * pl[2], C[3] * pl[0] + C[1] * pl[1] + C[5] * pl[2],
+                       C[4] * pl[0] + C[5] * pl[1] + C[2] * pl[2]};
+      const D imu = ct.mu != 0.0 ? 1.0 / ct.mu : 0.0;
+      const D kap[3] = {ak[0] * imu, ak[1] * imu, ak[2]};
+      A.jd[3 * c] = ak[0]; A.jd[3 * c + 1] = ak[1]; A.jd[3 * c + 2] = ak[2];
+      const D* g = A.p0[c].g;
+      ct.gmu = g[0] * pl[0] + g[1] * pl[1] - kap[0] * pv[0] - kap[1] * pv[1];
+      const D ag[3] = {ct.mu * g[0], ct.mu * g[1], g[2]}, nak[3] = {-ak[0], -ak[1], -ak[2]};
+      prog.witness_adjoint(ct, ag, lam, nak, A.w, -kap[2] * idt, 1.0);
+    }
+    Team::sync();
+    for (int i = Team::rank(); i < A.nv; i += Team::kSize) {
+      D s = 0.0;
+      for (int c = 0; c < A.K; ++c) {
+        const D* Jrow = A.J + (size_t)c * 3 * A.nv;
+        s += Jrow[i] * A.jd[3 * c] + Jrow[A.nv + i] * A.jd[3 * c + 1] + Jrow[2 * A.nv + i] * A.jd[3 * c + 2];
+      }
+      A.abar[i] = dt * (sv[i] - s);
+    }
+    Team::sync();
+    prog.chol_solve(A.LM, A.invdM, A.abar, A.bvec, A.tmp, A.nv);
+    const D* ys[4] = {lam, A.y0, A.bvec, A.a};
+    prog.twists(ys, 4, A.tw);
+    for (int b = Team::rank(); b < A.nb; b += Team::kSize) {
+      D g[kIota];
+      DPLL_UNROLL for (int i = 0; i < kIota; ++i) g[i] = 0.0;
+      auto tw = [&](int k, D (&wv)[3], D (&uv)[3]) {
+        const D* src = A.tw + ((size_t)k * A.nb + b) * 6;
+        DPLL_UNROLL for (int i = 0; i < 3; ++i) { wv[i] = src[i]; uv[i] = src[3 + i]; }
+      };
+      D Lw[3], Lu[3], Yw[3], Yu[3], Bw[3], Bu[3], Aw[3], Au[3], Vw[3], Vu[3], agw[3], agu[3];
+      tw(0, Lw, Lu); tw(1, Yw, Yu); tw(2, Bw, Bu); tw(3, Aw, Au);
+      load3(A.Vw + 3 * b, Vw); load3(A.Vu + 3 * b, Vu); load3(A.AGw + 3 * b, agw); load3(A.AGu + 3 * b, agu);
+      inertia_bilinear_grad<D>(-1.0, Lw, Lu, Yw, Yu, g);
+      D accw[3], accu[3];
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) { accw[i] = Aw[i] + agw[i]; accu[i] = Au[i] + agu[i]; }
+      inertia_bilinear_grad<D>(-1.0, Bw, Bu, accw, accu, g);
+      D cw[3], c1[3], c2[3], cu[3];
+      cross(Vw, Bw, cw); cross(Vw, Bu, c1); cross(Vu, Bw, c2);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) cu[i] = c1[i] + c2[i];
+      inertia_bilinear_grad<D>(1.0, cw, cu, Vw, Vu, g);
+      DPLL_UNROLL for (int i = 0; i < kIota; ++i) row[1 + kIota * b + i] += g[i];
+    }
+    prog.gather_geometry_grads(row);
+    Team::sync();
+  }
+
+  // d(total)/dx with y*, s and lambda held fixed: the partial derivative of
+  //   Phi(x) = xbar+_q . q+(q, v+ fixed) + s . v-(x) - lambda . G(x, y*),   G = M(q) y* - sum_c J_c(q)^T D_mu P_K(z_c(x, y*)),
+  // one forward-mode pass of (terms + contact geometry) per state component on the dual arena
+  template <typename X, typename P>
+  DPLL_HD void state_adjoint(const X* x, const X* xbar_next, const P* theta, const P* friction, const P* lengths, const D* sv, const D* lam,
+                             X* xbar) {
+    Forest<Du, Du, Team> dual(fd, B);
+    dual.derive(theta, friction, lengths);
+    for (int e = Team::rank(); e < 3 * A.np; e += Team::kSize) B.dirs[e] = Du(A.dirs[e]);  // the primal pass's directions: constants
+    Team::sync();
+    const D dt = fd.dt, idt = 1.0 / dt, mieps = -1.0 / kDynamicsEps;
+    const int nx = A.nq + A.nv;
+    for (int k = 0; k < nx; ++k) {
+      for (int i = Team::rank(); i < A.nq; i += Team::kSize) B.q[i] = Du(D(x[i]), i == k ? 1.0 : 0.0);
+      for (int i = Team::rank(); i < A.nv; i += Team::kSize) B.v[i] = Du(D(x[A.nq + i]), A.nq + i == k ? 1.0 : 0.0);
+      Team::sync();
+      dual.terms();
+      for (int i = Team::rank(); i < A.nv; i += Team::kSize) B.vp[i] = B.v[i] + Du(dt) * B.a[i];  // v-
+      Team::sync();
+      dual.contacts(lengths);
+      D part = 0.0;
+      // q+ with the rotation vector v+ dt held fixed, s . v-, -lambda . M y*
+      for (int b = Team::rank(); b < A.nb; b += Team::kSize) {
+        const int kind = fd.joint_kind[b], qi = fd.q_index[b], vi = fd.v_index[b];
+        if (kind == kJointFloating) {
+          const Du r[3] = {Du(A.w[vi] * dt), Du(A.w[vi + 1] * dt), Du(A.w[vi + 2] * dt)};
+          Du qq[4], qn[4];
+          DPLL_UNROLL for (int i = 0; i < 4; ++i) qq[i] = B.q[qi + i];
+          quat_exp_mul<Du>(qq, r, qn);
+          DPLL_UNROLL for (int i = 0; i < 4; ++i) part += D(xbar_next[qi + i]) * qn[i].d;
+          DPLL_UNROLL for (int i = 0; i < 3; ++i) part += D(xbar_next[qi + 4 + i]) * B.q[qi + 4 + i].d;
+        } else if (kind != kJointFixed) {
+          part += D(xbar_next[qi]) * B.q[qi].d;
+        }
+      }
+      for (int i = Team::rank(); i < A.nv; i += Team::kSize) {
+        Du my = Du(0.0);
+        for (int j = 0; j < A.nv; ++j) my += B.M[i * A.nv + j] * Du(A.y0[j]);
+        part += sv[i] * B.vp[i].d - lam[i] * my.d;
+      }
+      // + sum_c (J_c lambda) . D_mu P_K(z_c)
+      for (int c = Team::rank(); c < A.K; c += Team::kSize) {
+        const ContactRec<Du>& ct = B.ct[c];
+        const Du* Jrow = B.J + (size_t)c * 3 * A.nv;
+        Du jy[3], jv[3], jl[3];
+        DPLL_UNROLL for (int r = 0; r < 3; ++r) {
+          Du a = Du(0.0), b2 = Du(0.0), c2 = Du(0.0);
+          for (int i = 0; i < A.nv; ++i) {
+            a += Jrow[r * A.nv + i] * Du(A.y0[i]);
+            b2 += Jrow[r * A.nv + i] * B.vp[i];
+            c2 += Jrow[r * A.nv + i] * Du(lam[i]);
+          }
+          jy[r] = a; jv[r] = b2; jl[r] = c2;
+        }
+        const Du z[3] = {(ct.mu * jy[0] + ct.mu * jv[0]) * Du(mieps), (ct.mu * jy[1] + ct.mu * jv[1]) * Du(mieps),
+                         (jy[2] + jv[2] + ct.phi * Du(idt)) * Du(mieps)};
+        const D zv[3] = {z[0].v, z[1].v, z[2].v};
+        Proj<D> pr;
+        lorentz_project(zv, pr);
+        D dP[6];
+        proj_jacobian(pr, dP);
+        const Du f[3] = {Du(pr.g[0], dP[0] * z[0].d + dP[3] * z[1].d + dP[4] * z[2].d),
+                         Du(pr.g[1], dP[3] * z[0].d + dP[1] * z[1].d + dP[5] * z[2].d),
+                         Du(pr.g[2], dP[4] * z[0].d + dP[5] * z[1].d + dP[2] * z[2].d)};
+        const Du phic = ct.mu * (f[0] * jl[0] + f[1] * jl[1]) + f[2] * jl[2];
+        part += phic.d;
+      }
+      const D total = Team::sum(part);
+      if (Team::rank() == 0) xbar[k] = X(total);
+      Team::sync();
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // chain from the batch-summed row (iota space) to learnable parameter k of [theta | friction | lengths] (double; a handful of
 // flops per parameter, done by one thread per parameter in the finalize kernel)
 // ---------------------------------------------------------------------------------------------------------------------------

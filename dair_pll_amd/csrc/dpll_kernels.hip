@@ -72,6 +72,8 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
 #include "dpll_common.hpp"
 #include "dpll_general.hpp"
 #include "dpll_genmesh.hpp"
+#include "dpll_forest.hpp"
+#include "dpll_forest_api.hpp"
 #include "dpll_gjk.hpp"
 #include "dpll_mesh_kernels.hpp"
 #include "dpll_mesh_bf16.hpp"
@@ -1679,6 +1681,7 @@ int launch_genmesh_support(const dpll_model* m, int dtype, const dpll_mesh_param
 
 // `mp`: one dpll_mesh_params_t per body (n_joints + 1 of them)
 int check_mesh(const dpll_model* m, const dpll_mesh_params_t* mp, const char* who) {
+  if (m->forest) return fail(-2, "%s: a model of the forest build has no learned shapes", who);
   if (!mp) return fail(-1, "%s: null mesh parameter pointer", who);
   if (m->desc.n_geoms > 0) {  // general build: one entry per geometry, those of the learned shapes filled in
     int n_mesh = 0;
@@ -1747,7 +1750,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 20; }
+int dpll_abi_version(void) { return 21; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1817,7 +1820,34 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   return 0;
 }
 
-void dpll_model_destroy(dpll_model_t* model) { delete model; }
+int dpll_forest_model_create(const dpll_forest_desc_t* desc, dpll_model_t** out) {
+  if (!desc || !out) return fail(-1, "dpll_forest_model_create: null argument%s");
+  if (int rc = dpll_forest_api::check_desc(desc)) return rc;
+  dpll_model* m = new (std::nothrow) dpll_model;
+  dpll_forest::ForestDesc* fd = new (std::nothrow) dpll_forest::ForestDesc;
+  if (!m || !fd) {
+    delete m;
+    delete fd;
+    return fail(-4, "dpll_forest_model_create: out of memory%s");
+  }
+  std::memset(&m->desc, 0, sizeof(ModelDesc));
+  m->desc.n_joints = desc->n_v;  // (never read for a forest model; kept non-zero so that a stray specialised dispatch fails loudly)
+  m->desc.dt = desc->dt;
+  m->desc.inertia_mode = desc->inertia_mode;
+  static_assert(sizeof(dpll_forest::ForestDesc) == sizeof(dpll_forest_desc_t), "ForestDesc must mirror dpll_forest_desc_t");
+  std::memcpy(fd, desc, sizeof(dpll_forest::ForestDesc));
+  m->forest = fd;
+  m->opts[DPLL_F32] = default_opts(DPLL_F32, 2, true);
+  m->opts[DPLL_F64] = default_opts(DPLL_F64, 2, true);
+  m->opts[DPLL_F32].portfolio = m->opts[DPLL_F64].portfolio = 1;
+  *out = m;
+  return 0;
+}
+
+void dpll_model_destroy(dpll_model_t* model) {
+  if (model && model->forest) dpll_forest_api::release(model);
+  delete model;
+}
 
 int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts_t* opts) {
   if (!model || !opts || (dtype != DPLL_F32 && dtype != DPLL_F64)) return fail(-1, "dpll_model_set_solver: bad argument%s");
@@ -1849,13 +1879,15 @@ int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts
   return 0;
 }
 
-int dpll_n_x(const dpll_model_t* model) { return model ? 13 + 2 * model->desc.n_joints : -1; }
+int dpll_n_x(const dpll_model_t* model) { return !model ? -1 : (model->forest ? dpll_forest_api::n_x(model) : 13 + 2 * model->desc.n_joints); }
 int dpll_n_contacts(const dpll_model_t* model) {
   if (!model) return -1;
+  if (model->forest) return dpll_forest_api::n_contacts(model);
   return kQuery * (model->desc.n_geoms > 0 ? DPLL_GEN_SLOTS : model->desc.n_joints + 1);  // contact SLOTS of the build
 }
 int dpll_param_count(const dpll_model_t* model) {
   if (!model) return -1;
+  if (model->forest) return dpll_forest_api::param_count(model);
   if (model->desc.n_geoms > 0) return dpll_general::param_count(model);
   const int nb = model->desc.n_joints + 1;
   return 10 * nb + (nb + 1) + 3 * nb;
@@ -1863,6 +1895,7 @@ int dpll_param_count(const dpll_model_t* model) {
 
 int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
   if (!model || batch < 0) return -1;
+  if (model->forest) return dpll_forest_api::workspace_bytes(model, batch);
   if (model->desc.n_geoms > 0) return dpll_general::workspace_bytes(model, batch);
   const int nb = model->desc.n_joints + 1;
   // (the racing build of the loss launch: kRaceWaves-wave workgroups of kRaceWaves * 16 / copies items)
@@ -1877,6 +1910,7 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
 
 int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what) {
   if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || what < 0 || what > 3) return -1;
+  if (model->forest) return what >= 2 ? -1 : 1;
   if (what >= 2) {  // the shape of the loss launch: 2 = item workgroups (= partial rows), 3 = lanes of one copy of an item
     if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return -1;
     LossPlan pl;
@@ -1901,6 +1935,9 @@ int dpll_contactnets_loss(const dpll_model_t* model, int dtype, const dpll_param
   if (batch > 0 && (!x || !x_plus)) return fail(-1, "dpll_contactnets_loss: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_loss: row stride smaller than n_x%s");
+  if (model->forest)
+    return dpll_forest_api::loss(model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total, force, iters,
+                                 workspace, workspace_bytes, (hipStream_t)stream);
   if (model->desc.n_geoms > 0)
     return dpll_general::loss(model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad, loss_total, force,
                               iters, workspace, workspace_bytes, (hipStream_t)stream);
@@ -1913,7 +1950,7 @@ int dpll_contactnets_loss_allreduce(const dpll_model_t* model, int dtype, const 
                                     double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                     dpll_ar_t* ar, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_loss_allreduce")) return rc;
-  if (model->desc.n_geoms > 0)
+  if (model->desc.n_geoms > 0 || model->forest)
     return fail(-2, "dpll_contactnets_loss_allreduce: the general build exchanges gradients with dpll_ar_allreduce after dpll_contactnets_loss%s");
   // batch == 0 is a rank whose shard of a ragged tail batch is empty: it contributes a zero row and still takes part
   if ((batch > 0 && (!x || !x_plus)) || !grad || !loss_total || !ar) return fail(-1, "dpll_contactnets_loss_allreduce: null argument%s");
@@ -1930,7 +1967,7 @@ int dpll_contactnets_train_step(const dpll_model_t* model, int dtype, const dpll
                                 double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                 dpll_ar_t* ar, const dpll_adam_t* adam, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_train_step")) return rc;
-  if (model->desc.n_geoms > 0)
+  if (model->desc.n_geoms > 0 || model->forest)
     return fail(-2, "dpll_contactnets_train_step: specialised builds (the general build: dpll_contactnets_loss + an optimizer of the caller's)%s");
   if ((batch > 0 && (!x || !x_plus)) || !grad || !loss_total || !adam || !adam->params || !adam->exp_avg || !adam->exp_avg_sq || !adam->state)
     return fail(-1, "dpll_contactnets_train_step: null argument%s");
@@ -1954,7 +1991,7 @@ int dpll_profile_contactnets_loss(const dpll_model_t* model, int dtype, const dp
                                   float* ms_loss_kernel, float* ms_finalize_kernel) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_profile_contactnets_loss")) return rc;
   if (batch == 0 || !x || !x_plus || reps < 1 || reps > 100000) return fail(-1, "dpll_profile_contactnets_loss: bad argument%s");
-  if (model->desc.n_geoms > 0) return fail(-2, "dpll_profile_contactnets_loss: specialised builds only%s");
+  if (model->desc.n_geoms > 0 || model->forest) return fail(-2, "dpll_profile_contactnets_loss: specialised builds only%s");
   DPLL_DISPATCH(profile_loss, model, dtype, params, x, ld_x, x_plus, ld_xp, batch, scale, grad, workspace,
                 workspace_bytes, (hipStream_t)stream, reps, ms_loss_kernel, ms_finalize_kernel);
 }
@@ -1966,6 +2003,8 @@ int dpll_step(const dpll_model_t* model, int dtype, const dpll_params_t* params,
   if (!x || !x_next) return fail(-1, "dpll_step: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_next < nx) return fail(-1, "dpll_step: row stride smaller than n_x%s");
+  if (model->forest)
+    return dpll_forest_api::simulate(model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters, (hipStream_t)stream);
   if (model->desc.n_geoms > 0)
     return dpll_general::simulate(model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters, (hipStream_t)stream);
   DPLL_DISPATCH(launch_simulate, model, dtype, params, x, ld_x, batch, 1, x_next, ld_next, 0, 0, iters,
@@ -1979,6 +2018,9 @@ int dpll_step_backward(const dpll_model_t* model, int dtype, const dpll_params_t
   if (batch == 0 || !x || !grad_x_next || !grad) return fail(-1, "dpll_step_backward: bad argument%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_g < nx || (grad_x && ld_gx < nx)) return fail(-1, "dpll_step_backward: row stride smaller than n_x%s");
+  if (model->forest)
+    return dpll_forest_api::step_backward(model, dtype, params, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx, workspace,
+                                          workspace_bytes, (hipStream_t)stream);
   if (model->desc.n_geoms > 0)
     return dpll_general::step_backward(model, dtype, params, x, ld_x, grad_x_next, ld_g, batch, grad, grad_x, ld_gx, workspace,
                                        workspace_bytes, (hipStream_t)stream);
@@ -1994,6 +2036,9 @@ int dpll_simulate(const dpll_model_t* model, int dtype, const dpll_params_t* par
   if (!x0 || !traj) return fail(-1, "dpll_simulate: null state pointer%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx) return fail(-1, "dpll_simulate: row stride smaller than n_x%s");
+  if (model->forest)
+    return dpll_forest_api::simulate(model, dtype, params, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, 1, nullptr,
+                                     (hipStream_t)stream);
   if (model->desc.n_geoms > 0)
     return dpll_general::simulate(model, dtype, params, x0, ld_x, batch, steps, traj, (long long)(steps + 1) * nx, nx, 1, nullptr,
                                   (hipStream_t)stream);
@@ -2156,6 +2201,7 @@ int dpll_terms(const dpll_model_t* model, int dtype, const dpll_params_t* params
   if (batch == 0) return 0;
   if (!x) return fail(-1, "dpll_terms: null state pointer%s");
   if (ld_x < dpll_n_x(model)) return fail(-1, "dpll_terms: row stride smaller than n_x%s");
+  if (model->forest) return dpll_forest_api::terms(model, dtype, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);
   if (model->desc.n_geoms > 0)
     return dpll_general::terms(model, dtype, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);
   DPLL_DISPATCH(launch_terms, model, params, x, ld_x, batch, delassus, M, J, phi, a, (hipStream_t)stream);

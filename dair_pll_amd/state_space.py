@@ -65,3 +65,45 @@ class FloatingBaseSpace:
         x = torch.zeros(self.n_x)
         x[0] = 1.0
         return x
+
+
+class FixedBaseSpace:
+    """``FixedBaseSpace(n_joints)`` (``state_space.py:556-647``): a model whose root is welded to the world -- joint coordinates only."""
+
+    def __init__(self, n_joints: int) -> None:
+        self.n_joints = n_joints
+        self.n_q = self.n_v = n_joints
+        self.n_x = 2 * n_joints
+
+    def euler_step(self, q: Tensor, v: Tensor, dt: float) -> Tensor:
+        return q + v * dt
+
+    def zero_state(self) -> Tensor:
+        return torch.zeros(self.n_x)
+
+
+class ProductSpace(FloatingBaseSpace):
+    """``ProductSpace`` (``state_space.py:650-730``): the models of one system side by side -- coordinates of every factor
+    concatenated into ``q``, velocities into ``v`` (what ``drake_utils.py:309-335`` builds from the plant's models)."""
+
+    def __init__(self, spaces) -> None:  # pylint: disable=super-init-not-called
+        self.spaces = list(spaces)
+        self.n_joints = sum(space.n_joints for space in self.spaces)
+        self.n_q = sum(space.n_q for space in self.spaces)
+        self.n_v = sum(space.n_v for space in self.spaces)
+        self.n_x = self.n_q + self.n_v
+
+    def q_split(self, q: Tensor):
+        assert q.shape[-1] == self.n_q
+        return list(torch.split(q, [space.n_q for space in self.spaces], dim=-1))
+
+    def v_split(self, v: Tensor):
+        assert v.shape[-1] == self.n_v
+        return list(torch.split(v, [space.n_v for space in self.spaces], dim=-1))
+
+    def euler_step(self, q: Tensor, v: Tensor, dt: float) -> Tensor:
+        return torch.cat([space.euler_step(qi, vi, dt) for space, qi, vi in zip(self.spaces, self.q_split(q), self.v_split(v))], -1)
+
+    def zero_state(self) -> Tensor:
+        q = torch.cat([space.zero_state()[:space.n_q] for space in self.spaces])
+        return torch.cat((q, torch.zeros(self.n_v)))

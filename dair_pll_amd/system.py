@@ -25,8 +25,8 @@ from torch.nn import Module, ModuleList, Parameter
 from . import _capi
 from .inertia import pi_cm_to_theta
 from .integrator import VelocityIntegrator
-from .state_space import FloatingBaseSpace
-from .urdf import ModelSpec, check_supported, parse_urdf
+from .state_space import FixedBaseSpace, FloatingBaseSpace, ProductSpace
+from .urdf import ModelSpec, build_system_spec, check_forest_supported, check_supported, parse_urdf
 
 _DTYPES = {torch.float32: _capi.F32, torch.float64: _capi.F64}
 
@@ -246,30 +246,48 @@ class MultibodyLearnableSystem(Module):
 
     def __init__(self, init_urdfs: Dict[str, str], dt: float, output_urdfs_dir: Optional[str] = None,
                  inertia_mode: str = 'reference_literal', dtype: torch.dtype = torch.float32,
-                 device: Optional[str] = None, mesh_representation: str = 'deep_support') -> None:
+                 device: Optional[str] = None, mesh_representation: str = 'deep_support', build: str = 'auto') -> None:
         """``mesh_representation`` (an extension; see :func:`dair_pll_amd.urdf.parse_urdf`): ``'polygon'`` turns ``<mesh>``
-        collision elements into ``Polygon`` geometries over the OBJ's vertices instead of ``DeepSupportConvex``."""
+        collision elements into ``Polygon`` geometries over the OBJ's vertices instead of ``DeepSupportConvex``.
+        ``build``: ``'auto'`` picks the kernels by the system (below); ``'forest'`` runs a system the register-resident builds
+        would take on the forest build (tests hold the builds against each other)."""
+        if build not in ('auto', 'forest'):
+            raise ValueError("build must be 'auto' or 'forest'")
         super().__init__()
-        if len(init_urdfs) != 1:
-            raise NotImplementedError('one URDF (one floating-base chain) per system')
+        if len(init_urdfs) < 1:
+            raise ValueError('init_urdfs names no model')
         if dtype not in _DTYPES:
             raise TypeError('dtype must be torch.float32 or torch.float64')
         self.urdfs = dict(init_urdfs)
         self.output_urdfs_dir = output_urdfs_dir
-        self.spec = parse_urdf(next(iter(init_urdfs.values())), mesh_representation)
-        check_supported(self.spec)
+        models = {name: parse_urdf(path, mesh_representation) for name, path in init_urdfs.items()}
+        # One model inside the limits of the register-resident builds (cube / elbow; the general build: 3 joints, 3 geometries,
+        # 4 candidates) runs there; anything else -- several models in one system (multibody_learnable_system.py:51-54,
+        # drake_utils.py:309-335), longer trees, more geometries or candidates -- on the forest build (csrc/dpll_forest.hip)
+        self.forest = build == 'forest' or len(models) > 1 or next(iter(models.values())).fixed_base
+        if not self.forest:
+            try:
+                check_supported(next(iter(models.values())))
+            except NotImplementedError:
+                self.forest = True
+        if self.forest:
+            self.spec = build_system_spec(models)
+            check_forest_supported(self.spec)
+            self.space = ProductSpace([(FixedBaseSpace if spec.fixed_base else FloatingBaseSpace)(spec.n_joints) for spec in self.spec.models])
+        else:
+            self.spec = next(iter(models.values()))
+            self.space = FloatingBaseSpace(self.spec.n_joints)
         self.dt = dt
         self.inertia_mode = inertia_mode
         self.dtype = dtype
         dev = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
-        self.space = FloatingBaseSpace(self.spec.n_joints)
         self.multibody_terms = MultibodyTerms(self.spec, dtype, dev)
         object.__setattr__(self.multibody_terms, '_owner', self)
         self.integrator = VelocityIntegrator(self.space, self.sim_step, dt)
         self.integrator.fused_simulate = self._fused_simulate
         self.max_batch_dim = 1  # multibody_learnable_system.py:80
         self.carry_callback = lambda: torch.tensor([False])  # :79
-        self._desc = _capi.make_desc(self.spec, dt, inertia_mode)
+        self._desc = _capi.make_forest_desc(self.spec, dt, inertia_mode) if self.forest else _capi.make_desc(self.spec, dt, inertia_mode)
         self._handle: Optional[ctypes.c_void_p] = None
         self._flat: Optional[Tensor] = None
         self._grad_buf: Optional[Tensor] = None  # [loss_total | flat gradient]: one buffer = one all-reduce
@@ -285,7 +303,14 @@ class MultibodyLearnableSystem(Module):
     def _geom_slots(self) -> int:
         """geometry slots of the build that serves this model: one per body (specialised builds) or always ``DPLL_GEN_SLOTS``
         (general: three geometries and, behind them, the slot of a body-body pair)"""
+        if self.forest:
+            return len(self.spec.geoms())  # (the forest build: exactly the model's geometries)
         return self.spec.n_joints + 1 if self.spec.is_fast() else _capi.GEN_SLOTS
+
+    def _n_contact_slots(self) -> int:
+        """contacts per item in the kernels' force / phi / J / D layouts: 4 per geometry slot, or -- the forest build -- the
+        model's own contacts"""
+        return self.spec.n_contacts if self.forest else 4 * self._geom_slots()
 
     def _geo_stride(self) -> int:
         """numbers per geometry in the lengths block: a box's 3 (specialised builds) or ``DPLL_GEOM_BLOCK`` (general)"""
@@ -297,7 +322,7 @@ class MultibodyLearnableSystem(Module):
         radius or a polygon's vertices at the start of the geometry's block; the rest, and slots the model does not use, are
         padding), then -- mesh systems, which have no lengths block -- the network weights."""
         terms = self.multibody_terms
-        n_b, slots, stride = self.spec.n_joints + 1, self._geom_slots(), self._geo_stride()
+        n_b, slots, stride = self.spec.n_bodies, self._geom_slots(), self._geo_stride()
         out = [(terms.lagrangian_terms.inertial_parameters, 0), (terms.contact_terms.friction_params, 10 * n_b)]
         lengths0 = 10 * n_b + 1 + slots
         # (the general build always carries its lengths block; the specialised mesh builds have none)
@@ -376,7 +401,7 @@ class MultibodyLearnableSystem(Module):
                     break
         if not ok:
             flat = torch.zeros(total, dtype=first.dtype, device=first.device)
-            n_b, slots = self.spec.n_joints + 1, self._geom_slots()
+            n_b, slots = self.spec.n_bodies, self._geom_slots()
             flat[10 * n_b:10 * n_b + 1 + slots] = 1.0  # friction of geometry slots the model does not use
             for p, offset in layout:
                 flat[offset:offset + p.numel()] = p.detach().reshape(-1)
@@ -406,7 +431,8 @@ class MultibodyLearnableSystem(Module):
     def _model(self) -> ctypes.c_void_p:
         if self._handle is None:
             handle = ctypes.c_void_p()
-            _capi.check(_capi.library().dpll_model_create(ctypes.byref(self._desc), ctypes.byref(handle)))
+            create = _capi.library().dpll_forest_model_create if self.forest else _capi.library().dpll_model_create
+            _capi.check(create(ctypes.byref(self._desc), ctypes.byref(handle)))
             self._handle = handle
         return self._handle
 
@@ -447,7 +473,7 @@ class MultibodyLearnableSystem(Module):
         return tensor if tensor.stride(-1) == 1 and tensor.stride(0) >= width else tensor.contiguous()
 
     def _params_struct(self, flat: Tensor) -> _capi.Params:
-        n_b, slots = self.spec.n_joints + 1, self._geom_slots()
+        n_b, slots = self.spec.n_bodies, self._geom_slots()
         base, size = flat.data_ptr(), flat.element_size()
         return _capi.Params(base, base + 10 * n_b * size, base + (10 * n_b + slots + 1) * size)
 
@@ -629,7 +655,7 @@ class MultibodyLearnableSystem(Module):
         batch_shape = x.shape[:-1]
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
-        force = torch.empty((xf.shape[0], 3 * 4 * self._geom_slots()), dtype=self.dtype, device=xf.device)
+        force = torch.empty((xf.shape[0], 3 * self._n_contact_slots()), dtype=self.dtype, device=xf.device)
         iters = torch.empty(xf.shape[0], dtype=torch.int32, device=xf.device)
         loss, _, _ = self._launch_loss(xf, xpf, None, 1.0, False, force=force, iters=iters)
         force = force[:, self._contact_rows(force.device)]  # the kernels' contact slots -> the model's contacts
@@ -640,7 +666,7 @@ class MultibodyLearnableSystem(Module):
         contacts (a sphere uses one of its geometry's four slots, unused geometry slots none), in the reference's
         order (multibody_terms.py:415-426)"""
         slots = self.spec.contact_slots()
-        k_slots = 4 * self._geom_slots()
+        k_slots = self._n_contact_slots()
         rows = slots + [k_slots + 2 * s + t for s in slots for t in (0, 1)]
         return torch.tensor(rows, dtype=torch.long, device=device)
 
@@ -765,17 +791,19 @@ class MultibodyLearnableSystem(Module):
         theta = self.multibody_terms.lagrangian_terms.inertial_parameters.detach().double().cpu().numpy()
         friction = self.multibody_terms.contact_terms.get_friction_coefficients().detach().cpu()
         out: Dict[str, float] = {}
+        labels = self._body_labels()
         for index, body in enumerate(self.spec.bodies):
+            label = labels[index]
             pi_cm = theta_to_pi_cm(theta[index])
-            out[f'{body.name}_m'] = float(pi_cm[0])
+            out[f'{label}_m'] = float(pi_cm[0])
             for axis, value in zip('xyz', pi_cm[1:4] / pi_cm[0]):
-                out[f'{body.name}_com_{axis}'] = float(value)
+                out[f'{label}_com_{axis}'] = float(value)
             for name, value in zip(('I_xx', 'I_yy', 'I_zz', 'I_xy', 'I_xz', 'I_yz'), pi_cm[4:]):
-                out[f'{body.name}_{name}'] = float(value)
+                out[f'{label}_{name}'] = float(value)
             mine = [g for g, (b, _) in enumerate(self.spec.geoms()) if b == index]
             for count, g in enumerate(mine):
                 # one geometry per body is all the reference's key scheme distinguishes; further ones get a suffix
-                prefix = body.name if count == 0 else f'{body.name}_g{count}'
+                prefix = label if count == 0 else f'{label}_g{count}'
                 geometry = self.multibody_terms.contact_terms.geometries[g + 1]
                 if isinstance(geometry, Box):
                     for axis, value in zip('xyz', geometry.get_half_lengths().detach().cpu().reshape(-1)):
@@ -786,6 +814,13 @@ class MultibodyLearnableSystem(Module):
                     out.update({f'{prefix}_{key}': value for key, value in geometry.scalars().items()})
                 out[f'{prefix}_mu'] = float(friction[g + 1])
         return out
+
+    def _body_labels(self) -> List[str]:
+        """a body's name in the scalar summaries: the link name, prefixed by its model's name when the system has several models
+        (the reference's unique_body_identifier, ``drake_utils.py:123-126``: ``{model instance}_{body}``)"""
+        if not self.forest or len(self.spec.models) == 1:
+            return [body.name for body in self.spec.bodies]
+        return [f'{self.spec.names[m]}_{body.name}' for m, body in zip(self.spec.body_model(), self.spec.bodies)]
 
     def _pi_cm(self) -> np.ndarray:
         from .inertia import theta_to_pi_cm
@@ -846,6 +881,7 @@ class MultibodyLearnableSystem(Module):
         friction = self.multibody_terms.contact_terms.get_friction_coefficients().detach().double().cpu().numpy()
         meshes = self.extract_meshes()
         bodies = []
+        body_model = self.spec.body_model() if self.forest else [0] * self.spec.n_bodies
         for index, body in enumerate(self.spec.bodies):
             shapes = []  # this link's <collision> elements in order
             for g, (b, _) in enumerate(self.spec.geoms()):
@@ -868,9 +904,12 @@ class MultibodyLearnableSystem(Module):
                 shapes.append((shape, float(friction[g + 1])))
             bodies.append((body.name, pi_cm[index], shapes))
         new_urdfs = {}
-        for name, source in self.urdfs.items():
-            target = os.path.join(self.output_urdfs_dir, os.path.basename(source))
-            export.save_string(target, export.render_urdf(source, bodies))
+        for model, (name, source) in enumerate(self.urdfs.items()):
+            # (several models may come from ONE file -- two cubes -- so a model's file carries its name when there are several)
+            base = os.path.basename(source) if len(self.urdfs) == 1 else f'{name}.urdf'
+            target = os.path.join(self.output_urdfs_dir, base)
+            mine = [entry for entry, owner in zip(bodies, body_model) if owner == model]
+            export.save_string(target, export.render_urdf(source, mine))
             new_urdfs[name] = target
         return new_urdfs
 
@@ -880,7 +919,7 @@ class MultibodyLearnableSystem(Module):
         batch_shape = q.shape[:-1]
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state')
         flat = self._packed()
-        n, n_v, k = x.shape[0], self.space.n_v, 4 * self._geom_slots()
+        n, n_v, k = x.shape[0], self.space.n_v, self._n_contact_slots()
         new = lambda *shape: torch.empty((n,) + shape, dtype=self.dtype, device=x.device)
         delassus, mass, jac, phi, acc = new(3 * k, 3 * k), new(n_v, n_v), new(3 * k, n_v), new(k), new(n_v)
         params = self._params_struct(flat)

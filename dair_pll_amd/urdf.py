@@ -72,18 +72,24 @@ class ModelSpec:
     # the root link is welded to the world (a URDF whose root is a link named `world`: Drake welds it, and the reference gives
     # the model a FixedBaseSpace, drake_utils.py:329-332): no base coordinates
     fixed_base: bool = False
+    mount_origin: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0])   # of a fixed base: its root frame in the world
+    mount_rotation: List[List[float]] = field(default_factory=lambda: _identity())
 
     @property
     def n_joints(self) -> int:
         return len(self.bodies) - 1
 
     @property
+    def n_bodies(self) -> int:
+        return len(self.bodies)
+
+    @property
     def n_q(self) -> int:
-        return 7 + self.n_joints
+        return (0 if self.fixed_base else 7) + self.n_joints
 
     @property
     def n_v(self) -> int:
-        return 6 + self.n_joints
+        return (0 if self.fixed_base else 6) + self.n_joints
 
     def geoms(self):
         """``[(body index, GeomSpec)]`` in body order: the order of ``friction_params[1:]`` and of the contact blocks"""
@@ -107,8 +113,9 @@ class ModelSpec:
         joint rotations down the tree).  The kernels work in body frames that all coincide at zero angles; a vector with
         coordinates ``v`` in the URDF's frame of body b has coordinates ``A_b v`` there (``_capi.make_desc``)."""
         out = []
-        for body in self.bodies:
-            out.append(_identity() if body.parent < 0 else _matmul(out[body.parent], body.joint_rotation))
+        for body in self.bodies:  # (a fixed base: the root's kernel frame is the world's, so its alignment is the mount's rotation)
+            out.append((self.mount_rotation if self.fixed_base else _identity()) if body.parent < 0
+                       else _matmul(out[body.parent], body.joint_rotation))
         return out
 
     def rotated(self) -> bool:
@@ -192,6 +199,8 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
     order = []
     for link in root.findall('link'):
         inertial = link.find('inertial')
+        if link.get('name') == 'world':  # (Drake's world frame: a joint from it welds a model to the world, see below)
+            continue
         if inertial is None:
             raise ValueError(f'link {link.get("name")} has no <inertial>')
         origin = inertial.find('origin')
@@ -231,10 +240,18 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
         order.append(body.name)
     joints = []
     children = set()
+    mount = None
     for joint in root.findall('joint'):
         if joint.get('type') not in ('continuous', 'revolute', 'prismatic', 'fixed'):  # (limits are not modelled, as in the reference)
             raise NotImplementedError(f'joint type {joint.get("type")!r} is not supported')
         j_origin = joint.find('origin')
+        if joint.find('parent').get('link') == 'world':
+            # a model welded to the world: its root has no coordinates (the reference gives such a model a FixedBaseSpace,
+            # drake_utils.py:329-332); the joint's <origin> is where -- and how turned -- the root sits
+            if joint.get('type') != 'fixed':
+                raise NotImplementedError('a joint from the world must be fixed (a free model needs no joint to the world)')
+            mount = (joint.find('child').get('link'), _vec(j_origin.get('xyz') if j_origin is not None else None), _rotation(j_origin))
+            continue
         axis = _vec(joint.find('axis').get('xyz')) if joint.find('axis') is not None else [1.0, 0.0, 0.0]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((joint.find('parent').get('link'), joint.find('child').get('link'),
@@ -261,6 +278,10 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
     if len(chain) != len(order):
         raise ValueError('disconnected links')
     spec = ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain], welded=welded)
+    if mount is not None:
+        if welded.get(mount[0], mount[0]) != chain[0]:
+            raise ValueError('the link welded to the world must be the root of the model')
+        spec.fixed_base, spec.mount_origin, spec.mount_rotation = True, mount[1], mount[2]
     spec.pairs = _collision_candidates(root, spec)
     return spec
 
@@ -366,8 +387,28 @@ class SystemSpec:
     models: List[ModelSpec]
     pairs: List[Tuple[int, int]] = field(default_factory=list)
 
+    @property
     def bodies(self) -> List[BodySpec]:
         return [body for spec in self.models for body in spec.bodies]
+
+    @property
+    def n_bodies(self) -> int:
+        return sum(len(spec.bodies) for spec in self.models)
+
+    @property
+    def n_joints(self) -> int:
+        return sum(spec.n_joints for spec in self.models)
+
+    def is_fast(self) -> bool:
+        return False
+
+    def contact_slots(self) -> List[int]:
+        """the forest build's contacts ARE the model's (no padding slots)"""
+        return list(range(self.n_contacts))
+
+    def body_model(self) -> List[int]:
+        """model index of every body of the system"""
+        return [m for m, spec in enumerate(self.models) for _ in spec.bodies]
 
     def geoms(self):
         """``[(body index in the system, GeomSpec)]``: the order of ``friction_params[1:]`` and of the contact blocks"""
@@ -420,7 +461,7 @@ def build_system_spec(models) -> SystemSpec:
 def check_forest_supported(system: SystemSpec) -> None:
     """What the forest build takes; anything else fails loudly at construction."""
     geoms = system.geoms()
-    if len(system.bodies()) > FOREST_MAX_BODIES:
+    if system.n_bodies > FOREST_MAX_BODIES:
         raise NotImplementedError(f'at most {FOREST_MAX_BODIES} bodies per system')
     if not 1 <= len(geoms) <= FOREST_MAX_GEOMS:
         raise NotImplementedError(f'between 1 and {FOREST_MAX_GEOMS} collision geometries per system')

@@ -90,6 +90,43 @@ typedef struct dpll_model_desc {
   int32_t reserved;
 } dpll_model_desc_t;
 
+/* ---- the forest build: several models in one system, any tree, limits an order of magnitude above the general build's ----
+ * What the reference's MultibodyLearnableSystem(init_urdfs: Dict[str, str], ...) describes (multibody_learnable_system.py:51-54):
+ * every URDF one model with a floating (or, welded to the world, fixed) base, state = the models' states one after the other
+ * (ProductSpace of FloatingBaseSpace / FixedBaseSpace, drake_utils.py:309-335, state_space.py:650-730), collision candidates
+ * between any two geometries Drake does not filter -- inside a model and across models.  One wave works on one item with
+ * everything in LDS (csrc/dpll_forest.hip): boxes, spheres, polygons; learned shapes stay on the general build. */
+#define DPLL_FOREST_MAX_BODIES 16
+#define DPLL_FOREST_MAX_GEOMS 12
+#define DPLL_FOREST_MAX_PAIRS 16
+#define DPLL_FOREST_MAX_CONTACTS 64   /* 4 per box / polygon, 1 per sphere, 1 per candidate */
+#define DPLL_FOREST_MAX_V 32          /* generalized velocities */
+/* joint kinds of a forest body beyond dpll_joint_kind: the root of a model, free in the world (q: quaternion wxyz + position,
+ * v: omega_body + v_world) or welded to it (no coordinates) */
+#define DPLL_JOINT_FLOATING 2
+#define DPLL_JOINT_FIXED 3
+
+typedef struct dpll_forest_desc {
+  int32_t n_bodies, n_geoms, n_pairs, n_contacts, n_q, n_v, inertia_mode, rotated, max_depth, reserved;
+  double dt, gravity_z;
+  int32_t parent[DPLL_FOREST_MAX_BODIES];      /* -1 for a root, else a body listed before this one */
+  int32_t joint_kind[DPLL_FOREST_MAX_BODIES];  /* dpll_joint_kind | DPLL_JOINT_FLOATING | DPLL_JOINT_FIXED */
+  int32_t q_index[DPLL_FOREST_MAX_BODIES];     /* first coordinate of the body's joint in q */
+  int32_t v_index[DPLL_FOREST_MAX_BODIES];     /* first velocity of the body's joint in v (after its parent's) */
+  int32_t depth[DPLL_FOREST_MAX_BODIES];       /* joints between the body and its root */
+  double joint_origin[DPLL_FOREST_MAX_BODIES][3]; /* in the parent's frame (a fixed root: in the world); frames as in dpll_model_desc_t */
+  double joint_axis[DPLL_FOREST_MAX_BODIES][3];
+  double body_rot[DPLL_FOREST_MAX_BODIES][3][3];
+  int32_t dof_body[DPLL_FOREST_MAX_V];         /* velocity i belongs to the joint of this body */
+  int32_t geom_body[DPLL_FOREST_MAX_GEOMS], geom_kind[DPLL_FOREST_MAX_GEOMS], geom_nverts[DPLL_FOREST_MAX_GEOMS];
+  double geom_origin[DPLL_FOREST_MAX_GEOMS][3];
+  double geom_rot[DPLL_FOREST_MAX_GEOMS][3][3];
+  int32_t pair_a[DPLL_FOREST_MAX_PAIRS], pair_b[DPLL_FOREST_MAX_PAIRS];
+  /* contact c, in the reference's order: witness contact_slot[c] of geometry contact_geom[c] against the ground -- every
+   * geometry's 4 (a sphere's 1) in geometry order --, then (contact_geom[c] = -1) the contact of candidate contact_slot[c] */
+  int32_t contact_geom[DPLL_FOREST_MAX_CONTACTS], contact_slot[DPLL_FOREST_MAX_CONTACTS];
+} dpll_forest_desc_t;
+
 typedef struct dpll_solver_opts {
   int32_t max_iter;  /* Newton iterations */
   int32_t max_ls;    /* line-search evaluations per iteration */
@@ -149,6 +186,12 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
 int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts_t* opts);
 
 int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
+/* A model on the forest build.  The handle works with every entry point below that takes a dpll_model_t (loss, step,
+ * simulate, step backward, terms; not the *_mesh, allreduce-fused and train-step ones).  Layouts: state rows (n_q + n_v);
+ * parameters [theta (n_bodies, 10) | friction (1 + n_geoms) | lengths (n_geoms, DPLL_GEOM_BLOCK)]; forces / phi / J / D over
+ * the model's n_contacts contacts in the reference's order (no padding slots).  racing copies: none. */
+int dpll_forest_model_create(const dpll_forest_desc_t* desc, dpll_model_t** out);
+
 int dpll_n_contacts(const dpll_model_t* model);   /* fast builds 4 n_bodies; general build 4 DPLL_GEN_SLOTS contact SLOTS: slot
                                                      4 g + s = witness s of geometry g (a sphere: s = 0 only), slot
                                                      4 DPLL_MAX_GEOMS + p = body-body candidate p; the others are masked */

@@ -98,6 +98,8 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     order = []
     for link in root.findall('link'):
         name = link.get('name')
+        if name == 'world':
+            continue
         inertial = link.find('inertial')
         origin = inertial.find('origin')
         inertia = inertial.find('inertia')
@@ -148,10 +150,16 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     children = set()
     joints = []
     for joint in root.findall('joint'):
-        assert joint.get('type') in ('continuous', 'revolute', 'prismatic'), 'only revolute and prismatic joints supported'
         j_origin = joint.find('origin')
         parent = joint.find('parent').get('link')
         child = joint.find('child').get('link')
+        if parent == 'world' and joint.get('type') == 'fixed':
+            # a model welded to the world (Drake welds a link named `world`; the reference gives the model a FixedBaseSpace,
+            # drake_utils.py:329-332): its root has no coordinates; the mount is the joint's <origin>
+            links[child]['mount'] = (_floats(j_origin.get('xyz') if j_origin is not None else None, 3), _origin_rotation(j_origin))
+            continue
+        assert joint.get('type') in ('continuous', 'revolute', 'prismatic'), 'only revolute and prismatic joints supported'
+
         axis = _floats(joint.find('axis').get('xyz'), 3) if joint.find('axis') is not None else [1., 0., 0.]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((parent, child, _floats(j_origin.get('xyz') if j_origin is not None else None, 3),
@@ -174,8 +182,59 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     assert len(sorted_names) == len(order)
     bodies = [links[n] for n in sorted_names]
     spec = {'name': root.get('name'), 'bodies': bodies, 'n_joints': len(bodies) - 1, 'ground_mu': GROUND_MU}
+    spec['fixed_base'] = 'mount' in bodies[0]
     spec['pairs'] = collision_candidates(root, spec)
     return spec
+
+
+def system_spec(urdfs, mesh_representation: str = 'deep_support') -> Dict:
+    """One spec for the models of a system -- ``init_urdfs: Dict[str, str]`` of the reference's constructor
+    (multibody_learnable_system.py:51-54), or one path.  Bodies of all models in order, every body with the place of its joint's
+    coordinates in the ProductSpace state (drake_utils.py:309-335, state_space.py:650-730: per model [quaternion, position,
+    joint coordinates] / [omega_body, v_world, joint rates]; a fixed-base model: joint coordinates only); candidates inside
+    each model as collision_candidates finds them plus every geometry of one model against every geometry of another."""
+    if isinstance(urdfs, str):
+        urdfs = {'model': urdfs}
+    specs = [parse_urdf(path, mesh_representation) for path in urdfs.values()]
+    if len(specs) == 1 and not specs[0]['fixed_base']:
+        return specs[0]
+    bodies, own, model_of_geom = [], set(), []
+    q_off = v_off = geom_off = 0
+    for m, spec in enumerate(specs):
+        first = len(bodies)
+        fixed = spec['fixed_base']
+        base_q, base_v = (0, 0) if fixed else (7, 6)
+        for index, body in enumerate(spec['bodies']):
+            entry = dict(body)
+            entry['model'] = m
+            if index == 0:
+                entry.update(parent=-1, q_index=q_off, v_index=v_off, fixed=fixed)
+            else:
+                entry.update(parent=first + body['parent'], q_index=q_off + base_q + index - 1, v_index=v_off + base_v + index - 1)
+            bodies.append(entry)
+        own |= {(geom_off + a, geom_off + b) for a, b in spec['pairs']}
+        n_geoms = sum(len(body['geoms']) for body in spec['bodies'])
+        model_of_geom += [m] * n_geoms
+        geom_off += n_geoms
+        q_off += base_q + spec['n_joints']
+        v_off += base_v + spec['n_joints']
+    merged = {'name': '+'.join(urdfs.keys()), 'bodies': bodies, 'n_joints': sum(spec['n_joints'] for spec in specs),
+              'ground_mu': GROUND_MU, 'n_q': q_off, 'n_v': v_off, 'models': specs, 'fixed_base': False}
+    table = geometry_table(merged)
+    pairs = []
+    for ia in range(1, len(table)):
+        for ib in range(ia + 1, len(table)):
+            swap = _TYPE_ORDER[table[ia]['kind']] > _TYPE_ORDER[table[ib]['kind']]
+            pair = (ib, ia) if swap else (ia, ib)
+            if model_of_geom[ia - 1] != model_of_geom[ib - 1] or pair in own:
+                pairs.append(pair)
+    merged['pairs'] = pairs
+    return merged
+
+
+def state_sizes(spec: Dict) -> Tuple[int, int]:
+    """(n_q, n_v) of a spec: one floating-base model, or what system_spec recorded"""
+    return spec.get('n_q', 7 + spec['n_joints']), spec.get('n_v', 6 + spec['n_joints'])
 
 
 PAIR_TIE = 1e-12  # metres: support values closer than this are a tie (witness vertex of a body-body contact)
@@ -397,7 +456,7 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
     (6 x n_v, so V_b = S_b v), and -- if v is given -- V_b and the velocity-product
     (bias) spatial acceleration A_b (value of dV_b/dt at zero generalised acceleration)."""
     n_bodies = len(spec['bodies'])
-    n_v = 6 + spec['n_joints']
+    _, n_v = state_sizes(spec)
     batch = q.shape[:-1]
     dtype = q.dtype
     rot: List[Tensor] = []
@@ -406,32 +465,44 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
     vel: List[Tensor] = []
     acc: List[Tensor] = []
     for index, body in enumerate(spec['bodies']):
-        if body['parent'] < 0:
-            r_b = quat_to_rot(q[..., :4])
-            o_b = q[..., 4:7]
+        # where the body's joint sits in q / v: one floating-base model (joint j drives body j + 1, breadth-first order), or
+        # the places system_spec recorded for the models of a ProductSpace
+        qi = body.get('q_index', 0 if body['parent'] < 0 else 7 + index - 1)
+        vi = body.get('v_index', 0 if body['parent'] < 0 else 6 + index - 1)
+        if body['parent'] < 0 and (body.get('fixed') or spec.get('fixed_base')):
+            # welded to the world at its mount: no coordinates, no velocity
+            xyz, mount = body['mount']
+            r_b = torch.tensor(mount, dtype=dtype).expand(batch + (3, 3))
+            o_b = torch.tensor(xyz, dtype=dtype).expand(batch + (3,))
             s_b = torch.zeros(batch + (6, n_v), dtype=dtype)
-            s_b[..., 0, 0] = 1.
-            s_b[..., 1, 1] = 1.
-            s_b[..., 2, 2] = 1.
-            s_b[..., 3:6, 3:6] = r_b.transpose(-1, -2)
+            if v is not None:
+                v_b = torch.zeros(batch + (6,), dtype=dtype)
+                a_b = torch.zeros(batch + (6,), dtype=dtype)
+        elif body['parent'] < 0:
+            r_b = quat_to_rot(q[..., qi:qi + 4])
+            o_b = q[..., qi + 4:qi + 7]
+            s_b = torch.zeros(batch + (6, n_v), dtype=dtype)
+            s_b[..., 0, vi] = 1.
+            s_b[..., 1, vi + 1] = 1.
+            s_b[..., 2, vi + 2] = 1.
+            s_b[..., 3:6, vi + 3:vi + 6] = r_b.transpose(-1, -2)
             if v is not None:
                 v_b = (s_b @ v.unsqueeze(-1)).squeeze(-1)
                 zero3 = torch.zeros(batch + (3,), dtype=dtype)
                 a_b = torch.cat((zero3, -torch.cross(v_b[..., :3], v_b[..., 3:], dim=-1)), -1)
         else:
             parent = body['parent']
-            joint = index - 1  # joint j drives body j+1 (breadth-first order)
             axis = torch.tensor(body['joint_axis'], dtype=dtype)
             p_j = torch.tensor(body['joint_origin'], dtype=dtype)
             r_joint = torch.tensor(body['joint_rot'], dtype=dtype)
             if body['joint_kind'] == 'prismatic':
                 # child frame = joint frame moved along the axis (given in the joint frame) by the joint coordinate
                 r_pc = r_joint.expand(batch + (3, 3))
-                p_j = p_j + q[..., 7 + joint].unsqueeze(-1) * (r_joint @ axis)
+                p_j = p_j + q[..., qi].unsqueeze(-1) * (r_joint @ axis)
                 s_col = torch.cat((torch.zeros(3, dtype=dtype), axis))
             else:
                 # child frame = joint frame (the <origin> of the joint, rpy included) turned about the axis by the angle
-                r_pc = r_joint @ axis_rotation(axis, q[..., 7 + joint])
+                r_pc = r_joint @ axis_rotation(axis, q[..., qi])
                 s_col = torch.cat((axis, torch.zeros(3, dtype=dtype)))
             e_cp = r_pc.transpose(-1, -2)
             r_b = rot[parent] @ r_pc
@@ -442,10 +513,10 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
             x_cp = torch.cat((x_top, x_bottom), -2)
             s_b = x_cp @ jac[parent]
             s_b = s_b.clone()
-            s_b[..., :, 6 + joint] = s_b[..., :, 6 + joint] + s_col
+            s_b[..., :, vi] = s_b[..., :, vi] + s_col
             if v is not None:
                 v_b = (s_b @ v.unsqueeze(-1)).squeeze(-1)
-                rate = v[..., 6 + joint].unsqueeze(-1)
+                rate = v[..., vi].unsqueeze(-1)
                 a_b = (x_cp @ acc[parent].unsqueeze(-1)).squeeze(-1) + motion_cross(v_b, s_col * rate)
         rot.append(r_b)
         org.append(o_b)
@@ -493,7 +564,7 @@ def geometry_kinematics(spec: Dict, q: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
     of each geometry origin in dair_pll velocity coordinates (*, n_g, 6, n_v) (:355-376)."""
     rot, org, jac, _, _ = chain_kinematics(spec, q)
     batch = q.shape[:-1]
-    n_v = 6 + spec['n_joints']
+    _, n_v = state_sizes(spec)
     rots, trans, jacs = [], [], []
     for geom in geometry_table(spec):
         if geom['body'] < 0:
@@ -870,17 +941,17 @@ class OracleSystem:
     ``friction`` (n_geometries,), per-geometry ``length_params`` (1, 3) for boxes or ICNN
     weights for meshes."""
 
-    def __init__(self, urdf: str, dt: float, inertia_mode: str = 'reference_literal',
+    def __init__(self, urdf, dt: float, inertia_mode: str = 'reference_literal',
                  dtype=torch.float64, mesh_seed: int = 0, mesh_params: Optional[Dict] = None,
                  mesh_representation: str = 'deep_support'):
-        self.spec = parse_urdf(urdf, mesh_representation)
+        """``urdf``: one path, or ``{name: path}`` -- the models of one system (reference ``init_urdfs``)"""
+        self.spec = system_spec(urdf, mesh_representation)
         self.dt = dt
         self.dtype = dtype
         self.inertia_mode = inertia_mode
         self.geoms = geometry_table(self.spec)
         self.n_joints = self.spec['n_joints']
-        self.n_q = 7 + self.n_joints
-        self.n_v = 6 + self.n_joints
+        self.n_q, self.n_v = state_sizes(self.spec)
         self.n_x = self.n_q + self.n_v
         # witness points per geometry: 4 (box: geometry.py:490; mesh: :47-48), 1 for a sphere (:440-452)
         self.n_contacts = sum(1 if g['kind'] == 'sphere' else N_QUERY for g in self.geoms[1:]) + len(self.spec['pairs'])
@@ -1141,8 +1212,19 @@ class OracleSystem:
         q, v = self.q_v(x)
         v_next = self.forward_dynamics(q, v)
         dq = v_next * self.dt
-        quat_next = quat_multiply(q[..., :4], quat_exp(dq[..., :3]))
-        q_next = torch.cat((quat_next, q[..., 4:] + dq[..., 3:]), -1)
+        # ProductSpace.exponential (state_space.py:709-719): every floating base by the quaternion exponential, everything
+        # else (positions, joint coordinates) additively
+        q_next = q.clone()
+        for index, body in enumerate(self.spec['bodies']):
+            qi = body.get('q_index', 0 if body['parent'] < 0 else 7 + index - 1)
+            vi = body.get('v_index', 0 if body['parent'] < 0 else 6 + index - 1)
+            if body['parent'] < 0 and (body.get('fixed') or self.spec.get('fixed_base')):
+                continue
+            if body['parent'] < 0:
+                q_next[..., qi:qi + 4] = quat_multiply(q[..., qi:qi + 4], quat_exp(dq[..., vi:vi + 3]))
+                q_next[..., qi + 4:qi + 7] = q[..., qi + 4:qi + 7] + dq[..., vi + 3:vi + 6]
+            else:
+                q_next[..., qi] = q[..., qi] + dq[..., vi]
         return torch.cat((q_next, v_next), -1)
 
     def simulate(self, x_0: Tensor, steps: int) -> Tensor:

@@ -210,9 +210,10 @@ def pair_member(base, geometry):
     return geometry
 
 
-def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0, mesh_representation: str = 'deep_support'):
-    """The reference's MultibodyLearnableSystem with Drake-dependent construction bypassed."""
-    spec = O.parse_urdf(urdf, mesh_representation)
+def build_reference_system(urdf, inertia_mode: str, mesh_seed: int = 0, mesh_representation: str = 'deep_support'):
+    """The reference's MultibodyLearnableSystem with Drake-dependent construction bypassed.  ``urdf``: one path, or
+    ``{name: path}`` -- the ``init_urdfs`` of a system of several models (multibody_learnable_system.py:51-54)."""
+    spec = O.system_spec(urdf, mesh_representation)
     geoms = O.geometry_table(spec)
     n_joints = spec['n_joints']
 
@@ -265,7 +266,11 @@ def build_reference_system(urdf: str, inertia_mode: str, mesh_seed: int = 0, mes
     mt.contact_terms = ct
 
     system = MultibodyLearnableSystem.__new__(MultibodyLearnableSystem)
-    space = state_space.ProductSpace([state_space.FixedBaseSpace(0), state_space.FloatingBaseSpace(n_joints)])
+    # the plant's state space as generate_state_space builds it (drake_utils.py:309-335): the world model (no coordinates),
+    # then one FloatingBaseSpace -- or, for a model welded to the world, FixedBaseSpace -- per model
+    models = spec.get('models', [spec])
+    space = state_space.ProductSpace([state_space.FixedBaseSpace(0)] + [
+        (state_space.FixedBaseSpace if model['fixed_base'] else state_space.FloatingBaseSpace)(model['n_joints']) for model in models])
     System.__init__(system, space, VelocityIntegrator(space, system.sim_step, DT))
     system.multibody_terms = mt
     system.solver = RecordingSolver()
@@ -293,8 +298,8 @@ def record_case(name: str, urdf: str, x: torch.Tensor, x_plus: torch.Tensor, ine
     system, _ = build_reference_system(urdf, inertia_mode, mesh_representation=mesh_representation)
     if prepare is not None:  # e.g. move the parameters off their URDF values before anything is recorded
         prepare(system)
-    out = {'urdf': os.path.basename(urdf), 'dt': DT, 'inertia_mode': inertia_mode,
-           'x': x.numpy(), 'x_plus': x_plus.numpy()}
+    out = {'urdf': os.path.basename(urdf) if isinstance(urdf, str) else ' '.join(f'{k}={os.path.basename(v)}' for k, v in urdf.items()),
+           'dt': DT, 'inertia_mode': inertia_mode, 'x': x.numpy(), 'x_plus': x_plus.numpy()}
     for key, value in named_values(system).items():
         out['param/' + key] = value
 
@@ -623,6 +628,77 @@ def record_pair_cases(n_traj: int = 10, steps: int = 36, keep_every: int = 3, se
     record_case('clasp_mesh_literal', urdf, x, x_plus, 'reference_literal', sim_steps=2)
 
 
+FOREST_CASES = {
+    # name -> init_urdfs of the system (this repository's assets)
+    'chain6': {'chain6': 'chain6.urdf'},                                  # 5 hinges, 6 boxes, 10 body-body candidates
+    'rake': {'rake': 'rake.urdf'},                                        # one body, 5 geometries (2 boxes, 3 spheres)
+    'two_cubes': {'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'},          # two models: two free cubes that can collide
+    'pendulum_cube': {'pendulum': 'pendulum.urdf', 'cube': 'cube.urdf'},  # a fixed-base model next to a free one
+}
+
+
+def forest_tosses(name: str, n_traj: int, steps: int, keep_every: int, seed: int):
+    """(x, x_plus) pairs of seeded tosses of a system of several models / a long tree, rolled out by the reference's own
+    simulate on the stub-built system: every free model starts with a random attitude 5-12 cm above the ground, spinning,
+    the models of a system 8 cm apart and moving towards each other; joints anywhere (the candidates of a long chain may
+    start overlapping: the contact model takes that, and both sides of the parity check see the same states)."""
+    urdfs = {key: os.path.join(REPO, 'assets', value) for key, value in FOREST_CASES[name].items()}
+    system, spec = build_reference_system(urdfs, 'reference_literal')
+    models = spec.get('models', [spec])
+    gen = torch.Generator().manual_seed(seed)
+    qs, vs = [], []
+    for m, model in enumerate(models):
+        n_j = model['n_joints']
+        joints = 1.2 * torch.randn((n_traj, n_j), generator=gen)
+        rates = 3.0 * torch.randn((n_traj, n_j), generator=gen)
+        if n_j > 0 and model['pairs'] and len(models) == 1:
+            # a long chain: joint angles drawn until no two links overlap (a function of the joints alone), half of the tosses
+            # with some pair of links within 2 cm of each other -- as pair_tosses starts the short trees
+            trial = torch.zeros((6000, 7 + n_j))
+            trial[:, 0] = 1.0
+            trial[:, 7:] = 1.6 * torch.randn((6000, n_j), generator=gen)
+            with torch.no_grad():
+                phi = system.multibody_terms.contact_terms(trial)[0][:, -len(model['pairs']):]
+            free = (phi > 0.002).all(dim=-1)
+            near = free & (phi.min(dim=-1).values < 0.02)
+            picks = torch.cat((trial[near][:n_traj // 2, 7:], trial[free & ~near][:n_traj - min(n_traj // 2, int(near.sum())), 7:]))
+            assert picks.shape[0] == n_traj, (int(free.sum()), int(near.sum()))
+            joints = picks
+        if model['fixed_base']:
+            qs.append(joints)
+            vs.append(rates)
+            continue
+        quat = torch.randn((n_traj, 4), generator=gen)
+        quat = quat / quat.norm(dim=-1, keepdim=True)
+        side = (m - 0.5 * (len(models) - 1)) * 0.08
+        pos = torch.cat((side + 0.01 * torch.randn((n_traj, 1), generator=gen), 0.02 * torch.randn((n_traj, 1), generator=gen),
+                         0.05 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
+        lin = torch.cat((-6.0 * side + 0.3 * torch.randn((n_traj, 1), generator=gen), 0.4 * torch.randn((n_traj, 2), generator=gen)), -1)
+        if name == 'pendulum_cube':  # the cube is thrown at the mast / under the arm
+            pos = torch.cat((0.2 - 0.1 + 0.02 * torch.randn((n_traj, 1), generator=gen), 0.1 + 0.02 * torch.randn((n_traj, 1), generator=gen),
+                             0.05 + 0.05 * torch.rand((n_traj, 1), generator=gen)), -1)
+            lin = torch.cat((0.8 + 0.3 * torch.randn((n_traj, 1), generator=gen), 0.3 * torch.randn((n_traj, 2), generator=gen)), -1)
+        qs.append(torch.cat((quat, pos, joints), -1))
+        vs.append(torch.cat((4.0 * torch.randn((n_traj, 3), generator=gen), lin, rates), -1))
+    x_0 = torch.cat(qs + vs, -1)
+    with torch.no_grad():
+        traj, _ = system.simulate(x_0.unsqueeze(-2), torch.zeros((n_traj, 1)), steps)
+    x = traj[:, :-1][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+    x_plus = traj[:, 1:][:, ::keep_every].reshape(-1, traj.shape[-1]).clone()
+    return urdfs, x, x_plus
+
+
+def record_forest_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0, names=tuple(FOREST_CASES)) -> None:
+    """SURVEY 8f-3, what the reference's generality reaches beyond one short tree: several models in one system (init_urdfs with
+    more than one entry: a ProductSpace of the models' spaces, candidates between the models), a model welded to the world
+    (FixedBaseSpace), five joints, five geometries on a body, ten candidates -- through the reference's own MultibodyTerms /
+    contactnets_loss / forward_dynamics / simulate exactly as record_case does for its assets."""
+    for name in names:
+        urdfs, x, x_plus = forest_tosses(name, n_traj, steps, keep_every, seed)
+        record_case(name + '_literal', urdfs if len(urdfs) > 1 or name == 'pendulum_cube' else next(iter(urdfs.values())), x, x_plus,
+                    'reference_literal', sim_steps=3)
+
+
 def record_elbow_mesh() -> None:
     """contactnets_elbow_mesh.urdf: a DeepSupportConvex on each link (two independent networks), on every 4th of the
     synthetic elbow pairs."""
@@ -650,6 +726,7 @@ def main() -> None:
     record_elbow_mesh()
     record_polygon_cases()
     record_pair_cases()
+    record_forest_cases()
 
 
 if __name__ == '__main__':

@@ -42,7 +42,7 @@ def params_of(system_spec):
     """(theta, friction, lengths) at their URDF values: friction (1 + n_geoms,), lengths (n_geoms, 24) -- a box's half lengths, a
     sphere's radius in column 0, a polygon's vertices row-major"""
     from dair_pll_amd.inertia import pi_cm_to_theta
-    theta = np.stack([pi_cm_to_theta(np.array([b.mass] + [b.mass * c for c in b.com] + list(b.inertia_cm))) for b in system_spec.bodies()])
+    theta = np.stack([pi_cm_to_theta(np.array([b.mass] + [b.mass * c for c in b.com] + list(b.inertia_cm))) for b in system_spec.bodies])
     geoms = system_spec.geoms()
     friction = np.array(system_spec.friction_init(), dtype=np.float64)
     lengths = np.zeros((len(geoms), GEO_STRIDE))
@@ -104,3 +104,16 @@ def terms(desc: ForestDesc, theta, friction, lengths, x):
                                        _ptr(phi), _ptr(J))
     assert status == 0
     return M, a, phi, J
+
+
+def step_backward(desc: ForestDesc, theta, friction, lengths, x, xbar_next, opts=None, want_state=False):
+    """d(sum xbar_next . x_next)/d[theta | friction | lengths] (float64); with want_state also d/dx (B, n_x)."""
+    arr = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    theta, friction, lengths, x, xbar_next = map(arr, (theta, friction, lengths, x, xbar_next))
+    grad = np.zeros(lib().forestsim_param_count(ctypes.byref(desc)), dtype=np.float64)
+    opts = opts or default_opts(np.float64)
+    xbar = np.zeros_like(x) if want_state else None
+    status = lib().forestsim_step_backward_f64(ctypes.byref(desc), ctypes.byref(opts), _ptr(theta), _ptr(friction), _ptr(lengths), _ptr(x),
+                                               _ptr(xbar_next), c_int64(x.shape[0]), _ptr(grad), _ptr(xbar))
+    assert status == 0
+    return (grad, xbar) if want_state else grad

@@ -86,9 +86,29 @@ int terms_batch(const ForestDesc& fd, const T* theta, const T* friction, const T
   return 0;
 }
 
+// gradient of sum(xbar_next . x_next) with respect to [theta | friction | lengths] and (xbar != null) to the state
+int step_backward_batch(const ForestDesc& fd, const SolverOpts& opt, const double* theta, const double* friction, const double* lengths,
+                        const double* x, const double* xbar_next, int64_t B, double* grad, double* xbar) {
+  Item<double, double> item(fd);
+  Item<DualT<double>, DualT<double>> dual(fd);
+  ForestBackward<HostTeam> back(fd, item.arena, dual.arena);
+  Forest<double, double, HostTeam> prog(fd, item.arena);
+  const int nx = fd.n_q + fd.n_v;
+  std::vector<double> row(row_width(fd), 0.0);
+  prog.derive(theta, friction, lengths);
+  for (int64_t i = 0; i < B; ++i)
+    back.run(x + i * nx, xbar_next + i * nx, theta, friction, lengths, opt, row.data(), xbar ? xbar + i * nx : (double*)nullptr);
+  for (int k = 0; k < param_count(fd); ++k) grad[k] = chain_param(fd, theta, friction, lengths, row.data(), k);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+int forestsim_step_backward_f64(const ForestDesc* fd, const SolverOpts* opt, const double* theta, const double* friction, const double* lengths,
+                                const double* x, const double* xbar_next, int64_t B, double* grad, double* xbar) {
+  return step_backward_batch(*fd, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
+}
 int forestsim_sizeof_desc() { return (int)sizeof(ForestDesc); }
 int forestsim_param_count(const ForestDesc* fd) { return param_count(*fd); }
 int forestsim_loss_f64(const ForestDesc* fd, const SolverOpts* opt, const double* theta, const double* friction, const double* lengths,

@@ -30,7 +30,7 @@ def fixture_params(g, system):
 
 
 def reference_gradient(g, system):
-    n_b, n_g = len(system.bodies()), len(system.geoms())
+    n_b, n_g = system.n_bodies, len(system.geoms())
     out = np.zeros(10 * n_b + 1 + n_g + 24 * n_g)
     out[:10 * n_b] = g['grad/' + P + 'lagrangian_terms.inertial_parameters'].ravel()
     out[10 * n_b:10 * n_b + 1 + n_g] = g['grad/' + P + 'contact_terms.friction_params']
@@ -42,11 +42,15 @@ def reference_gradient(g, system):
     return out
 
 
+FOREST = {'chain6': {'chain6': 'chain6.urdf'}, 'rake': {'rake': 'rake.urdf'}, 'two_cubes': {'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'},
+          'pendulum_cube': {'pendulum': 'pendulum.urdf', 'cube': 'cube.urdf'}}
+MODELS += list(FOREST)
 worst = {}
 for name in (sys.argv[1:] or MODELS):
     urdf, representation = SOURCES.get(name, (name + '.urdf', 'deep_support'))
     g = np.load(os.path.join('tests', 'golden', name + '_literal.npz'))
-    system = build_system_spec({name: parse_urdf(os.path.join('assets', urdf), representation)})
+    models = FOREST.get(name, {name: urdf})
+    system = build_system_spec({key: parse_urdf(os.path.join('assets', value), representation) for key, value in models.items()})
     desc = _capi.make_forest_desc(system, float(g['dt']), str(g['inertia_mode']))
     theta, friction, lengths = fixture_params(g, system)
     out = forest.loss(desc, theta, friction, lengths, g['x'], g['x_plus'])
