@@ -200,8 +200,8 @@ __global__ __launch_bounds__(kWave) void forest_step_backward_kernel(const Fores
   Arena<DualT<double>, DualT<double>> B;
   size_t off = ((size_t)width * sizeof(double) + 15) & ~(size_t)15;
   off += A.carve(forest_smem + off, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
-  if (STATE) B.carve(forest_smem + off, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
-  else B.carve(nullptr, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  if (STATE) B.carve(forest_smem + off, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs, true);
+  else B.carve(nullptr, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs, true);
   for (int e = threadIdx.x; e < width; e += kWave) row[e] = 0.0;
   Forest<double, double, WaveTeam> prog(fd, A);
   prog.derive(theta, friction, lengths);
@@ -361,7 +361,7 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
   if (!dev) return dpll_fail(-5, "dpll_step_backward (forest build): could not place the model description on the device%s");
   if (!workspace || ws_bytes < dpll_forest_api::workspace_bytes(m, batch)) return dpll_fail(-3, "dpll_step_backward: workspace too small%s");
   const size_t head = round16((size_t)row_width(fd) * sizeof(double));
-  const size_t lds = head + arena_bytes<double, double>(fd) + (grad_x ? arena_bytes<DualT<double>, DualT<double>>(fd) : 0);
+  const size_t lds = head + arena_bytes<double, double>(fd) + (grad_x ? arena_bytes<DualT<double>, DualT<double>>(fd, true) : 0);
   if (grad_x) {
     if (int rc = allow_lds(forest_step_backward_kernel<T, true>, lds, "dpll_step_backward")) return rc;
   } else {
@@ -430,7 +430,8 @@ int check_desc(const dpll_forest_desc_t* d) {
     const int nq = kind == kJointFloating ? 7 : (kind == kJointFixed ? 0 : 1), nv = dofs_of(kind);
     if (d->q_index[b] < 0 || d->q_index[b] + nq > d->n_q || d->v_index[b] < 0 || d->v_index[b] + nv > d->n_v)
       return dpll_fail(-1, "dpll_forest_model_create: q_index / v_index out of range%s");
-    if (!root && d->v_index[b] <= d->v_index[parent]) return dpll_fail(-1, "dpll_forest_model_create: a body's velocities come after its parent's%s");
+    if (!root && d->v_index[b] < d->v_index[parent] + dofs_of(d->joint_kind[parent]))
+      return dpll_fail(-1, "dpll_forest_model_create: a body's velocities come after its parent's%s");
     for (int i = 0; i < nv; ++i)
       if (d->dof_body[d->v_index[b] + i] != b) return dpll_fail(-1, "dpll_forest_model_create: dof_body does not match v_index%s");
     n_q += nq;

@@ -117,9 +117,30 @@ template <typename S, typename SA> struct Arena {
   S *dv, *gv, *w, *Mdv, *u, *abar, *bvec, *vp;
   S *tw;                                // body twists of up to four vectors [4][nb][6]
   S *scal;                              // a few scalars shared by the team
-  DPLL_HD size_t carve(char* base, int nb_, int nv_, int nq_, int K_, int ng_, int np_) {
+  S *cphi, *cmu;                        // the contacts' signed distances and friction coefficients (also in the records)
+  // lite: an arena for terms + contact geometry only (the dual passes of the state adjoint): no contact records, no solver
+  // or adjoint blocks
+  DPLL_HD size_t carve(char* base, int nb_, int nv_, int nq_, int K_, int ng_, int np_, bool lite = false) {
     nb = nb_; nv = nv_; nq = nq_; K = K_; ng = ng_; np = np_;
     Bump m{base, 0};
+    if (lite) {
+      q = m.take<SA>(nq); v = m.take<S>(nv);
+      R = m.take<SA>(9 * nb); o = m.take<SA>(3 * nb); Rpc = m.take<SA>(9 * nb); pj = m.take<SA>(3 * nb); axw = m.take<SA>(3 * nb);
+      iota = m.take<S>(kIota * nb); mu_g = m.take<S>(ng); mu_p = m.take<S>(np > 0 ? np : 1); habs = m.take<S>(3 * ng);
+      Vw = m.take<S>(3 * nb); Vu = m.take<S>(3 * nb); AGw = m.take<S>(3 * nb); AGu = m.take<S>(3 * nb);
+      Wn = m.take<S>(3 * nb); Wf = m.take<S>(3 * nb); comp = m.take<S>(kIota * nb);
+      M = m.take<S>(nv * nv); LM = m.take<S>(nv * nv); invdM = m.take<S>(nv); a = m.take<S>(nv); F = m.take<S>(nv);
+      J = m.take<S>((size_t)K * 3 * nv);
+      ct = nullptr;
+      dirs = m.take<SA>(3 * (np > 0 ? np : 1)); setA = setB = nullptr;
+      H = invd = CJ = Cc = y0 = My0 = jtg0 = y1 = My1 = jtg1 = nullptr;
+      p0 = p1 = nullptr;
+      grad = d = Md = jd = tmp2 = force = dv = gv = w = Mdv = u = abar = bvec = scal = nullptr;
+      tmp = m.take<S>(nv); vp = m.take<S>(nv);
+      tw = m.take<S>((size_t)nb * 6);
+      cphi = m.take<S>(K); cmu = m.take<S>(K);
+      return (m.off + 15) & ~(size_t)15;
+    }
     q = m.take<SA>(nq); v = m.take<S>(nv);
     R = m.take<SA>(9 * nb); o = m.take<SA>(3 * nb); Rpc = m.take<SA>(9 * nb); pj = m.take<SA>(3 * nb); axw = m.take<SA>(3 * nb);
     iota = m.take<S>(kIota * nb); mu_g = m.take<S>(ng); mu_p = m.take<S>(np > 0 ? np : 1); habs = m.take<S>(3 * ng);
@@ -138,13 +159,14 @@ template <typename S, typename SA> struct Arena {
     bvec = m.take<S>(nv); vp = m.take<S>(nv);
     tw = m.take<S>((size_t)4 * nb * 6);
     scal = m.take<S>(16);
+    cphi = m.take<S>(K); cmu = m.take<S>(K);
     return (m.off + 15) & ~(size_t)15;
   }
 };
 
-template <typename S, typename SA> DPLL_HD size_t arena_bytes(const ForestDesc& fd) {
+template <typename S, typename SA> DPLL_HD size_t arena_bytes(const ForestDesc& fd, bool lite = false) {
   Arena<S, SA> a;
-  return a.carve(nullptr, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  return a.carve(nullptr, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs, lite);
 }
 
 // [loss | d/d iota (nb, 10) | d/d mu of the ground pairs (ng) | d/d mu of the candidates (np) | d/d geometry blocks (ng, 24)]
@@ -643,7 +665,13 @@ template <typename S, typename SA, class Team> struct Forest {
 
   // contact c: geometry, signed distance, dense Jacobian rows (contact frame: t_x, t_y, n)
   template <typename P> DPLL_HD void contact(int c, const P* lengths) {
-    ContactRec<S>& ct = A.ct[c];
+    ContactRec<S> local;  // (a lite arena keeps no records: signed distance and coefficient go to cphi / cmu, the rest is dropped)
+    ContactRec<S>& ct = A.ct ? A.ct[c] : local;
+    contact_into(c, lengths, ct);
+    A.cphi[c] = ct.phi;
+    A.cmu[c] = ct.mu;
+  }
+  template <typename P> DPLL_HD void contact_into(int c, const P* lengths, ContactRec<S>& ct) {
     S* Jrow = A.J + (size_t)c * 3 * A.nv;
     for (int e = 0; e < 3 * A.nv; ++e) Jrow[e] = S(0);
     const int g = fd.contact_geom[c], slot = fd.contact_slot[c];
@@ -1378,7 +1406,7 @@ template <class Team> struct ForestBackward {
       }
       // + sum_c (J_c lambda) . D_mu P_K(z_c)
       for (int c = Team::rank(); c < A.K; c += Team::kSize) {
-        const ContactRec<Du>& ct = B.ct[c];
+        const struct { Du mu, phi; } ct = {B.cmu[c], B.cphi[c]};
         const Du* Jrow = B.J + (size_t)c * 3 * A.nv;
         Du jy[3], jv[3], jl[3];
         DPLL_UNROLL for (int r = 0; r < 3; ++r) {

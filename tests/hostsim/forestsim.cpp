@@ -14,8 +14,8 @@ namespace {
 template <typename S, typename SA> struct Item {
   std::vector<char> storage;
   Arena<S, SA> arena;
-  explicit Item(const ForestDesc& fd) : storage(arena_bytes<S, SA>(fd) + 64) {
-    arena.carve(storage.data(), fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  explicit Item(const ForestDesc& fd, bool lite = false) : storage(arena_bytes<S, SA>(fd, lite) + 64) {
+    arena.carve(storage.data(), fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs, lite);
   }
 };
 
@@ -90,7 +90,7 @@ int terms_batch(const ForestDesc& fd, const T* theta, const T* friction, const T
 int step_backward_batch(const ForestDesc& fd, const SolverOpts& opt, const double* theta, const double* friction, const double* lengths,
                         const double* x, const double* xbar_next, int64_t B, double* grad, double* xbar) {
   Item<double, double> item(fd);
-  Item<DualT<double>, DualT<double>> dual(fd);
+  Item<DualT<double>, DualT<double>> dual(fd, true);
   ForestBackward<HostTeam> back(fd, item.arena, dual.arena);
   Forest<double, double, HostTeam> prog(fd, item.arena);
   const int nx = fd.n_q + fd.n_v;
@@ -111,6 +111,11 @@ int forestsim_step_backward_f64(const ForestDesc* fd, const SolverOpts* opt, con
 }
 int forestsim_sizeof_desc() { return (int)sizeof(ForestDesc); }
 int forestsim_param_count(const ForestDesc* fd) { return param_count(*fd); }
+// bytes of an item's arena: kind 0 float storage, 1 double, 2 the dual (lite) arena of the state adjoint
+int64_t forestsim_arena_bytes(const ForestDesc* fd, int kind) {
+  return kind == 0 ? (int64_t)arena_bytes<float, double>(*fd) : (kind == 1 ? (int64_t)arena_bytes<double, double>(*fd)
+                                                                           : (int64_t)arena_bytes<DualT<double>, DualT<double>>(*fd, true));
+}
 int forestsim_loss_f64(const ForestDesc* fd, const SolverOpts* opt, const double* theta, const double* friction, const double* lengths,
                        const double* x, const double* xp, int64_t B, const double* weights, double scale, double* loss, double* grad,
                        double* force, int32_t* iters) {

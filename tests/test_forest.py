@@ -1,0 +1,404 @@
+"""Systems beyond one short tree: several models in one system (``init_urdfs`` with more than one entry: the
+reference's ProductSpace of the models' spaces, collision candidates between the models), a model welded to the world
+(FixedBaseSpace), five joints, five geometries on one body, ten body-body candidates -- the FOREST build
+(csrc/dpll_forest.hpp: one program for the host checker and the device, csrc/dpll_forest.hip: one wave per item).
+
+Fixtures `{chain6, rake, two_cubes, pendulum_cube}_literal.npz` were recorded by running the reference's own MultibodyTerms /
+contactnets_loss / forward_dynamics / simulate on these systems (oracle/gen_golden.py record_forest_cases; the third-party
+pieces supplied by the oracle as for every other fixture).  CPU tests: the oracle and the host build of the forest program
+against them -- and the host build against EVERY other fixture model, which the forest program takes as well; GPU tests
+(`-m gpu`): the kernels through the C ABI."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ASSET_DIR
+from hostsim import forest
+from dair_pll_amd import _capi
+from dair_pll_amd.urdf import build_system_spec, check_forest_supported, parse_urdf
+from oracle import dpll_oracle as O
+
+P = 'multibody_terms.'
+FOREST = {'chain6': {'chain6': 'chain6.urdf'}, 'rake': {'rake': 'rake.urdf'}, 'two_cubes': {'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'},
+          'pendulum_cube': {'pendulum': 'pendulum.urdf', 'cube': 'cube.urdf'}}
+# the models of the specialised and general builds: (URDF, what a <mesh> is read as)
+OTHERS = {'cube_box': ('cube.urdf', 'deep_support'), 'elbow_box': ('elbow.urdf', 'deep_support'), 'chain3': ('chain3.urdf', 'deep_support'),
+          'gripper': ('gripper.urdf', 'deep_support'), 'polycube': ('cube_mesh.urdf', 'polygon'), 'clasp_ball': ('clasp_ball.urdf', 'polygon'),
+          'pincer': ('pincer.urdf', 'deep_support'), 'slider': ('slider.urdf', 'deep_support'), 'grasp': ('grasp.urdf', 'deep_support')}
+KEYS = {'box': 'length_params', 'sphere': 'length_param', 'polygon': 'vertices'}
+
+
+def urdfs_of(name):
+    if name in FOREST:
+        return {key: os.path.join(ASSET_DIR, value) for key, value in FOREST[name].items()}, 'deep_support'
+    urdf, representation = OTHERS[name]
+    return {name: os.path.join(ASSET_DIR, urdf)}, representation
+
+
+def system_spec_of(name):
+    urdfs, representation = urdfs_of(name)
+    return build_system_spec({key: parse_urdf(path, representation) for key, path in urdfs.items()})
+
+
+def fixture_params(g, system):
+    """(theta, friction, lengths) of the fixture in the forest build's layout"""
+    _, _, lengths = forest.params_of(system)
+    for index, (_, geom) in enumerate(system.geoms()):
+        value = g['param/' + P + f'contact_terms.geometries.{index + 1}.{KEYS[geom.kind]}'].ravel()
+        lengths[index, :len(value)] = value
+    return g['param/' + P + 'lagrangian_terms.inertial_parameters'].copy(), g['param/' + P + 'contact_terms.friction_params'].copy(), lengths
+
+
+def reference_gradient(g, system):
+    """the reference run's gradients as [theta | friction | lengths (n_geoms, 24)]"""
+    n_b, n_g = system.n_bodies, len(system.geoms())
+    out = np.zeros(10 * n_b + 1 + n_g + 24 * n_g)
+    out[:10 * n_b] = g['grad/' + P + 'lagrangian_terms.inertial_parameters'].ravel()
+    out[10 * n_b:10 * n_b + 1 + n_g] = g['grad/' + P + 'contact_terms.friction_params']
+    for index, (_, geom) in enumerate(system.geoms()):
+        value = g['grad/' + P + f'contact_terms.geometries.{index + 1}.{KEYS[geom.kind]}'].ravel()
+        out[10 * n_b + 1 + n_g + 24 * index:10 * n_b + 1 + n_g + 24 * index + len(value)] = value
+    return out
+
+
+def test_system_spec_of_several_models():
+    """state layout, candidates and limits of a system of several URDFs (drake_utils.py:309-335, state_space.py:650-730)"""
+    two = system_spec_of('two_cubes')
+    assert (two.n_q, two.n_v, two.n_bodies, two.n_contacts) == (14, 12, 2, 9) and two.pairs == [(0, 1)]
+    mixed = system_spec_of('pendulum_cube')  # a fixed-base model: joint coordinates only
+    assert (mixed.n_q, mixed.n_v, mixed.n_bodies) == (1 + 7, 1 + 6, 3) and mixed.models[0].fixed_base and not mixed.models[1].fixed_base
+    assert mixed.pairs == [(0, 2), (2, 1)]  # mast x cube; cube x tip, swapped into the reference's type order (box before sphere)
+    chain = system_spec_of('chain6')
+    assert (chain.n_q, chain.n_v, chain.n_contacts) == (12, 11, 24 + 10) and len(chain.pairs) == 10
+    desc = _capi.make_forest_desc(mixed, 0.0068)
+    assert [desc.joint_kind[b] for b in range(3)] == [_capi.JOINT_FIXED, 0, _capi.JOINT_FLOATING]
+    assert [desc.q_index[b] for b in range(3)] == [0, 0, 1] and [desc.v_index[b] for b in range(3)] == [0, 0, 1]
+    assert [desc.contact_geom[c] for c in range(desc.n_contacts)] == [0] * 4 + [1] + [2] * 4 + [-1, -1]
+    # limits: seventeen cubes are one body too many
+    many = build_system_spec({f'c{i}': parse_urdf(os.path.join(ASSET_DIR, 'cube.urdf')) for i in range(13)})
+    with pytest.raises(NotImplementedError):
+        check_forest_supported(many)
+    # the oracle's merged spec agrees on the layout and on the candidates (its geometry table counts the ground as 0)
+    urdfs, _ = urdfs_of('pendulum_cube')
+    merged = O.system_spec(urdfs)
+    assert O.state_sizes(merged) == (8, 7) and merged['pairs'] == [(a + 1, b + 1) for a, b in mixed.pairs]
+
+
+@pytest.mark.parametrize('name', list(FOREST))
+def test_oracle_reproduces_the_reference_run(golden, name):
+    g = golden(name + '_literal')
+    urdfs, _ = urdfs_of(name)
+    system = O.OracleSystem(urdfs, float(g['dt']))
+    system.theta = torch.tensor(g['param/' + P + 'lagrangian_terms.inertial_parameters'])
+    system.friction = torch.tensor(g['param/' + P + 'contact_terms.friction_params'])
+    system.requires_grad_()
+    x, xp = torch.tensor(g['x']), torch.tensor(g['x_plus'])
+    loss = system.contactnets_loss(x, xp)
+    assert (loss.detach() - torch.tensor(g['loss'])).abs().max() < 1e-11 * max(1.0, np.abs(g['loss']).max())
+    loss.mean().backward()
+    for key, value in system.named_parameters().items():
+        ref = g['grad/' + key]
+        assert np.abs(value.grad.numpy() - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), key
+    with torch.no_grad():
+        assert (system.step(x) - torch.tensor(g['dynamics/x_next'])).abs().max() < 1e-9
+
+
+@pytest.mark.parametrize('name', list(FOREST) + list(OTHERS))
+def test_host_build_of_the_forest_program_against_the_reference_run(golden, name):
+    """loss, every gradient, next state and terms of the forest program (team of one lane) against the reference-run
+    fixtures, float64 and float32 -- the four systems only the forest build takes and a sample of every other family"""
+    g = golden(name + '_literal')
+    system = system_spec_of(name)
+    desc = _capi.make_forest_desc(system, float(g['dt']), str(g['inertia_mode']))
+    theta, friction, lengths = fixture_params(g, system)
+    ref_grad = reference_gradient(g, system)
+    out = forest.loss(desc, theta, friction, lengths, g['x'], g['x_plus'])
+    assert np.abs(out['loss'] - g['loss']).max() < 1e-10 * max(1.0, np.abs(g['loss']).max())
+    assert np.abs(out['grad'] - ref_grad).max() < 1e-9 * max(1.0, np.abs(ref_grad).max())
+    x_next, iters = forest.step(desc, theta, friction, lengths, g['x'])
+    assert iters.max() < 60 and np.abs(x_next - g['dynamics/x_next']).max() < 1e-9 * max(1.0, np.abs(g['dynamics/x_next']).max())
+    M, a, phi, J = forest.terms(desc, theta, friction, lengths, g['x_plus'])
+    assert np.abs(M - g['terms/M']).max() < 1e-12 and np.abs(a - g['terms/a']).max() < 1e-9 * max(1.0, np.abs(g['terms/a']).max())
+    assert np.abs(np.sort(phi, -1) - np.sort(g['terms/phi'], -1)).max() < 1e-12  # (witness order within a geometry: quirk Q3)
+    # float32 storage (kinematics and signed distances in double, as the device build)
+    out32 = forest.loss(desc, theta, friction, lengths, g['x'], g['x_plus'], dtype=np.float32)
+    next32, _ = forest.step(desc, theta, friction, lengths, g['x'], dtype=np.float32)
+    assert np.abs(out32['loss'] - g['loss']).max() < 1e-4 * max(1.0, np.abs(g['loss']).max())
+    assert np.abs(out32['grad'] - ref_grad).max() < 2e-3 * max(1.0, np.abs(ref_grad).max())
+    assert np.abs(next32 - g['dynamics/x_next']).max() < 1e-4 * max(1.0, np.abs(g['dynamics/x_next']).max())
+
+
+@pytest.mark.parametrize('name', ['two_cubes', 'pendulum_cube', 'chain6'])
+def test_host_step_backward_is_the_derivative_of_the_step(golden, name):
+    """gradient of sum(w . step(x)) by the forest program's implicit differentiation: with respect to the state against
+    central differences of its own step (every component, the quaternions included), with respect to the parameters
+    against central differences in three directions of parameter space"""
+    g = golden(name + '_literal')
+    system = system_spec_of(name)
+    desc = _capi.make_forest_desc(system, float(g['dt']))
+    theta, friction, lengths = fixture_params(g, system)
+    rows = np.linspace(0, g['x'].shape[0] - 1, 3).astype(int)
+    x = g['x'][rows]
+    w = np.random.default_rng(0).standard_normal(x.shape)
+    grad, xbar = forest.step_backward(desc, theta, friction, lengths, x, w, want_state=True)
+    value = lambda th, fr, le, xx: (forest.step(desc, th, fr, le, xx)[0] * w).sum()
+    h = 1e-6
+    for item in range(len(rows)):
+        for k in range(x.shape[1]):
+            e = np.zeros_like(x)
+            e[item, k] = h
+            fd = (value(theta, friction, lengths, x + e) - value(theta, friction, lengths, x - e)) / (2 * h)
+            assert abs(fd - xbar[item, k]) <= 2e-5 * max(1.0, np.abs(xbar[item]).max()), (name, item, k, fd, xbar[item, k])
+    n_b, n_g = system.n_bodies, len(system.geoms())
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        d_th, d_fr = rng.standard_normal(theta.shape), rng.standard_normal(friction.shape)
+        d_le = np.zeros_like(lengths)
+        for index, (_, geom) in enumerate(system.geoms()):
+            d_le[index, :3 if geom.kind == 'box' else 1] = rng.standard_normal(3 if geom.kind == 'box' else 1)
+        h = 1e-7
+        fd = (value(theta + h * d_th, friction + h * d_fr, lengths + h * d_le, x) - value(theta - h * d_th, friction - h * d_fr, lengths - h * d_le, x)) / (2 * h)
+        mine = grad[:10 * n_b] @ d_th.ravel() + grad[10 * n_b:10 * n_b + 1 + n_g] @ d_fr + grad[10 * n_b + 1 + n_g:] @ d_le.ravel()
+        assert abs(fd - mine) <= 1e-4 * max(1.0, abs(mine)), (name, fd, mine)
+
+
+def test_forest_models_through_the_c_abi_without_a_gpu():
+    """dpll_forest_model_create validates the description; the size queries answer for a forest model"""
+    lib = _capi.library()
+    system = system_spec_of('two_cubes')
+    desc = _capi.make_forest_desc(system, 0.0068)
+    handle = ctypes.c_void_p()
+    assert lib.dpll_forest_model_create(ctypes.byref(desc), ctypes.byref(handle)) == 0
+    assert lib.dpll_n_x(handle) == 26 and lib.dpll_n_contacts(handle) == 9 and lib.dpll_param_count(handle) == 20 + 3 + 48
+    assert lib.dpll_racing_copies(handle, _capi.F32, 4096, 0) == 1
+    width = 1 + 20 + 2 + 1 + 48
+    rows = lib.dpll_workspace_bytes(handle, 4096) // 8 // (width + width % 2)
+    assert rows == 2048 + 32  # rows of the launch + the rows folded 64 at a time
+    params = _capi.Params(None, None, None)
+    assert lib.dpll_contactnets_loss(handle, _capi.F32, ctypes.byref(params), None, 26, None, 26, 4, None, 1.0, None, None, None, None, None,
+                                     None, 0, None) != 0 and b'null parameter pointer' in lib.dpll_last_error()
+    lib.dpll_model_destroy(handle)
+    for field, value, message in (('n_bodies', 17, b'bodies'), ('n_v', 13, b'n_q / n_v'), ('n_contacts', 8, b'contacts'), ('max_depth', 3, b'max_depth')):
+        bad = _capi.ForestDesc.from_buffer_copy(desc)
+        setattr(bad, field, value)
+        assert lib.dpll_forest_model_create(ctypes.byref(bad), ctypes.byref(handle)) != 0 and message in lib.dpll_last_error(), field
+    bad = _capi.ForestDesc.from_buffer_copy(desc)
+    bad.geom_kind[1] = 3  # a learned shape: the general build's
+    assert lib.dpll_forest_model_create(ctypes.byref(bad), ctypes.byref(handle)) != 0 and b'learned shapes' in lib.dpll_last_error()
+
+
+def test_system_of_several_urdfs_host_side():
+    """MultibodyLearnableSystem({...two URDFs...}): the reference's constructor argument (multibody_learnable_system.py:51-54);
+    parameter tree, state space and scalar names without touching a GPU"""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.state_space import ProductSpace
+    urdfs, _ = urdfs_of('pendulum_cube')
+    system = MultibodyLearnableSystem(urdfs, 0.0068, dtype=torch.float64, device='cpu')
+    assert system.forest and isinstance(system.space, ProductSpace) and (system.space.n_q, system.space.n_v) == (8, 7)
+    names = dict(system.named_parameters())
+    assert names[P + 'lagrangian_terms.inertial_parameters'].shape == (3, 10) and names[P + 'contact_terms.friction_params'].shape == (4,)
+    assert names[P + 'contact_terms.geometries.1.length_params'].shape == (1, 3) and names[P + 'contact_terms.geometries.2.length_param'].shape == ()
+    scalars = system.scalars()
+    assert {'pendulum_mast_m', 'pendulum_arm_radius', 'cube_body_len_x', 'cube_body_mu'} <= set(scalars)
+    # the Lie-group Euler step of the product space against the oracle's
+    oracle = O.OracleSystem(urdfs, 0.0068)
+    x = torch.randn(5, 15, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    x[:, 1:5] /= x[:, 1:5].norm(dim=-1, keepdim=True)
+    v_next = torch.randn(5, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    mine = system.space.euler_step(x[:, :8], v_next, 0.0068)
+    oracle.forward_dynamics = lambda q, v: v_next
+    assert torch.allclose(mine, oracle.step(x)[:, :8], atol=1e-15)
+    with pytest.raises(_capi.DpllError):  # no CPU fallback
+        system.contactnets_loss(x, torch.zeros(5, 0), x)
+    # one model inside the general build's limits stays there unless asked otherwise
+    assert not MultibodyLearnableSystem({'c': os.path.join(ASSET_DIR, 'chain3.urdf')}, 0.0068, device='cpu').forest
+    assert MultibodyLearnableSystem({'c': os.path.join(ASSET_DIR, 'chain6.urdf')}, 0.0068, device='cpu').forest
+
+
+# ---- the kernels (MI355X) ---------------------------------------------------------------------------------------------------------
+def gpu_system(g, name, dtype, build='auto'):
+    from dair_pll_amd import MultibodyLearnableSystem
+    urdfs, representation = urdfs_of(name)
+    system = MultibodyLearnableSystem(urdfs, float(g['dt']), dtype=dtype, device='cuda:0', mesh_representation=representation, build=build)
+    system.load_state_dict({key: torch.tensor(g['param/' + key]) for key, _ in system.named_parameters()})
+    return system
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
+@pytest.mark.parametrize('name', list(FOREST))
+def test_gpu_forest_matches_the_reference_run(golden, name, dtype):
+    """loss, every gradient, next state, rollouts and terms of the four systems through the C ABI; tolerances of north_star:
+    1e-10 / 1e-4 on loss and next state (relative to the batch's largest value for chain6, whose tosses reach losses of 10)"""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, dtype)
+    assert system.forest
+    f64 = dtype == torch.float64
+    x, xp = (torch.tensor(g[key], dtype=dtype, device='cuda:0') for key in ('x', 'x_plus'))
+    u = torch.zeros((x.shape[0], 0), device='cuda:0')
+    loss = system.contactnets_loss(x, u, xp)
+    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4) * max(1.0, np.abs(g['loss']).max())
+    loss.mean().backward()
+    for key, param in system.named_parameters():
+        ref = g['grad/' + key]
+        assert np.abs(param.grad.cpu().double().numpy() - ref).max() <= (1e-9 if f64 else 2e-3) * max(1.0, np.abs(ref).max()), key
+    with torch.no_grad():
+        nxt = system.step(x)
+        rows = g['simulate/rows']
+        traj, _ = system.simulate(x[rows].unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), int(g['simulate/steps']))
+        q, v = system.space.q_v(xp)
+        D, M, J, phi, a = system.multibody_terms(q, v, u)
+    tol = 1e-9 if f64 else 1e-4
+    assert np.abs(nxt.cpu().double().numpy() - g['dynamics/x_next']).max() < tol * max(1.0, np.abs(g['dynamics/x_next']).max())
+    assert np.abs(traj.cpu().double().numpy() - g['simulate/traj']).max() < (1e-8 if f64 else 1e-3) * max(1.0, np.abs(g['simulate/traj']).max())
+    k = system.spec.n_contacts
+    assert D.shape[1:] == (3 * k, 3 * k) and J.shape[1:] == (3 * k, system.space.n_v) and phi.shape[1:] == (k,)
+    assert np.abs(M.cpu().double().numpy() - g['terms/M']).max() < (1e-12 if f64 else 1e-5)
+    assert np.abs(a.cpu().double().numpy() - g['terms/a']).max() < (1e-9 if f64 else 2e-3) * max(1.0, np.abs(g['terms/a']).max())
+    assert np.abs(np.sort(phi.cpu().double().numpy(), -1) - np.sort(g['terms/phi'], -1)).max() < (1e-12 if f64 else 1e-5)
+    # (contacts of one geometry come in the kernels' order, quirk Q3: the spectrum of D and the normal rows' norms do not care)
+    eig = lambda m: np.sort(np.linalg.eigvalsh(0.5 * (m + np.swapaxes(m, -1, -2))), -1)
+    assert np.abs(eig(D.cpu().double().numpy()) - eig(g['terms/D'])).max() < (1e-8 if f64 else 2e-2) * max(1.0, np.abs(eig(g['terms/D'])).max())
+    norms = lambda j: np.sort(np.linalg.norm(j[:, :k], axis=-1), -1)
+    assert np.abs(norms(J.cpu().double().numpy()) - norms(g['terms/J'])).max() < (1e-10 if f64 else 1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cube_box', 'chain3', 'gripper', 'clasp_ball', 'pincer', 'slider'])
+def test_gpu_forest_build_takes_the_other_builds_models(golden, name):
+    """the forest kernels (build='forest') on models of the specialised and general builds against the same reference-run
+    fixtures: one program for every system the reference takes"""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, torch.float64, build='forest')
+    x, xp = (torch.tensor(g[key], device='cuda:0') for key in ('x', 'x_plus'))
+    loss = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp)
+    assert np.abs(loss.detach().cpu().numpy() - g['loss']).max() < 1e-10 * max(1.0, np.abs(g['loss']).max())
+    loss.mean().backward()
+    for key, param in system.named_parameters():
+        assert np.abs(param.grad.cpu().numpy() - g['grad/' + key]).max() <= 1e-9 * max(1.0, np.abs(g['grad/' + key]).max()), key
+    with torch.no_grad():
+        assert np.abs(system.step(x).cpu().numpy() - g['dynamics/x_next']).max() < 1e-9 * max(1.0, np.abs(g['dynamics/x_next']).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['two_cubes', 'pendulum_cube', 'chain6'])
+def test_gpu_forest_step_backward_and_rollout_gradients(golden, name):
+    """the step's backward on the device (parameters and state) against the host build of the same program; a 3-step rollout's
+    gradient through torch autograd (one node per step) against the oracle's autograd"""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, torch.float64)
+    rows = np.linspace(0, g['x'].shape[0] - 1, 12).astype(int)
+    x_np = g['x'][rows]
+    w = torch.randn(x_np.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    x = torch.tensor(x_np, device='cuda:0').requires_grad_(True)
+    (system.step(x) * w.cuda()).sum().backward()
+    spec = system.spec
+    theta, friction, lengths = fixture_params(g, spec)
+    host_grad, host_xbar = forest.step_backward(system._desc, theta, friction, lengths, x_np, w.numpy(), want_state=True)
+    mine = np.concatenate([p.grad.reshape(-1).cpu().numpy() for p in system._param_list()])
+    host = np.concatenate([host_grad[off:off + p.numel()] for p, off in system._layout()[0]])
+    assert np.abs(mine - host).max() <= 1e-9 * max(1.0, np.abs(host).max())
+    assert np.abs(x.grad.cpu().numpy() - host_xbar).max() <= 1e-9 * max(1.0, np.abs(host_xbar).max())
+    # float32 storage: the same kernel in double arithmetic on rounded inputs
+    s32 = gpu_system(g, name, torch.float32)
+    x32 = torch.tensor(x_np, dtype=torch.float32, device='cuda:0').requires_grad_(True)
+    (s32.step(x32) * w.float().cuda()).sum().backward()
+    mine32 = np.concatenate([p.grad.reshape(-1).double().cpu().numpy() for p in s32._param_list()])
+    assert np.isfinite(mine32).all() and np.abs(mine32 - host).max() <= 5e-2 * max(1.0, np.abs(host).max())
+    # rollout gradient against the oracle (three steps; the state adjoint carries the gradient from step to step)
+    urdfs, _ = urdfs_of(name)
+    oracle = O.OracleSystem(urdfs, float(g['dt']))
+    oracle.theta = torch.tensor(g['param/' + P + 'lagrangian_terms.inertial_parameters'])
+    oracle.friction = torch.tensor(g['param/' + P + 'contact_terms.friction_params'])
+    oracle.requires_grad_()
+    few = x_np[:4]
+    w3 = torch.randn((4, 3, few.shape[1]), generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    ref_traj = oracle.simulate(torch.tensor(few), 3)
+    (ref_traj[:, 1:] * w3).sum().backward()
+    system.zero_grad()
+    traj, _ = system.simulate(torch.tensor(few, device='cuda:0').unsqueeze(-2), torch.zeros((4, 1), device='cuda:0'), 3)
+    (traj[:, 1:] * w3.cuda()).sum().backward()
+    ref_named = oracle.named_parameters()
+    for key, param in system.named_parameters():
+        ref = ref_named[key].grad.numpy()
+        assert np.abs(param.grad.cpu().numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), key
+
+
+@pytest.mark.gpu
+def test_gpu_forest_batch_sizes_and_workspace():
+    """an item's results do not depend on the batch it sits in (1, 3, 2049, 5000 items: fewer items than workgroups, exactly
+    one each, a looped grid); the gradient of a mean over a tiled batch is the batch's; the workspace is exactly what
+    dpll_workspace_bytes says (canaries around it); an empty shard returns zeros"""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'two_cubes_literal.npz'))
+    system = gpu_system(g, 'two_cubes', torch.float64)
+    x, xp = (torch.tensor(g[key], device='cuda:0') for key in ('x', 'x_plus'))
+    u = lambda t: torch.zeros(t.shape[:-1] + (0,), device='cuda:0')
+    with torch.no_grad():
+        base_loss, base_next = system.contactnets_loss(x, u(x), xp), system.step(x)
+    gen = torch.Generator().manual_seed(4)
+    for size in (1, 3, 2049, 5000):
+        pick = torch.randint(0, x.shape[0], (size,), generator=gen).cuda()
+        with torch.no_grad():
+            loss, nxt = system.contactnets_loss(x[pick], u(x[pick]), xp[pick]), system.step(x[pick])
+        assert torch.equal(loss, base_loss[pick]) and torch.equal(nxt, base_next[pick])
+
+    def grads(xb, xpb):
+        system.zero_grad()
+        system.contactnets_loss(xb, u(xb), xpb).mean().backward()
+        return torch.cat([p.grad.reshape(-1) for p in system._param_list()]).clone()
+    whole, tiled = grads(x, xp), grads(x.repeat(40, 1), xp.repeat(40, 1))
+    assert (tiled - whole).abs().max() <= 1e-12 * max(1.0, whole.abs().max().item())
+    lib = _capi.library()
+    flat = system._packed()
+    params = system._params_struct(flat)
+    for batch in (1, 96, 2049):
+        pick = torch.arange(batch, device='cuda:0') % x.shape[0]
+        xb, xpb = x[pick].contiguous(), xp[pick].contiguous()
+        need = lib.dpll_workspace_bytes(system._model(), batch)
+        arena = torch.full((need + 8192,), 0xA5, dtype=torch.uint8, device='cuda:0')
+        ws = arena[4096:4096 + need]
+        grad, total = torch.zeros(flat.numel(), dtype=torch.float64, device='cuda:0'), torch.zeros(1, dtype=torch.float64, device='cuda:0')
+        _capi.check(lib.dpll_contactnets_loss(system._model(), _capi.F64, ctypes.byref(params), xb.data_ptr(), xb.stride(0), xpb.data_ptr(),
+                                              xpb.stride(0), batch, None, 1.0 / batch, None, grad.data_ptr(), total.data_ptr(), None, None,
+                                              ws.data_ptr(), need, system._stream()))
+        torch.cuda.synchronize()
+        assert (arena[:4096] == 0xA5).all() and (arena[4096 + need:] == 0xA5).all() and torch.isfinite(grad).all()
+        assert lib.dpll_contactnets_loss(system._model(), _capi.F64, ctypes.byref(params), xb.data_ptr(), xb.stride(0), xpb.data_ptr(),
+                                         xpb.stride(0), batch, None, 1.0 / batch, None, grad.data_ptr(), total.data_ptr(), None, None,
+                                         ws.data_ptr(), need - 1, system._stream()) != 0
+    # an empty shard of a data-parallel batch: zero row, zero gradient
+    _capi.check(lib.dpll_contactnets_loss(system._model(), _capi.F64, ctypes.byref(params), None, 26, None, 26, 0, None, 1.0, None, grad.data_ptr(),
+                                          total.data_ptr(), None, None, ws.data_ptr(), need, system._stream()))
+    torch.cuda.synchronize()
+    assert total.item() == 0.0 and (grad == 0).all()
+
+
+@pytest.mark.gpu
+def test_gpu_two_cubes_learn_their_size_from_a_collision():
+    """end to end on a system of two URDFs: tosses simulated with the true parameters, a model whose second cube starts 15 %
+    too large; the ContactNets loss falls under the trainer's Adam and the half lengths move towards the truth"""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.trainer import ContactNetsTrainer
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'two_cubes_literal.npz'))
+    urdfs, _ = urdfs_of('two_cubes')
+    truth = MultibodyLearnableSystem(urdfs, float(g['dt']), dtype=torch.float64, device='cuda:0')
+    x0 = torch.tensor(g['x'][::3], device='cuda:0')
+    with torch.no_grad():
+        traj, _ = truth.simulate(x0.unsqueeze(-2), torch.zeros((x0.shape[0], 1), device='cuda:0'), 12)
+    x, xp = traj[:, :-1].reshape(-1, 26), traj[:, 1:].reshape(-1, 26)
+    model = MultibodyLearnableSystem(urdfs, float(g['dt']), dtype=torch.float64, device='cuda:0')
+    with torch.no_grad():
+        model.multibody_terms.contact_terms.geometries[2].length_params.mul_(1.15)
+    u = torch.zeros((x.shape[0], 0), device='cuda:0')
+    with torch.no_grad():
+        first = model.contactnets_loss(x, u, xp).mean().item()
+    trainer = ContactNetsTrainer(model, lr=2e-3, batch_size=128)
+    trainer.fit(x, xp, epochs=30)
+    with torch.no_grad():
+        last = model.contactnets_loss(x, u, xp).mean().item()
+    half = model.multibody_terms.contact_terms.geometries[2].length_params.abs().mean().item()
+    assert last < 0.5 * first, (first, last)
+    assert abs(half - 0.0524) < abs(1.15 * 0.0524 - 0.0524), half
