@@ -24,7 +24,8 @@ ABI_VERSION = 21  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdpll_hip.so')
+# (DPLL_HIP_LIBRARY: a diagnostic knob -- tools/diag A/B runs load another build of the same library; never a fallback)
+LIB_PATH = os.environ.get('DPLL_HIP_LIBRARY') or os.path.join(_HERE, 'csrc', 'libdpll_hip.so')
 
 
 class ModelDesc(ctypes.Structure):

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 #include "dpll_common.hpp"
 #include "dpll_forest.hpp"
@@ -45,15 +46,28 @@ struct WaveLanes {  // the lane-group policy of dpll_core.hpp's direction search
     }
   }
 };
-struct WaveTeam {
-  static constexpr int kSize = kWave;
-  static __device__ __forceinline__ int rank() { return (int)threadIdx.x; }
+// The team that works on an item: the whole wavefront (G = 64: one item per wave) or a 16-lane DPP row (G = 16: four items per
+// wave, for systems small enough that most phases would leave three quarters of a wave idle).  Barriers are workgroup barriers
+// either way (one wave per workgroup): teams of one wave walk through every phase together.
+template <int G> struct GroupTeam {
+  static_assert(G == 16 || G == kWave, "a DPP row or the whole wave");
+  static constexpr int kSize = G;
+  static constexpr int kTeams = kWave / G;
+  static __device__ __forceinline__ int rank() { return (int)(threadIdx.x & (G - 1)); }
+  static __device__ __forceinline__ int team() { return (int)(threadIdx.x / G); }
   static __device__ __forceinline__ void sync() { __syncthreads(); }
-  static __device__ __forceinline__ float sum(float x) { return wave_sum_of_groups<1>(x); }
-  static __device__ __forceinline__ double sum(double x) { return wave_sum_of_groups<1>(x); }
-  static __device__ __forceinline__ bool any(bool x) { return __any(x) != 0; }
-  using Lanes = WaveLanes;
+  template <typename T> static __device__ __forceinline__ T sum(T x) {
+    if constexpr (G == kWave) return wave_sum_of_groups<1>(x);
+    else return GpuLanes<16>::group_sum(x);
+  }
+  static __device__ __forceinline__ bool any(bool x) {
+    if constexpr (G == kWave) return __any(x) != 0;
+    else return GpuLanes<16>::group_any(x);
+  }
+  static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
+  using Lanes = typename std::conditional<G == kWave, WaveLanes, GpuLanes<16>>::type;
 };
+using WaveTeam = GroupTeam<kWave>;
 
 // the description from device memory into LDS, by the whole wave
 __device__ __forceinline__ void fetch_desc(const ForestDesc* __restrict__ src, ForestDesc& dst) {
@@ -65,35 +79,47 @@ __device__ __forceinline__ void fetch_desc(const ForestDesc* __restrict__ src, F
 
 extern __shared__ __align__(16) char forest_smem[];
 
+// waves per SIMD the item kernels are compiled for (register budget 512 / this): an item's wave spends most of its time waiting
+// on LDS round trips and barriers, so resident waves -- not registers per wave -- are what fills a SIMD
+#ifndef DPLL_FOREST_OCC
+#define DPLL_FOREST_OCC 2
+#endif
+
 // ---- ContactNets loss, forward + backward ------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kWave) void forest_loss_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
+// G: lanes per item (16: four items per wave; 64: one).  LDS: [the teams' partial rows | the teams' arenas]
+template <typename T, int G>
+__global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_loss_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
                                                             const T* __restrict__ friction, const T* __restrict__ lengths,
                                                             const T* __restrict__ x, long long ld_x, const T* __restrict__ xp, long long ld_xp,
                                                             long long batch, const T* __restrict__ weights, double scale, T* __restrict__ loss,
                                                             T* __restrict__ force, int* __restrict__ iters, double* __restrict__ partials,
-                                                            int want_grad, int row_stride) {
+                                                            int want_grad, int row_stride, unsigned arena_stride) {
+  using Team = GroupTeam<G>;
   __shared__ ForestDesc fd;
   fetch_desc(fdp, fd);
-  const int width = row_width(fd);
-  double* row = reinterpret_cast<double*>(forest_smem);
+  const int width = row_width(fd), team = Team::team(), rank = Team::rank();
+  const size_t row_bytes = ((size_t)width * sizeof(double) + 15) & ~(size_t)15;
+  double* row = reinterpret_cast<double*>(forest_smem + (size_t)team * row_bytes);
   Arena<T, double> A;
-  A.carve(forest_smem + (((size_t)width * sizeof(double) + 15) & ~(size_t)15), fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
-  for (int e = threadIdx.x; e < width; e += kWave) row[e] = 0.0;
-  Forest<T, double, WaveTeam> prog(fd, A);
+  A.carve(forest_smem + Team::kTeams * row_bytes + (size_t)team * arena_stride, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  for (int e = rank; e < width; e += G) row[e] = 0.0;
+  Forest<T, double, Team> prog(fd, A);
   prog.derive(theta, friction, lengths);
   const int K = fd.n_contacts;
-  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
-    const T w = T(scale) * (weights ? weights[item] : T(1));
+  for (long long base = (long long)blockIdx.x * Team::kTeams; base < batch; base += (long long)gridDim.x * Team::kTeams) {
+    const long long mine = base + team;
+    const bool valid = mine < batch;
+    const long long item = valid ? mine : batch - 1;  // (an idle team shadows the last item with weight zero: it meets every barrier)
+    const T w = valid ? T(scale) * (weights ? weights[item] : T(1)) : T(0);
     int n_it = 0;
     const T L = prog.loss(x + item * ld_x, xp + item * ld_xp, lengths, opt, w, want_grad != 0, row, n_it);
-    if (threadIdx.x == 0) {
+    if (valid && rank == 0) {
       if (loss) loss[item] = L;
       if (iters) iters[item] = n_it;
     }
-    if (force) {  // reference ordering: normals, then (t_x, t_y) per contact (multibody_terms.py:415-426)
+    if (force && valid) {  // reference ordering: normals, then (t_x, t_y) per contact (multibody_terms.py:415-426)
       T* dst = force + item * (3 * K);
-      for (int c = threadIdx.x; c < K; c += kWave) {
+      for (int c = rank; c < K; c += G) {
         dst[c] = A.force[3 * c + 2];
         dst[K + 2 * c] = A.force[3 * c];
         dst[K + 2 * c + 1] = A.force[3 * c + 1];
@@ -103,7 +129,11 @@ __global__ __launch_bounds__(kWave) void forest_loss_kernel(const ForestDesc* __
   }
   if (!want_grad) return;
   __syncthreads();
-  for (int e = threadIdx.x; e < width; e += kWave) partials[(long long)blockIdx.x * row_stride + e] = row[e];
+  for (int e = threadIdx.x; e < width; e += kWave) {  // the teams' rows in team order: one row per workgroup
+    double v = 0.0;
+    for (int t = 0; t < Team::kTeams; ++t) v += reinterpret_cast<const double*>(forest_smem + (size_t)t * row_bytes)[e];
+    partials[(long long)blockIdx.x * row_stride + e] = v;
+  }
 }
 
 // ---- rows -> parameters: blocks of kFold rows are summed first, the finalize kernel sums those and applies the chain ------------
@@ -151,37 +181,47 @@ __global__ __launch_bounds__(kRowThreads) void forest_finalize_kernel(const Fore
 }
 
 // ---- simulation: `steps` VelocityIntegrator steps per item, the current state in LDS ---------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kWave) void forest_simulate_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
+template <typename T, int G>
+__global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_simulate_kernel(const ForestDesc* __restrict__ fdp, SolverOpts opt, const T* __restrict__ theta,
                                                                 const T* __restrict__ friction, const T* __restrict__ lengths,
                                                                 const T* __restrict__ x0, long long ld_x, long long batch, long long steps,
                                                                 T* __restrict__ out, long long ld_item, long long ld_step, int write_x0,
-                                                                int* __restrict__ iters) {
+                                                                int* __restrict__ iters, unsigned arena_stride) {
+  using Team = GroupTeam<G>;
   __shared__ ForestDesc fd;
   fetch_desc(fdp, fd);
-  const int nx = fd.n_q + fd.n_v;
-  T* cur = reinterpret_cast<T*>(forest_smem);
+  const int nx = fd.n_q + fd.n_v, team = Team::team(), rank = Team::rank();
+  const size_t state_bytes = ((size_t)2 * nx * sizeof(T) + 15) & ~(size_t)15;
+  T* cur = reinterpret_cast<T*>(forest_smem + (size_t)team * state_bytes);
   T* nxt = cur + nx;
   Arena<T, double> A;
-  A.carve(forest_smem + (((size_t)2 * nx * sizeof(T) + 15) & ~(size_t)15), fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
-  Forest<T, double, WaveTeam> prog(fd, A);
+  A.carve(forest_smem + Team::kTeams * state_bytes + (size_t)team * arena_stride, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
+  Forest<T, double, Team> prog(fd, A);
   prog.derive(theta, friction, lengths);
-  for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
-    for (int i = threadIdx.x; i < nx; i += kWave) cur[i] = x0[item * ld_x + i];
+  for (long long base = (long long)blockIdx.x * Team::kTeams; base < batch; base += (long long)gridDim.x * Team::kTeams) {
+    const long long mine = base + team;
+    const bool valid = mine < batch;
+    const long long item = valid ? mine : batch - 1;
+    for (int i = rank; i < nx; i += G) cur[i] = x0[item * ld_x + i];
     __syncthreads();
     T* dst = out + item * ld_item;
     if (write_x0) {
-      for (int i = threadIdx.x; i < nx; i += kWave) dst[i] = cur[i];
+      if (valid)
+        for (int i = rank; i < nx; i += G) dst[i] = cur[i];
       dst += ld_step;
     }
     int total = 0;
     for (long long s = 0; s < steps; ++s) {
       total += prog.step(cur, lengths, opt, nxt);
-      for (int i = threadIdx.x; i < nx; i += kWave) { const T v = nxt[i]; cur[i] = v; dst[i] = v; }
+      for (int i = rank; i < nx; i += G) {
+        const T v = nxt[i];
+        cur[i] = v;
+        if (valid) dst[i] = v;
+      }
       __syncthreads();
       dst += ld_step;
     }
-    if (iters && threadIdx.x == 0) iters[item] = total;
+    if (iters && valid && rank == 0) iters[item] = total;
   }
 }
 
@@ -285,17 +325,29 @@ const ForestDesc* device_desc(const dpll_model* m) {
 }
 
 int stride_of(const ForestDesc& fd) { return (row_width(fd) + 1) & ~1; }
-int grid_for(long long batch, size_t lds_bytes) {
-  // workgroups that can be resident at once (160 KB of LDS per CU, at most 8 one-wave workgroups per CU), capped at the batch
+// Lanes per item of the loss and rollout launches: four items per wave (16 lanes each) for the smallest systems (cube- and
+// elbow-sized: 4096 cube pairs 261 -> 161 us per loss + gradients); else the whole wave on one item -- four items per wave pay for
+// the slowest of the four at every iteration and take four passes where 64 lanes take one (two cubes 580 -> 860 us, gripper
+// 482 -> 598 us: measured)
+template <typename T> int lanes_per_item(const ForestDesc& fd) {
+  const size_t arena = arena_bytes<T, double>(fd);
+  return (4 * arena <= 96 * 1024 && fd.n_contacts <= 8 && fd.n_v <= 8) ? 16 : kWave;
+}
+int grid_for(long long batch, size_t lds_bytes, int items_per_wave = 1) {
+  batch = (batch + items_per_wave - 1) / items_per_wave;
+  // workgroups that can be resident at once (160 KB of LDS per CU, DPLL_FOREST_OCC one-wave workgroups per SIMD), capped at the batch
   long long per_cu = (long long)((160 * 1024) / (lds_bytes + sizeof(ForestDesc) + 256));
   if (per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
+  if (per_cu > 4 * DPLL_FOREST_OCC) per_cu = 4 * DPLL_FOREST_OCC;
   long long blocks = 256 * per_cu;
   if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
   if (blocks > batch) blocks = batch;
   return (int)(blocks < 1 ? 1 : blocks);
 }
 long long folded_rows(long long rows) { return (rows + kFold - 1) / kFold; }
+// rows a gradient launch may write, whatever the batch, dtype and lanes per item: what the workspace is laid out for
+// ([rows (max_rows) | folded rows])
+int max_rows(const ForestDesc&) { return kMaxLossBlocks; }
 
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* who) {
   if (bytes + sizeof(ForestDesc) + 4096 > 160 * 1024) return dpll_fail(-2, "%s: the model needs more LDS per item than a CU has", who);
@@ -318,18 +370,28 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   } else if (loss_total) {
     return dpll_fail(-3, "dpll_contactnets_loss: loss_total requires grad%s");
   }
-  const size_t lds = round16((size_t)row_width(fd) * sizeof(double)) + arena_bytes<T, double>(fd);
-  if (int rc = allow_lds(forest_loss_kernel<T>, lds, "dpll_contactnets_loss")) return rc;
-  const int rows = batch > 0 ? grid_for(batch, lds) : 0;
+  const int lanes = lanes_per_item<T>(fd), teams = kWave / lanes;
+  const size_t arena = arena_bytes<T, double>(fd);
+  const size_t lds = teams * (round16((size_t)row_width(fd) * sizeof(double)) + arena);
+  if (lanes == 16) {
+    if (int rc = allow_lds(forest_loss_kernel<T, 16>, lds, "dpll_contactnets_loss")) return rc;
+  } else {
+    if (int rc = allow_lds(forest_loss_kernel<T, kWave>, lds, "dpll_contactnets_loss")) return rc;
+  }
+  const int rows = batch > 0 ? grid_for(batch, lds, teams) : 0;
   const int stride = stride_of(fd);
   if (rows > 0) {
-    hipLaunchKernelGGL((forest_loss_kernel<T>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[dtype], (const T*)p->theta, (const T*)p->friction,
-                       (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)weights, scale, (T*)loss, (T*)force,
-                       (int*)iters, (double*)workspace, want_grad, stride);
+#define DPLL_FOREST_LOSS(G_)                                                                                                                    \
+    hipLaunchKernelGGL((forest_loss_kernel<T, G_>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[dtype], (const T*)p->theta,                \
+                       (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)weights, scale,   \
+                       (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad, stride, (unsigned)arena)
+    if (lanes == 16) DPLL_FOREST_LOSS(16);
+    else DPLL_FOREST_LOSS(kWave);
+#undef DPLL_FOREST_LOSS
     if (int rc = dpll_check_launch("forest_loss_kernel")) return rc;
   }
   if (!want_grad) return 0;
-  double* folded = (double*)workspace + (long long)grid_for(batch > 0 ? batch : 1, lds) * stride;
+  double* folded = (double*)workspace + (long long)max_rows(fd) * stride;
   const int n_folded = (int)folded_rows(rows);
   if (n_folded > 0) {
     hipLaunchKernelGGL(forest_fold_kernel, dim3(n_folded), dim3(kRowThreads), 0, stream, (const double*)workspace, rows, row_width(fd), stride, folded);
@@ -346,10 +408,19 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   const ForestDesc& fd = host_desc(m);
   const ForestDesc* dev = device_desc(m);
   if (!dev) return dpll_fail(-5, "dpll_simulate (forest build): could not place the model description on the device%s");
-  const size_t lds = round16((size_t)2 * (fd.n_q + fd.n_v) * sizeof(T)) + arena_bytes<T, double>(fd);
-  if (int rc = allow_lds(forest_simulate_kernel<T>, lds, "dpll_simulate")) return rc;
-  hipLaunchKernelGGL((forest_simulate_kernel<T>), dim3(grid_for(batch, lds)), dim3(kWave), lds, stream, dev, m->opts[dtype], (const T*)p->theta,
-                     (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps, (T*)out, ld_item, ld_step, write_x0, (int*)iters);
+  const int lanes = lanes_per_item<T>(fd), teams = kWave / lanes;
+  const size_t arena = arena_bytes<T, double>(fd);
+  const size_t lds = teams * (round16((size_t)2 * (fd.n_q + fd.n_v) * sizeof(T)) + arena);
+#define DPLL_FOREST_SIM(G_)                                                                                                                     \
+  do {                                                                                                                                          \
+    if (int rc = allow_lds(forest_simulate_kernel<T, G_>, lds, "dpll_simulate")) return rc;                                                      \
+    hipLaunchKernelGGL((forest_simulate_kernel<T, G_>), dim3(grid_for(batch, lds, teams)), dim3(kWave), lds, stream, dev, m->opts[dtype],         \
+                       (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps, (T*)out, ld_item,      \
+                       ld_step, write_x0, (int*)iters, (unsigned)arena);                                                                         \
+  } while (0)
+  if (lanes == 16) DPLL_FOREST_SIM(16);
+  else DPLL_FOREST_SIM(kWave);
+#undef DPLL_FOREST_SIM
   return dpll_check_launch("forest_simulate_kernel");
 }
 
@@ -367,10 +438,9 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
   } else {
     if (int rc = allow_lds(forest_step_backward_kernel<T, false>, lds, "dpll_step_backward")) return rc;
   }
-  // (rows: never more than the loss launch of the same batch writes -- the workspace is sized for those)
-  const size_t loss_lds = round16((size_t)row_width(fd) * sizeof(double)) + arena_bytes<float, double>(fd);
+  // (rows: never more than the workspace is sized for)
   int rows = grid_for(batch, lds);
-  const int cap = grid_for(batch, loss_lds);
+  const int cap = max_rows(fd);
   if (rows > cap) rows = cap;
   const int stride = stride_of(fd);
   if (grad_x)
@@ -466,8 +536,8 @@ int n_contacts(const dpll_model* m) { return m->forest->n_contacts; }
 int param_count(const dpll_model* m) { return dpll_forest::param_count(*m->forest); }
 long long workspace_bytes(const dpll_model* m, long long batch) {
   const ForestDesc& fd = *m->forest;
-  const size_t lds = round16((size_t)row_width(fd) * sizeof(double)) + arena_bytes<float, double>(fd);  // (the launch with the most rows)
-  const long long rows = grid_for(batch > 0 ? batch : 1, lds);
+  (void)batch;
+  const long long rows = max_rows(fd);
   return (rows + folded_rows(rows)) * stride_of(fd) * (long long)sizeof(double);
 }
 void release(dpll_model* m) {

@@ -65,6 +65,7 @@ struct HostTeam {
   static DPLL_HD void sync() {}
   template <typename T> static DPLL_HD T sum(T x) { return x; }
   static DPLL_HD bool any(bool x) { return x; }
+  static DPLL_HD bool wave_any(bool x) { return x; }  // over every team that shares the wavefront (the device: 1 or 4 teams)
   using Lanes = OneLane;  // the lane-group policy dpll_core.hpp's direction search takes
 };
 
@@ -118,6 +119,7 @@ template <typename S, typename SA> struct Arena {
   S *tw;                                // body twists of up to four vectors [4][nb][6]
   S *scal;                              // a few scalars shared by the team
   S *cphi, *cmu;                        // the contacts' signed distances and friction coefficients (also in the records)
+  short *tri_i, *tri_j;                 // entry e of a lower triangle in row-major order -> (row, column); filled by derive()
   // lite: an arena for terms + contact geometry only (the dual passes of the state adjoint): no contact records, no solver
   // or adjoint blocks
   DPLL_HD size_t carve(char* base, int nb_, int nv_, int nq_, int K_, int ng_, int np_, bool lite = false) {
@@ -139,6 +141,7 @@ template <typename S, typename SA> struct Arena {
       tmp = m.take<S>(nv); vp = m.take<S>(nv);
       tw = m.take<S>((size_t)nb * 6);
       cphi = m.take<S>(K); cmu = m.take<S>(K);
+      tri_i = m.take<short>(nv * (nv + 1) / 2); tri_j = m.take<short>(nv * (nv + 1) / 2);
       return (m.off + 15) & ~(size_t)15;
     }
     q = m.take<SA>(nq); v = m.take<S>(nv);
@@ -160,6 +163,7 @@ template <typename S, typename SA> struct Arena {
     tw = m.take<S>((size_t)4 * nb * 6);
     scal = m.take<S>(16);
     cphi = m.take<S>(K); cmu = m.take<S>(K);
+    tri_i = m.take<short>(nv * (nv + 1) / 2); tri_j = m.take<short>(nv * (nv + 1) / 2);
     return (m.off + 15) & ~(size_t)15;
   }
 };
@@ -223,6 +227,8 @@ template <typename S, typename SA, class Team> struct Forest {
       const S ma = cst<S>(fabs(double(friction[1 + fd.pair_a[p]]))), mb = cst<S>(fabs(double(friction[1 + fd.pair_b[p]])));
       A.mu_p[p] = S(2) * ma * mb / (ma + mb);
     }
+    for (int i = Team::rank(); i < A.nv; i += Team::kSize)
+      for (int j = 0; j <= i; ++j) { A.tri_i[i * (i + 1) / 2 + j] = (short)i; A.tri_j[i * (i + 1) / 2 + j] = (short)j; }
     Team::sync();
   }
 
@@ -484,7 +490,11 @@ template <typename S, typename SA, class Team> struct Forest {
   }
 
   // ---- dense symmetric positive definite n x n (row-major, lower triangle used): the wave factors column by column ----------------
-  // L overwrites the strict lower triangle of Aio, invd = 1 / diag(L); `fast`: the 1-ulp reciprocal square root of the float build
+  // L overwrites the strict lower triangle of Aio, invd = 1 / diag(L); `fast`: the 1-ulp reciprocal square root of the float build.
+  // Then the factor is INVERTED into the strict upper triangle (entry (j, i), j < i, holds (L^-1)[i][j]; its diagonal is invd):
+  // column j of L^-1 is one lane's forward substitution, no barrier between the columns -- and every solve with the factor
+  // is two matrix-vector products (two barriers) instead of 2 n dependent column steps (2 n barriers), which is what a wave
+  // that waits at every barrier pays for.
   DPLL_HD void cholesky(S* Aio, S* invd, int n, bool fast) {
     for (int j = 0; j < n; ++j) {
       Team::sync();
@@ -497,31 +507,32 @@ template <typename S, typename SA, class Team> struct Forest {
       Team::sync();
       const int m = n - j - 1;
       for (int e = Team::rank(); e < m * (m + 1) / 2; e += Team::kSize) {
-        int r = 0;
-        while ((r + 1) * (r + 2) / 2 <= e) ++r;
-        const int c = e - r * (r + 1) / 2;
-        const int i = j + 1 + r, k = j + 1 + c;
+        const int i = j + 1 + A.tri_i[e], k = j + 1 + A.tri_j[e];
         Aio[i * n + k] -= Aio[i * n + j] * Aio[k * n + j];
       }
     }
     Team::sync();
-  }
-  // x = (L L^T)^-1 b; work: n numbers of scratch (b is not changed; x may alias neither)
-  DPLL_HD void chol_solve(const S* L, const S* invd, const S* b, S* x, S* work, int n) {
-    for (int i = Team::rank(); i < n; i += Team::kSize) work[i] = b[i];
-    for (int p = 0; p < n; ++p) {
-      Team::sync();
-      const S yp = work[p] * invd[p];
-      for (int i = p + 1 + Team::rank(); i < n; i += Team::kSize) work[i] -= L[i * n + p] * yp;
-      if (Team::rank() == 0) x[p] = yp;  // (x holds y until the backward sweep overwrites it)
+    for (int j = Team::rank(); j < n; j += Team::kSize) {
+      for (int i = j + 1; i < n; ++i) {
+        S acc = Aio[i * n + j] * invd[j];
+        for (int p = j + 1; p < i; ++p) acc += Aio[i * n + p] * Aio[j * n + p];
+        Aio[j * n + i] = -acc * invd[i];
+      }
     }
     Team::sync();
-    for (int i = Team::rank(); i < n; i += Team::kSize) work[i] = x[i];
-    for (int p = n - 1; p >= 0; --p) {
-      Team::sync();
-      const S xp = work[p] * invd[p];
-      for (int i = Team::rank(); i < p; i += Team::kSize) work[i] -= L[p * n + i] * xp;
-      if (Team::rank() == 0) x[p] = xp;
+  }
+  // x = (L L^T)^-1 b with the inverted factor of `cholesky`; work: n numbers of scratch (x may alias neither b nor work)
+  DPLL_HD void chol_solve(const S* L, const S* invd, const S* b, S* x, S* work, int n) {
+    for (int i = Team::rank(); i < n; i += Team::kSize) {  // y = L^-1 b
+      S acc = invd[i] * b[i];
+      for (int j = 0; j < i; ++j) acc += L[j * n + i] * b[j];
+      work[i] = acc;
+    }
+    Team::sync();
+    for (int i = Team::rank(); i < n; i += Team::kSize) {  // x = L^-T y
+      S acc = invd[i] * work[i];
+      for (int k = i + 1; k < n; ++k) acc += L[i * n + k] * work[k];
+      x[i] = acc;
     }
     Team::sync();
   }
@@ -821,9 +832,13 @@ template <typename S, typename SA, class Team> struct Forest {
   }
   // the state at y + alpha d from the state at y (sap_advance); returns the sum of the normal components
   DPLL_HD S advance(const S* y, const S* My, const ConePoint<S>* cur, S alpha, S* yn, S* Myn, ConePoint<S>* nxt, S* jtgn) {
-    for (int i = Team::rank(); i < A.nv; i += Team::kSize) { yn[i] = y[i] + alpha * A.d[i]; Myn[i] = My[i] + alpha * A.Md[i]; }
+    const bool move = alpha != S(0);  // (a team that stands still copies its state: no 0 * inf of a direction it no longer needs)
+    for (int i = Team::rank(); i < A.nv; i += Team::kSize) {
+      yn[i] = move ? y[i] + alpha * A.d[i] : y[i];
+      Myn[i] = move ? My[i] + alpha * A.Md[i] : My[i];
+    }
     for (int c = Team::rank(); c < A.K; c += Team::kSize) {
-      DPLL_UNROLL for (int r = 0; r < 3; ++r) nxt[c].zs[r] = cur[c].zs[r] - alpha * A.jd[3 * c + r];
+      DPLL_UNROLL for (int r = 0; r < 3; ++r) nxt[c].zs[r] = move ? cur[c].zs[r] - alpha * A.jd[3 * c + r] : cur[c].zs[r];
       project_point(nxt[c]);
     }
     Team::sync();
@@ -857,12 +872,22 @@ template <typename S, typename SA, class Team> struct Forest {
     Team::sync();
     S nsum = gather_jtg(cur, jtg);
     Team::sync();
+    // Several teams may share a wavefront (the device build for small systems: four items per wave, 16 lanes each): every
+    // barrier below is then met by all of them, so loops and branches that contain one are decided for the WAVE
+    // (Team::wave_any) and an item that has finished -- or does not take a branch -- goes through it with its state held.
+    bool active = true;
     for (int it = 0; it < opt.max_iter; ++it) {
+      if (!Team::wave_any(active)) break;
       const S ieps = fast ? fast_rcp(eps_c) : S(1) / eps_c;
       const bool final_stage = stage >= last_stage;
       for (int i = Team::rank(); i < A.nv; i += Team::kSize) A.grad[i] = My[i] - ieps * jtg[i];
       const bool any_force = nsum > S(0);
-      // H = M + sum_c J_c^T C_c J_c,  C = D_mu dP D_mu / eps (contacts in the polar region add nothing)
+      // H = M + sum_c J_c^T C_c J_c,  C = D_mu dP D_mu / eps (contacts in the polar region add nothing).  With every contact of
+      // the wave's items in the polar region -- airborne items, most of a toss -- H IS M, whose factor is there already.
+      S n_act = S(0);
+      for (int c = Team::rank(); c < A.K; c += Team::kSize) n_act += cur[c].polar ? S(0) : S(1);
+      const bool any_contact = Team::wave_any(Team::sum(n_act) > S(0));
+      if (any_contact) {
       for (int c = Team::rank(); c < A.K; c += Team::kSize) {
         const ConePoint<S>& p = cur[c];
         const S tx = p.that[0], ty = p.that[1];
@@ -885,9 +910,7 @@ template <typename S, typename SA, class Team> struct Forest {
       }
       Team::sync();
       for (int e = Team::rank(); e < A.nv * (A.nv + 1) / 2; e += Team::kSize) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        const int j = e - i * (i + 1) / 2;
+        const int i = A.tri_i[e], j = A.tri_j[e];
         S h = A.M[i * A.nv + j];
         for (int c = 0; c < A.K; ++c) {
           if (cur[c].polar) continue;
@@ -899,6 +922,9 @@ template <typename S, typename SA, class Team> struct Forest {
       }
       cholesky(A.H, A.invd, A.nv, fast);
       chol_solve(A.H, A.invd, A.grad, A.d, A.tmp, A.nv);
+      } else {
+        chol_solve(A.LM, A.invdM, A.grad, A.d, A.tmp, A.nv);
+      }
       for (int i = Team::rank(); i < A.nv; i += Team::kSize) A.d[i] = -A.d[i];
       Team::sync();
       const S dec2 = -dot(A.grad, A.d, A.nv);
@@ -911,7 +937,7 @@ template <typename S, typename SA, class Team> struct Forest {
       best = tmin(best, dec2);
       const bool stalled = stall >= 3 && !(dec2 > (final_stage ? stol2 : stage_tol2) * scale2);
       const bool force_free = !(dec2 > S(0)) && !any_force;
-      const bool moving = dec2 > S(0);
+      const bool moving = active && dec2 > S(0);
       const S slope_tol = (final_stage ? ls_tol : S(opt.stage_ls_tol)) * dec2;
       const int ls_full = final_stage ? opt.max_ls : opt.stage_max_ls;
       const int ls_cap = (opt.fast_ls > 0 && stall < 2) ? (opt.fast_ls < ls_full ? opt.fast_ls : ls_full) : ls_full;
@@ -929,19 +955,21 @@ template <typename S, typename SA, class Team> struct Forest {
       for (int i = Team::rank(); i < A.nv; i += Team::kSize) f1 += (Myt[i] - ieps * jtgt[i]) * A.d[i];
       const S first1 = Team::sum(f1);
       const bool reject = moving && !(tabs(first1) <= slope_tol) && (first1 > S(0) || ls_cap > 1);
-      if (reject) {
+      if (Team::wave_any(reject)) {
         S c1 = S(0);
         for (int c = Team::rank(); c < A.K; c += Team::kSize) c1 += quadratic(trial[c], A.jd + 3 * c);
         const S curv1 = Team::sum(c1);
         const S dMd = tmax(dot(A.d, A.Md, A.nv), S(0));
         const S second1 = dMd + ieps * curv1;
         const S newton = S(1) - first1 / second1;
-        alpha = (newton > S(0) && newton < S(1)) ? newton : S(0.5);
-        if (ls_cap > 1) {  // stalled: the derivative-based bracketing search, re-projecting the cone residuals at every probe
+        alpha = reject ? ((newton > S(0) && newton < S(1)) ? newton : S(0.5)) : alpha;
+        const bool full = reject && ls_cap > 1;
+        if (Team::wave_any(full)) {  // stalled: the derivative-based bracketing search, re-projecting the cone residuals at every probe
           const S yMd = dot(My, A.d, A.nv);
           S lo = S(0), hi = S(-1), a_s = S(1);
-          bool searching = true;
-          for (int ls = 0; ls < opt.max_ls && searching; ++ls) {
+          bool searching = full;
+          for (int ls = 0; ls < opt.max_ls; ++ls) {
+            if (!Team::wave_any(searching)) break;
             S part1 = S(0), part2 = S(0);
             for (int c = Team::rank(); c < A.K; c += Team::kSize) {
               ConePoint<S> pa;
@@ -960,13 +988,15 @@ template <typename S, typename SA, class Team> struct Forest {
             const bool bad = !((nwt > lo_n) && (hi_n < S(0) || nwt < hi_n));
             const S nxt = bad ? mid : nwt;
             ok = ok || (hi_n >= S(0) && (hi_n - lo_n) <= S(4) * (sizeof(S) == 4 ? S(1.2e-7) : S(2.3e-16)) * hi_n);
-            const bool out = !ok && (ls + 1 >= ls_cap);
-            lo = lo_n; hi = hi_n;
-            a_s = !ok ? (out ? (lo_n > S(0) ? lo_n : nxt) : nxt) : a_s;
-            searching = !ok && !out;
+            const bool out = searching && !ok && (ls + 1 >= ls_cap);
+            lo = searching ? lo_n : lo;
+            hi = searching ? hi_n : hi;
+            a_s = (searching && !ok) ? (out ? (lo_n > S(0) ? lo_n : nxt) : nxt) : a_s;
+            searching = searching && !ok && !out;
           }
-          alpha = a_s;
+          alpha = full ? a_s : alpha;
         }
+        // (a team that kept its step recomputes the state it has: same expressions, same values)
         nsum_t = advance(y, My, cur, alpha, yt, Myt, trial, jtgt);
       }
       DPLL_ITER_HOOK(it, moving, alpha);
@@ -978,11 +1008,11 @@ template <typename S, typename SA, class Team> struct Forest {
         ConePoint<S>* tp = cur; cur = trial; trial = tp;
         nsum = nsum_t;
       }
-      iters = it + 1;
+      iters = active ? it + 1 : iters;
       const bool stage_done = converged || stalled || (!final_stage && it_stage + 1 >= opt.stage_max_iter);
-      const bool next_stage = !final_stage && stage_done && !force_free;
+      const bool next_stage = active && !final_stage && stage_done && !force_free;
       const bool ends = (final_stage && stage_done) || force_free;
-      if (ends) break;
+      active = active && !ends;
       stage = next_stage ? stage + 1 : stage;
       eps_c = next_stage ? eps_c * inv_factor : eps_c;
       it_stage = next_stage ? 0 : it_stage + 1;
@@ -1295,9 +1325,7 @@ template <class Team> struct ForestBackward {
     }
     Team::sync();
     for (int e = Team::rank(); e < A.nv * (A.nv + 1) / 2; e += Team::kSize) {
-      int i = 0;
-      while ((i + 1) * (i + 2) / 2 <= e) ++i;
-      const int j = e - i * (i + 1) / 2;
+      const int i = A.tri_i[e], j = A.tri_j[e];
       D h = A.M[i * A.nv + j];
       for (int c = 0; c < A.K; ++c) {
         const D* Jrow = A.J + (size_t)c * 3 * A.nv;
