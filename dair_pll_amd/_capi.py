@@ -298,6 +298,8 @@ def library() -> ctypes.CDLL:
     lib.dpll_contactnets_train_step.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                                 c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                                 POINTER(AdamState), c_void_p]
+    lib.dpll_contactnets_train_step_mesh.argtypes = [c_void_p, c_int, POINTER(Params), POINTER(MeshParams), c_void_p, c_int64, c_void_p, c_int64,
+                                                     c_int64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int64, POINTER(AdamState), c_void_p]
     lib.dpll_ar_destroy.argtypes = [c_void_p]
     lib.dpll_ar_destroy.restype = None
     lib.dpll_terms.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_void_p,
@@ -318,4 +320,4 @@ EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
                     'dpll_profile_contactnets_loss_mesh',
                     'dpll_step_mesh', 'dpll_simulate_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
-                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh', 'dpll_contactnets_train_step']
+                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh', 'dpll_contactnets_train_step', 'dpll_contactnets_train_step_mesh']

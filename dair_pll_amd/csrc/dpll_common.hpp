@@ -99,7 +99,9 @@ template <int G, int P = 1> struct GpuLanes {
     const S ov = dpp_mov<CTRL>(value);
     const int oi = dpp_mov<CTRL>(index);
     const S o0 = dpp_mov<CTRL>(d[0]), o1 = dpp_mov<CTRL>(d[1]), o2 = dpp_mov<CTRL>(d[2]);
-    const bool take = ov > value || (ov == value && oi < index);
+    // (values within kPairTie of each other are a tie: the lower candidate number wins, as inside a lane's own sequence)
+    const bool tie = !(ov > value + S(kPairTie)) && !(value > ov + S(kPairTie));
+    const bool take = tie ? oi < index : ov > value;
     value = take ? ov : value;
     index = take ? oi : index;
     d[0] = take ? o0 : d[0]; d[1] = take ? o1 : d[1]; d[2] = take ? o2 : d[2];
@@ -344,6 +346,51 @@ __device__ __forceinline__ void store_iota_row(const LossGrad<T, NJ, NG, GP>& ac
 
 
 }  // namespace
+
+// Adam on the learnable parameters, done by the threads that have just written their gradient entry
+// (experiment.py:213-228: torch.optim.Adam; the update of torch's _single_tensor_adam, no amsgrad): a training step is then the
+// loss launch and the kernel that ends it -- the optimizer costs no launch of its own.  params == nullptr: no update.
+struct AdamArgs {
+  void* params;      // (P,) the flat buffer the kernels read their parameters from: updated in place
+  void* exp_avg;     // (P,)
+  void* exp_avg_sq;  // (P,)
+  double* state;     // (3,) [steps taken, beta1^steps, beta2^steps]: advanced once per step (no pow on the device)
+  double lr, beta1, beta2, eps, weight_decay;
+};
+// parameter k with gradient g; pow1 / pow2 = beta^steps of THIS step; returns the updated value
+template <typename T> __device__ __forceinline__ T adam_apply(const AdamArgs& adam, long long k, double g_in, double pow1, double pow2) {
+  T* p = (T*)adam.params + k;
+  T* m = (T*)adam.exp_avg + k;
+  T* v = (T*)adam.exp_avg_sq + k;
+  const double g = g_in + adam.weight_decay * double(*p);
+  const double m1 = double(*m) + (g - double(*m)) * (1.0 - adam.beta1);
+  const double v1 = adam.beta2 * double(*v) + (1.0 - adam.beta2) * g * g;
+  const double denom = sqrt(v1) / sqrt(1.0 - pow2) + adam.eps;
+  *m = T(m1);
+  *v = T(v1);
+  const T updated = T(double(*p) - (adam.lr / (1.0 - pow1)) * m1 / denom);
+  *p = updated;
+  return updated;
+}
+// the running products of a step, read by every thread before one of them advances the state
+__device__ __forceinline__ void adam_powers(const AdamArgs& adam, double& steps, double& pow1, double& pow2) {
+  steps = adam.state[0] + 1.0;
+  pow1 = adam.state[1] * adam.beta1;
+  pow2 = adam.state[2] * adam.beta2;
+}
+// which entries of the general build's flat parameter buffer [theta | friction (1 + slots) | lengths (slots, stride)] belong to a
+// parameter of the model (the rest is padding, which an optimizer must leave alone: weight decay would move it)
+__host__ __device__ inline bool general_param_is_real(const dpll::ModelDesc& md, int k) {
+  const int nb = md.n_joints + 1, slots = dpll::kGenSlots, stride = dpll::GeneralDesc::kGeoStride;
+  if (k < 10 * nb) return true;
+  k -= 10 * nb;
+  if (k < 1 + slots) return k <= md.n_geoms;
+  k -= 1 + slots;
+  const int g = k / stride, e = k % stride;
+  if (g >= md.n_geoms) return false;
+  const int kind = md.geom_kind[g];
+  return kind == dpll::kGeomBox ? e < 3 : (kind == dpll::kGeomSphere ? e < 1 : (kind == dpll::kGeomPolygon ? e < 3 * md.geom_nverts[g] : false));
+}
 
 struct dpll_ar {
   int rank, world;

@@ -1479,12 +1479,14 @@ DPLL_HD void pair_try(const S (&n)[3], int k, const S (*a)[3], int na, const S (
   }
   const S inv = S(1) / tsqrt(n2);
   const S sp = (bmin - amax) * inv, sm = (amin - bmax) * inv;
-  if (sp > best.sep) {
+  // (a candidate replaces the best so far only when it separates by MORE than kPairTie more: separations that differ by
+  // rounding -- two faces of overlapping boxes that are equally deep -- are a tie, and a tie goes to the lower number)
+  if (sp > best.sep + S(kPairTie)) {
     best.sep = sp;
     best.k = k;
     DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = n[i] * inv;
   }
-  if (sm > best.sep) {
+  if (sm > best.sep + S(kPairTie)) {
     best.sep = sm;
     best.k = k;
     DPLL_UNROLL for (int i = 0; i < 3; ++i) best.d[i] = -n[i] * inv;

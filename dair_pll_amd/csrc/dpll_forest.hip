@@ -39,7 +39,8 @@ struct WaveLanes {  // the lane-group policy of dpll_core.hpp's direction search
       const S ov = __shfl_xor(value, off);
       const int oi = __shfl_xor(index, off);
       const S o0 = __shfl_xor(d[0], off), o1 = __shfl_xor(d[1], off), o2 = __shfl_xor(d[2], off);
-      const bool take = ov > value || (ov == value && oi < index);
+      const bool tie = !(ov > value + S(kPairTie)) && !(value > ov + S(kPairTie));  // (dpll_common.hpp best_step)
+      const bool take = tie ? oi < index : ov > value;
       value = take ? ov : value;
       index = take ? oi : index;
       d[0] = take ? o0 : d[0]; d[1] = take ? o1 : d[1]; d[2] = take ? o2 : d[2];
@@ -160,7 +161,7 @@ template <typename T>
 __global__ __launch_bounds__(kRowThreads) void forest_finalize_kernel(const ForestDesc* __restrict__ fdp, const T* __restrict__ theta,
                                                                       const T* __restrict__ friction, const T* __restrict__ lengths,
                                                                       const double* __restrict__ folded, int n_rows, int row_stride,
-                                                                      T* __restrict__ grad, T* __restrict__ loss_total) {
+                                                                      T* __restrict__ grad, T* __restrict__ loss_total, AdamArgs adam) {
   __shared__ ForestDesc fd;
   __shared__ double tot[kRowThreads];
   {
@@ -174,10 +175,26 @@ __global__ __launch_bounds__(kRowThreads) void forest_finalize_kernel(const Fore
   if (col < width)
     for (int r = 0; r < n_rows; ++r) s += folded[(long long)r * row_stride + col];
   tot[col] = s;
-  __syncthreads();
+  double steps = 0.0, pow1 = 0.0, pow2 = 0.0;
+  if (adam.params) adam_powers(adam, steps, pow1, pow2);
+  __syncthreads();  // (column totals in place; every thread has read the optimizer state before thread 0 advances it)
   const int n_params = param_count(fd);
-  for (int k = threadIdx.x; k < n_params; k += kRowThreads) grad[k] = T(chain_param(fd, theta, friction, lengths, tot, k));
-  if (threadIdx.x == 0 && loss_total) *loss_total = T(tot[0]);
+  // the chain reads the parameters the gradient was taken at: every thread finishes its chains before any parameter moves
+  double mine[2] = {0.0, 0.0};  // (at most 10 * 16 + 13 + 288 = 461 parameters: one per thread; two keeps the loop general)
+  int count = 0;
+  for (int k = threadIdx.x; k < n_params; k += kRowThreads) mine[count++ & 1] = chain_param(fd, theta, friction, lengths, tot, k);
+  __syncthreads();
+  count = 0;
+  for (int k = threadIdx.x; k < n_params; k += kRowThreads) {
+    const T g = T(mine[count++ & 1]);
+    grad[k] = g;
+    // fused training step: Adam on parameter k by the thread that wrote its gradient (padding entries are left alone)
+    if (adam.params && param_is_real(fd, k)) adam_apply<T>(adam, k, double(g), pow1, pow2);
+  }
+  if (threadIdx.x == 0) {
+    if (loss_total) *loss_total = T(tot[0]);
+    if (adam.params) { adam.state[0] = steps; adam.state[1] = pow1; adam.state[2] = pow2; }
+  }
 }
 
 // ---- simulation: `steps` VelocityIntegrator steps per item, the current state in LDS ---------------------------------------------
@@ -360,7 +377,7 @@ size_t round16(size_t n) { return (n + 15) & ~(size_t)15; }
 template <typename T>
 int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp,
                 long long batch, const void* weights, double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
-                void* workspace, long long ws_bytes, hipStream_t stream) {
+                void* workspace, long long ws_bytes, hipStream_t stream, const AdamArgs* adam) {
   const ForestDesc& fd = host_desc(m);
   const ForestDesc* dev = device_desc(m);
   if (!dev) return dpll_fail(-5, "dpll_contactnets_loss (forest build): could not place the model description on the device%s");
@@ -398,7 +415,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
     if (int rc = dpll_check_launch("forest_fold_kernel")) return rc;
   }
   hipLaunchKernelGGL((forest_finalize_kernel<T>), dim3(1), dim3(kRowThreads), 0, stream, dev, (const T*)p->theta, (const T*)p->friction,
-                     (const T*)p->lengths, (const double*)folded, n_folded, stride, (T*)grad, (T*)loss_total);
+                     (const T*)p->lengths, (const double*)folded, n_folded, stride, (T*)grad, (T*)loss_total, adam ? *adam : AdamArgs{});
   return dpll_check_launch("forest_finalize_kernel");
 }
 
@@ -457,7 +474,7 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
   hipLaunchKernelGGL(forest_fold_kernel, dim3(n_folded), dim3(kRowThreads), 0, stream, (const double*)workspace, rows, row_width(fd), stride, folded);
   if (int rc = dpll_check_launch("forest_fold_kernel")) return rc;
   hipLaunchKernelGGL((forest_finalize_kernel<T>), dim3(1), dim3(kRowThreads), 0, stream, dev, (const T*)p->theta, (const T*)p->friction,
-                     (const T*)p->lengths, (const double*)folded, n_folded, stride, (T*)grad, (T*)nullptr);
+                     (const T*)p->lengths, (const double*)folded, n_folded, stride, (T*)grad, (T*)nullptr, AdamArgs{});
   return dpll_check_launch("forest_finalize_kernel");
 }
 
@@ -555,9 +572,9 @@ void release(dpll_model* m) {
 
 int loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp, long long batch,
          const void* weights, double scale, void* loss_out, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
-         long long ws_bytes, hipStream_t stream) {
+         long long ws_bytes, hipStream_t stream, const AdamArgs* adam) {
   DPLL_FOREST_DISPATCH(launch_loss, m, dtype, p, x, ld_x, xp, ld_xp, batch, weights, scale, loss_out, grad, loss_total, force, iters, workspace,
-                       ws_bytes, stream);
+                       ws_bytes, stream, adam);
 }
 int simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch, long long steps, void* out,
              long long ld_item, long long ld_step, int write_x0, int32_t* iters, hipStream_t stream) {

@@ -1503,4 +1503,13 @@ DPLL_HD double chain_param(const ForestDesc& fd, const P* theta, const P* fricti
   return row[len0 + e] * (pl > 0.0 ? 1.0 : (pl < 0.0 ? -1.0 : 0.0));
 }
 
+// which entries of [theta | friction | lengths (n_geoms, 24)] belong to a parameter of the model (the tail of a geometry's block is
+// padding, which an optimizer must leave alone)
+DPLL_HD bool param_is_real(const ForestDesc& fd, int k) {
+  const int head = 10 * fd.n_bodies + 1 + fd.n_geoms;
+  if (k < head) return true;
+  const int g = (k - head) / kGeoStride, e = (k - head) % kGeoStride, kind = fd.geom_kind[g];
+  return kind == kGeomBox ? e < 3 : (kind == kGeomSphere ? e < 1 : e < 3 * fd.geom_nverts[g]);
+}
+
 }  // namespace dpll_forest

@@ -7,6 +7,7 @@
 #include "../../include/dpll.h"
 
 struct dpll_model;
+struct AdamArgs;
 
 namespace dpll_forest_api {
 // validates the description; 0 or a negative status with dpll_last_error set
@@ -18,7 +19,7 @@ long long workspace_bytes(const dpll_model* m, long long batch);
 void release(dpll_model* m);  // the device copy of the description
 int loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp,
          long long batch, const void* weights, double scale, void* loss_out, void* grad, void* loss_total, void* force,
-         int32_t* iters, void* workspace, long long ws_bytes, hipStream_t stream);
+         int32_t* iters, void* workspace, long long ws_bytes, hipStream_t stream, const AdamArgs* adam = nullptr);
 int simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch,
              long long steps, void* out, long long ld_item, long long ld_step, int write_x0, int32_t* iters, hipStream_t stream);
 int step_backward(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* gx,

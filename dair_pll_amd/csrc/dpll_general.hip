@@ -21,7 +21,7 @@ namespace {
 template <typename T, int NJ>
 int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp,
                 long long ld_xp, long long batch, const void* weights, double scale, void* loss, void* grad, void* loss_total,
-                void* force, int32_t* iters, void* workspace, long long workspace_bytes, hipStream_t stream) {
+                void* force, int32_t* iters, void* workspace, long long workspace_bytes, hipStream_t stream, const AdamArgs* adam) {
   using D = GD<T, NJ>;
   const int rows = batch > 0 ? row_blocks(batch) : 0;
   const int want_grad = grad != nullptr;
@@ -36,7 +36,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad,
                      (const T*)nullptr, (T*)nullptr, (const double*)nullptr);
   if (int rc = dpll_check_launch("gen_loss_kernel")) return rc;
-  if (want_grad) return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)loss_total, stream);
+  if (want_grad) return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)loss_total, stream, m, adam);
   return 0;
 }
 
@@ -119,9 +119,9 @@ long long workspace_bytes(const dpll_model* m, long long batch) {
 
 int loss(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, const void* xp, long long ld_xp,
          long long batch, const void* weights, double scale, void* loss_out, void* grad, void* loss_total, void* force,
-         int32_t* iters, void* workspace, long long ws_bytes, hipStream_t stream) {
+         int32_t* iters, void* workspace, long long ws_bytes, hipStream_t stream, const AdamArgs* adam) {
   DPLL_GEN_DISPATCH(launch_loss, m, dtype, p, x, ld_x, xp, ld_xp, batch, weights, scale, loss_out, grad, loss_total, force, iters,
-                    workspace, ws_bytes, stream);
+                    workspace, ws_bytes, stream, adam);
 }
 
 int simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch,

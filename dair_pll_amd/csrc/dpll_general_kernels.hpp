@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256) void gen_fold_rows_kernel(const double* __rest
   for (; r < r1; ++r) s += partials[(long long)r * D::PI + col];
   folded[(long long)blockIdx.x * D::PI + col] = s;
 }
+// adam (fused training step, dpll_contactnets_train_step): the thread that writes gradient entry k also applies Adam to
+// parameter k -- entries of the flat buffer that are padding (unused geometry slots, the tail of a geometry's block) are left alone
 template <typename T, int NJ>
 __global__ __launch_bounds__(256) void gen_finalize_kernel(const double* __restrict__ folded, int n_rows, const double* __restrict__ chain,
-                                                           T* __restrict__ grad, T* __restrict__ loss_total) {
+                                                           T* __restrict__ grad, T* __restrict__ loss_total, AdamArgs adam, GeneralDesc md) {
   using D = GD<T, NJ>;
   static_assert(D::PI <= 256, "row must fit 256 columns");
   __shared__ double tot[256];
@@ -141,14 +143,18 @@ __global__ __launch_bounds__(256) void gen_finalize_kernel(const double* __restr
   if (col < D::PIOTA)
     for (int r = 0; r < n_rows; ++r) s += folded[(long long)r * D::PI + col];
   tot[col] = s;
-  __syncthreads();
+  double steps = 0.0, pow1 = 0.0, pow2 = 0.0;
+  if (adam.params) adam_powers(adam, steps, pow1, pow2);
+  __syncthreads();  // (column totals in place; every thread has read the optimizer state before thread 0 advances it)
   if (threadIdx.x < D::PI) {
     const int k = (int)threadIdx.x - 1;
     const double v = k < 0 ? tot[0] : apply_chain<D::NB, kNG, kGP>(tot, chain, k);
     if (k < 0) {
       if (loss_total) *loss_total = T(v);
+      if (adam.params) { adam.state[0] = steps; adam.state[1] = pow1; adam.state[2] = pow2; }
     } else {
       grad[k] = T(v);
+      if (adam.params && general_param_is_real(md, k)) adam_apply<T>(adam, k, double(T(v)), pow1, pow2);
     }
   }
 }
@@ -364,7 +370,8 @@ int row_blocks(long long batch) {
 // workspace: [rows (n, PI) | chain matrix | folded rows (ceil(n / kFoldRows), PI)]
 long long folded_rows(long long rows) { return (rows + kFoldRows - 1) / kFoldRows; }
 template <typename T, int NJ>
-int finalize_rows(double* workspace, int rows, T* grad, T* loss_total, hipStream_t stream) {
+int finalize_rows(double* workspace, int rows, T* grad, T* loss_total, hipStream_t stream, const dpll_model* m = nullptr,
+                  const AdamArgs* adam = nullptr) {
   using D = GD<T, NJ>;
   double* chain = workspace + (long long)rows * D::PI;
   double* folded = chain + D::CHAIN;
@@ -374,7 +381,7 @@ int finalize_rows(double* workspace, int rows, T* grad, T* loss_total, hipStream
     if (int rc = dpll_check_launch("gen_fold_rows_kernel")) return rc;
   }
   hipLaunchKernelGGL((gen_finalize_kernel<T, NJ>), dim3(1), dim3(256), 0, stream, (const double*)folded, n_folded, (const double*)chain,
-                     grad, loss_total);
+                     grad, loss_total, (adam && m) ? *adam : AdamArgs{}, m ? general_desc(m) : GeneralDesc{});
   return dpll_check_launch("gen_finalize_kernel");
 }
 

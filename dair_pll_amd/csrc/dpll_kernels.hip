@@ -298,17 +298,6 @@ __device__ __forceinline__ double finalize_column(const double* __restrict__ par
 // FUSED: the row [loss | gradients] is summed over the ranks of a data-parallel job before it is written, with the
 // one-shot peer-memory exchange of dpll_allreduce.hpp (same protocol and call counter as dpll_ar_allreduce): the
 // gradient exchange costs no launch of its own.
-// Adam on the (<= 30) learnable parameters, done by the threads that have just written their gradient entry
-// (experiment.py:213-228: torch.optim.Adam; the update of torch's _single_tensor_adam, no amsgrad): a training step is
-// then the loss launch and this kernel -- the optimizer costs no launch of its own.  params == nullptr: no update.
-struct AdamArgs {
-  void* params;      // (P,) the flat buffer the kernels read their parameters from: updated in place
-  void* exp_avg;     // (P,)
-  void* exp_avg_sq;  // (P,)
-  double* state;     // (3,) [steps taken, beta1^steps, beta2^steps]: advanced by the kernel (no pow on the device)
-  double lr, beta1, beta2, eps, weight_decay;
-};
-
 // GROUPS: row groups = waves / 2 of the one workgroup (32: 1024 threads; 8: 256 threads, for launches of <= 256 rows)
 template <typename T, int NJ, bool FUSED = false, int GROUPS = 32>
 __global__ __launch_bounds__(GROUPS * 32) void finalize_kernel(const double* __restrict__ partials, int n_rows,
@@ -368,22 +357,11 @@ __global__ __launch_bounds__(GROUPS * 32) void finalize_kernel(const double* __r
   bool exchange_ok = true;
   if constexpr (FUSED) exchange_ok = err == nullptr || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
   if (adam.params && exchange_ok) {  // (uniform: kernel arguments and one word every thread reads alike)
-    const double steps = adam.state[0] + 1.0, pow1 = adam.state[1] * adam.beta1, pow2 = adam.state[2] * adam.beta2;
+    double steps, pow1, pow2;
+    adam_powers(adam, steps, pow1, pow2);
     __syncthreads();  // every thread has read the state before thread 0 advances it
     if (threadIdx.x == 0) { adam.state[0] = steps; adam.state[1] = pow1; adam.state[2] = pow2; }
-    if (threadIdx.x >= 1 && threadIdx.x < D::PI) {
-      const int k = (int)threadIdx.x - 1;
-      T* p = (T*)adam.params + k;
-      T* m = (T*)adam.exp_avg + k;
-      T* v = (T*)adam.exp_avg_sq + k;
-      const double g = double(value) + adam.weight_decay * double(*p);
-      const double m1 = double(*m) + (g - double(*m)) * (1.0 - adam.beta1);
-      const double v1 = adam.beta2 * double(*v) + (1.0 - adam.beta2) * g * g;
-      const double denom = sqrt(v1) / sqrt(1.0 - pow2) + adam.eps;
-      *m = T(m1);
-      *v = T(v1);
-      *p = T(double(*p) - (adam.lr / (1.0 - pow1)) * m1 / denom);
-    }
+    if (threadIdx.x >= 1 && threadIdx.x < D::PI) adam_apply<T>(adam, (int)threadIdx.x - 1, double(value), pow1, pow2);
   }
 }
 
@@ -1238,7 +1216,7 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
 // are in place; grad_w = this network's slice of the gradient, grad_head / loss_total only with the first network
 template <typename T, int NB>
 int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, QuatSource<T> q, T* grad_w, T* grad_head,
-                  T* loss_total, hipStream_t stream, const T* adjoints = nullptr) {
+                  T* loss_total, hipStream_t stream, const T* adjoints = nullptr, const AdamArgs* adam = nullptr, long long w_offset = 0) {
   char* nb = pl.net(ws, g);
   const T* RB = adjoints ? adjoints : (const T*)(ws + pl.off_RB) + 12 * g;
   if constexpr (std::is_same<T, float>::value) {
@@ -1276,7 +1254,7 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
   mesh_mark(stream);
   hipLaunchKernelGGL((icnn_reduce_kernel<T, NB>), dim3(kRedBlocks), dim3(256), 0, stream, w,
                      (const double*)(ws + pl.off_rows), pl.loss_blocks, pl.row_stride, (const double*)(nb + pl.off_b1), pl.b1_blocks,
-                     (const T*)(nb + pl.off_slabs), pl.n_slabs, grad_w, grad_head, loss_total);
+                     (const T*)(nb + pl.off_slabs), pl.n_slabs, grad_w, grad_head, loss_total, adam ? *adam : AdamArgs{}, w_offset);
   mesh_mark(stream);
   return check_launch("icnn backward");
 }
@@ -1285,13 +1263,17 @@ constexpr int kNetParams = kW * kW + 7 * kW;  // [Wh | Wd0 | Wd1 | wout] of one 
 
 template <typename T, int NJ>
 int mesh_backward_all(const MeshPlan& pl, const dpll_mesh_params_t* mp, char* ws, const T* state, long long ld, void* grad,
-                      void* loss_total, hipStream_t stream) {
+                      void* loss_total, hipStream_t stream, const AdamArgs* adam = nullptr) {
   constexpr int NB = NJ + 1, kHead = 10 * NB + 1 + NB;
   for (int g = 0; g < NB; ++g)
     if (int rc = mesh_backward<T, NB>(pl, g, mesh_weights<T>(mp, g, NB), ws, quat_source<T, NJ>(pl, ws, state, ld, g),
                                       (T*)grad + kHead + (size_t)g * kNetParams, g == 0 ? (T*)grad : (T*)nullptr,
-                                      g == 0 ? (T*)loss_total : (T*)nullptr, stream))
+                                      g == 0 ? (T*)loss_total : (T*)nullptr, stream, nullptr, adam, kHead + (long long)g * kNetParams))
       return rc;
+  if (adam) {  // (every reduce launch has read the optimizer state: one thread moves it a step on)
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, *adam);
+    return check_launch("adam_advance_kernel");
+  }
   return 0;
 }
 
@@ -1311,7 +1293,7 @@ template <typename T, int NJ>
 int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
                      long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
                      void* loss, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
-                     long long workspace_bytes, hipStream_t stream) {
+                     long long workspace_bytes, hipStream_t stream, const AdamArgs* adam = nullptr) {
   const MeshPlan pl = mesh_plan<T, NJ>(batch);
   if (!workspace || (size_t)workspace_bytes < pl.total) return fail(-3, "dpll_contactnets_loss_mesh: workspace too small%s");
   if (!grad && loss_total) return fail(-3, "dpll_contactnets_loss_mesh: loss_total requires grad%s");
@@ -1337,7 +1319,7 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   mesh_mark(stream);
   if (int rc = check_launch("loss_kernel (mesh)")) return rc;
   if (!want_grad) return 0;
-  return mesh_backward_all<T, NJ>(pl, mp, ws, (const T*)xp, ld_xp, grad, loss_total, stream);
+  return mesh_backward_all<T, NJ>(pl, mp, ws, (const T*)xp, ld_xp, grad, loss_total, stream, adam);
 }
 
 // Integrator.simulate with the network shapes: per step the two forward GEMMs of every network on the current state
@@ -1967,10 +1949,26 @@ int dpll_contactnets_train_step(const dpll_model_t* model, int dtype, const dpll
                                 double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                 dpll_ar_t* ar, const dpll_adam_t* adam, void* stream) {
   if (int rc = check_common(model, dtype, params, batch, "dpll_contactnets_train_step")) return rc;
-  if (model->desc.n_geoms > 0 || model->forest)
-    return fail(-2, "dpll_contactnets_train_step: specialised builds (the general build: dpll_contactnets_loss + an optimizer of the caller's)%s");
   if ((batch > 0 && (!x || !x_plus)) || !grad || !loss_total || !adam || !adam->params || !adam->exp_avg || !adam->exp_avg_sq || !adam->state)
     return fail(-1, "dpll_contactnets_train_step: null argument%s");
+  if (model->desc.n_geoms > 0 || model->forest) {
+    // the general and the forest build: Adam in the kernel that chains the folded rows to the parameters; the gradient exchange
+    // of a data-parallel job stays a call of its own (dpll_ar_allreduce between dpll_contactnets_loss and an optimizer)
+    if (ar) return fail(-2, "dpll_contactnets_train_step: the general and forest builds take no exchange handle%s");
+    if (batch == 0) return fail(-1, "dpll_contactnets_train_step: empty batch%s");
+    const int nx_g = dpll_n_x(model);
+    if (ld_x < nx_g || ld_xp < nx_g) return fail(-1, "dpll_contactnets_train_step: row stride smaller than n_x%s");
+    if ((const void*)adam->params != params->theta)
+      return fail(-1, "dpll_contactnets_train_step: adam.params must be the flat buffer params.theta points to ([theta | friction | lengths])%s");
+    if (!(adam->lr >= 0.0) || !(adam->beta1 >= 0.0 && adam->beta1 < 1.0) || !(adam->beta2 >= 0.0 && adam->beta2 < 1.0) || !(adam->eps >= 0.0) || !(adam->weight_decay >= 0.0))
+      return fail(-1, "dpll_contactnets_train_step: Adam hyper-parameters out of range%s");
+    const AdamArgs args{adam->params, adam->exp_avg, adam->exp_avg_sq, adam->state, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay};
+    if (model->forest)
+      return dpll_forest_api::loss(model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total, nullptr, nullptr,
+                                   workspace, workspace_bytes, (hipStream_t)stream, &args);
+    return dpll_general::loss(model, dtype, params, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total, nullptr, nullptr,
+                              workspace, workspace_bytes, (hipStream_t)stream, &args);
+  }
   if (batch == 0 && !ar) return fail(-1, "dpll_contactnets_train_step: empty batch%s");
   const int nx = dpll_n_x(model);
   if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_train_step: row stride smaller than n_x%s");
@@ -2090,6 +2088,27 @@ int dpll_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_
                force, iters, workspace, workspace_bytes, (hipStream_t)stream);
   DPLL_MESH_DISPATCH(launch_mesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, loss, grad,
                      loss_total, force, iters, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int dpll_contactnets_train_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
+                                     const void* x, int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
+                                     double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
+                                     const dpll_adam_t* adam, void* stream) {
+  if (!params) return fail(-1, "dpll_contactnets_train_step_mesh: null parameter pointer%s");
+  if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_contactnets_train_step_mesh")) return rc;
+  if (model->desc.n_geoms > 0)
+    return fail(-2, "dpll_contactnets_train_step_mesh: the specialised mesh builds (cube / elbow with a learned shape per body)%s");
+  if (batch == 0 || !x || !x_plus || !grad || !loss_total || !adam || !adam->params || !adam->exp_avg || !adam->exp_avg_sq || !adam->state)
+    return fail(-1, "dpll_contactnets_train_step_mesh: null argument or empty batch%s");
+  const int nx = dpll_n_x(model);
+  if (ld_x < nx || ld_xp < nx) return fail(-1, "dpll_contactnets_train_step_mesh: row stride smaller than n_x%s");
+  if ((const void*)adam->params != params->theta)
+    return fail(-1, "dpll_contactnets_train_step_mesh: adam.params must be the flat buffer params.theta points to ([theta | friction | networks])%s");
+  if (!(adam->lr >= 0.0) || !(adam->beta1 >= 0.0 && adam->beta1 < 1.0) || !(adam->beta2 >= 0.0 && adam->beta2 < 1.0) || !(adam->eps >= 0.0) || !(adam->weight_decay >= 0.0))
+    return fail(-1, "dpll_contactnets_train_step_mesh: Adam hyper-parameters out of range%s");
+  const AdamArgs args{adam->params, adam->exp_avg, adam->exp_avg_sq, adam->state, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay};
+  DPLL_MESH_DISPATCH(launch_mesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total,
+                     nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, &args);
 }
 
 int dpll_profile_contactnets_loss_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params,

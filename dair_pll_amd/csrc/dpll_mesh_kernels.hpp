@@ -344,7 +344,11 @@ template <typename T, int NB>
 __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, const double* __restrict__ rows,
                                                           int n_rows, int row_stride, const double* __restrict__ b1, int b1_blocks,
                                                           const T* __restrict__ slabs, int n_slabs,
-                                                          T* __restrict__ grad_w, T* __restrict__ grad_head, T* __restrict__ loss_total) {
+                                                          T* __restrict__ grad_w, T* __restrict__ grad_head, T* __restrict__ loss_total,
+                                                          AdamArgs adam, long long w_offset) {
+  // adam (the fused training step, dpll_contactnets_train_step_mesh): the thread that writes a gradient entry applies Adam to
+  // its parameter -- entry i of grad_w is parameter w_offset + i of the flat buffer, entry k of grad_head parameter k.  The
+  // optimizer state is only READ here (several launches, many workgroups per step): adam_advance_kernel moves it once.
   constexpr int kHead = 10 * NB + 1 + NB;     // theta, friction
   constexpr int kCols = 1 + 10 * NB + 4 * NB; // columns of a row: [loss | iota | mu_pair | lengths (unused)]
   static_assert(kCols <= 32 && kHead < 64, "head must fit the wave that chains it");
@@ -382,10 +386,14 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
   double s = 0.0;
 #pragma unroll
   for (int g = 0; g < kRedGroups; ++g) s += red[g][threadIdx.x];
+  double steps = 0.0, pow1 = 0.0, pow2 = 0.0;
+  if (adam.params) adam_powers(adam, steps, pow1, pow2);
   if (b < kRedWhBlocks) {
     const long long idx = (long long)b * kRedOut + threadIdx.x;
     const T raw = w.Wh[idx];
-    grad_w[idx] = T(s * (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0)));
+    const T gv = T(s * (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0)));
+    grad_w[idx] = gv;
+    if (adam.params) adam_apply<T>(adam, w_offset + idx, double(gv), pow1, pow2);
   } else if (b < kRedWhBlocks + kRedB1Blocks) {
     const int c = (b - kRedWhBlocks) * kRedOut + threadIdx.x;
     if (c >= 6 * kW) {
@@ -393,6 +401,7 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
       s *= (raw > T(0) ? 1.0 : (raw < T(0) ? -1.0 : 0.0));
     }
     grad_w[kW * kW + c] = T(s);
+    if (adam.params) adam_apply<T>(adam, w_offset + kW * kW + c, double(T(s)), pow1, pow2);
   } else if (grad_head) {
     // head: the rows are in iota space, the chain matrix to (theta, friction) sits behind them; threads 0..63 are one
     // wave: every lane gathers the column totals, thread 1 + k chains parameter k
@@ -403,8 +412,18 @@ __global__ __launch_bounds__(256) void icnn_reduce_kernel(IcnnWeights<T> w, cons
     if (threadIdx.x == 0) {
       if (loss_total) *loss_total = T(s);
     } else if (k < kHead) {
-      grad_head[k] = T(apply_chain<NB, NB>(tot, rows + (long long)n_rows * row_stride, k));
+      const T gv = T(apply_chain<NB, NB>(tot, rows + (long long)n_rows * row_stride, k));
+      grad_head[k] = gv;
+      if (adam.params) adam_apply<T>(adam, k, double(gv), pow1, pow2);
     }
+  }
+}
+// the optimizer state [steps, beta1^steps, beta2^steps] one step on: after the reduce launches of every network have read it
+__global__ void adam_advance_kernel(AdamArgs adam) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double steps, pow1, pow2;
+    adam_powers(adam, steps, pow1, pow2);
+    adam.state[0] = steps; adam.state[1] = pow1; adam.state[2] = pow2;
   }
 }
 

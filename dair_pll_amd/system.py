@@ -566,9 +566,15 @@ class MultibodyLearnableSystem(Module):
         """One whole training step -- the mean loss of the batch, its gradients, the gradient exchange when a process group
         is bound (peer transport) and the Adam update of every parameter, in place -- in the loss launch and ONE more
         kernel (``dpll_contactnets_train_step``; ``experiment.py:332-363``).  Returns the mean loss (one-element device
-        tensor); ``.grad`` of every parameter holds the gradient the update used.  Box geometry, cube / elbow topology."""
-        if not self.spec.is_fast() or self._mesh() is not None:
-            raise NotImplementedError('the fused training step serves the specialised box builds; use contactnets_loss_and_grad + an optimizer')
+        tensor); ``.grad`` of every parameter holds the gradient the update used.  Every build takes it: the specialised box builds
+        (with the gradient exchange of a process group inside the same kernel), the general and the forest build (Adam in the
+        kernel that chains the folded rows; single process) and the specialised mesh builds (Adam where the network's weight
+        gradients are reduced); not the general build with learned shapes."""
+        if self._mesh() is not None:
+            return self._mesh_train_step(x, x_plus, adam)
+        if not self.spec.is_fast() and self.grad_world > 1:
+            raise NotImplementedError('the fused training step of the general / forest build is single process: use '
+                                      'contactnets_loss_and_grad + GradientAllReduce + an optimizer')
         lib = _capi.library()
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
@@ -587,6 +593,32 @@ class MultibodyLearnableSystem(Module):
             None, 1.0 / denom, _ptr(self._flat_grad), _ptr(self._loss_total), _ptr(self._workspace), ws_bytes, self._fused_ar,
             ctypes.byref(state), self._stream()))
         self._grad_reduced = self._fused_ar is not None
+        for param, piece in zip(self._param_list(), self._split_flat(self._flat_grad)):
+            if param.grad is None or param.grad.data_ptr() != piece.data_ptr():
+                param.grad = piece
+        return self._loss_total
+
+    def _mesh_train_step(self, x: Tensor, x_plus: Tensor, adam: 'FusedAdamState') -> Tensor:
+        """:meth:`contactnets_train_step` of a system with learned shapes on the specialised builds (cube / elbow with a
+        ``DeepSupportConvex`` per body): ``dpll_contactnets_train_step_mesh``"""
+        if not self.spec.is_fast():
+            raise NotImplementedError('the fused training step of the general build with learned shapes is not built: use '
+                                      'contactnets_loss_and_grad + an optimizer')
+        if self.grad_world > 1:
+            raise NotImplementedError('the fused training step of a mesh system is single process')
+        lib = _capi.library()
+        xf = self._check_input(x, self.space.n_x, 'x')
+        xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
+        flat = self._packed()
+        if self._flat_grad is None or self._flat_grad.device != xf.device:
+            self._alloc_grad_buffer(flat.numel(), xf.device)
+        workspace = self._mesh_workspace(xf.shape[0], xf.device)
+        adam.bind(flat)
+        params, mesh, state = self._params_struct(flat), self._mesh_struct(flat), adam.struct(flat)
+        _capi.check(lib.dpll_contactnets_train_step_mesh(
+            self._model(), _DTYPES[self.dtype], ctypes.byref(params), mesh, _ptr(xf), xf.stride(0), _ptr(xpf), xpf.stride(0), xf.shape[0],
+            None, 1.0 / xf.shape[0], _ptr(self._flat_grad), _ptr(self._loss_total), _ptr(workspace), workspace.numel(), ctypes.byref(state),
+            self._stream()))
         for param, piece in zip(self._param_list(), self._split_flat(self._flat_grad)):
             if param.grad is None or param.grad.data_ptr() != piece.data_ptr():
                 param.grad = piece

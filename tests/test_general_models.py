@@ -355,39 +355,54 @@ def test_gpu_matches_the_host_build_on_many_random_states(golden, name):
     assert iters.max() < 100
     xd = x.cuda()
     x_next = system.step(xd).detach().cpu().numpy()
-    # Deeply overlapping boxes have several directions of (nearly) equal penetration: which one wins is decided by the
-    # last bits of the candidates' values (the device contracts multiply-adds, the host compiler does not), and the two
-    # answers are different contacts -- a handful of items in 2048 for the models with box-box candidates; those are
-    # left out of the comparison, every other item must agree
+    # Deeply overlapping boxes have several directions of equal penetration up to rounding (the device contracts
+    # multiply-adds, the host compiler does not): the direction search treats separations within kPairTie (1e-12 m) as a tie
+    # and gives it to the candidate with the lowest number -- in a lane's own sequence and in the butterfly over the lanes --
+    # so device and host pick the SAME contact (round 3 tolerated 8 of 2048 items on different, equally deep contacts)
     row_scale = np.maximum(1.0, np.abs(x_next_host).max(axis=1))
     same = np.abs(x_next - x_next_host).max(axis=1) < 1e-8 * row_scale
-    assert same.all() if not spec.pairs else (~same).sum() <= 8, (~same).sum()
+    assert same.all(), (~same).sum()
     # the loss of the transition to a perturbed next state (so that its solve is not the dynamics' own)
     xp = torch.tensor(x_next_host)
     xp[:, -(6 + n_j):] += 0.05 * torch.randn((n, 6 + n_j), generator=gen, dtype=torch.float64)
     host = hostsim.loss(desc, theta, friction, lengths, x.numpy(), xp.numpy())
     loss = system.contactnets_loss(xd, torch.zeros((n, 0), device='cuda:0'), xp.cuda())
     same_loss = np.abs(loss.detach().cpu().numpy() - host['loss']) < 1e-9 * np.maximum(1.0, np.abs(host['loss']))
-    assert same_loss.all() if not spec.pairs else (~same_loss).sum() <= 8, (~same_loss).sum()
-    if not same_loss.all():  # gradients of the items both builds see alike
-        keep = np.where(same_loss)[0]
-        host = hostsim.loss(desc, theta, friction, lengths, x.numpy()[keep], xp.numpy()[keep])
-        loss = system.contactnets_loss(xd[keep], torch.zeros((len(keep), 0), device='cuda:0'), xp.cuda()[keep])
+    assert same_loss.all(), (~same_loss).sum()
     loss.mean().backward()
     ref = host['grad']  # (kernel layout: [theta | friction (1 + 4 slots) | lengths (4 slots, 24)]; the module's parameters in order)
     mine = reference_gradient({'grad/' + key: p.grad.cpu().numpy() for key, p in system.named_parameters()}, spec)
     assert np.abs(mine - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max())
-    # the float32 kernels on the same states: finite everywhere, and the float64 answer at float32 accuracy for all but
-    # the few items whose active set sits on an edge
+    # The float32 kernels on the same states, at north_star's tolerance (1e-4 on next state and loss) for EVERY item whose answer
+    # float32 inputs can resolve at all: both precisions get the float32-rounded states (no input rounding in the comparison),
+    # and an item is excused only if the float64 kernels themselves move by more than a quarter of the tolerance when its
+    # inputs are nudged by two float32 ulps -- its active set sits within float32 resolution of an edge (a corner about to
+    # touch, a contact between sticking and sliding), the one thing no float32 kernel can decide; at most 1 % of the states.
     s32 = gpu_system(g, name, torch.float32)
+    tol = 1e-4
+    x32, xp32 = xd.float(), xp.cuda().float()
+    xr, xpr = x32.double(), xp32.double()
+    u0 = torch.zeros((n, 0), device='cuda:0')
     with torch.no_grad():
-        next32 = s32.step(xd.float()).double().cpu().numpy()
-        loss32 = s32.contactnets_loss(xd.float(), torch.zeros((n, 0), device='cuda:0'), xp.cuda().float()).double().cpu().numpy()
-        loss64 = system.contactnets_loss(xd, torch.zeros((n, 0), device='cuda:0'), xp.cuda()).cpu().numpy()
+        next32 = s32.step(x32).double().cpu().numpy()
+        loss32 = s32.contactnets_loss(x32, u0, xp32).double().cpu().numpy()
+        next64, loss64 = system.step(xr).cpu().numpy(), system.contactnets_loss(xr, u0, xpr).cpu().numpy()
+        scale_next = np.maximum(1.0, np.abs(next64).max(axis=1))
+        scale_loss = np.maximum(1.0, np.abs(loss64))
+        sens_next, sens_loss = np.zeros(n), np.zeros(n)
+        nudge = torch.Generator().manual_seed(7)
+        for _ in range(3):
+            sx = (1 + 2.4e-7 * (2.0 * torch.randint(0, 2, xr.shape, generator=nudge) - 1.0)).cuda()
+            sp = (1 + 2.4e-7 * (2.0 * torch.randint(0, 2, xr.shape, generator=nudge) - 1.0)).cuda()
+            sens_next = np.maximum(sens_next, np.abs(system.step(xr * sx).cpu().numpy() - next64).max(axis=1) / scale_next)
+            sens_loss = np.maximum(sens_loss, np.abs(system.contactnets_loss(xr * sx, u0, xpr * sp).cpu().numpy() - loss64) / scale_loss)
     assert np.isfinite(next32).all() and np.isfinite(loss32).all()
-    close_next = np.abs(next32 - x_next).max(axis=1) < 2e-3 * row_scale
-    close_loss = np.abs(loss32 - loss64) < 2e-3 * np.maximum(1.0, np.abs(loss64))
-    assert close_next.mean() > 0.98 and close_loss.mean() > 0.98, (close_next.mean(), close_loss.mean())
+    err_next = np.abs(next32 - next64).max(axis=1) / scale_next
+    err_loss = np.abs(loss32 - loss64) / scale_loss
+    edge_next, edge_loss = sens_next > tol / 4, sens_loss > tol / 4
+    assert ((err_next <= tol) | edge_next).all(), (int(((err_next > tol) & ~edge_next).sum()), err_next[~edge_next].max())
+    assert ((err_loss <= tol) | edge_loss).all(), (int(((err_loss > tol) & ~edge_loss).sum()), err_loss[~edge_loss].max())
+    assert edge_next.mean() <= 0.01 and edge_loss.mean() <= 0.01, (edge_next.mean(), edge_loss.mean())
 
 
 @pytest.mark.gpu

@@ -278,10 +278,86 @@ def test_fused_adam_step_is_torch_adam(model, dtype):
     assert torch.allclose(t_eager.optimizer.exp_avg[:n].reshape(state['exp_avg'].shape), state['exp_avg'], rtol=1e-4, atol=1e-9)
 
 
-def test_fused_training_step_refuses_models_it_does_not_serve():
+FUSED_CASES = {
+    # name -> (init_urdfs, fixture, mesh_representation): the general build (a prismatic joint + turned frames; a body-body pair), the
+    # forest build (two models in one system), the specialised mesh build (every weight of the network is a parameter)
+    'slider': ({'slider': 'slider.urdf'}, 'slider_literal', 'deep_support'),
+    'clasp': ({'clasp': 'clasp.urdf'}, 'clasp_literal', 'deep_support'),
+    'two_cubes': ({'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'}, 'two_cubes_literal', 'deep_support'),
+    'cube_mesh': ({'cube': 'cube_mesh.urdf'}, 'cube_mesh_literal', 'deep_support'),
+}
+
+
+@pytest.mark.parametrize('case', list(FUSED_CASES))
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_fused_adam_step_of_the_other_builds_is_torch_adam(case, dtype):
+    """dpll_contactnets_train_step on the general and the forest build (Adam in the kernel that chains the folded rows; padding
+    entries of the flat buffer untouched) and dpll_contactnets_train_step_mesh on the specialised mesh build (Adam where the
+    network's weight gradients are reduced): twelve steps with weight decay against torch.optim.Adam fed by
+    contactnets_loss_and_grad -- same parameters, same step count; eagerly and as a replayed hipGraph."""
     from dair_pll_amd import MultibodyLearnableSystem
     from dair_pll_amd.system import FusedAdamState
-    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, 'chain3.urdf')}, 0.0068, device='cuda:0')
+    urdfs, fixture, representation = FUSED_CASES[case]
+    g = np.load(os.path.join(GOLDEN_DIR, fixture + '.npz'))
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+
+    def make():
+        torch.manual_seed(0)  # (the mesh system draws its network at construction)
+        system = MultibodyLearnableSystem({k: os.path.join(ASSET_DIR, v) for k, v in urdfs.items()}, float(g['dt']), dtype=dtype, device='cuda:0',
+                                          mesh_representation=representation)
+        with torch.no_grad():
+            system.multibody_terms.contact_terms.friction_params[1] = 0.5
+        return system
+
+    ref, fused, graphed = make(), make(), make()
+    flat0 = fused._packed().clone()
+    optimizer = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-3)
+    adam, adam_g = FusedAdamState(lr=1e-3, weight_decay=1e-3), FusedAdamState(lr=1e-3, weight_decay=1e-3)
+    graphed.contactnets_train_step(x, xp, adam_g)  # warm-up of the path to be captured, undone below
+    with torch.no_grad():
+        graphed._packed().copy_(flat0)
+        for t, value in zip((adam_g.exp_avg, adam_g.exp_avg_sq), (0.0, 0.0)):
+            t.fill_(value)
+        adam_g.state.copy_(torch.tensor([0.0, 1.0, 1.0], dtype=torch.float64))
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            graphed.contactnets_train_step(x, xp, adam_g)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.no_grad():  # (capture does not execute: nothing to undo)
+        assert torch.equal(graphed._packed(), flat0)
+    for _ in range(12):
+        ref.contactnets_loss_and_grad(x, xp)
+        optimizer.step()
+        fused.contactnets_train_step(x, xp, adam)
+        graph.replay()
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 1e-9
+    moved = 0.0
+    for (name, p_ref), (_, p_fused), (_, p_graph), (_, p_start) in zip(ref.named_parameters(), fused.named_parameters(), graphed.named_parameters(),
+                                                                       make().named_parameters()):
+        scale = max(1.0, p_ref.abs().max().item())
+        assert (p_ref - p_fused).abs().max().item() <= tol * scale, (name, (p_ref - p_fused).abs().max().item())
+        assert (p_fused - p_graph).abs().max().item() <= tol * scale, name
+        moved = max(moved, (p_ref - p_start).abs().max().item())
+    assert moved > 1e-3 and adam.step.item() == 12.0 and adam_g.step.item() == 12.0
+    # what is not a parameter stays what it was: padding of the flat buffer (general build: unused geometry slots; every build
+    # but the mesh one: the tail of each geometry's block)
+    layout, total = fused._layout()
+    real = torch.zeros(total, dtype=torch.bool)
+    for p, offset in layout:
+        real[offset:offset + p.numel()] = True
+    assert torch.equal(fused._packed().cpu()[~real], flat0.cpu()[~real])
+
+
+def test_fused_training_step_refuses_models_it_does_not_serve():
+    """the general build WITH learned shapes has no fused step (its network gradients take the general item kernels' route)"""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.system import FusedAdamState
+    system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, 'clasp_mesh.urdf')}, 0.0068, device='cuda:0')
     x = torch.zeros((4, system.space.n_x), device='cuda:0')
     with pytest.raises(NotImplementedError):
         system.contactnets_train_step(x, x, FusedAdamState())
