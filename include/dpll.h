@@ -186,7 +186,7 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
 int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts_t* opts);
 
 int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
-/* A model on the forest build.  The handle works with every entry point below that takes a dpll_model_t (loss, step,
+/* A model on the forest build.  The handle works with every entry point below that takes a model handle (loss, step,
  * simulate, step backward, terms; not the *_mesh, allreduce-fused and train-step ones).  Layouts: state rows (n_q + n_v);
  * parameters [theta (n_bodies, 10) | friction (1 + n_geoms) | lengths (n_geoms, DPLL_GEOM_BLOCK)]; forces / phi / J / D over
  * the model's n_contacts contacts in the reference's order (no padding slots).  racing copies: none. */
