@@ -36,12 +36,15 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 matrix rate: 256 CUs x 256 flop/clk x 2.4 GHz (v_mfma_f32_32x32x2_f32: 64 cyc/SIMD)
 VALU_F64_PEAK_TFLOPS = 78.6   # f64 vector FMA rate
-N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17, 'slider': 17, 'clasp_mesh': 17}
+N_X = {'cube': 13, 'elbow': 15, 'mesh': 13, 'elbow_mesh': 15, 'clasp': 17, 'slider': 17, 'clasp_mesh': 17, 'two_cubes': 26, 'chain6': 23}
 ELEM = {'f32': 4, 'f64': 8}
 URDF = {'cube': 'cube.urdf', 'elbow': 'elbow.urdf', 'mesh': 'cube_mesh.urdf', 'elbow_mesh': 'elbow_mesh.urdf', 'clasp': 'clasp.urdf',
-        'slider': 'slider.urdf', 'clasp_mesh': 'clasp_mesh.urdf'}  # (clasp: a box-box body-body candidate; slider: a prismatic joint, turned frames -- the general build)
+        'slider': 'slider.urdf', 'clasp_mesh': 'clasp_mesh.urdf',  # (clasp: a box-box body-body candidate; slider: a prismatic joint, turned frames -- the general build)
+        # the forest build (csrc/dpll_forest.hip): two models in one system; a five-joint chain with ten body-body candidates
+        'two_cubes': {'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'}, 'chain6': 'chain6.urdf'}
 FIXTURE = {'cube': 'cube_box_4096.npz', 'elbow': 'elbow_box_4096.npz', 'mesh': 'cube_box_4096.npz', 'elbow_mesh': 'elbow_box_4096.npz',
-           'clasp': 'clasp_literal.npz', 'slider': 'slider_literal.npz', 'clasp_mesh': 'clasp_mesh_literal.npz'}
+           'clasp': 'clasp_literal.npz', 'slider': 'slider_literal.npz', 'clasp_mesh': 'clasp_mesh_literal.npz',
+           'two_cubes': 'two_cubes_literal.npz', 'chain6': 'chain6_literal.npz'}
 # (clasp_mesh: two learned shapes whose pair is a collision candidate -- the reference's own body-body case: GJK / EPA + ICNN)
 # (what the fixtures are: DESIGN.md section 2; ranks > 0 take the same pairs permuted, other batch sizes resample with replacement)
 DATA = {'cube': 'fixture: 4096 of the 57,812 real cube-toss pairs of the reference data set (tests/golden/cube_box_4096.npz), URDF-initial parameters',
@@ -195,7 +198,7 @@ class Timer:
 def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
-    if workload in ('elbow_mesh', 'clasp', 'slider', 'clasp_mesh'):
+    if workload in ('elbow_mesh', 'clasp', 'slider', 'clasp_mesh', 'two_cubes', 'chain6'):
         return None  # no per-kernel utility for these pipelines: run_loss_config prices the whole step
     if workload == 'mesh':
         mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
@@ -249,7 +252,8 @@ def build_system(workload, dtype_name, dt, device):
     from dair_pll_amd import MultibodyLearnableSystem
     torch.manual_seed(0)  # mesh workload: ICNN weights from the reference's init distributions
     dtype = torch.float32 if dtype_name == 'f32' else torch.float64
-    return MultibodyLearnableSystem({workload: os.path.join(REPO, 'assets', URDF[workload])}, dt, dtype=dtype, device=str(device))
+    urdfs = URDF[workload] if isinstance(URDF[workload], dict) else {workload: URDF[workload]}
+    return MultibodyLearnableSystem({k: os.path.join(REPO, 'assets', v) for k, v in urdfs.items()}, dt, dtype=dtype, device=str(device))
 
 
 def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device, use_graph=True, steps_per_graph=50, mesh_gemm=0):
@@ -279,10 +283,11 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
                     'kernel': 'whole step: hull extraction + GJK/EPA query kernel + 8 GEMM launches + general item kernel + reductions', 'kernel_ms': step_ms}
         else:
             gbs = bytes_per_step(workload, dtype_name) * batch / (step_ms * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-                    'kernel': 'gen_loss_kernel + row fold + finalize (general build: one lane per contact slot)', 'kernel_ms': step_ms}
+            kernel = ('forest_loss_kernel + row fold + finalize (forest build: one wave per item, blocks in LDS)' if workload in ('two_cubes', 'chain6')
+                      else 'gen_loss_kernel + row fold + finalize (general build: one lane per contact slot)')
+            roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'kernel': kernel, 'kernel_ms': step_ms}
     if mesh_gemm:
-        workload = f'{workload} (ICNN GEMMs: bf16 matrix cores, operands split into {mesh_gemm} bf16 planes)'
+        workload = f'{workload} (ICNN GEMMs on the bf16 matrix cores, {mesh_gemm} planes)'
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
             'racing_copies': system.racing_copies(batch), 'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
@@ -343,7 +348,7 @@ def self_launch(n_gpus: int) -> int:
     return subprocess.run(command, env=env, check=False).returncode
 
 
-def run_train_config(dtype_name, batch, steps, device, fused):
+def run_train_config(dtype_name, batch, steps, device, fused, workload='cube'):
     """One training step of the loop the kernel lives in (experiment.py:332-363 with the optimizer of :213-228): the mean
     ContactNets loss of a 4096-pair batch, its gradients and the Adam update of every parameter -- 20 steps per hipGraph,
     median of 5 repeats of `steps` steps.  `fused`: the update is done by the finalize kernel of the loss launch
@@ -351,8 +356,8 @@ def run_train_config(dtype_name, batch, steps, device, fused):
     (The batch is fixed: the shuffled gather of a real epoch is two index_select launches more, ContactNetsTrainer.)"""
     from dair_pll_amd.system import FusedAdamState
     dtype = torch.float32 if dtype_name == 'f32' else torch.float64
-    x_np, xp_np, dt = load_pairs(batch, 0, 'cube')
-    system = build_system('cube', dtype_name, dt, device)
+    x_np, xp_np, dt = load_pairs(batch, 0, workload)
+    system = build_system(workload, dtype_name, dt, device)
     x, xp = torch.tensor(x_np, dtype=dtype, device=device), torch.tensor(xp_np, dtype=dtype, device=device)
     if fused:
         adam = FusedAdamState(lr=1e-3)
@@ -369,7 +374,7 @@ def run_train_config(dtype_name, batch, steps, device, fused):
     torch.cuda.synchronize()
     timer = Timer(step, steps, 20, True, 20, torch.cuda.synchronize, lambda t: t)
     elapsed, _ = timer.measure(5)
-    return {'workload': 'train_step (cube: loss + gradients + ' + ('Adam in the finalize kernel' if fused else 'torch.optim.Adam') + ')',
+    return {'workload': f'train_step ({workload}, ' + ('fused Adam' if fused else 'torch.optim.Adam') + ')',
             'dtype': dtype_name, 'batch': batch, 'value': steps * batch / elapsed, 'optimizer_steps_per_s': steps / elapsed,
             'ms_per_step': elapsed / steps * 1e3, 'launch': timer.launch, 'mean_loss': step().item()}
 
@@ -597,7 +602,8 @@ def main() -> None:
             configs = []
             for w, d, b, k in (('elbow', 'f32', 4096, 1000), ('elbow', 'f64', 4096, 500), ('mesh', 'f32', 4096, 200),
                                ('cube', 'f64', 4096, 1000), ('cube', 'f32', 16384, 400), ('cube', 'f32', 65536, 200), ('cube', 'f64', 65536, 100),
-                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50), ('slider', 'f32', 4096, 50), ('clasp_mesh', 'f32', 4096, 20)):
+                               ('elbow_mesh', 'f32', 4096, 100), ('clasp', 'f32', 4096, 50), ('slider', 'f32', 4096, 50), ('clasp_mesh', 'f32', 4096, 20),
+                               ('two_cubes', 'f32', 4096, 20), ('chain6', 'f32', 4096, 10)):
                 try:
                     configs.append(run_loss_config(w, d, b, k, max(10, k // 10), 3, device))
                 except Exception as exc:  # noqa: BLE001
@@ -611,13 +617,20 @@ def main() -> None:
                 configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=2))
             except Exception as exc:  # noqa: BLE001
                 configs.append({'workload': 'mesh (bf16 planes)', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
-            for fused in (False, True):
+            for w, k, fused in (('cube', 400, False), ('cube', 400, True), ('slider', 60, True), ('mesh', 60, True)):
                 try:
-                    configs.append(run_train_config('f32', 4096, 400, device, fused))
+                    configs.append(run_train_config('f32', 4096, k, device, fused, w))
                 except Exception as exc:  # noqa: BLE001
-                    configs.append({'workload': 'train_step', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
-            # compact: no launch / note strings (DESIGN.md section 5 has them), the kernel name only inside `roofline`
-            line['configs'] = [{k: v for k, v in c.items() if k not in ('launch', 'unit', 'steps')} for c in configs]
+                    configs.append({'workload': f'train_step ({w})', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
+            # compact (the driver keeps an 8 KB tail of stdout): no launch / note strings (DESIGN.md section 5 has them), the
+            # roofline of a configuration as [bound, achieved, fraction of peak] -- the peaks are the headline's (8 TB/s HBM,
+            # 157.3 TFLOP/s f32 MFMA) and the kernel behind every figure is named in DESIGN.md section 5's table
+            def short(c):
+                out = {k: v for k, v in c.items() if k not in ('launch', 'unit', 'steps', 'roofline', 'optimizer_steps_per_s')}
+                if 'roofline' in c:
+                    out['roofline'] = [c['roofline']['bound'], c['roofline']['achieved'], c['roofline']['frac']]
+                return out
+            line['configs'] = [short(c) for c in configs]
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(x_np, xp_np, dt, args.workload)
         print(json.dumps(compact(line), separators=(',', ':')), flush=True)

@@ -159,9 +159,12 @@ DPLL_HD bool bad_number(double x) {
 // double and the host build: exact division / sqrt.
 template <typename T> DPLL_HD T fast_rcp(T x) { return T(1) / x; }
 template <typename T> DPLL_HD T fast_rsqrt(T x) { return T(1) / tsqrt(x); }
+template <typename T> DPLL_HD T fast_sqrt(T x) { return tsqrt(x); }
 #if defined(__HIP_DEVICE_COMPILE__)
 template <> DPLL_HD float fast_rcp<float>(float x) { return __builtin_amdgcn_rcpf(x); }
 template <> DPLL_HD float fast_rsqrt<float>(float x) { return __builtin_amdgcn_rsqf(x); }
+// (v_sqrt_f32, 1 ulp, instead of sqrtf's correctly rounded sequence of a dozen instructions: for quantities that only scale a tolerance)
+template <> DPLL_HD float fast_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
 #endif
 
 template <typename T> DPLL_HD void cross(const T (&a)[3], const T (&b)[3], T (&c)[3]) {
@@ -1071,7 +1074,7 @@ DPLL_HD int sap_newton(const T (&M)[6 + NJ][6 + NJ], const JT (&Jc)[KPL], const 
     // Newton decrement and stopping rule (the step below is still taken: it only improves y)
     const T dec2 = -dotn<T, NV>(grad, d);
     const T ynorm2 = dotn<T, NV>(cur.yT, cur.My);
-    const T scale = T(1) + tsqrt(tmax(ynorm2, T(0)));
+    const T scale = T(1) + fast_sqrt(tmax(ynorm2, T(0)));
     const T scale2 = scale * scale;
     const bool converged = !(dec2 > (final_stage ? tol2 : stage_tol2) * scale2);
     const bool improved = dec2 < T(0.25) * best;  // decrement still halving?

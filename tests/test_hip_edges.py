@@ -444,3 +444,57 @@ def test_double_solves_refined_from_float_agree_with_all_double(urdf, case):
         assert np.abs(out[mode][0].cpu().numpy() - g['loss']).max() < 1e-10
     # the double phase of the refined solve is short: most of its iterations are the float ones
     assert out[1][2].max().item() <= out[0][2].max().item() + 4
+
+
+def test_racing_table_out_of_sample():
+    """The racing schedules were picked on 4096-pair samples of the toss data at URDF-initial parameters:
+    here they are held (1) on the cube after 200 optimizer steps of the toss-data example from its wrong start -- other
+    parameters, so other cone problems -- and (2) on 4096 elbow pairs of tosses drawn with another seed and rolled out by the
+    kernels themselves.  Whatever the data: same losses, no item needs more iterations than the launch without copies
+    (copy 0 IS that schedule) and the slowest item does not regress; the gain is printed for the record."""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.system import FusedAdamState
+    from dair_pll_amd.trainer import load_tosses, slice_pairs
+    report = []
+    # (1) the cube with trained parameters
+    path = os.path.join(ASSET_DIR, 'contactnets_cube_tosses.npz')
+    px, pxp = slice_pairs(load_tosses(path))
+    x_all, xp_all = px.to(device='cuda:0', dtype=torch.float32), pxp.to(device='cuda:0', dtype=torch.float32)
+    system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, float(np.load(path)['dt']), dtype=torch.float32, device='cuda:0')
+    with torch.no_grad():
+        system.multibody_terms.contact_terms.geometries[1].length_params.mul_(1.25)
+        system.multibody_terms.contact_terms.friction_params[1] = 0.6
+    adam = FusedAdamState(lr=1e-3)
+    order = torch.randperm(x_all.shape[0], generator=torch.Generator().manual_seed(0)).cuda()
+    for step in range(200):
+        idx = order[(step * 4096) % (x_all.shape[0] - 4096):][:4096]
+        system.contactnets_train_step(x_all[idx], xp_all[idx], adam)
+    moved = system.multibody_terms.contact_terms.geometries[1].length_params.detach().abs().mean().item()
+    assert abs(moved - 1.25 * 0.0524) > 1e-3  # (the parameters did move)
+    pick = torch.randperm(x_all.shape[0], generator=torch.Generator().manual_seed(11))[:4096].cuda()
+    cases = [('cube after 200 steps', system, x_all[pick], xp_all[pick])]
+    # (2) elbow tosses with another seed, rolled out by the kernels
+    g = np.load(os.path.join(GOLDEN_DIR, 'elbow_box_4096.npz'))
+    elbow = MultibodyLearnableSystem({'elbow': os.path.join(ASSET_DIR, 'elbow.urdf')}, float(g['dt']), dtype=torch.float32, device='cuda:0')
+    gen = torch.Generator().manual_seed(12345)
+    n = 64
+    quat = torch.randn((n, 4), generator=gen)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    x0 = torch.cat((quat, 0.1 * torch.randn((n, 2), generator=gen), 0.15 + 0.1 * torch.rand((n, 1), generator=gen), 1.0 * torch.randn((n, 1), generator=gen),
+                    3.0 * torch.randn((n, 3), generator=gen), 0.6 * torch.randn((n, 3), generator=gen), 2.0 * torch.randn((n, 1), generator=gen)), -1).cuda()
+    with torch.no_grad():
+        traj, _ = elbow.simulate(x0.unsqueeze(-2), torch.zeros((n, 1), device='cuda:0'), 100)
+    ex, exp_ = traj[:, :-1].reshape(-1, 15), traj[:, 1:].reshape(-1, 15)
+    keep = torch.randperm(ex.shape[0], generator=torch.Generator().manual_seed(5))[:4096].cuda()
+    cases.append(('elbow, other seed', elbow, ex[keep].contiguous(), exp_[keep].contiguous()))
+    for label, model, x, xp in cases:
+        model.set_solver(portfolio=1)
+        loss_1, _, it_1 = model.contact_forces(x, xp)
+        model.set_solver(portfolio=0)
+        assert model.racing_copies(4096) == 4
+        loss_4, _, it_4 = model.contact_forces(x, xp)
+        assert torch.isfinite(loss_4).all() and (loss_4 - loss_1).abs().max().item() <= 5e-6 * max(1.0, loss_1.abs().max().item())
+        slack = 1 if label.startswith('elbow') else 0  # (the elbow's four-copy build sums its contacts in another order: +1 at most)
+        assert (it_4 <= it_1 + slack).all() and it_4.max().item() <= it_1.max().item()
+        report.append(f'{label}: slowest item {it_1.max().item()} -> {it_4.max().item()} iterations, mean {it_1.float().mean().item():.2f} -> {it_4.float().mean().item():.2f}')
+    print('racing copies out of sample | ' + ' | '.join(report))
