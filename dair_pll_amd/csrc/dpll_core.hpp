@@ -1465,20 +1465,36 @@ template <typename S> struct PairBest {
   S d[3];
   int k;  // number of the candidate that set it (ties between lanes: the earliest candidate wins, as in one lane)
 };
-template <typename S>
+// PAD8: both sets are stored with kMaxPolyVerts entries, the ones past the count repeating vertex 0 (a repeated vertex changes
+// no maximum or minimum): the loops have a fixed length, and the loads of a set are issued together instead of one
+// round trip to memory per vertex.
+template <typename S, bool PAD8 = false>
 DPLL_HD void pair_try(const S (&n)[3], int k, const S (*a)[3], int na, const S (*b)[3], int nb, PairBest<S>& best) {
   const S n2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
   if (!(n2 > S(0))) return;
   S amax = S(-3.0e38), amin = S(3.0e38), bmax = S(-3.0e38), bmin = S(3.0e38);
-  for (int i = 0; i < na; ++i) {
-    const S t = n[0] * a[i][0] + n[1] * a[i][1] + n[2] * a[i][2];
-    amax = tmax(amax, t);
-    amin = tmin(amin, t);
-  }
-  for (int j = 0; j < nb; ++j) {
-    const S t = n[0] * b[j][0] + n[1] * b[j][1] + n[2] * b[j][2];
-    bmax = tmax(bmax, t);
-    bmin = tmin(bmin, t);
+  if constexpr (PAD8) {
+    DPLL_UNROLL for (int i = 0; i < kMaxPolyVerts; ++i) {
+      const S t = n[0] * a[i][0] + n[1] * a[i][1] + n[2] * a[i][2];
+      amax = tmax(amax, t);
+      amin = tmin(amin, t);
+    }
+    DPLL_UNROLL for (int j = 0; j < kMaxPolyVerts; ++j) {
+      const S t = n[0] * b[j][0] + n[1] * b[j][1] + n[2] * b[j][2];
+      bmax = tmax(bmax, t);
+      bmin = tmin(bmin, t);
+    }
+  } else {
+    for (int i = 0; i < na; ++i) {
+      const S t = n[0] * a[i][0] + n[1] * a[i][1] + n[2] * a[i][2];
+      amax = tmax(amax, t);
+      amin = tmin(amin, t);
+    }
+    for (int j = 0; j < nb; ++j) {
+      const S t = n[0] * b[j][0] + n[1] * b[j][1] + n[2] * b[j][2];
+      bmax = tmax(bmax, t);
+      bmin = tmin(bmin, t);
+    }
   }
   const S inv = S(1) / tsqrt(n2);
   const S sp = (bmin - amax) * inv, sm = (amin - bmax) * inv;
@@ -1498,44 +1514,61 @@ DPLL_HD void pair_try(const S (&n)[3], int k, const S (*a)[3], int na, const S (
 // Features of a vertex set that can define the direction: its edges (vertex-edge candidates), one edge per edge
 // DIRECTION (edge x edge candidates) and one vertex triple per face normal.  A box: its 12 edges, 3 axis edges and 3
 // faces; a polygon's hull is not known, so every vertex pair and triple stands in (a superset: correct, slower).
-struct PairFeatures {
-  int n_edges, n_dirs, n_tris;
-  unsigned char edges[28][2], dirs[28][2], tris[56][3];
-};
-DPLL_HD void pair_features(int kind, int nv, PairFeatures& f) {
-  f.n_edges = 0; f.n_dirs = 0; f.n_tris = 0;
-  if (kind == kGeomBox) {  // corner u = bits (x y z), reference geometry.py:39-41
-    for (int u = 0; u < 8; ++u)
-      for (int bit = 1; bit <= 4; bit <<= 1)
-        if (!(u & bit)) { f.edges[f.n_edges][0] = (unsigned char)u; f.edges[f.n_edges][1] = (unsigned char)(u | bit); ++f.n_edges; }
-    for (int bit = 1; bit <= 4; bit <<= 1) { f.dirs[f.n_dirs][0] = 0; f.dirs[f.n_dirs][1] = (unsigned char)bit; ++f.n_dirs; }
-    const unsigned char faces[3][3] = {{0, 1, 2}, {0, 1, 4}, {0, 2, 4}};
-    for (int t = 0; t < 3; ++t) { for (int i = 0; i < 3; ++i) f.tris[t][i] = faces[t][i]; }
-    f.n_tris = 3;
+// Feature number -> vertex numbers is ARITHMETIC (no per-lane tables: a table indexed by the lane lives in scratch
+// memory, and the search paid more for reading it than for its dot products).
+struct PairFeatureCounts { int n_edges, n_dirs, n_tris; };
+DPLL_HD PairFeatureCounts pair_feature_counts(int kind, int nv) {
+  if (kind == kGeomBox) return {12, 3, 3};
+  const int pairs = nv * (nv - 1) / 2;
+  return {pairs, pairs, pairs * (nv - 2) / 3};
+}
+// m-th vertex pair (i < j, ordered by i then j) of nv vertices
+DPLL_HD void nth_pair(int nv, int m, int& i, int& j) {
+  i = 0;
+  while (m >= nv - 1 - i) { m -= nv - 1 - i; ++i; }
+  j = i + 1 + m;
+}
+// edge m: a box's corners u = bits (x y z), reference geometry.py:39-41 -- edges (u, u | bit) for u ascending, bit = 1, 2, 4
+DPLL_HD void pair_edge(int kind, int nv, int m, int& k, int& l) {
+  if (kind == kGeomBox) {
+    // k = 0 0 0 1 1 2 2 3 4 4 5 6,  l = 1 2 4 3 5 3 6 7 5 6 7 7 as 3-bit fields
+    constexpr unsigned long long kLo = 0ull | (0ull << 3) | (0ull << 6) | (1ull << 9) | (1ull << 12) | (2ull << 15) | (2ull << 18) | (3ull << 21) |
+                                       (4ull << 24) | (4ull << 27) | (5ull << 30) | (6ull << 33);
+    constexpr unsigned long long kHi = 1ull | (2ull << 3) | (4ull << 6) | (3ull << 9) | (5ull << 12) | (3ull << 15) | (6ull << 18) | (7ull << 21) |
+                                       (5ull << 24) | (6ull << 27) | (7ull << 30) | (7ull << 33);
+    k = int((kLo >> (3 * m)) & 7ull);
+    l = int((kHi >> (3 * m)) & 7ull);
     return;
   }
-  for (int i = 0; i < nv; ++i)
-    for (int j = i + 1; j < nv; ++j) {
-      f.edges[f.n_edges][0] = f.dirs[f.n_edges][0] = (unsigned char)i;
-      f.edges[f.n_edges][1] = f.dirs[f.n_edges][1] = (unsigned char)j;
-      ++f.n_edges;
-      for (int k = j + 1; k < nv; ++k) { f.tris[f.n_tris][0] = (unsigned char)i; f.tris[f.n_tris][1] = (unsigned char)j; f.tris[f.n_tris][2] = (unsigned char)k; ++f.n_tris; }
-    }
-  f.n_dirs = f.n_edges;
+  nth_pair(nv, m, k, l);
+}
+DPLL_HD void pair_dir(int kind, int nv, int m, int& k, int& l) {
+  if (kind == kGeomBox) { k = 0; l = 1 << m; return; }
+  nth_pair(nv, m, k, l);
+}
+DPLL_HD void pair_tri(int kind, int nv, int r, int& i, int& j, int& k) {
+  if (kind == kGeomBox) { i = 0; j = r < 2 ? 1 : 2; k = r == 0 ? 2 : 4; return; }  // faces (0 1 2), (0 1 4), (0 2 4)
+  i = 0;
+  while (true) {  // triples that start with i: pairs of the nv - 1 - i vertices after it
+    const int rest = nv - 1 - i, count = rest * (rest - 1) / 2;
+    if (r < count) break;
+    r -= count; ++i;
+  }
+  int jj, kk;
+  nth_pair(nv - 1 - i, r, jj, kk);
+  j = i + 1 + jj; k = i + 1 + kk;
 }
 // vertex sets a (na) and b (nb) in one frame -> unit d from A towards B; runtime loops (the sets live in memory).
 // The candidates are numbered -- vertex-vertex, vertex(A)-edge(B), vertex(B)-edge(A), faces of A, faces of B, edge x edge
 // -- and the lanes of the item's group take 16 consecutive numbers at a time (all of them busy at once), then agree on
 // the best with one butterfly; one lane alone walks the same numbers in order.
-template <typename S, class Lanes>
+template <typename S, class Lanes, bool PAD8 = false>
 DPLL_HD_CALL void pair_direction(const S (*a)[3], int na, int kind_a, const S (*b)[3], int nb, int kind_b, S (&d)[3]) {
   PairBest<S> best;
   best.sep = S(-3.0e38);
   best.d[0] = S(0); best.d[1] = S(0); best.d[2] = S(1);
   best.k = 0x7fffffff;
-  PairFeatures fa, fb;  // (every entry below the n_* counts is written by pair_features; nothing beyond them is read)
-  pair_features(kind_a, na, fa);
-  pair_features(kind_b, nb, fb);
+  const PairFeatureCounts fa = pair_feature_counts(kind_a, na), fb = pair_feature_counts(kind_b, nb);
   const int n_vv = na * nb, n_veb = na * fb.n_edges, n_vea = nb * fa.n_edges, n_ta = fa.n_tris, n_tb = fb.n_tris;
   const int total = n_vv + n_veb + n_vea + n_ta + n_tb + fa.n_dirs * fb.n_dirs;
   const int lane = Lanes::lane_in_group();
@@ -1552,9 +1585,10 @@ DPLL_HD_CALL void pair_direction(const S (*a)[3], int na, int kind_a, const S (*
       if (!first) r -= n_veb;
       const S (*p)[3] = first ? a : b;
       const S (*e)[3] = first ? b : a;
-      const PairFeatures& fe = first ? fb : fa;
-      const int i = r / fe.n_edges, m = r % fe.n_edges;
-      const int k = fe.edges[m][0], l = fe.edges[m][1];
+      const int ne = first ? fb.n_edges : fa.n_edges;
+      const int i = r / ne, m = r % ne;
+      int k, l;
+      pair_edge(first ? kind_b : kind_a, first ? nb : na, m, k, l);
       const S ed[3] = {e[l][0] - e[k][0], e[l][1] - e[k][1], e[l][2] - e[k][2]};
       const S w[3] = {e[k][0] - p[i][0], e[k][1] - p[i][1], e[k][2] - p[i][2]};
       const S ee = ed[0] * ed[0] + ed[1] * ed[1] + ed[2] * ed[2];
@@ -1564,20 +1598,22 @@ DPLL_HD_CALL void pair_direction(const S (*a)[3], int na, int kind_a, const S (*
       const bool first = r < n_ta;
       if (!first) r -= n_ta;
       const S (*p)[3] = first ? a : b;
-      const PairFeatures& fp = first ? fa : fb;
-      const int i = fp.tris[r][0], j = fp.tris[r][1], k = fp.tris[r][2];
+      int i, j, k;
+      pair_tri(first ? kind_a : kind_b, first ? na : nb, r, i, j, k);
       const S u[3] = {p[j][0] - p[i][0], p[j][1] - p[i][1], p[j][2] - p[i][2]};
       const S v[3] = {p[k][0] - p[i][0], p[k][1] - p[i][1], p[k][2] - p[i][2]};
       cross(u, v, n);
     } else {  // edge direction x edge direction
       r -= n_ta + n_tb;
       const int m = r / fb.n_dirs, o = r % fb.n_dirs;
-      const int i = fa.dirs[m][0], j = fa.dirs[m][1], k = fb.dirs[o][0], l = fb.dirs[o][1];
+      int i, j, k, l;
+      pair_dir(kind_a, na, m, i, j);
+      pair_dir(kind_b, nb, o, k, l);
       const S u[3] = {a[j][0] - a[i][0], a[j][1] - a[i][1], a[j][2] - a[i][2]};
       const S v[3] = {b[l][0] - b[k][0], b[l][1] - b[k][1], b[l][2] - b[k][2]};
       cross(u, v, n);
     }
-    pair_try(n, c, a, na, b, nb, best);
+    pair_try<S, PAD8>(n, c, a, na, b, nb, best);
   }
   Lanes::group_best(best.sep, best.k, best.d);
   DPLL_UNROLL for (int i = 0; i < 3; ++i) d[i] = best.d[i];

@@ -17,6 +17,24 @@
 #include <type_traits>
 
 #include "dpll_common.hpp"
+
+// Diagnostic build only (-DDPLL_FOREST_STAMPS, never shipped; tools/diag/forest_stamps.py): shader-clock ticks per phase of the
+// per-item program, summed over the items of workgroup 0
+#ifdef DPLL_FOREST_STAMPS
+__device__ unsigned long long g_fstamps[32][2];
+__device__ unsigned long long g_flast;
+#define DPLL_FSTAMP(slot)                                                                        \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long t_;                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                                                   \
+      if ((slot) != 0) { g_fstamps[slot][0] += t_ - g_flast; g_fstamps[slot][1] += 1; }          \
+      g_flast = t_;                                                                              \
+    }                                                                                            \
+  } while (0)
+#endif
 #include "dpll_forest.hpp"
 #include "dpll_forest_api.hpp"
 
@@ -50,6 +68,27 @@ struct WaveLanes {  // the lane-group policy of dpll_core.hpp's direction search
 // The team that works on an item: the whole wavefront (G = 64: one item per wave) or a 16-lane DPP row (G = 16: four items per
 // wave, for systems small enough that most phases would leave three quarters of a wave idle).  Barriers are workgroup barriers
 // either way (one wave per workgroup): teams of one wave walk through every phase together.
+// f(integral_constant<J>) for J = FROM, FROM + 1, ... while J < n (n uniform over the wave: ONE branch leaves the unrolled chain)
+template <int J, int JMAX> struct RowsUp {
+  template <class F> static __device__ __forceinline__ void run(int n, F&& f) {
+    if constexpr (J < JMAX) {
+      if (J < n) {
+        f(std::integral_constant<int, J>{});
+        RowsUp<J + 1, JMAX>::run(n, f);
+      }
+    }
+  }
+};
+// ... and for J = JMAX - 1 down to 0, those with J < n
+template <int J> struct RowsDown {
+  template <class F> static __device__ __forceinline__ void run(int n, F&& f) {
+    if constexpr (J >= 0) {
+      if (J < n) f(std::integral_constant<int, J>{});
+      RowsDown<J - 1>::run(n, f);
+    }
+  }
+};
+
 template <int G> struct GroupTeam {
   static_assert(G == 16 || G == kWave, "a DPP row or the whole wave");
   static constexpr int kSize = G;
@@ -67,6 +106,116 @@ template <int G> struct GroupTeam {
   }
   static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
   using Lanes = typename std::conditional<G == kWave, WaveLanes, GpuLanes<16>>::type;
+
+  // ---- dense factorisations with ONE ROW PER LANE in registers (dpll_forest.hpp cholesky / chol_solve hand over to these) ------
+  // The column-by-column factorisation in LDS pays two barriers and four dependent LDS round trips per column, on a wave that
+  // has nothing else to run meanwhile.  Here lane i keeps row i in registers and column j reaches the others as a lane
+  // broadcast (v_readlane: a scalar; teams of 16: DPP row_newbcast): n^2 / 2 multiply-adds per lane and no memory in between.
+  static constexpr bool kLaneRows = true;
+  static constexpr int kRowsMax = G == kWave ? dpll_forest::kMaxV : 8;  // (teams of 16 are given systems of <= 8 velocities)
+  template <int J> static __device__ __forceinline__ int bcast_word(int x) {
+    if constexpr (G == kWave) return __builtin_amdgcn_readlane(x, J);
+    else return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false);  // row_newbcast:J
+  }
+  template <int J> static __device__ __forceinline__ float bcast(float x) { return __int_as_float(bcast_word<J>(__float_as_int(x))); }
+  template <int J> static __device__ __forceinline__ double bcast(double x) {
+    const int lo = bcast_word<J>(__double2loint(x)), hi = bcast_word<J>(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+  }
+  // Aio (n x n, row-major, lower triangle used) -> L in its strict lower triangle, invd = 1 / diag(L); same operations in the
+  // same order as the LDS version (right-looking: entry (i, k) loses L_ij L_kj for j ascending)
+  // (the entry points are real functions -- one copy per kernel, several call sites -- so they say themselves what inlining
+  // would have told the compiler: the pointers are LDS, n is the same in every lane; and they pick the unrolled length)
+  template <typename S> using Lds = __attribute__((address_space(3))) S*;
+  template <typename S> using LdsConst = const __attribute__((address_space(3))) S*;
+  template <typename S> static __device__ __forceinline__ void factor_rows(S* Aio_, S* invd_, int n_, bool fast_) {
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    const bool fast = __builtin_amdgcn_readfirstlane(fast_ ? 1 : 0) != 0;
+    Lds<S> Aio = (Lds<S>)Aio_;
+    Lds<S> invd = (Lds<S>)invd_;
+    if (n <= 8) factor_rows_n<S, 8>(Aio, invd, n, fast);
+    else if constexpr (kRowsMax > 8) {
+      if (n <= 16) factor_rows_n<S, 16>(Aio, invd, n, fast);
+      else factor_rows_n<S, kRowsMax>(Aio, invd, n, fast);
+    }
+  }
+  template <typename S> static __device__ __forceinline__ void solve_rows(const S* L_, const S* invd_, const S* b_, S* x_, int n_) {
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    LdsConst<S> L = (LdsConst<S>)L_;
+    LdsConst<S> invd = (LdsConst<S>)invd_;
+    LdsConst<S> b = (LdsConst<S>)b_;
+    Lds<S> x = (Lds<S>)x_;
+    if (n <= 8) solve_rows_n<S, 8>(L, invd, b, x, n);
+    else if constexpr (kRowsMax > 8) {
+      if (n <= 16) solve_rows_n<S, 16>(L, invd, b, x, n);
+      else solve_rows_n<S, kRowsMax>(L, invd, b, x, n);
+    }
+  }
+  // Aio (n x n, row-major, lower triangle used) -> L in its strict lower triangle (the upper one is scratch afterwards),
+  // invd = 1 / diag(L); same operations in the same order as the LDS version (right-looking: entry (i, k) loses L_ij L_kj
+  // for j ascending)
+  template <typename S, int NMAX> static __device__ __forceinline__ void factor_rows_n(Lds<S> Aio, Lds<S> invd, int n, bool fast) {
+    const int i = rank();
+    const bool mine = i < n;
+    const int row = mine ? i : 0;  // (lanes without a row follow along on a copy of row 0: no branches around the loads)
+    S r[NMAX];
+    sync();
+    RowsUp<0, NMAX>::run(n, [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      r[j] = Aio[row * n + j];
+    });
+    S my_id = S(1);
+    RowsUp<0, NMAX>::run(n, [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const S djj = bcast<j>(r[j]);
+      S id;
+      if constexpr (sizeof(S) == 4) id = fast ? fast_rsqrt(djj) : S(1) / tsqrt(djj);
+      else id = S(1) / tsqrt(djj);
+      r[j] = r[j] * id;
+      my_id = i == j ? id : my_id;
+      RowsUp<j + 1, NMAX>::run(n, [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        r[k] -= r[j] * bcast<k>(r[j]);
+      });
+    });
+    if (mine) {
+      RowsUp<0, NMAX>::run(n, [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        Aio[i * n + j] = r[j];
+      });
+      invd[i] = my_id;
+    }
+    sync();
+  }
+  // x = (L L^T)^-1 b by substitution: lane i holds row i of L (forward) and column i (backward)
+  template <typename S, int NMAX>
+  static __device__ __forceinline__ void solve_rows_n(LdsConst<S> L, LdsConst<S> invd, LdsConst<S> b, Lds<S> x, int n) {
+    const int i = rank();
+    const bool mine = i < n;
+    const int me = mine ? i : 0;
+    S row[NMAX], col[NMAX];
+    RowsUp<0, NMAX>::run(n, [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const S lower = L[me * n + j], upper = L[j * n + me];
+      row[j] = (mine && j < i) ? lower : S(0);
+      col[j] = (mine && j > i) ? upper : S(0);
+    });
+    const S my_id = mine ? S(invd[me]) : S(0);
+    S t = mine ? S(b[me]) : S(0);
+    RowsUp<0, NMAX>::run(n, [&](auto jc) {  // y = L^-1 b: y_j is final once rows 0 .. j - 1 have been taken out
+      constexpr int j = decltype(jc)::value;
+      const S yj = bcast<j>(t * my_id);
+      t -= row[j] * yj;
+    });
+    t = t * my_id;
+    RowsDown<NMAX - 1>::run(n, [&](auto jc) {  // x = L^-T y
+      constexpr int j = decltype(jc)::value;
+      const S xj = bcast<j>(t * my_id);
+      t -= col[j] * xj;
+    });
+    if (mine) x[i] = t * my_id;
+    sync();
+  }
 };
 using WaveTeam = GroupTeam<kWave>;
 
@@ -492,6 +641,17 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
 }
 
 }  // namespace
+
+#ifdef DPLL_FOREST_STAMPS
+extern "C" int dpll_debug_forest_stamps(unsigned long long* host_out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fstamps), sizeof(unsigned long long) * 64);
+  if (reset) {
+    unsigned long long zero[64] = {};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fstamps), zero, sizeof(zero));
+  }
+  return rc;
+}
+#endif
 
 namespace dpll_forest_api {
 

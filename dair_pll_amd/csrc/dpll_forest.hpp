@@ -22,6 +22,18 @@
 
 #include "dpll_core.hpp"
 
+// run-time loops over LDS-resident blocks: four trips in flight at once (a trip alone waits out an LDS round trip per load)
+#if defined(__clang__)
+#define DPLL_PIPE _Pragma("unroll 4")
+#else
+#define DPLL_PIPE
+#endif
+
+// diagnostic builds (tools/diag/forest_stamps.py) time the phases of an item with the shader clock; nothing in the shipped build
+#ifndef DPLL_FSTAMP
+#define DPLL_FSTAMP(slot) do {} while (0)
+#endif
+
 namespace dpll_forest {
 
 using namespace dpll;
@@ -67,6 +79,8 @@ struct HostTeam {
   static DPLL_HD bool any(bool x) { return x; }
   static DPLL_HD bool wave_any(bool x) { return x; }  // over every team that shares the wavefront (the device: 1 or 4 teams)
   using Lanes = OneLane;  // the lane-group policy dpll_core.hpp's direction search takes
+  static constexpr bool kLaneRows = false;  // (the device teams factor dense matrices with a row per lane in registers)
+  static constexpr int kRowsMax = 0;
 };
 
 // ---- an item's storage (LDS on the device) ---------------------------------------------------------------------------------
@@ -496,6 +510,9 @@ template <typename S, typename SA, class Team> struct Forest {
   // is two matrix-vector products (two barriers) instead of 2 n dependent column steps (2 n barriers), which is what a wave
   // that waits at every barrier pays for.
   DPLL_HD void cholesky(S* Aio, S* invd, int n, bool fast) {
+    if constexpr (Team::kLaneRows && !IsDual<S>::value) {  // (a factor made there is solved there: chol_solve tests the same)
+      if (n <= Team::kRowsMax) { Team::template factor_rows<S>(Aio, invd, n, fast); return; }
+    }
     for (int j = 0; j < n; ++j) {
       Team::sync();
       const S djj = Aio[j * n + j];
@@ -515,7 +532,7 @@ template <typename S, typename SA, class Team> struct Forest {
     for (int j = Team::rank(); j < n; j += Team::kSize) {
       for (int i = j + 1; i < n; ++i) {
         S acc = Aio[i * n + j] * invd[j];
-        for (int p = j + 1; p < i; ++p) acc += Aio[i * n + p] * Aio[j * n + p];
+        DPLL_PIPE for (int p = j + 1; p < i; ++p) acc += Aio[i * n + p] * Aio[j * n + p];
         Aio[j * n + i] = -acc * invd[i];
       }
     }
@@ -523,15 +540,18 @@ template <typename S, typename SA, class Team> struct Forest {
   }
   // x = (L L^T)^-1 b with the inverted factor of `cholesky`; work: n numbers of scratch (x may alias neither b nor work)
   DPLL_HD void chol_solve(const S* L, const S* invd, const S* b, S* x, S* work, int n) {
+    if constexpr (Team::kLaneRows && !IsDual<S>::value) {
+      if (n <= Team::kRowsMax) { Team::template solve_rows<S>(L, invd, b, x, n); return; }
+    }
     for (int i = Team::rank(); i < n; i += Team::kSize) {  // y = L^-1 b
       S acc = invd[i] * b[i];
-      for (int j = 0; j < i; ++j) acc += L[j * n + i] * b[j];
+      DPLL_PIPE for (int j = 0; j < i; ++j) acc += L[j * n + i] * b[j];
       work[i] = acc;
     }
     Team::sync();
     for (int i = Team::rank(); i < n; i += Team::kSize) {  // x = L^-T y
       S acc = invd[i] * work[i];
-      for (int k = i + 1; k < n; ++k) acc += L[i * n + k] * work[k];
+      DPLL_PIPE for (int k = i + 1; k < n; ++k) acc += L[i * n + k] * work[k];
       x[i] = acc;
     }
     Team::sync();
@@ -539,7 +559,7 @@ template <typename S, typename SA, class Team> struct Forest {
   DPLL_HD void symv(const S* Mat, const S* x, S* y, int n) {
     for (int i = Team::rank(); i < n; i += Team::kSize) {
       S s = S(0);
-      for (int j = 0; j < n; ++j) s += Mat[i * n + j] * x[j];
+      DPLL_PIPE for (int j = 0; j < n; ++j) s += Mat[i * n + j] * x[j];
       y[i] = s;
     }
     Team::sync();
@@ -553,12 +573,16 @@ template <typename S, typename SA, class Team> struct Forest {
   // M, its factor, a = M^-1 F at (q, v) of the arena
   DPLL_HD void terms() {
     kinematics();
+    DPLL_FSTAMP(1);
     mass_matrix();
+    DPLL_FSTAMP(2);
     bias_forces();
+    DPLL_FSTAMP(3);
     for (int e = Team::rank(); e < A.nv * A.nv; e += Team::kSize) A.LM[e] = A.M[e];
     Team::sync();
     cholesky(A.LM, A.invdM, A.nv, false);
     chol_solve(A.LM, A.invdM, A.F, A.a, A.tmp, A.nv);
+    DPLL_FSTAMP(4);
   }
 
   // ---- contacts ------------------------------------------------------------------------------------------------------------------
@@ -622,22 +646,21 @@ template <typename S, typename SA, class Team> struct Forest {
     if (fd.rotated & 2) mat3_mul_const<SA>(Rg, fd.geom_rot[g]);
     DPLL_UNROLL for (int i = 0; i < 3; ++i) gorg[i] = cst<SA>(fd.geom_origin[g][i]);
   }
-  // vertex set of geometry g in its own frame (+ a sphere's radius as a margin)
-  template <typename P> DPLL_HD void geometry_vertices(int g, const P* lengths, SA (*v)[3], int& nv, SA& margin) const {
+  // vertex set of geometry g in its own frame (+ a sphere's radius as a margin): the count, and ONE vertex at a time (an array
+  // of them indexed by a run-time number would live in scratch memory)
+  DPLL_HD int geometry_nverts(int g, SA& margin) const {
     const int kind = fd.geom_kind[g];
-    margin = SA(0);
+    margin = kind == kGeomSphere ? SA(A.habs[3 * g]) : SA(0);
+    return kind == kGeomSphere ? 1 : (kind == kGeomPolygon ? fd.geom_nverts[g] : 8);
+  }
+  template <typename P> DPLL_HD void geometry_vertex(int g, const P* lengths, int u, SA (&v)[3]) const {
+    const int kind = fd.geom_kind[g];
     if (kind == kGeomSphere) {
-      nv = 1;
-      v[0][0] = SA(0); v[0][1] = SA(0); v[0][2] = SA(0);
-      margin = SA(A.habs[3 * g]);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) v[i] = SA(0);
     } else if (kind == kGeomPolygon) {
-      nv = fd.geom_nverts[g];
-      for (int u = 0; u < nv; ++u)
-        for (int i = 0; i < 3; ++i) v[u][i] = cst<SA>(double(lengths[kGeoStride * g + 3 * u + i]));
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) v[i] = cst<SA>(double(lengths[kGeoStride * g + 3 * u + i]));
     } else {
-      nv = 8;
-      for (int u = 0; u < 8; ++u)
-        for (int i = 0; i < 3; ++i) v[u][i] = (((u >> (2 - i)) & 1) ? SA(1) : SA(-1)) * SA(A.habs[3 * g + i]);
+      DPLL_UNROLL for (int i = 0; i < 3; ++i) v[i] = (((u >> (2 - i)) & 1) ? SA(1) : SA(-1)) * SA(A.habs[3 * g + i]);
     }
   }
   // directions of the body-body candidates (frame of A), searched by the team together (dpll_core.hpp pair_direction: fcl's role)
@@ -645,29 +668,32 @@ template <typename S, typename SA, class Team> struct Forest {
     if constexpr (!IsDual<SA>::value) {
       for (int p = 0; p < A.np; ++p) {
         const int ga = fd.pair_a[p], gb = fd.pair_b[p];
-        SA RA[3][3], RB[3][3], oA[3], oB[3], gA[3], gB[3], cA[3], cB[3], va[kMaxPolyVerts][3], vb[kMaxPolyVerts][3], mA, mB;
-        int na, nb;
+        SA RA[3][3], RB[3][3], oA[3], oB[3], gA[3], gB[3], cA[3], cB[3], mA, mB;
         geometry_frame(ga, RA, oA, gA);
         geometry_frame(gb, RB, oB, gB);
         mat3_vec(RA, gA, cA); mat3_vec(RB, gB, cB);
         DPLL_UNROLL for (int i = 0; i < 3; ++i) { cA[i] += oA[i]; cB[i] += oB[i]; }
-        geometry_vertices(ga, lengths, va, na, mA);
-        geometry_vertices(gb, lengths, vb, nb, mB);
+        const int na = geometry_nverts(ga, mA), nb = geometry_nverts(gb, mB);
         SA (*sa)[3] = reinterpret_cast<SA (*)[3]>(A.setA);
         SA (*sb)[3] = reinterpret_cast<SA (*)[3]>(A.setB);
         Team::sync();
-        for (int u = Team::rank(); u < na; u += Team::kSize)
-          DPLL_UNROLL for (int i = 0; i < 3; ++i) sa[u][i] = va[u][i];
-        for (int u = Team::rank(); u < nb; u += Team::kSize) {
-          SA wv[3], rel[3], out[3];
-          mat3_vec(RB, vb[u], wv);
+        // (both sets padded to kMaxPolyVerts with repeats of vertex 0: fixed-length loops in the search)
+        for (int u = Team::rank(); u < kMaxPolyVerts; u += Team::kSize) {
+          SA vu[3];
+          geometry_vertex(ga, lengths, u < na ? u : 0, vu);
+          DPLL_UNROLL for (int i = 0; i < 3; ++i) sa[u][i] = vu[i];
+        }
+        for (int u = Team::rank(); u < kMaxPolyVerts; u += Team::kSize) {
+          SA vu[3], wv[3], rel[3], out[3];
+          geometry_vertex(gb, lengths, u < nb ? u : 0, vu);
+          mat3_vec(RB, vu, wv);
           DPLL_UNROLL for (int i = 0; i < 3; ++i) rel[i] = wv[i] + cB[i] - cA[i];
           mat3t_vec(RA, rel, out);
           DPLL_UNROLL for (int i = 0; i < 3; ++i) sb[u][i] = out[i];
         }
         Team::sync();
         SA dA[3];
-        pair_direction<SA, typename Team::Lanes>(sa, na, fd.geom_kind[ga], sb, nb, fd.geom_kind[gb], dA);
+        pair_direction<SA, typename Team::Lanes, true>(sa, na, fd.geom_kind[ga], sb, nb, fd.geom_kind[gb], dA);
         if (Team::rank() == 0) { DPLL_UNROLL for (int i = 0; i < 3; ++i) A.dirs[3 * p + i] = dA[i]; }
       }
       Team::sync();
@@ -737,12 +763,10 @@ template <typename S, typename SA, class Team> struct Forest {
     // candidate `slot`: ONE contact along the direction found up front (geometry.py:585-643, multibody_terms.py:464-513)
     const int p = slot, ga = fd.pair_a[p], gb = fd.pair_b[p];
     const int kindA = fd.geom_kind[ga], kindB = fd.geom_kind[gb];
-    SA RA[3][3], RB[3][3], oA[3], oB[3], gorgA[3], gorgB[3], va[kMaxPolyVerts][3], vb[kMaxPolyVerts][3], marginA, marginB;
-    int na, nb;
+    SA RA[3][3], RB[3][3], oA[3], oB[3], gorgA[3], gorgB[3], marginA, marginB;
     geometry_frame(ga, RA, oA, gorgA);
     geometry_frame(gb, RB, oB, gorgB);
-    geometry_vertices(ga, lengths, va, na, marginA);
-    geometry_vertices(gb, lengths, vb, nb, marginB);
+    const int na = geometry_nverts(ga, marginA), nb = geometry_nverts(gb, marginB);
     SA dA[3], dW[3], dB[3], ndW[3];
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dA[i] = A.dirs[3 * p + i];
     mat3_vec(RA, dA, dW);
@@ -751,15 +775,21 @@ template <typename S, typename SA, class Team> struct Forest {
     int ia = 0, ib = 0;
     SA besta = cst<SA>(-3.0e38), bestb = cst<SA>(-3.0e38);
     for (int u = 0; u < na; ++u) {
-      const SA t = dA[0] * va[u][0] + dA[1] * va[u][1] + dA[2] * va[u][2];
+      SA vu[3];
+      geometry_vertex(ga, lengths, u, vu);
+      const SA t = dA[0] * vu[0] + dA[1] * vu[1] + dA[2] * vu[2];
       if (t > besta + cst<SA>(kPairTie)) { besta = t; ia = u; }
     }
     for (int u = 0; u < nb; ++u) {
-      const SA t = dB[0] * vb[u][0] + dB[1] * vb[u][1] + dB[2] * vb[u][2];
+      SA vu[3];
+      geometry_vertex(gb, lengths, u, vu);
+      const SA t = dB[0] * vu[0] + dB[1] * vu[1] + dB[2] * vu[2];
       if (t > bestb + cst<SA>(kPairTie)) { bestb = t; ib = u; }
     }
-    SA witA[3], witB[3];
-    DPLL_UNROLL for (int i = 0; i < 3; ++i) { witA[i] = va[ia][i] + marginA * dA[i]; witB[i] = vb[ib][i] + marginB * dB[i]; }
+    SA witA[3], witB[3], vA[3], vB[3];
+    geometry_vertex(ga, lengths, ia, vA);
+    geometry_vertex(gb, lengths, ib, vB);
+    DPLL_UNROLL for (int i = 0; i < 3; ++i) { witA[i] = vA[i] + marginA * dA[i]; witB[i] = vB[i] + marginB * dB[i]; }
     DPLL_UNROLL for (int i = 0; i < 3; ++i) {
       ct.sgn_a[i] = kindA == kGeomBox ? (((ia >> (2 - i)) & 1) ? S(1) : S(-1)) : S(0);
       ct.sgn[i] = kindB == kGeomBox ? (((ib >> (2 - i)) & 1) ? S(1) : S(-1)) : S(0);
@@ -792,15 +822,17 @@ template <typename S, typename SA, class Team> struct Forest {
   }
   template <typename P> DPLL_HD void contacts(const P* lengths) {
     pair_directions(lengths);
+    DPLL_FSTAMP(5);
     for (int c = Team::rank(); c < A.K; c += Team::kSize) contact(c, lengths);
     Team::sync();
+    DPLL_FSTAMP(6);
   }
   // out = J_c y (contact frame: t_x, t_y, n)
   DPLL_HD void jac_apply(int c, const S* y, S (&out)[3]) const {
     const S* Jrow = A.J + (size_t)c * 3 * A.nv;
     DPLL_UNROLL for (int r = 0; r < 3; ++r) {
       S s = S(0);
-      for (int i = 0; i < A.nv; ++i) s += Jrow[r * A.nv + i] * y[i];
+      DPLL_PIPE for (int i = 0; i < A.nv; ++i) s += Jrow[r * A.nv + i] * y[i];
       out[r] = s;
     }
   }
@@ -818,10 +850,9 @@ template <typename S, typename SA, class Team> struct Forest {
   DPLL_HD S gather_jtg(const ConePoint<S>* pts, S* jtg) {
     for (int i = Team::rank(); i < A.nv; i += Team::kSize) {
       S s = S(0);
-      for (int c = 0; c < A.K; ++c) {
-        if (pts[c].polar) continue;
+      DPLL_PIPE for (int c = 0; c < A.K; ++c) {  // (a contact in the polar region has g = 0: no branch needed)
         const S* Jrow = A.J + (size_t)c * 3 * A.nv;
-        const S mu = A.ct[c].mu;
+        const S mu = A.cmu[c];
         s += Jrow[i] * (mu * pts[c].g[0]) + Jrow[A.nv + i] * (mu * pts[c].g[1]) + Jrow[2 * A.nv + i] * pts[c].g[2];
       }
       jtg[i] = s;
@@ -878,6 +909,7 @@ template <typename S, typename SA, class Team> struct Forest {
     bool active = true;
     for (int it = 0; it < opt.max_iter; ++it) {
       if (!Team::wave_any(active)) break;
+      DPLL_FSTAMP(8);
       const S ieps = fast ? fast_rcp(eps_c) : S(1) / eps_c;
       const bool final_stage = stage >= last_stage;
       for (int i = Team::rank(); i < A.nv; i += Team::kSize) A.grad[i] = My[i] - ieps * jtg[i];
@@ -899,9 +931,8 @@ template <typename S, typename SA, class Team> struct Forest {
       Team::sync();
       for (int e = Team::rank(); e < A.K * A.nv; e += Team::kSize) {
         const int c = e / A.nv, j = e % A.nv;
-        if (cur[c].polar) continue;
         const S* Jrow = A.J + (size_t)c * 3 * A.nv;
-        const S* C = A.Cc + 6 * c;
+        const S* C = A.Cc + 6 * c;  // (all zero for a contact in the polar region: cp = a = b = 0)
         const S j0 = Jrow[j], j1 = Jrow[A.nv + j], j2 = Jrow[2 * A.nv + j];
         S* dst = A.CJ + (size_t)c * 3 * A.nv;
         dst[j] = C[0] * j0 + C[3] * j1 + C[4] * j2;
@@ -912,21 +943,23 @@ template <typename S, typename SA, class Team> struct Forest {
       for (int e = Team::rank(); e < A.nv * (A.nv + 1) / 2; e += Team::kSize) {
         const int i = A.tri_i[e], j = A.tri_j[e];
         S h = A.M[i * A.nv + j];
-        for (int c = 0; c < A.K; ++c) {
-          if (cur[c].polar) continue;
+        DPLL_PIPE for (int c = 0; c < A.K; ++c) {  // (C J of a contact in the polar region is written as zeros below)
           const S* Jrow = A.J + (size_t)c * 3 * A.nv;
           const S* CJ = A.CJ + (size_t)c * 3 * A.nv;
           h += Jrow[i] * CJ[j] + Jrow[A.nv + i] * CJ[A.nv + j] + Jrow[2 * A.nv + i] * CJ[2 * A.nv + j];
         }
         A.H[i * A.nv + j] = h;
       }
+      DPLL_FSTAMP(9);
       cholesky(A.H, A.invd, A.nv, fast);
+      DPLL_FSTAMP(10);
       chol_solve(A.H, A.invd, A.grad, A.d, A.tmp, A.nv);
       } else {
         chol_solve(A.LM, A.invdM, A.grad, A.d, A.tmp, A.nv);
       }
       for (int i = Team::rank(); i < A.nv; i += Team::kSize) A.d[i] = -A.d[i];
       Team::sync();
+      DPLL_FSTAMP(11);
       const S dec2 = -dot(A.grad, A.d, A.nv);
       const S ynorm2 = dot(y, My, A.nv);
       const S scale = S(1) + tsqrt(tmax(ynorm2, S(0)));
@@ -948,9 +981,12 @@ template <typename S, typename SA, class Team> struct Forest {
         const S mu = A.ct[c].mu;
         A.jd[3 * c] = mu * t[0]; A.jd[3 * c + 1] = mu * t[1]; A.jd[3 * c + 2] = t[2];
       }
+      DPLL_FSTAMP(12);
       symv(A.M, A.d, A.Md, A.nv);
       S alpha = moving ? S(1) : S(0);
+      DPLL_FSTAMP(13);
       S nsum_t = advance(y, My, cur, alpha, yt, Myt, trial, jtgt);
+      DPLL_FSTAMP(14);
       S f1 = S(0);
       for (int i = Team::rank(); i < A.nv; i += Team::kSize) f1 += (Myt[i] - ieps * jtgt[i]) * A.d[i];
       const S first1 = Team::sum(f1);
@@ -1000,6 +1036,7 @@ template <typename S, typename SA, class Team> struct Forest {
         nsum_t = advance(y, My, cur, alpha, yt, Myt, trial, jtgt);
       }
       DPLL_ITER_HOOK(it, moving, alpha);
+      DPLL_FSTAMP(15);
       {  // the trial state is the current one from here on
         S* t;
         t = y; y = yt; yt = t;
@@ -1041,6 +1078,7 @@ template <typename S, typename SA, class Team> struct Forest {
   template <typename X, typename P>
   DPLL_HD S loss(const X* x, const X* xp, const P* lengths, const SolverOpts& opt, S weight, bool want_grad, double* row, int& iters) {
     const S dt = S(fd.dt), eps = S(kLossEps);
+    DPLL_FSTAMP(0);
     load_state(xp);  // terms at the NEXT state (quirk Q6)
     terms();
     for (int i = Team::rank(); i < A.nv; i += Team::kSize) {
@@ -1066,9 +1104,11 @@ template <typename S, typename SA, class Team> struct Forest {
     }
     const S pen = Team::sum(pen_part);
     Team::sync();
+    DPLL_FSTAMP(7);
     const int n_stages = opt.loss_n_stages > 0 ? opt.loss_n_stages : opt.n_stages;
     const S factor = S(opt.loss_n_stages > 0 ? opt.loss_stage_factor : opt.stage_factor);
     iters = solve(eps, opt, n_stages, factor);
+    DPLL_FSTAMP(16);
     // invalid-solve mask (multibody_learnable_system.py:186-192)
     bool bad_part = false;
     for (int e = Team::rank(); e < 3 * A.K; e += Team::kSize) bad_part = bad_part || bad_number(A.force[e]) || tabs(A.force[e]) > S(kInvalidForce);
@@ -1088,10 +1128,10 @@ template <typename S, typename SA, class Team> struct Forest {
     const S fq = Team::sum(fq_part), ff = Team::sum(ff_part);
     for (int i = Team::rank(); i < A.nv; i += Team::kSize) {
       S s = S(0);
-      for (int c = 0; c < A.K; ++c) {
+      DPLL_PIPE for (int c = 0; c < A.K; ++c) {
         const S* Jrow = A.J + (size_t)c * 3 * A.nv;
         const S* f = A.force + 3 * c;
-        const S mu = A.ct[c].mu;
+        const S mu = A.cmu[c];
         s += Jrow[i] * (mu * f[0]) + Jrow[A.nv + i] * (mu * f[1]) + Jrow[2 * A.nv + i] * f[2];
       }
       A.gv[i] = s;
@@ -1101,6 +1141,7 @@ template <typename S, typename SA, class Team> struct Forest {
     symv(A.M, A.dv, A.Mdv, A.nv);
     const S constant = bad ? S(0) : (S(0.5) * dot(A.dv, A.Mdv, A.nv) + pen);
     const S value = S(0.5) * (dot(A.gv, A.w, A.nv) + eps * ff) + fq + constant;
+    DPLL_FSTAMP(17);
     if (!want_grad) return value;
     // ---- adjoint (dpll_core.hpp loss_item): w = y*, u = w - dv, abar = -dt (M dv - g), b = M^-1 abar -----------------------------
     const S wt = bad ? S(0) : weight;
@@ -1113,6 +1154,7 @@ template <typename S, typename SA, class Team> struct Forest {
     chol_solve(A.LM, A.invdM, A.abar, A.bvec, A.tmp, A.nv);
     const S* ys[4] = {A.w, A.dv, A.bvec, A.a};
     twists(ys, 4, A.tw);
+    DPLL_FSTAMP(18);
     for (int b = Team::rank(); b < A.nb; b += Team::kSize) {
       S g[kIota];
       DPLL_UNROLL for (int i = 0; i < kIota; ++i) g[i] = S(0);
@@ -1150,8 +1192,10 @@ template <typename S, typename SA, class Team> struct Forest {
       witness_adjoint(ct, alpha, A.u, beta, A.vp, phibar, wt);
     }
     Team::sync();
+    DPLL_FSTAMP(19);
     gather_geometry_grads(row);
     if (Team::rank() == 0) row[0] += double(weight) * double(value);
+    DPLL_FSTAMP(20);
     return value;
   }
 
