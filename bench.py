@@ -220,7 +220,7 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
     passes = [system.profile_loss_kernels(x, xp, reps=200) for _ in range(3)]  # (HIP events on the launch stream, 200 launches each)
     ms_loss, ms_fin = sorted(p[0] for p in passes)[1], sorted(p[1] for p in passes)[1]
     achieved = alg_bytes / (ms_loss * 1e-3) / 1e9
-    traffic = valu_frac = source = lib_match = None
+    traffic = valu_frac = useful_frac = source = lib_match = None
     path = newest_profile('hbm_traffic.json')
     try:  # HBM bytes per launch / VALU issue slots from the committed PMC passes, only for the configuration they measured
         with open(path) as handle:
@@ -237,6 +237,10 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
                 # (clock_rate in kHz where this torch build reports it; else the 2.4 GHz peak engine clock of the part)
                 simds, hz = 4 * props.multi_processor_count, (getattr(props, 'clock_rate', 0) or 2.4e6) * 1e3
                 valu_frac = counters['SQ_INSTS_VALU'] * 4.0 / (ms_loss * 1e-3 * hz * simds)
+                # the instructions one solve per item executes (the same launch without racing copies: portfolio = 1) over the
+                # time of the launch WITH copies: what the copies' discarded work must not be credited with
+                if 'SQ_INSTS_VALU_portfolio1' in counters:
+                    useful_frac = counters['SQ_INSTS_VALU_portfolio1'] * 4.0 / (ms_loss * 1e-3 * hz * simds)
     except (OSError, KeyError, ValueError, IndexError, TypeError, AttributeError):
         pass
     return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
@@ -244,7 +248,7 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
             'traffic_source': f'{source} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)' if traffic else None,
             'traffic_of_loaded_library': lib_match,
             'kernel': 'loss_kernel', 'kernel_ms': ms_loss, 'finalize_kernel_ms': ms_fin,
-            'algorithmic_bytes_per_launch': alg_bytes, 'valu_issue_frac': valu_frac,
+            'algorithmic_bytes_per_launch': alg_bytes, 'valu_issue_frac': valu_frac, 'useful_valu_issue_frac': useful_frac,
             'note': 'latency bound by construction (SURVEY 8d, DESIGN 5): independent 6-7-dimensional cone solves, 0.44 MB per launch'}
 
 
@@ -392,6 +396,9 @@ def main() -> None:
     parser.add_argument('--mesh-gemm', type=int, choices=[0, 2, 3], default=0,
                         help='mesh workload: form of the ICNN GEMM kernels (0 = f32 MFMA, 2 / 3 = bf16 matrix cores on 2 / 3 bf16 planes)')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    parser.add_argument('--portfolio', type=int, default=None,
+                        help='diagnostic: racing copies of the cone solve per item (1 = none; default: what the library picks) -- the '
+                             'counter pass behind roofline.useful_valu_issue_frac runs with 1')
     parser.add_argument('--steps-per-graph', type=int, default=50,
                         help='steps captured per hipGraph (amortises the ~10 us replay floor); the timed region '
                              'still runs exactly --steps steps, serialised on one stream')
@@ -472,6 +479,8 @@ def main() -> None:
     system = build_system(args.workload, args.dtype, dt, device)
     if args.mesh_gemm and args.workload == 'mesh':
         system.set_solver(mesh_gemm=args.mesh_gemm)
+    if args.portfolio is not None:
+        system.set_solver(portfolio=args.portfolio)
     x = torch.tensor(x_np, dtype=dtype, device=device)
     xp = torch.tensor(xp_np, dtype=dtype, device=device)
 

@@ -196,8 +196,9 @@ int launch_loss_items(const dpll_model* m, int dtype, const dpll_params_t* p, co
   return dpll_check_launch("gen_loss_kernel (mesh)");
 }
 template <typename T, int NJ>
-int launch_finalize(long long batch, void* rows_ws, void* grad, void* loss_total, hipStream_t stream) {
-  return finalize_rows<T, NJ>((double*)rows_ws, row_blocks(batch), (T*)grad, (T*)loss_total, stream);
+int launch_finalize(const dpll_model* m, long long batch, void* rows_ws, void* grad, void* loss_total, hipStream_t stream,
+                    const AdamArgs* adam) {
+  return finalize_rows<T, NJ>((double*)rows_ws, row_blocks(batch), (T*)grad, (T*)loss_total, stream, m, adam);
 }
 template <typename T, int NJ>
 int launch_step_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch,
@@ -279,8 +280,9 @@ int loss_items(const dpll_model* m, int dtype, const dpll_params_t* p, const voi
                         want_grad, wit, rbar, pdirs, stream);
 }
 
-int finalize(const dpll_model* m, int dtype, long long batch, void* rows, void* grad, void* loss_total, hipStream_t stream) {
-  DPLL_GENMESH_DISPATCH(launch_finalize, batch, rows, grad, loss_total, stream);
+int finalize(const dpll_model* m, int dtype, long long batch, void* rows, void* grad, void* loss_total, hipStream_t stream,
+             const AdamArgs* adam) {
+  DPLL_GENMESH_DISPATCH(launch_finalize, m, batch, rows, grad, loss_total, stream, adam);
 }
 
 int step_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* x_next,

@@ -10,6 +10,7 @@
 #include "../../include/dpll.h"
 
 struct dpll_model;
+struct AdamArgs;
 
 namespace dpll_genmesh {
 
@@ -41,7 +42,9 @@ int loss_items(const dpll_model* m, int dtype, const dpll_params_t* p, const voi
                long long batch, const void* weights, double scale, void* loss_out, void* force, int32_t* iters, void* rows,
                int want_grad, const void* wit, void* rbar, const double* pdirs, hipStream_t stream);
 // sums the rows loss_items left and chains them to [theta | friction | lengths] (the head of the gradient)
-int finalize(const dpll_model* m, int dtype, long long batch, void* rows, void* grad, void* loss_total, hipStream_t stream);
+// adam: the fused training step -- the kernel that writes the head of the gradient applies Adam to the head of the parameters
+int finalize(const dpll_model* m, int dtype, long long batch, void* rows, void* grad, void* loss_total, hipStream_t stream,
+             const AdamArgs* adam = nullptr);
 int step_items(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* x_next,
                long long ld_next, const void* wit, const double* pdirs, hipStream_t stream);
 // backward of one step (parameter rows + state adjoint + witness adjoints); finalize() chains the rows afterwards

@@ -1552,7 +1552,7 @@ template <typename T>
 int launch_genmesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
                         long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
                         void* loss, void* grad, void* loss_total, void* force, int32_t* iters, void* workspace,
-                        long long workspace_bytes, hipStream_t stream) {
+                        long long workspace_bytes, hipStream_t stream, const AdamArgs* adam = nullptr) {
   const GenMeshPlan gp = genmesh_plan<T>(m, batch);
   if (!workspace || (size_t)workspace_bytes < gp.total) return fail(-3, "dpll_contactnets_loss_mesh: workspace too small%s");
   if (!grad && loss_total) return fail(-3, "dpll_contactnets_loss_mesh: loss_total requires grad%s");
@@ -1571,10 +1571,12 @@ int launch_genmesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, 
     const MeshPlan pl = genmesh_block<T>(gp, gp.qpi[g] * batch);
     if (int rc = mesh_backward<T, 1>(pl, k, genmesh_weights<T>(gp, mp, g, ws), ws, QuatSource<T>{nullptr, 0},
                                      (T*)grad + head + (size_t)k * kNetParams, (T*)nullptr, (T*)nullptr, stream,
-                                     (const T*)(ws + gp.off_RB)))
+                                     (const T*)(ws + gp.off_RB), adam, head + (long long)k * kNetParams))
       return rc;
   }
-  return dpll_genmesh::finalize(m, dtype, batch, ws + gp.off_rows, grad, loss_total, stream);
+  // (fused training step: every network's reduce kernel has applied Adam to the weights it owns, reading the optimizer state;
+  // the finalize kernel -- the last launch -- applies it to the head and moves the state a step on)
+  return dpll_genmesh::finalize(m, dtype, batch, ws + gp.off_rows, grad, loss_total, stream, adam);
 }
 
 // backward of dpll_step_mesh for a general model with learned shapes: support points at x, the step's backward (rows for the
@@ -2096,8 +2098,6 @@ int dpll_contactnets_train_step_mesh(const dpll_model_t* model, int dtype, const
                                      const dpll_adam_t* adam, void* stream) {
   if (!params) return fail(-1, "dpll_contactnets_train_step_mesh: null parameter pointer%s");
   if (int rc = check_mesh_call(model, dtype, params, mesh, "dpll_contactnets_train_step_mesh")) return rc;
-  if (model->desc.n_geoms > 0)
-    return fail(-2, "dpll_contactnets_train_step_mesh: the specialised mesh builds (cube / elbow with a learned shape per body)%s");
   if (batch == 0 || !x || !x_plus || !grad || !loss_total || !adam || !adam->params || !adam->exp_avg || !adam->exp_avg_sq || !adam->state)
     return fail(-1, "dpll_contactnets_train_step_mesh: null argument or empty batch%s");
   const int nx = dpll_n_x(model);
@@ -2107,6 +2107,8 @@ int dpll_contactnets_train_step_mesh(const dpll_model_t* model, int dtype, const
   if (!(adam->lr >= 0.0) || !(adam->beta1 >= 0.0 && adam->beta1 < 1.0) || !(adam->beta2 >= 0.0 && adam->beta2 < 1.0) || !(adam->eps >= 0.0) || !(adam->weight_decay >= 0.0))
     return fail(-1, "dpll_contactnets_train_step_mesh: Adam hyper-parameters out of range%s");
   const AdamArgs args{adam->params, adam->exp_avg, adam->exp_avg_sq, adam->state, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay};
+  DPLL_GENMESH(launch_genmesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total,
+               nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, &args);
   DPLL_MESH_DISPATCH(launch_mesh_loss, model, dtype, params, mesh, x, ld_x, x_plus, ld_xp, batch, weights, scale, nullptr, grad, loss_total,
                      nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, &args);
 }

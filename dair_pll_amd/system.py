@@ -599,11 +599,8 @@ class MultibodyLearnableSystem(Module):
         return self._loss_total
 
     def _mesh_train_step(self, x: Tensor, x_plus: Tensor, adam: 'FusedAdamState') -> Tensor:
-        """:meth:`contactnets_train_step` of a system with learned shapes on the specialised builds (cube / elbow with a
-        ``DeepSupportConvex`` per body): ``dpll_contactnets_train_step_mesh``"""
-        if not self.spec.is_fast():
-            raise NotImplementedError('the fused training step of the general build with learned shapes is not built: use '
-                                      'contactnets_loss_and_grad + an optimizer')
+        """:meth:`contactnets_train_step` of a system with learned shapes (the cube / elbow with a ``DeepSupportConvex`` per
+        body, or a general tree with learned shapes among its geometries): ``dpll_contactnets_train_step_mesh``"""
         if self.grad_world > 1:
             raise NotImplementedError('the fused training step of a mesh system is single process')
         lib = _capi.library()

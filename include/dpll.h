@@ -365,15 +365,17 @@ typedef struct dpll_adam {
 
 /* (Which builds: the specialised box builds with the exchange of `ar` inside the same kernel; the general and the forest build
  * with ar = NULL -- Adam in the kernel that chains the folded rows, entries of the flat buffer that are padding left alone; the
- * specialised mesh builds through dpll_contactnets_train_step_mesh below.) */
+ * models with learned shapes through dpll_contactnets_train_step_mesh below.) */
 int dpll_contactnets_train_step(const dpll_model_t* model, int dtype, const dpll_params_t* params, const void* x,
                                 int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
                                 double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                 dpll_ar_t* ar, const dpll_adam_t* adam, void* stream);
 
-/* The same for a cube / elbow with a learned shape per body (the specialised mesh builds): the kernel that reduces a network's
- * weight gradients applies Adam to them, the head ([theta | friction]) is updated where it is chained; adam.params is the flat
- * buffer [theta | friction | network 0 (Wh, Wd0, Wd1, wout) | network 1 ...] params.theta and the mesh pointers point into. */
+/* The same for models with learned shapes -- a cube / elbow with one per body (the specialised mesh builds) or a general tree
+ * with learned shapes among its geometries: the kernel that reduces a network's weight gradients applies Adam to them, the head
+ * ([theta | friction], general build: [theta | friction | lengths] with its padding left alone) is updated where it is chained;
+ * adam.params is the flat buffer [head | network 0 (Wh, Wd0, Wd1, wout) | network 1 ...] params.theta and the mesh pointers
+ * point into. */
 int dpll_contactnets_train_step_mesh(const dpll_model_t* model, int dtype, const dpll_params_t* params, const dpll_mesh_params_t* mesh,
                                      const void* x, int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
                                      double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,

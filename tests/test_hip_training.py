@@ -285,6 +285,9 @@ FUSED_CASES = {
     'clasp': ({'clasp': 'clasp.urdf'}, 'clasp_literal', 'deep_support'),
     'two_cubes': ({'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'}, 'two_cubes_literal', 'deep_support'),
     'cube_mesh': ({'cube': 'cube_mesh.urdf'}, 'cube_mesh_literal', 'deep_support'),
+    # a general tree with two learned shapes and a candidate between them: head by the general finalize kernel, each network's
+    # weights by its own reduce kernel, the optimizer state moved on by the last launch
+    'clasp_mesh': ({'clasp_mesh': 'clasp_mesh.urdf'}, 'clasp_mesh_literal', 'deep_support'),
 }
 
 
@@ -353,11 +356,12 @@ def test_fused_adam_step_of_the_other_builds_is_torch_adam(case, dtype):
     assert torch.equal(fused._packed().cpu()[~real], flat0.cpu()[~real])
 
 
-def test_fused_training_step_refuses_models_it_does_not_serve():
-    """the general build WITH learned shapes has no fused step (its network gradients take the general item kernels' route)"""
+def test_fused_training_step_refuses_what_it_cannot_do():
+    """a multi-process gradient exchange inside the fused step of a mesh system is not built: refused, not skipped silently"""
     from dair_pll_amd import MultibodyLearnableSystem
     from dair_pll_amd.system import FusedAdamState
     system = MultibodyLearnableSystem({'m': os.path.join(ASSET_DIR, 'clasp_mesh.urdf')}, 0.0068, device='cuda:0')
     x = torch.zeros((4, system.space.n_x), device='cuda:0')
+    system.grad_world = 2
     with pytest.raises(NotImplementedError):
         system.contactnets_train_step(x, x, FusedAdamState())

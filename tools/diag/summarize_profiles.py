@@ -2,10 +2,10 @@
 import csv, json, os, re, shutil, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r03p')
+SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r04p')
 DST = os.environ.get('DPLL_PROFILE_DST', os.path.join(REPO, 'profiles'))  # (on the GPU box: a directory under gpurun_out/)
 os.makedirs(DST, exist_ok=True)
-TAG = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 KERNEL = 'loss_kernel<float, 0, false'  # <T, NJ, MESH, DENSE>: the box builds
 
 
@@ -21,7 +21,8 @@ def counter_means(path):
 shutil.copy(os.path.join(SRC, 'stats', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_f32_kernel_stats.csv'))
 for sub, name in (('stats_mesh', 'mesh_f32'), ('stats_f64', 'f64'), ('stats_elbow', 'elbow_f32'), ('stats_elbow_f64', 'elbow_f64'),
                   ('stats_b65536', 'f32_b65536'), ('stats_b65536_f64', 'f64_b65536'), ('stats_sim', 'simulate'),
-                  ('stats_mesh_bf16', 'mesh_bf16x3'), ('stats_general', 'general_build'), ('stats_clasp_mesh', 'clasp_mesh')):
+                  ('stats_mesh_bf16', 'mesh_bf16x3'), ('stats_general', 'general_build'), ('stats_clasp_mesh', 'clasp_mesh'),
+                  ('stats_forest', 'forest_build')):
     src = os.path.join(SRC, sub, 'run_kernel_stats.csv')
     if os.path.exists(src):
         shutil.copy(src, os.path.join(DST, f'{TAG}_bench_{name}_kernel_stats.csv'))
@@ -29,6 +30,10 @@ shutil.copy(os.path.join(SRC, 'stats', 'trace_tail.csv'), os.path.join(DST, f'{T
 means = {}
 for sub in ('pmc_sq1', 'pmc_sq2'):
     means.update(counter_means(os.path.join(SRC, sub, 'run_counter_collection.csv')))
+p1 = os.path.join(SRC, 'pmc_sq1_p1', 'run_counter_collection.csv')  # the same launch without racing copies (bench.py --portfolio 1)
+if os.path.exists(p1):
+    for name, value in counter_means(p1).items():
+        means[name + '_portfolio1'] = value
 with open(os.path.join(DST, f'{TAG}_loss_kernel_pmc.csv'), 'w') as f:
     f.write('counter,mean_per_dispatch,dispatches\n')
     for name, (mean, n) in means.items():
@@ -44,7 +49,7 @@ for sub, name in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
 fetch_kb, n_f = traffic['FETCH_SIZE']
 write_kb, n_w = traffic['WRITE_SIZE']
 template = os.path.join(DST, f'{TAG}_hbm_traffic.json')
-old = json.load(open(template if os.path.exists(template) else os.path.join(REPO, 'profiles', 'r02_hbm_traffic.json')))
+old = json.load(open(template if os.path.exists(template) else os.path.join(REPO, 'profiles', 'r03_hbm_traffic.json')))
 old['kernel'] = 'loss_kernel<float,0,false,false>'
 import hashlib
 old['lib_sha256'] = hashlib.sha256(open(os.path.join(REPO, 'dair_pll_amd', 'csrc', 'libdpll_hip.so'), 'rb').read()).hexdigest()  # the library the passes ran (built here, shipped to the box)
