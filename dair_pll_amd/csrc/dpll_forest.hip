@@ -47,13 +47,15 @@ static_assert(dpll_forest::kMaxBodies == DPLL_FOREST_MAX_BODIES && dpll_forest::
                   dpll_forest::kMaxPairs == DPLL_FOREST_MAX_PAIRS && kMaxContacts == DPLL_FOREST_MAX_CONTACTS && kMaxV == DPLL_FOREST_MAX_V,
               "limits");
 
-struct WaveLanes {  // the lane-group policy of dpll_core.hpp's direction search: the whole wave is one group
-  static constexpr int kGroup = kWave;
+// the lane-group policy of dpll_core.hpp's direction search for a team of W = 32 or 64 lanes (butterflies through the LDS
+// crossbar: the partner of lane l at distance off < W is in the same team)
+template <int W> struct ShflLanes {
+  static constexpr int kGroup = W;
   static constexpr int kVariants = 1;
-  static __device__ __forceinline__ int lane_in_group() { return (int)(threadIdx.x & (kWave - 1)); }
+  static __device__ __forceinline__ int lane_in_group() { return (int)(threadIdx.x & (W - 1)); }
   template <typename S> static __device__ __forceinline__ void group_best(S& value, int& index, S (&d)[3]) {
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
+    for (int off = 1; off < W; off <<= 1) {
       const S ov = __shfl_xor(value, off);
       const int oi = __shfl_xor(index, off);
       const S o0 = __shfl_xor(d[0], off), o1 = __shfl_xor(d[1], off), o2 = __shfl_xor(d[2], off);
@@ -65,8 +67,11 @@ struct WaveLanes {  // the lane-group policy of dpll_core.hpp's direction search
     }
   }
 };
-// The team that works on an item: the whole wavefront (G = 64: one item per wave) or a 16-lane DPP row (G = 16: four items per
-// wave, for systems small enough that most phases would leave three quarters of a wave idle).  Barriers are workgroup barriers
+using WaveLanes = ShflLanes<kWave>;
+// The team that works on an item: the whole wavefront (G = 64: one item per wave), half of it (G = 32: two items per wave --
+// an instruction costs a lone wave its four cycles whether 9 lanes have work or 64, so systems whose phases are narrower
+// than 32 lanes lose nothing per item and a wave finishes two) or a 16-lane DPP row (G = 16: four items per wave, for
+// systems small enough that most phases would leave three quarters of a wave idle).  Barriers are workgroup barriers
 // either way (one wave per workgroup): teams of one wave walk through every phase together.
 // f(integral_constant<J>) for J = FROM, FROM + 1, ... while J < n (n uniform over the wave: ONE branch leaves the unrolled chain)
 template <int J, int JMAX> struct RowsUp {
@@ -90,7 +95,7 @@ template <int J> struct RowsDown {
 };
 
 template <int G> struct GroupTeam {
-  static_assert(G == 16 || G == kWave, "a DPP row or the whole wave");
+  static_assert(G == 16 || G == 32 || G == kWave, "a DPP row, half the wave or the whole wave");
   static constexpr int kSize = G;
   static constexpr int kTeams = kWave / G;
   static __device__ __forceinline__ int rank() { return (int)(threadIdx.x & (G - 1)); }
@@ -98,24 +103,31 @@ template <int G> struct GroupTeam {
   static __device__ __forceinline__ void sync() { __syncthreads(); }
   template <typename T> static __device__ __forceinline__ T sum(T x) {
     if constexpr (G == kWave) return wave_sum_of_groups<1>(x);
-    else return GpuLanes<16>::group_sum(x);
+    else if constexpr (G == 32) {
+      x = GpuLanes<16>::group_sum(x);  // both rows of the half hold their own sum
+      return x + __shfl_xor(x, 16);
+    } else return GpuLanes<16>::group_sum(x);
   }
   static __device__ __forceinline__ bool any(bool x) {
     if constexpr (G == kWave) return __any(x) != 0;
+    else if constexpr (G == 32) return (unsigned)(__ballot(x) >> (32 * team())) != 0u;
     else return GpuLanes<16>::group_any(x);
   }
   static __device__ __forceinline__ bool wave_any(bool x) { return __any(x) != 0; }
-  using Lanes = typename std::conditional<G == kWave, WaveLanes, GpuLanes<16>>::type;
+  using Lanes = typename std::conditional<G == 16, GpuLanes<16>, ShflLanes<G>>::type;
 
   // ---- dense factorisations with ONE ROW PER LANE in registers (dpll_forest.hpp cholesky / chol_solve hand over to these) ------
   // The column-by-column factorisation in LDS pays two barriers and four dependent LDS round trips per column, on a wave that
   // has nothing else to run meanwhile.  Here lane i keeps row i in registers and column j reaches the others as a lane
   // broadcast (v_readlane: a scalar; teams of 16: DPP row_newbcast): n^2 / 2 multiply-adds per lane and no memory in between.
   static constexpr bool kLaneRows = true;
-  static constexpr int kRowsMax = G == kWave ? dpll_forest::kMaxV : 8;  // (teams of 16 are given systems of <= 8 velocities)
+  static constexpr int kRowsMax = G == 16 ? 8 : dpll_forest::kMaxV;  // (teams of 16 are given systems of <= 8 velocities)
   template <int J> static __device__ __forceinline__ int bcast_word(int x) {
     if constexpr (G == kWave) return __builtin_amdgcn_readlane(x, J);
-    else return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false);  // row_newbcast:J
+    else if constexpr (G == 32) {  // lane J of either half, each team keeps its own
+      const int lo = __builtin_amdgcn_readlane(x, J), hi = __builtin_amdgcn_readlane(x, 32 + J);
+      return threadIdx.x & 32 ? hi : lo;
+    } else return __builtin_amdgcn_update_dpp(x, x, 0x150 + J, 0xf, 0xf, false);  // row_newbcast:J
   }
   template <int J> static __device__ __forceinline__ float bcast(float x) { return __int_as_float(bcast_word<J>(__float_as_int(x))); }
   template <int J> static __device__ __forceinline__ double bcast(double x) {
@@ -495,9 +507,16 @@ int stride_of(const ForestDesc& fd) { return (row_width(fd) + 1) & ~1; }
 // elbow-sized: 4096 cube pairs 261 -> 161 us per loss + gradients); else the whole wave on one item -- four items per wave pay for
 // the slowest of the four at every iteration and take four passes where 64 lanes take one (two cubes 580 -> 860 us, gripper
 // 482 -> 598 us: measured)
+// Half a wave per item (round 4, after the factorisations moved to registers): systems of at most 16 contacts and velocities
+// and 2 candidates -- no phase of theirs is wider than 32 lanes except the direction search, which takes its rounds anyway
+#ifndef DPLL_FOREST_HALF
+#define DPLL_FOREST_HALF 1
+#endif
 template <typename T> int lanes_per_item(const ForestDesc& fd) {
   const size_t arena = arena_bytes<T, double>(fd);
-  return (4 * arena <= 96 * 1024 && fd.n_contacts <= 8 && fd.n_v <= 8) ? 16 : kWave;
+  if (4 * arena <= 96 * 1024 && fd.n_contacts <= 8 && fd.n_v <= 8) return 16;
+  if (DPLL_FOREST_HALF && 2 * arena <= 64 * 1024 && fd.n_contacts <= 16 && fd.n_v <= 16 && fd.n_pairs <= 2) return 32;
+  return kWave;
 }
 int grid_for(long long batch, size_t lds_bytes, int items_per_wave = 1) {
   batch = (batch + items_per_wave - 1) / items_per_wave;
@@ -541,6 +560,8 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   const size_t lds = teams * (round16((size_t)row_width(fd) * sizeof(double)) + arena);
   if (lanes == 16) {
     if (int rc = allow_lds(forest_loss_kernel<T, 16>, lds, "dpll_contactnets_loss")) return rc;
+  } else if (lanes == 32) {
+    if (int rc = allow_lds(forest_loss_kernel<T, 32>, lds, "dpll_contactnets_loss")) return rc;
   } else {
     if (int rc = allow_lds(forest_loss_kernel<T, kWave>, lds, "dpll_contactnets_loss")) return rc;
   }
@@ -552,6 +573,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                        (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)weights, scale,   \
                        (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad, stride, (unsigned)arena)
     if (lanes == 16) DPLL_FOREST_LOSS(16);
+    else if (lanes == 32) DPLL_FOREST_LOSS(32);
     else DPLL_FOREST_LOSS(kWave);
 #undef DPLL_FOREST_LOSS
     if (int rc = dpll_check_launch("forest_loss_kernel")) return rc;
@@ -585,6 +607,7 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
                        ld_step, write_x0, (int*)iters, (unsigned)arena);                                                                         \
   } while (0)
   if (lanes == 16) DPLL_FOREST_SIM(16);
+  else if (lanes == 32) DPLL_FOREST_SIM(32);
   else DPLL_FOREST_SIM(kWave);
 #undef DPLL_FOREST_SIM
   return dpll_check_launch("forest_simulate_kernel");
