@@ -507,10 +507,12 @@ int stride_of(const ForestDesc& fd) { return (row_width(fd) + 1) & ~1; }
 // elbow-sized: 4096 cube pairs 261 -> 161 us per loss + gradients); else the whole wave on one item -- four items per wave pay for
 // the slowest of the four at every iteration and take four passes where 64 lanes take one (two cubes 580 -> 860 us, gripper
 // 482 -> 598 us: measured)
-// Half a wave per item (round 4, after the factorisations moved to registers): systems of at most 16 contacts and velocities
-// and 2 candidates -- no phase of theirs is wider than 32 lanes except the direction search, which takes its rounds anyway
+// Half a wave per item (GroupTeam<32>, built with -DDPLL_FOREST_HALF=1 only): measured in round 4 after the factorisations moved
+// to registers and NOT adopted -- 4096 items, f32 loss + gradients, one item per wave vs two: two_cubes 365 -> 430 us, gripper
+// 350 -> 395, pendulum + cube 385 -> 403, rake 442 -> 429: the phases wider than 32 lanes (271 direction candidates, 78
+// Hessian entries) take their extra rounds and the wave pays for the slower of its two items at every iteration
 #ifndef DPLL_FOREST_HALF
-#define DPLL_FOREST_HALF 1
+#define DPLL_FOREST_HALF 0
 #endif
 template <typename T> int lanes_per_item(const ForestDesc& fd) {
   const size_t arena = arena_bytes<T, double>(fd);
@@ -560,8 +562,10 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   const size_t lds = teams * (round16((size_t)row_width(fd) * sizeof(double)) + arena);
   if (lanes == 16) {
     if (int rc = allow_lds(forest_loss_kernel<T, 16>, lds, "dpll_contactnets_loss")) return rc;
+#if DPLL_FOREST_HALF
   } else if (lanes == 32) {
     if (int rc = allow_lds(forest_loss_kernel<T, 32>, lds, "dpll_contactnets_loss")) return rc;
+#endif
   } else {
     if (int rc = allow_lds(forest_loss_kernel<T, kWave>, lds, "dpll_contactnets_loss")) return rc;
   }
@@ -573,7 +577,9 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                        (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)weights, scale,   \
                        (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad, stride, (unsigned)arena)
     if (lanes == 16) DPLL_FOREST_LOSS(16);
+#if DPLL_FOREST_HALF
     else if (lanes == 32) DPLL_FOREST_LOSS(32);
+#endif
     else DPLL_FOREST_LOSS(kWave);
 #undef DPLL_FOREST_LOSS
     if (int rc = dpll_check_launch("forest_loss_kernel")) return rc;
@@ -607,7 +613,9 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
                        ld_step, write_x0, (int*)iters, (unsigned)arena);                                                                         \
   } while (0)
   if (lanes == 16) DPLL_FOREST_SIM(16);
+#if DPLL_FOREST_HALF
   else if (lanes == 32) DPLL_FOREST_SIM(32);
+#endif
   else DPLL_FOREST_SIM(kWave);
 #undef DPLL_FOREST_SIM
   return dpll_check_launch("forest_simulate_kernel");
