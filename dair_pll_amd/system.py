@@ -865,15 +865,17 @@ class MultibodyLearnableSystem(Module):
             body = self.spec.bodies[index]
             geometry = self.multibody_terms.contact_terms.geometries[g + 1]
             if isinstance(geometry, DeepSupportConvex):
-                if _differs_from_identity(self.spec.geoms()[g][1].rotation):
-                    raise NotImplementedError('mesh extraction of a learned shape whose collision <origin> carries an rpy')
+                # a geometry turned in its body (rpy on the collision <origin>): the kernels query the network along
+                # -(row 2 of R_WB R_BG), so the BODY-frame direction that makes the query d is R_BG d; the support points come
+                # back in the geometry frame, which is the frame the exported mesh lives in (the URDF keeps the origin)
+                r_bg = torch.tensor(self.spec.geoms()[g][1].rotation, dtype=torch.float64)
                 k_mesh = sum(1 for _, other in self.spec.geoms()[:g] if other.kind == 'mesh')  # rows of support_points
 
-                def support(directions: np.ndarray, geometry=geometry, k_mesh=k_mesh) -> np.ndarray:
+                def support(directions: np.ndarray, geometry=geometry, k_mesh=k_mesh, r_bg=r_bg) -> np.ndarray:
                     # the HIP kernels evaluate the network (dpll_mesh_support_points): a state whose rotation takes
                     # the direction to -e_z makes the kernel's first query (perturbation row 0 = 0) that direction
                     param = geometry.network.output_weight
-                    d = torch.tensor(directions, dtype=torch.float64)
+                    d = torch.tensor(directions, dtype=torch.float64) @ r_bg.t()
                     w = 1.0 - d[:, 2]                                    # 1 + d . (-e_z)
                     axis = torch.stack((-d[:, 1], d[:, 0], torch.zeros_like(w)), -1)  # d x (-e_z)
                     flip = w < 1e-12                                     # d = +e_z: half turn about x

@@ -135,6 +135,31 @@ def test_learned_shape_export(golden, tmp_path):
     assert np.allclose(np.array(spec.bodies[0].geoms[0].vertices), vertices, atol=0, rtol=1e-15)
 
 
+def test_learned_shape_turned_in_its_body_exports_the_same_hull(tmp_path):
+    """a learned shape whose collision <origin> carries an rpy (the reference exports any pose, urdf_utils.py:255-384): the
+    hull is extracted in the geometry's own frame -- the same network gives the same vertices whether the geometry sits
+    turned in its body (general build with a learned shape) or not (the specialised mesh build) -- and the written URDF
+    keeps the origin"""
+    from dair_pll_amd import MultibodyLearnableSystem
+    from dair_pll_amd.urdf import parse_urdf
+    meshes = {}
+    for name in ('cube_mesh', 'cube_mesh_turned'):
+        torch.manual_seed(3)  # (the network is drawn at construction: the same weights for both)
+        system = MultibodyLearnableSystem({'model': os.path.join(ASSET_DIR, name + '.urdf')}, 0.0068, dtype=torch.float64, device='cuda:0',
+                                          output_urdfs_dir=str(tmp_path / name))
+        os.makedirs(system.output_urdfs_dir, exist_ok=True)
+        meshes[name] = system.extract_meshes()['body']
+        written = parse_urdf(system.generate_updated_urdfs()['model'])
+        assert written.bodies[0].geoms[0].kind == 'mesh'
+        if name == 'cube_mesh_turned':
+            assert system.spec.is_fast() is False
+            assert np.allclose(written.bodies[0].geoms[0].rotation, system.spec.geoms()[0][1].rotation, atol=1e-12)
+            assert np.allclose(written.bodies[0].geoms[0].origin, [0.004, -0.003, 0.002], atol=1e-15)
+    plain, turned = meshes['cube_mesh'][0], meshes['cube_mesh_turned'][0]
+    dist = np.abs(plain[:, None, :] - turned[None, :, :]).max(axis=2)
+    assert dist.min(axis=1).max() < 1e-10 and dist.min(axis=0).max() < 1e-10
+
+
 @pytest.mark.parametrize('case', CASES)
 def test_mesh_terms_match_reference_run(golden, case):
     """MultibodyTerms.forward (D, M, J, phi, a) with the learned shape; the reference's top-k leaves the order of
