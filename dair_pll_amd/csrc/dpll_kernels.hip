@@ -123,7 +123,7 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(cons
   using D = Dims<T, NJ>;
   constexpr int G = D::K / KPL;  // lanes of one copy of an item
   using Lanes = GpuLanes<G, RACE>;
-  static_assert(RACE == 1 || !MESH, "racing copies: box geometry");
+  static_assert(RACE == 1 || !MESH || KPL == 1, "racing copies with learned shapes: one contact per lane");
   static_assert(KPL == 1 || !MESH, "several contacts per lane: box geometry");
   constexpr int kItems = WAVES * (kWave / G) / RACE;  // items per workgroup
   if constexpr (!DENSE) claim_whole_simd<T>();  // (this build serves the launches of at most one wave per SIMD: the launchers
@@ -162,8 +162,11 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(cons
     if constexpr (MESH) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) wit[0][i] = witness[(it * D::K + cidx) * 3 + i];
+      bool winner = true;
       if constexpr (KPL == 1)
-        L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, wit, rb);
+        L = loss_item<T, typename Acc<T>::type, NJ, 1, Lanes>(md, dp, opt, xr, xpr, cidx, w, want_grad != 0, acc, f, n_it, wit, rb, nullptr,
+                                                              nullptr, &winner);
+      if constexpr (RACE > 1) valid = valid && winner;  // (the copies read the same witness; the winner alone writes its adjoint)
       if (rbar_out && valid) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) rbar_out[(it * D::K + cidx) * 3 + i] = rb[0][i];
@@ -1309,11 +1312,27 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
                      (const T*)xp, ld_xp, batch, (const T*)p->theta, (const T*)p->friction, (const T*)nullptr,                    \
                      (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows),                     \
                      want_grad, (const T*)(ws + pl.off_P), want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr, m->desc, m->opts[dtype])
-  if constexpr (std::is_same<T, float>::value) {
-    if (pl.loss_blocks > kSimds) DPLL_MESH_LOSS(true);
-    else DPLL_MESH_LOSS(false);
-  } else {
-    DPLL_MESH_LOSS(false);
+  // Racing copies (round 4; what the box cube has run since round 3): a launch of at most 4096 cube pairs gives every item
+  // four copies of its cone solve on the SIMDs a 256-wave launch leaves idle -- the copies read the same support points, the
+  // winner writes the witness adjoints; four-wave workgroups share one partial row, so the reduce kernel sums as many rows
+  const RaceShape shape = race_shape<T, NJ>(m, dtype, batch);
+  bool raced = false;
+  if constexpr (NJ == 0) {
+    if (shape.copies == 4 && shape.lanes == Dims<T, NJ>::G && loss_blocks<T, NJ>(batch, 4, shape.lanes) == pl.loss_blocks) {
+      hipLaunchKernelGGL((loss_kernel<T, NJ, true, false, 4>), dim3(pl.loss_blocks + 1), dim3(kRaceWaves * kWave), 0, stream, (const T*)x, ld_x,
+                         (const T*)xp, ld_xp, batch, (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)weights, scale,
+                         (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows), want_grad, (const T*)(ws + pl.off_P),
+                         want_grad ? (T*)(ws + pl.off_RB) : (T*)nullptr, m->desc, m->opts[dtype]);
+      raced = true;
+    }
+  }
+  if (!raced) {
+    if constexpr (std::is_same<T, float>::value) {
+      if (pl.loss_blocks > kSimds) DPLL_MESH_LOSS(true);
+      else DPLL_MESH_LOSS(false);
+    } else {
+      DPLL_MESH_LOSS(false);
+    }
   }
 #undef DPLL_MESH_LOSS
   mesh_mark(stream);
