@@ -315,8 +315,10 @@ def test_fused_adam_step_of_the_other_builds_is_torch_adam(case, dtype):
 
     ref, fused, graphed = make(), make(), make()
     flat0 = fused._packed().clone()
-    optimizer = torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-3)
-    adam, adam_g = FusedAdamState(lr=1e-3, weight_decay=1e-3), FusedAdamState(lr=1e-3, weight_decay=1e-3)
+    # (learned shapes: a step far shorter than the networks' weights -- about 2e-3 -- so that few of them can cross zero, see below)
+    lr = 2e-5 if 'mesh' in case else 1e-3
+    optimizer = torch.optim.Adam(ref.parameters(), lr=lr, weight_decay=1e-3)
+    adam, adam_g = FusedAdamState(lr=lr, weight_decay=1e-3), FusedAdamState(lr=lr, weight_decay=1e-3)
     graphed.contactnets_train_step(x, xp, adam_g)  # warm-up of the path to be captured, undone below
     with torch.no_grad():
         graphed._packed().copy_(flat0)
@@ -332,10 +334,16 @@ def test_fused_adam_step_of_the_other_builds_is_torch_adam(case, dtype):
     torch.cuda.current_stream().wait_stream(side)
     with torch.no_grad():  # (capture does not execute: nothing to undo)
         assert torch.equal(graphed._packed(), flat0)
-    for _ in range(12):
+    for step in range(12):
         ref.contactnets_loss_and_grad(x, xp)
+        if step == 0:
+            first_grad = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).clone()
         optimizer.step()
         fused.contactnets_train_step(x, xp, adam)
+        if step == 0:  # same parameters, same kernels: the gradient the fused update used IS the one loss_and_grad returns
+            fused_grad = torch.cat([p.grad.reshape(-1) for p in fused.parameters()])
+            worst = (first_grad - fused_grad).abs().argmax().item()
+            assert torch.equal(first_grad, fused_grad), (worst, first_grad[worst].item(), fused_grad[worst].item())
         graph.replay()
     torch.cuda.synchronize()
     tol = 3e-5 if dtype == torch.float32 else 1e-9
@@ -343,10 +351,23 @@ def test_fused_adam_step_of_the_other_builds_is_torch_adam(case, dtype):
     for (name, p_ref), (_, p_fused), (_, p_graph), (_, p_start) in zip(ref.named_parameters(), fused.named_parameters(), graphed.named_parameters(),
                                                                        make().named_parameters()):
         scale = max(1.0, p_ref.abs().max().item())
-        assert (p_ref - p_fused).abs().max().item() <= tol * scale, (name, (p_ref - p_fused).abs().max().item())
+        diff = (p_ref - p_fused).abs()
+        if 'hidden_weights' in name or 'output_weight' in name:
+            # these weights enter the network through their ABSOLUTE value: a weight that the twelve steps (each at most a few
+            # lr long) can carry across zero sees the sign of its gradient flip there, and on which side of zero a step lands is
+            # decided by the last bit -- torch's float32 Adam and the kernel's (double inside) part ways by up to the steps
+            # that follow.  Held to the tolerance: every weight that cannot reach zero; the others to the length of the path.
+            reach = 12 * 3 * lr
+            far = p_start.abs() > reach
+            assert far.float().mean().item() > 0.5, name  # (the check must not be vacuous)
+            assert diff[far].max().item() <= tol * scale, (name, diff[far].max().item())
+            assert diff.max().item() <= 2 * reach, (name, diff.max().item())
+        else:
+            assert diff.max().item() <= tol * scale, (name, diff.max().item())
+        # (eager and replayed: the same launches on the same numbers)
         assert (p_fused - p_graph).abs().max().item() <= tol * scale, name
         moved = max(moved, (p_ref - p_start).abs().max().item())
-    assert moved > 1e-3 and adam.step.item() == 12.0 and adam_g.step.item() == 12.0
+    assert moved > 5 * lr and adam.step.item() == 12.0 and adam_g.step.item() == 12.0
     # what is not a parameter stays what it was: padding of the flat buffer (general build: unused geometry slots; every build
     # but the mesh one: the tail of each geometry's block)
     layout, total = fused._layout()
