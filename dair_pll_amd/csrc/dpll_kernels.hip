@@ -1912,8 +1912,13 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch) {
 }
 
 int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what) {
-  if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || what < 0 || what > 3) return -1;
-  if (model->forest) return what >= 2 ? -1 : 1;
+  if (!model || (dtype != DPLL_F32 && dtype != DPLL_F64) || batch < 0 || what < 0 || what > 4) return -1;
+  if (model->forest) return what >= 2 && what != 4 ? -1 : 1;
+  if (what == 4) {  // the loss launch of dpll_contactnets_loss_mesh: the single-body build races like the box cube (launch_mesh_loss)
+    if (model->desc.n_geoms > 0 || model->desc.n_joints != 0) return 1;
+    const RaceShape shape = race_shape(0, dtype == DPLL_F32, model->opts[dtype].portfolio, batch);
+    return (shape.copies == 4 && shape.lanes == kQuery) ? 4 : 1;
+  }
   if (what >= 2) {  // the shape of the loss launch: 2 = item workgroups (= partial rows), 3 = lanes of one copy of an item
     if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return -1;
     LossPlan pl;

@@ -444,8 +444,8 @@ class MultibodyLearnableSystem(Module):
 
     def racing_copies(self, batch: int, rollout: bool = False) -> int:
         """Racing copies per item (``dpll_solver_opts_t.portfolio``) of a loss (or rollout) launch of ``batch`` items."""
-        if self._mesh() is not None:  # (learned shapes: the support points come from the ICNN kernels, no copies)
-            return 1
+        if self._mesh() is not None:  # (learned shapes: the loss launch of a single body races, rollouts do not)
+            return 1 if rollout else int(_capi.library().dpll_racing_copies(self._model(), _DTYPES[self.dtype], batch, 4))
         return int(_capi.library().dpll_racing_copies(self._model(), _DTYPES[self.dtype], batch, 1 if rollout else 0))
 
     def set_solver(self, **kwargs) -> None:

@@ -203,7 +203,8 @@ int64_t dpll_workspace_bytes(const dpll_model_t* model, int64_t batch);
 
 /* Racing copies per item (dpll_solver_opts_t.portfolio) that a launch of `batch` items would run with the model's current
  * solver settings: what = 0 the loss launch (dpll_contactnets_loss and its variants), 1 the rollout / step launch
- * (dpll_simulate, dpll_step).  1 = no copies (always: general build, learned shapes).  -1 on a bad argument.
+ * (dpll_simulate, dpll_step), 4 the loss launch of dpll_contactnets_loss_mesh (a single body with a learned shape races like
+ * the box cube).  1 = no copies (always: general and forest build).  -1 on a bad argument.
  * The SHAPE of the loss launch (specialised builds only, else -1): what = 2 its item workgroups (= partial rows; the grid has
  * one more, which writes the chain matrix), what = 3 the lanes of one copy of an item (1: the wide build). */
 int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int what);

@@ -135,6 +135,35 @@ def test_learned_shape_export(golden, tmp_path):
     assert np.allclose(np.array(spec.bodies[0].geoms[0].vertices), vertices, atol=0, rtol=1e-15)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_racing_copies_in_the_mesh_loss_launch(golden, dtype):
+    """the loss launch of a single body with a learned shape races four copies of the cone solve like the box cube (<= 4096
+    pairs): the copies read the same support points, the winner writes the witness adjoints -- loss, every gradient incl. the
+    network's weights and the forces agree with the launch without copies to the solver's tolerance, bitwise from run to run"""
+    g = golden('cube_box_4096')
+    from dair_pll_amd import MultibodyLearnableSystem
+    x = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=dtype, device='cuda:0')
+    out = {}
+    for copies in (0, 1):
+        torch.manual_seed(0)
+        system = MultibodyLearnableSystem({'model': os.path.join(ASSET_DIR, 'cube_mesh.urdf')}, float(g['dt']), dtype=dtype, device='cuda:0')
+        system.set_solver(portfolio=copies)
+        assert system.racing_copies(4096) == (4 if copies == 0 else 1) and system.racing_copies(4097) == 1
+        assert system.racing_copies(4096, rollout=True) == 1
+        total = system.contactnets_loss_and_grad(x, xp).item()
+        grads = torch.cat([p.grad.reshape(-1).double() for p in system.parameters()]).cpu()
+        again = system.contactnets_loss_and_grad(x, xp).item()
+        assert again == total and torch.equal(grads, torch.cat([p.grad.reshape(-1).double() for p in system.parameters()]).cpu())
+        with torch.no_grad():
+            per_item = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp).double().cpu()
+        out[copies] = (total, grads, per_item)
+    tol = 2e-5 if dtype == torch.float32 else 1e-9
+    assert abs(out[0][0] - out[1][0]) <= tol * abs(out[1][0])
+    assert (out[0][2] - out[1][2]).abs().max() <= tol * out[1][2].abs().max()
+    assert (out[0][1] - out[1][1]).abs().max() <= 50 * tol * out[1][1].abs().max()
+
+
 def test_learned_shape_turned_in_its_body_exports_the_same_hull(tmp_path):
     """a learned shape whose collision <origin> carries an rpy (the reference exports any pose, urdf_utils.py:255-384): the
     hull is extracted in the geometry's own frame -- the same network gives the same vertices whether the geometry sits
