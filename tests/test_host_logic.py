@@ -130,7 +130,10 @@ def test_racing_copies_and_solver_settings_through_the_c_abi():
         assert lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 0) == (4 if dtype == _capi.F32 else 1)  # (two contacts per lane)
         assert lib.dpll_racing_copies(handles['elbow'], dtype, 4097, 0) == 1 and lib.dpll_racing_copies(handles['elbow'], dtype, 4096, 1) == 1
         assert lib.dpll_racing_copies(handles['gripper'], dtype, 512, 0) == 1
-    assert lib.dpll_racing_copies(handles['cube'], 7, 4096, 0) == -1 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 4) == -1
+    assert lib.dpll_racing_copies(handles['cube'], 7, 4096, 0) == -1 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 5) == -1
+    # what = 4: the loss launch of the mesh entry points -- a single body races like the box cube, the others never
+    assert lib.dpll_racing_copies(handles['cube'], _capi.F32, 4096, 4) == 4 and lib.dpll_racing_copies(handles['cube'], _capi.F32, 4097, 4) == 1
+    assert lib.dpll_racing_copies(handles['elbow'], _capi.F32, 4096, 4) == 1 and lib.dpll_racing_copies(handles['gripper'], _capi.F32, 512, 4) == 1
     # the shape of the loss launch (what = 2: item workgroups, 3: lanes per copy): the racing launch writes as many rows as the
     # plain one; the wide build (one lane per item) in four-wave workgroups from 512 waves on
     assert [lib.dpll_racing_copies(handles['cube'], _capi.F32, b, 2) for b in (4096, 4097, 16384, 65536)] == [256, 257, 256, 256]
