@@ -23,11 +23,13 @@ _lib = None
 GEO_STRIDE = 24
 
 
-def build(force: bool = False) -> str:
+def build(force: bool = False, sanitize: bool = False) -> str:
+    out = _LIB if not sanitize else os.path.join(_HERE, 'libforestsim_asan.so')
     newest = max(os.path.getmtime(path) for path in [_SRC] + _HEADERS)
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
-        subprocess.check_call(['g++', '-std=c++17', '-shared', '-fPIC', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-variable', '-O2', '-o', _LIB, _SRC])
-    return _LIB
+    if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
+        flags = ['-O1', '-fsanitize=address,undefined', '-fno-omit-frame-pointer'] if sanitize else ['-O2']
+        subprocess.check_call(['g++', '-std=c++17', '-shared', '-fPIC', '-Wall', '-Wno-unknown-pragmas', '-Wno-unused-variable', *flags, '-o', out, _SRC])
+    return out
 
 
 def lib():

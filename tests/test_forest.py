@@ -165,6 +165,40 @@ def test_host_step_backward_is_the_derivative_of_the_step(golden, name):
         assert abs(fd - mine) <= 1e-4 * max(1.0, abs(mine)), (name, fd, mine)
 
 
+def test_sanitized_host_build_of_the_forest_program_runs_clean():
+    """ASan + UBSan build of the forest program (the run-time-sized LDS arena is a heap block here: a carve that overlaps or a
+    loop that runs past a block's size is an out-of-bounds access) on a system of every kind, in a child process"""
+    import subprocess
+    import sys
+    lib = forest.build(sanitize=True)
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = f'''
+import sys, ctypes, numpy as np
+sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r})
+from hostsim import forest
+forest._lib = ctypes.CDLL({lib!r})
+import test_forest as T
+from dair_pll_amd import _capi
+for name in ('two_cubes', 'pendulum_cube', 'rake', 'chain6'):
+    g = np.load({os.path.join(here, 'golden')!r} + '/' + name + '_literal.npz')
+    spec = T.system_spec_of(name)
+    desc = _capi.make_forest_desc(spec, float(g['dt']), str(g['inertia_mode']))
+    theta, friction, lengths = T.fixture_params(g, spec)
+    n = 6 if name == 'chain6' else 16
+    for dtype in (np.float64, np.float32):
+        forest.loss(desc, theta, friction, lengths, g['x'][:n], g['x_plus'][:n], dtype=dtype)
+        forest.step(desc, theta, friction, lengths, g['x'][:n], dtype=dtype)
+    forest.terms(desc, theta, friction, lengths, g['x'][:n])
+    forest.step_backward(desc, theta, friction, lengths, g['x'][:4], np.ones_like(g['x'][:4]), want_state=True)
+print('sanitized ok')
+'''
+    asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so']).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0', PYTHONPATH=here)
+    result = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=1200)
+    assert result.returncode == 0 and 'sanitized ok' in result.stdout, result.stderr[-3000:]
+    assert 'runtime error' not in result.stderr, result.stderr[-3000:]
+
+
 def test_forest_models_through_the_c_abi_without_a_gpu():
     """dpll_forest_model_create validates the description; the size queries answer for a forest model"""
     lib = _capi.library()
