@@ -187,9 +187,12 @@ int dpll_model_get_solver(const dpll_model_t* model, int dtype, dpll_solver_opts
 
 int dpll_n_x(const dpll_model_t* model);          /* 13 + 2 n_joints */
 /* A model on the forest build.  The handle works with every entry point below that takes a model handle (loss, step,
- * simulate, step backward, terms; not the *_mesh, allreduce-fused and train-step ones).  Layouts: state rows (n_q + n_v);
- * parameters [theta (n_bodies, 10) | friction (1 + n_geoms) | lengths (n_geoms, DPLL_GEOM_BLOCK)]; forces / phi / J / D over
- * the model's n_contacts contacts in the reference's order (no padding slots).  racing copies: none. */
+ * simulate, step backward, terms, the fused training step with ar = NULL; not the *_mesh and allreduce-fused ones).
+ * Layouts: state rows (n_q + n_v); parameters [theta (n_bodies, 10) | friction (1 + n_geoms) | lengths (n_geoms,
+ * DPLL_GEOM_BLOCK)]; forces / phi / J / D over the model's n_contacts contacts in the reference's order (no padding slots).
+ * racing copies: none.  Creation touches no device (it works in a process without a GPU); the FIRST compute call on a handle
+ * places the description in device memory (one hipMalloc + hipMemcpy, and hipFuncSetAttribute for arenas over 48 KB): make
+ * one call before capturing the handle's launches in a hipGraph; every later call allocates nothing and is capturable. */
 int dpll_forest_model_create(const dpll_forest_desc_t* desc, dpll_model_t** out);
 
 int dpll_n_contacts(const dpll_model_t* model);   /* fast builds 4 n_bodies; general build 4 DPLL_GEN_SLOTS contact SLOTS: slot
