@@ -216,7 +216,8 @@ def test_gpu_loss_gradients_dynamics(golden, name, dtype):
     u = torch.zeros(x.shape[:-1] + (0,), device='cuda:0')
     f64 = dtype == torch.float64
     loss = system.contactnets_loss(x, u, xp)
-    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-4)
+    # (float32: north_star's budget is 1e-4; the loss evaluated without its big cancellation -- round 4 -- is within 1e-5 on every model)
+    assert np.abs(loss.detach().cpu().double().numpy() - g['loss']).max() < (1e-10 if f64 else 1e-5)
     loss.mean().backward()
     for key, param in system.named_parameters():
         ref = g['grad/' + key]

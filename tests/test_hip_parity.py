@@ -52,7 +52,7 @@ def test_loss_matches_reference_run(golden, case, dtype):
     err = np.abs(loss.detach().cpu().double().numpy() - g['loss']).max()
     assert err < TOL[dtype], err
     if dtype == torch.float32:
-        assert err < 5e-6  # what float32 with the double-accumulated cone residual actually achieves
+        assert err < 1e-6, err  # what float32 achieves with the double-accumulated cone residual and the loss evaluated as 1/2 u.(g - M dv) + f.r (round 3: 5e-6)
 
 
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
