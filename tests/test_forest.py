@@ -491,6 +491,33 @@ def test_gpu_forest_batch_sizes_and_workspace():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('name', ['two_cubes', 'pendulum_cube', 'rake'])
+def test_gpu_forest_long_rollouts_come_to_rest(golden, name, dtype):
+    """200-step rollouts from every fixture state (bodies land, slide, collide, some come to rest: tangential residuals fall to
+    denormal sizes, where a float reciprocal square root once returned inf on the device -- tests/test_hip_edges.py): finite
+    everywhere, no body gains speed out of nothing (contact only dissipates; gravity adds at most g t), float32 close to float64
+    over the first steps"""
+    g = golden(name + '_literal')
+    system = gpu_system(g, name, dtype)
+    x0 = torch.tensor(g['x'], dtype=dtype, device='cuda:0')
+    with torch.no_grad():
+        traj, _ = system.simulate(x0.unsqueeze(-2), torch.zeros((x0.shape[0], 1), device='cuda:0'), 200)
+    assert torch.isfinite(traj).all()
+    n_q = system.space.n_q
+    speed = traj[:, :, n_q:].abs().amax(dim=(1, 2))
+    start = traj[:, 0, n_q:].abs().amax(dim=-1)
+    # (a blow-up shows as speeds of 1e6 and more long before it shows as inf: what a fall of 200 steps can add is g t, or g t over
+    # a 2 cm lever arm once it has turned into spin)
+    assert (speed <= 3.0 * start + 9.81 * 200 * float(g['dt']) / 0.02).all(), (speed.max().item(), start.max().item())
+    if dtype == torch.float32:
+        ref = gpu_system(g, name, torch.float64)
+        with torch.no_grad():
+            t64, _ = ref.simulate(x0.double().unsqueeze(-2), torch.zeros((x0.shape[0], 1), device='cuda:0'), 3)
+        assert (traj[:, :4].double() - t64).abs().max().item() < 1e-3
+
+
+@pytest.mark.gpu
 def test_gpu_two_cubes_learn_their_size_from_a_collision():
     """end to end on a system of two URDFs: tosses simulated with the true parameters, a model whose second cube starts 15 %
     too large; the ContactNets loss falls under the trainer's Adam and the half lengths move towards the truth"""
