@@ -1,0 +1,528 @@
+// dpll_icnn_pipe.hip -- the ICNN GEMMs of the mesh-geometry path (DeepSupportConvex / HomogeneousICNN, geometry.py:309-325,
+// deep_support_function.py:213-266) as ONE-WAVE-PER-SIMD, SOFTWARE-PIPELINED kernels for gfx950 (round 5).
+//
+// Why a second form: the 8-wave kernels of dpll_mesh_kernels.hpp run two waves per SIMD and separate the
+// phases of a 32-row tile (queries -> fill -> 128 MFMAs -> epilogue) by workgroup barriers, so a tile costs the SUM of its
+// phases on the slower wave: 0.41 of the f32 matrix rate for four rounds.  Here a workgroup is FOUR waves, one per SIMD of
+// its CU, with the whole 512-register file each:
+//   * wave v owns output columns [64 v, 64 v + 64) of every tile: its 256 x 64 block of the weight matrix stays in 256
+//     registers for the whole launch (the compiler places what does not fit the 256 architectural VGPRs in AGPRs and feeds
+//     the MFMA from there: B operands may be AGPRs on gfx950);
+//   * a v_mfma_f32_32x32x2_f32 occupies the matrix pipe for 64 cycles and the wave's issue port for a few, so the SAME wave
+//     fills the NEXT tile's operand image, runs the PREVIOUS tile's epilogue and fetches the rows of the tile after next in
+//     the shadow of this tile's 256 MFMAs.  The two 32-column blocks of a wave are TWO CHAINS run one after the other (a
+//     dependent f32 MFMA chain issues at the pipe's full rate): while chain 0 of tile t runs, the epilogue of chain 1 of
+//     tile t - 1 reads that chain's accumulator (which chain 1 of tile t only claims afterwards), and while chain 1 runs,
+//     the epilogue of chain 0 of the SAME tile -- no accumulator is ever copied and 32 registers hold both.  A step = one
+//     16-byte LDS read + 4 MFMAs + either one row of the next tile's fill or one accumulator register of an epilogue;
+//   * ONE workgroup barrier per tile (the hand-over of the double-buffered operand image), no control flow inside a tile:
+//     rows beyond N and tiles beyond the last are handled by clamped addresses, zeroed inputs and a spare "dump" tile.
+// Operand maps of v_mfma_f32_32x32x2_f32:  A: lane l holds A[i = l & 31][k = l >> 5];  B: lane l holds B[k = l >> 5][j = l & 31];
+// C/D: 16 registers, col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "dpll_icnn_pipe_api.hpp"
+
+namespace {
+
+using namespace dpll;
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+constexpr int kW = kIcnnWidth;       // 256
+constexpr int kRows = dpll_pipe::kTileRows;
+constexpr int kMaskWords = kW / 32;  // 8
+constexpr int kB1Cols = 7 * kW;      // partial row of bwd1: [d|wout| | dWd1 (3 W) | dWd0 (3 W)]
+// LDS image of a 32 x 256 A-operand tile (the layout of dpll_mesh_kernels.hpp): the four values lane (row, half) feeds to
+// steps 4 kq .. 4 kq + 3 (k = 2 (4 kq + e) + half) are one aligned float4; the 8-float pad per kq keeps the column-wise
+// fills on distinct banks
+constexpr int kXq = 32 * 8 + 8;
+constexpr int kXopFloats = 32 * kXq;
+__device__ __forceinline__ constexpr int xop(int row, int k) { return (k >> 3) * kXq + row * 8 + (k & 1) * 4 + ((k >> 1) & 3); }
+__device__ __forceinline__ constexpr int mfma_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+// fill order: step i of 32 handles row fill_row(i); four consecutive steps are the rows of ONE float4 of the operand-tile
+// layout bwd2 reads (rows 2 (4 q + e) + h, e = 0..3)
+__device__ __forceinline__ constexpr int fill_row(int i) { return 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1); }
+
+// per-row data of a tile in LDS: [0] = query (q0, q1, q2, -), [1] = r_bar (r0, r1, r2, -), [2..3] = the row's 8 mask words
+struct RowRing { f32x4 v[4][kRows][4]; };
+
+enum : int { kFwd1 = 0, kFwd2 = 1, kBwd1 = 2 };
+#ifndef DPLL_PIPE_SCHED
+#define DPLL_PIPE_SCHED 3
+#endif
+#ifndef DPLL_PIPE_VALU
+#define DPLL_PIPE_VALU 4
+#endif
+constexpr int kSideValu = DPLL_PIPE_VALU;  // VALU instructions scheduled behind each MFMA of a step
+
+struct PipeArgs {
+  const float* x; long long ld; long long N;
+  IcnnWeights<float> w;
+  const float* F;          // |Wh| (fwd1, bwd1) or |Wh|^T (fwd2) in fragment order (frag_index of dpll_mesh_kernels.hpp)
+  const float* a;          // |wout|
+  const uint32_t* M1in;    // fwd2, bwd1
+  uint32_t* M1out;         // fwd1
+  const float* U0in;       // bwd1 (accumulator layout)
+  float* U0out;            // fwd2
+  const float* RB;         // bwd1
+  float* P;                // fwd2
+  double* partial;         // bwd1
+  float* VbT;              // bwd1 (operand tiles for bwd2; one spare tile behind the last)
+};
+
+__device__ __forceinline__ float mask_factor(uint32_t word, int bit) { return ((word >> bit) & 1u) ? 1.0f : float(kIcnnSlope); }
+
+// DPP: lane 15 of rows 0 / 2 into every lane of rows 1 / 3 (gfx9 row_bcast:15, row_mask 0xA); other rows read 0
+__device__ __forceinline__ float row_bcast15(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ float dppf(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+#ifdef DPLL_PIPE_STAMPS
+// diagnostic build (tools/diag/pipe_bench.hip): shader-clock stamps of wave 0 of every workgroup
+__device__ unsigned long long g_pipe_stamps[256][16];
+#define PIPE_STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_pipe_stamps[blockIdx.x][i] = t_; } } while (0)
+#else
+#define PIPE_STAMP(i) do { } while (0)
+#endif
+
+template <int KIND>
+__global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][kXopFloats];
+  __shared__ RowRing ring;
+  // fwd2 only: per-wave partial support points of a tile (double buffered: written by the epilogue of one iteration, summed
+  // over the four waves in the next)
+  __shared__ float Pp[KIND == kFwd2 ? 4 : 1][8][kRows][4];  // [tile & 3][wave, column block][row]
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  PIPE_STAMP(0);
+  const long long N = g.N;
+  const long long n_tiles = (N + kRows - 1) / kRows;
+  const long long my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;  // tiles blockIdx.x + it gridDim.x
+  auto tile_of = [&](long long it) { return (long long)blockIdx.x + it * gridDim.x; };
+
+  // ---- this wave's 256 x 64 block of the weight matrix: 2 column blocks x 128 k-steps -------------------------------
+  float b[2][kW / 2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const f32x4* f = (const f32x4*)g.F + ((2 * wv + cb) * 32) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < kW / 8; ++q) {
+      const f32x4 v = f[q * 64];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[cb][4 * q + e] = v[e];
+    }
+  }
+  // ---- per-thread constants --------------------------------------------------------------------------------------
+  const int c = tid;  // fill role: column c of the operand tile
+  float d[3] = {0.f, 0.f, 0.f}, ac = 0.f;
+  if (KIND == kFwd1 || KIND == kBwd1) { d[0] = g.w.Wd0[c]; d[1] = g.w.Wd0[kW + c]; d[2] = g.w.Wd0[2 * kW + c]; }
+  if (KIND == kFwd2) ac = g.a[c];
+  int col[2];
+  float wd0[2][3], wd1[2][3], acol[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    col[cb] = 64 * wv + 32 * cb + l31;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { wd0[cb][i] = g.w.Wd0[i * kW + col[cb]]; wd1[cb][i] = g.w.Wd1[i * kW + col[cb]]; }
+    acol[cb] = (KIND == kFwd1) ? 0.f : g.a[col[cb]];
+  }
+  float pert3[3] = {0.f, 0.f, 0.f};
+  if (!g.w.dirs && tid < kRows) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pert3[i] = g.w.pert[3 * (tid & 3) + i];
+  }
+
+  // ---- row data of a tile: global -> registers (issue) -> LDS ring (commit) -----------------------------------------
+  struct RowRaw { float q[4]; float r; uint32_t m; bool ok; };
+  auto rows_issue = [&](long long tile) {
+    RowRaw raw;
+    const long long n0 = tile * kRows;
+    raw.ok = false; raw.r = 0.f; raw.m = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) raw.q[i] = 0.f;
+    if (tid < kRows) {  // the row's query direction (raw: explicit direction or the item's quaternion)
+      const long long n = n0 + tid;
+      raw.ok = n < N;
+      const long long nc = raw.ok ? n : N - 1;
+      if (g.w.dirs) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) raw.q[i] = g.w.dirs[3 * nc + i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw.q[i] = g.x[(nc >> 2) * g.ld + i];
+      }
+    }
+    if (KIND == kBwd1 && tid >= 64 && tid < 64 + 3 * kRows) {
+      const int t = tid - 64, r = t / 3, i = t - 3 * r;
+      const long long n = n0 + r;
+      const long long nc = n < N ? n : N - 1;
+      const float v = g.RB[icnn_point_index(nc, g.w) + i];
+      raw.r = n < N ? v : 0.f;
+    }
+    if (KIND != kFwd1) {
+      const long long n = n0 + (tid >> 3);
+      const long long nc = n < N ? n : N - 1;
+      const uint32_t v = g.M1in[nc * kMaskWords + (tid & 7)];
+      raw.m = n < N ? v : 0u;
+    }
+    return raw;
+  };
+  auto rows_commit = [&](const RowRaw& raw, int slot) {
+    if (tid < kRows) {
+      float q[3] = {0.f, 0.f, 1.f};
+      if (raw.ok) {
+        if (g.w.dirs) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) q[i] = raw.q[i];
+        } else {
+          icnn_query<float>(raw.q, pert3, q);
+        }
+      }
+      ring.v[slot][tid][0] = f32x4{q[0], q[1], q[2], 0.f};
+    }
+    if (KIND == kBwd1 && tid >= 64 && tid < 64 + 3 * kRows) {
+      const int t = tid - 64, r = t / 3, i = t - 3 * r;
+      ((float*)&ring.v[slot][r][1])[i] = raw.r;
+    }
+    if (KIND != kFwd1) ((uint32_t*)&ring.v[slot][tid >> 3][2])[tid & 7] = raw.m;
+  };
+
+  // ---- side work of the MFMA steps comes in two halves: the LDS reads of a step's inputs are issued ONE STEP AHEAD (side_in),
+  // so that their latency passes under four MFMAs instead of stalling the wave between them -----------------------------
+  struct SideIn { f32x4 a, b; uint32_t w; };
+
+  // ---- fill: step i = row fill_row(i) of column c of a tile's operand image ----------------------------------------
+  auto fill_load = [&](int i, int slot) {
+    const int rr = fill_row(i);
+    SideIn in;
+    in.a = f32x4{0.f, 0.f, 0.f, 0.f}; in.b = in.a; in.w = 0u;
+    if (KIND == kFwd1) in.a = ring.v[slot][rr][0];
+    if (KIND == kFwd2) in.w = ((const uint32_t*)&ring.v[slot][rr][2])[c >> 5];
+    if (KIND == kBwd1) { in.a = ring.v[slot][rr][0]; in.b = ring.v[slot][rr][1]; }
+    return in;
+  };
+  f32x4 vb4 = {0.f, 0.f, 0.f, 0.f};  // bwd1: the four rows of one float4 of the operand tile for bwd2
+  auto fill_step = [&](int i, const SideIn& in, float* __restrict__ X, float* __restrict__ vb_tile) {
+    const int rr = fill_row(i);
+    float val;
+    if (KIND == kFwd1) {
+      val = icnn_act(in.a[0] * d[0] + in.a[1] * d[1] + in.a[2] * d[2]);
+    } else if (KIND == kFwd2) {
+      val = ac * mask_factor(in.w, c & 31);
+    } else {
+      const float pre0 = in.a[0] * d[0] + in.a[1] * d[1] + in.a[2] * d[2];
+      val = (in.b[0] * d[0] + in.b[1] * d[1] + in.b[2] * d[2]) * icnn_mask(pre0);  // rows past N: r_bar = 0
+      vb4[i & 3] = val;
+      if ((i & 3) == 3)  // rows 8 q + 2 e + h, e = 0..3 -> float4 ((q * 32 + (c & 31)) * 2 + h) of block (tile, c >> 5)
+        ((f32x4*)(vb_tile + (c >> 5) * 1024))[((i >> 3) * 32 + (c & 31)) * 2 + ((i >> 2) & 1)] = vb4;
+    }
+    X[xop(rr, c)] = val;
+  };
+
+  // ---- epilogue state ------------------------------------------------------------------------------------------------
+  // The two 32-column blocks of a wave are two MFMA chains run one after the other; acc[1] enters tile t still holding chain 1
+  // of tile t - 1 (zero before the first tile), whose epilogue runs under chain 0 of tile t
+  f32x16 acc[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+  uint32_t mw = 0u;                        // fwd1: mask words of the chain's block, the word of row r in lane r
+  f32x4 u0s = {0.f, 0.f, 0.f, 0.f};        // fwd2: U0 values staged for 16-byte stores
+  // bwd1: U0 of the chain in accumulator layout (one float4 in use, the next in flight); column sums of the chain in float,
+  // the running totals over this workgroup's tiles in double in LDS (14 per thread: registers are the scarce resource)
+  f32x4 u0cur = {0.f, 0.f, 0.f, 0.f}, u0nxt = {0.f, 0.f, 0.f, 0.f};
+  const f32x4* u0src = nullptr;
+  float t_abar = 0.f, t_s1[3] = {0.f, 0.f, 0.f}, t_g0[3] = {0.f, 0.f, 0.f};
+  __shared__ double totals[KIND == kBwd1 ? 14 : 1][256];
+  if (KIND == kBwd1) {
+#pragma unroll
+    for (int j = 0; j < 14; ++j) totals[j][tid] = 0.0;
+  }
+
+  // epilogue of chain `cb` of a tile: begin (its U0 stream), 16 steps (one accumulator register each), end
+  auto epi_begin = [&](int cb, long long tile_c /* clamped to a readable tile */) {
+    if (KIND == kBwd1) {
+      u0src = (const f32x4*)(g.U0in + (tile_c * 4 + wv) * 2048) + (4 * cb) * 64 + lane;
+      u0nxt = u0src[0];
+      t_abar = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { t_s1[i] = 0.f; t_g0[i] = 0.f; }
+    }
+  };
+  auto epi_load = [&](int cb, int reg, int slot) {
+    const int row = mfma_row(reg, half);  // (half is a lane property: two rows per register)
+    SideIn in;
+    in.b = f32x4{0.f, 0.f, 0.f, 0.f};
+    in.a = ring.v[slot][row][KIND == kBwd1 ? 1 : 0];  // r_bar (bwd1) or the query
+    in.w = KIND == kFwd1 ? 0u : ((const uint32_t*)&ring.v[slot][row][2])[2 * wv + cb];
+    return in;
+  };
+  auto epi_step = [&](int cb, int reg, const SideIn& in, float* __restrict__ u0_tile, int pbuf) {
+    const int row = mfma_row(reg, half);
+    const float av = acc[cb][reg];
+    if (KIND == kFwd1) {
+      const f32x4 q = in.a;
+      const float pre1 = av + q[0] * wd1[cb][0] + q[1] * wd1[cb][1] + q[2] * wd1[cb][2];
+      const unsigned long long bal = __ballot(pre1 > 0.f);
+      // low word: rows of half 0, high word: rows of half 1; the word of row r goes to lane r
+      mw = lane == mfma_row(reg, 0) ? (uint32_t)(bal & 0xffffffffull) : mw;
+      mw = lane == mfma_row(reg, 1) ? (uint32_t)(bal >> 32) : mw;
+    } else if (KIND == kFwd2) {
+      const f32x4 q = in.a;
+      const uint32_t word = in.w;
+      const float pre0 = q[0] * wd0[cb][0] + q[1] * wd0[cb][1] + q[2] * wd0[cb][2];
+      const float u0 = av * icnn_mask(pre0);
+      const float u1 = acol[cb] * mask_factor(word, l31);
+      u0s[reg & 3] = u0;
+      if ((reg & 3) == 3) ((f32x4*)u0_tile)[(4 * cb + (reg >> 2)) * 64] = u0s;  // accumulator layout: float4 (4 cb + reg / 4) of this lane
+      float pr[3];  // this row's support-point terms of the block's 32 columns: summed over the lanes -> Pp[wave, block][row]
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float v = wd1[cb][i] * u1 + wd0[cb][i] * u0;
+        v += dppf<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dppf<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dppf<0x141>(v);  // row_half_mirror
+        v += dppf<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
+        v += row_bcast15(v);  // rows 1 / 3: + the sum of row 0 / 2 = the half's 32 columns
+        pr[i] = v;
+      }
+      if (l31 == 31) {
+        f32x4* dst = (f32x4*)&Pp[pbuf][2 * wv + cb][row][0];
+        *dst = f32x4{pr[0], pr[1], pr[2], 0.f};
+      }
+    } else {
+      const f32x4 r = in.a;
+      const float mf = mask_factor(in.w, l31);
+      const float u1b = av + r[0] * wd1[cb][0] + r[1] * wd1[cb][1] + r[2] * wd1[cb][2];
+      t_abar += u1b * mf;  // rows past N / tiles that do not exist: r_bar = 0 and a zero accumulator
+      if ((reg & 3) == 0) {
+        u0cur = u0nxt;
+        if (reg + 4 < 16) u0nxt = u0src[((reg >> 2) + 1) * 64];
+      }
+      const float u0 = u0cur[reg & 3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { t_s1[i] += r[i] * mf; t_g0[i] += r[i] * u0; }
+    }
+  };
+  auto epi_end = [&](int cb, long long tile) {
+    const long long n0 = tile * kRows;
+    if (KIND == kFwd1) {
+      if (lane < kRows && n0 + lane < N) g.M1out[(n0 + lane) * kMaskWords + 2 * wv + cb] = mw;
+    } else if (KIND == kBwd1) {
+      totals[7 * cb][tid] += double(t_abar);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { totals[7 * cb + 1 + i][tid] += double(t_s1[i]); totals[7 * cb + 4 + i][tid] += double(t_g0[i]); }
+    }
+  };
+  // fwd2: support points of a tile whose eight partials (wave, block) were written in EARLIER iterations (a barrier lies between)
+  auto p_store = [&](long long it_of_tile) {
+    if (KIND != kFwd2) return;
+    const long long tile = tile_of(it_of_tile);
+    const int pbuf = (int)(it_of_tile & 3);  // (by the workgroup's own count of tiles: tile numbers advance by the grid size)
+    if (tid < 3 * kRows) {
+      const int r = tid / 3, i = tid - 3 * r;
+      const long long n = tile * kRows + r;
+      if (n < N)
+        g.P[icnn_point_index(n, g.w) + i] = ((Pp[pbuf][0][r][i] + Pp[pbuf][1][r][i]) + (Pp[pbuf][2][r][i] + Pp[pbuf][3][r][i])) +
+                                            ((Pp[pbuf][4][r][i] + Pp[pbuf][5][r][i]) + (Pp[pbuf][6][r][i] + Pp[pbuf][7][r][i]));
+    }
+  };
+
+  // ---- prologue: ring zeroed (slot 3 serves the epilogue of the tile "before the first"), rows of the first two tiles,
+  // the first operand image ------------------------------------------------------------------------------------------
+  {
+    f32x4* z = &ring.v[0][0][0];
+    for (int i = tid; i < 4 * kRows * 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  {
+    const RowRaw r0 = rows_issue(tile_of(0));
+    const RowRaw r1 = rows_issue(tile_of(1));
+    rows_commit(r0, 0);
+    rows_commit(r1, 1);
+  }
+  __syncthreads();
+  const long long dump_tile = n_tiles;  // the spare tile behind the last one (VbT, U0out)
+  {
+    float* vb_tile = KIND == kBwd1 ? g.VbT + tile_of(0) * 8 * 1024 : nullptr;
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) fill_step(i, fill_load(i, 0), Xs[0], vb_tile);
+  }
+
+  // one chain: 32 steps of (16-byte LDS read, 4 MFMAs, `side(kq)`) over the operand image Xc
+  auto run_chain = [&](auto cbc, const float* __restrict__ Xc, auto side_in, auto side) {
+    constexpr int cb = decltype(cbc)::value;
+    const f32x4* xq = (const f32x4*)(Xc + l31 * 8 + half * 4);
+    f32x4 x4 = xq[0];
+    SideIn in = side_in(0);
+#pragma unroll
+    for (int kq = 0; kq < kW / 8; ++kq) {
+      const f32x4 xn = xq[(kq + 1 < kW / 8 ? kq + 1 : kq) * (kXq / 4)];
+      const SideIn in_next = side_in(kq + 1 < kW / 8 ? kq + 1 : kq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kq == 0 && e == 0) {
+          f32x16 zero;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[e], b[cb][0], zero, 0, 0, 0);
+        } else {
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[e], b[cb][4 * kq + e], acc[cb], 0, 0, 0);
+        }
+      }
+#ifndef DPLL_PIPE_NOSIDE
+      side(kq, in);
+#endif
+      x4 = xn;
+      in = in_next;
+      // the order the step is meant to issue in: behind every MFMA a share of the step's other work (the scheduler otherwise
+      // clusters the MFMAs, and the matrix pipe idles through the side work behind them)
+#ifndef DPLL_PIPE_NOSCHED
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, kSideValu, 0);  // VALU
+#if DPLL_PIPE_SCHED >= 2
+        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);          // one LDS access
+#endif
+#if DPLL_PIPE_SCHED >= 3
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);          // one global access
+#endif
+      }
+#endif
+#ifdef DPLL_PIPE_FENCE
+      __builtin_amdgcn_sched_barrier(0);  // (diagnostic: nothing moves across a step.  Measured worse: the groups above are then
+                                          // solved per step and mostly come out as four MFMAs in a row)
+#endif
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+
+  // ---- main loop, iteration it: chain 0 of tile it  | epilogue of chain 1 of tile it - 1 | rows 0..15 of the fill of tile it + 1
+  //                               chain 1 of tile it  | epilogue of chain 0 of tile it     | rows 16..31 of that fill
+  //                               and the row data of tile it + 2 (requested at the top, committed to the ring at the end)
+  PIPE_STAMP(1);
+  for (long long it = 0; it < my_tiles; ++it) {
+    __syncthreads();
+    if (it < 3) PIPE_STAMP(2 + 4 * (int)it);
+    const int cur = (int)(it & 1);
+    const long long t_cur = tile_of(it), t_next = tile_of(it + 1), t_prev = tile_of(it - 1);
+    const bool has_next = it + 1 < my_tiles, has_prev = it > 0;
+    const RowRaw raw = rows_issue(has_next ? tile_of(it + 2) : n_tiles);  // (beyond the last: every row masked)
+    if (KIND == kFwd2 && it >= 2) p_store(it - 2);
+    float* Xn = Xs[cur ^ 1];
+    const float* Xc = Xs[cur];
+    float* vb_tile = KIND == kBwd1 ? g.VbT + (has_next ? t_next : dump_tile) * 8 * 1024 : nullptr;
+    const int slot_next = (int)((it + 1) & 3), slot_cur = (int)(it & 3), slot_prev = (int)((it + 3) & 3);
+    {  // chain 0 | epilogue of chain 1 of the previous tile
+      float* u0_tile = KIND == kFwd2 ? g.U0out + ((has_prev ? t_prev : dump_tile) * 4 + wv) * 2048 + lane * 4 : nullptr;
+      const int pbuf = (int)((it + 3) & 3);
+      epi_begin(1, has_prev ? t_prev : t_cur);
+      run_chain(C0{}, Xc,
+                [&](int kq) { return (kq & 1) == 0 ? fill_load(kq >> 1, slot_next) : epi_load(1, kq >> 1, slot_prev); },
+                [&](int kq, const SideIn& in) {
+                  if ((kq & 1) == 0) fill_step(kq >> 1, in, Xn, vb_tile);
+                  else epi_step(1, kq >> 1, in, u0_tile, pbuf);
+                });
+      epi_end(1, has_prev ? t_prev : n_tiles);
+    }
+    if (it < 3) PIPE_STAMP(3 + 4 * (int)it);
+    {  // chain 1 | epilogue of chain 0 of this tile
+      float* u0_tile = KIND == kFwd2 ? g.U0out + (t_cur * 4 + wv) * 2048 + lane * 4 : nullptr;
+      const int pbuf = (int)(it & 3);
+      epi_begin(0, t_cur);
+      run_chain(C1{}, Xc,
+                [&](int kq) { return (kq & 1) == 0 ? fill_load(16 + (kq >> 1), slot_next) : epi_load(0, kq >> 1, slot_cur); },
+                [&](int kq, const SideIn& in) {
+                  if ((kq & 1) == 0) fill_step(16 + (kq >> 1), in, Xn, vb_tile);
+                  else epi_step(0, kq >> 1, in, u0_tile, pbuf);
+                });
+      epi_end(0, t_cur);
+    }
+    if (it < 3) PIPE_STAMP(4 + 4 * (int)it);
+    rows_commit(raw, (int)((it + 2) & 3));
+    if (it < 3) PIPE_STAMP(5 + 4 * (int)it);
+  }
+
+  // ---- drain: epilogue of chain 1 of the last tile; fwd2: the support points of the last two tiles ---------------------
+  {
+    const long long it = my_tiles, t_prev = tile_of(it - 1);
+    float* u0_tile = KIND == kFwd2 ? g.U0out + (t_prev * 4 + wv) * 2048 + lane * 4 : nullptr;
+    epi_begin(1, t_prev);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) epi_step(1, reg, epi_load(1, reg, (int)((it + 3) & 3)), u0_tile, (int)((it + 3) & 3));
+    epi_end(1, t_prev);
+    if (KIND == kFwd2) {
+      __syncthreads();
+      if (it >= 2) p_store(it - 2);
+      p_store(it - 1);
+    }
+  }
+  PIPE_STAMP(14);
+  if (KIND == kBwd1) {
+    // the two halves of the wave hold different rows of the same columns (threads tid and tid ^ 32)
+    __syncthreads();
+    if (half == 0) {
+      double* row = g.partial + (long long)blockIdx.x * kB1Cols;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        row[col[cb]] = totals[7 * cb][tid] + totals[7 * cb][tid ^ 32];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          // dWd1[i][col] = sum_rows r_bar[i] |wout[col]| m1
+          row[kW + i * kW + col[cb]] = double(acol[cb]) * (totals[7 * cb + 1 + i][tid] + totals[7 * cb + 1 + i][tid ^ 32]);
+          row[4 * kW + i * kW + col[cb]] = totals[7 * cb + 4 + i][tid] + totals[7 * cb + 4 + i][tid ^ 32];
+        }
+      }
+    }
+  }
+  PIPE_STAMP(15);
+}
+
+inline int check(const char* what) {
+  const hipError_t e = hipGetLastError();
+  (void)what;
+  return e == hipSuccess ? 0 : -4;
+}
+
+}  // namespace
+
+namespace dpll_pipe {
+
+int fwd1(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* Af, uint32_t* M1) {
+  if (N <= 0) return 0;
+  PipeArgs g{};
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.M1out = M1;
+  hipLaunchKernelGGL(icnn_pipe_kernel<kFwd1>, dim3(blocks(N)), dim3(256), 0, stream, g);
+  return check("icnn_pipe_kernel<fwd1>");
+}
+
+int fwd2(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* ATf, const float* a,
+         const uint32_t* M1, float* U0t, float* P) {
+  if (N <= 0) return 0;
+  PipeArgs g{};
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = ATf; g.a = a; g.M1in = M1; g.U0out = U0t; g.P = P;
+  hipLaunchKernelGGL(icnn_pipe_kernel<kFwd2>, dim3(blocks(N)), dim3(256), 0, stream, g);
+  return check("icnn_pipe_kernel<fwd2>");
+}
+
+int bwd1(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* Af, const float* a,
+         const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT) {
+  if (N <= 0) return 0;
+  PipeArgs g{};
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = VbT;
+  hipLaunchKernelGGL(icnn_pipe_kernel<kBwd1>, dim3(blocks(N)), dim3(256), 0, stream, g);
+  return check("icnn_pipe_kernel<bwd1>");
+}
+
+}  // namespace dpll_pipe

@@ -77,6 +77,7 @@ __device__ __forceinline__ unsigned long long dpll_clock_() {
 #include "dpll_gjk.hpp"
 #include "dpll_mesh_kernels.hpp"
 #include "dpll_mesh_bf16.hpp"
+#include "dpll_icnn_pipe_api.hpp"
 namespace {
 
 // ---- ContactNets loss, forward + backward -----------------------------------------------------
@@ -1071,9 +1072,11 @@ template <typename T> void plan_network_block(MeshPlan& pl, long long N) {
   pl.off_ATb = take(kMfma ? 2 * 3 * kW * kW : 0);
   pl.off_a = take(sizeof(T) * kW);
   pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
-  pl.off_U0 = take(sizeof(T) * kW * pl.N);
-  // MFMA path: Vb (icnn_bwd1) and U1 (icnn_fwd2) as operand tiles for icnn_bwd2, whole 32-row tiles
-  pl.off_Vb = take(kMfma ? sizeof(T) * kW * kMfmaRows * tiles : 0);
+  // (float: whole 32-row tiles + one spare -- the pipelined kernels (dpll_icnn_pipe.hip) keep U0 in the accumulator layout
+  // of the MFMA and send the stores of tiles that do not exist to the spare one)
+  pl.off_U0 = take(sizeof(T) * kW * (kMfma ? kMfmaRows * (tiles + 1) : pl.N));
+  // MFMA path: Vb (icnn_bwd1) as operand tiles for icnn_bwd2, whole 32-row tiles + the spare one
+  pl.off_Vb = take(kMfma ? sizeof(T) * kW * kMfmaRows * (tiles + 1) : 0);
   pl.off_U1 = take(0);  // (round 2 kept U1 operand tiles here)
   pl.off_b1 = take(sizeof(double) * kB1Cols * pl.b1_blocks);
   pl.off_slabs = take(sizeof(T) * kW * kW * pl.n_slabs);
@@ -1171,7 +1174,7 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
   constexpr bool kMfmaPath = std::is_same<T, float>::value;
   bool split_prep = false;  // (|W| in GEMM order: only the weights enter, so the steps of a rollout after the first skip it)
   if constexpr (std::is_same<T, float>::value) {
-    split_prep = t_mesh_gemm != 0;  // the bf16 forms read their own planes (and |wout|): nothing of the f32 layouts
+    split_prep = t_mesh_gemm >= 2;  // the bf16 forms read their own planes (and |wout|): nothing of the f32 layouts
     if (prep && t_mesh_gemm == 2)
       hipLaunchKernelGGL((icnn_prep_bf16_kernel<2>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + pl.off_Ab), (__bf16*)(nb + pl.off_ATb), (float*)a);
     if (prep && t_mesh_gemm == 3)
@@ -1195,7 +1198,12 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
     } while (0)
     if (t_mesh_gemm == 2) DPLL_FWD_BF16(2);
     else if (t_mesh_gemm == 3) DPLL_FWD_BF16(3);
-    else {
+    else if (t_mesh_gemm == 0) {  // the default: one wave per SIMD, software pipelined (dpll_icnn_pipe.hip)
+      if (int rc = dpll_pipe::fwd1(stream, q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1))) return rc;
+      mesh_mark(stream);
+      if (int rc = dpll_pipe::fwd2(stream, q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_ATf), (const float*)a,
+                                   (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0), (float*)P)) return rc;
+    } else {  // mesh_gemm = 1: the 8-wave kernels of rounds 1-4 (kept for A/B measurements)
       hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
                          (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1));
       mesh_mark(stream);
@@ -1235,7 +1243,15 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
     } while (0)
     if (t_mesh_gemm == 2) DPLL_BWD_BF16(2);
     else if (t_mesh_gemm == 3) DPLL_BWD_BF16(3);
-    else {
+    else if (t_mesh_gemm == 0) {
+      if (int rc = dpll_pipe::bwd1(stream, (const float*)q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a),
+                                   (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_U0), (const float*)RB,
+                                   (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb))) return rc;
+      mesh_mark(stream);
+      hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
+                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
+                         (float*)(nb + pl.off_slabs));
+    } else {
       hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
                          (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
                          (const float*)(nb + pl.off_U0), (const float*)RB, (double*)(nb + pl.off_b1),
@@ -1857,8 +1873,8 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
   if (opts->max_iter < 1 || opts->max_ls < 1 || opts->n_stages < 1 || opts->stage_max_iter < 1 || opts->stage_max_ls < 1 || !(opts->stage_factor >= 1.0))
     return fail(-1, "dpll_model_set_solver: iteration limits must be >= 1%s");
   if (opts->wide < -1 || opts->wide > 1) return fail(-1, "dpll_model_set_solver: wide must be -1, 0 or 1%s");
-  if (opts->mesh_gemm != 0 && opts->mesh_gemm != 2 && opts->mesh_gemm != 3)
-    return fail(-1, "dpll_model_set_solver: mesh_gemm must be 0 (f32 MFMA), 2 or 3 (bf16 planes)%s");
+  if (opts->mesh_gemm < 0 || opts->mesh_gemm > 3)
+    return fail(-1, "dpll_model_set_solver: mesh_gemm must be 0 (f32 MFMA, pipelined), 1 (f32 MFMA, the 8-wave kernels), 2 or 3 (bf16 planes)%s");
   if (opts->portfolio != 0 && opts->portfolio != 1 && opts->portfolio != 2 && opts->portfolio != 4)
     return fail(-1, "dpll_model_set_solver: portfolio must be 0 (by batch size), 1 (off), 2 or 4%s");
   for (int k = 0; k < 3; ++k)
