@@ -78,6 +78,35 @@ struct PipeArgs {
 
 __device__ __forceinline__ float mask_factor(uint32_t word, int bit) { return ((word >> bit) & 1u) ? 1.0f : float(kIcnnSlope); }
 
+// Four k-steps of a chain as ONE statement: v_mfma_f32_32x32x2_f32 runs on the vector ALU's own multipliers (its rate IS the f32
+// vector rate; tools/diag/mfma_fill.hip: every VALU instruction between two of them costs its full issue time plus ~10 cycles
+// for the switch), so the MFMAs of a step are kept back to back and the weights are read straight from accumulation registers
+// ("a": no v_accvgpr_read in front of the MFMA).  FIRST: the chain's first step starts from C = 0; LAST: the wait states an
+// XDL result needs before a VALU instruction may read it (hipcc pads nothing for an asm statement).
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void mfma_x4(f32x16& acc, const f32x4& x, float w0, float w1, float w2, float w3) {
+  if (FIRST) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+                 : "=&v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "a"(w0), "a"(w1), "a"(w2), "a"(w3));
+  } else if (LAST) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0\n\t"
+                 "s_nop 15\n\ts_nop 3"
+                 : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "a"(w0), "a"(w1), "a"(w2), "a"(w3));
+  } else {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+                 "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+                 : "+v"(acc) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "a"(w0), "a"(w1), "a"(w2), "a"(w3));
+  }
+}
+
 // DPP: lane 15 of rows 0 / 2 into every lane of rows 1 / 3 (gfx9 row_bcast:15, row_mask 0xA); other rows read 0
 __device__ __forceinline__ float row_bcast15(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
@@ -108,18 +137,9 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   const long long my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;  // tiles blockIdx.x + it gridDim.x
   auto tile_of = [&](long long it) { return (long long)blockIdx.x + it * gridDim.x; };
 
-  // ---- this wave's 256 x 64 block of the weight matrix: 2 column blocks x 128 k-steps -------------------------------
+  // ---- this wave's 256 x 64 block of the weight matrix: 2 column blocks x 128 k-steps (requested in the prologue, BEHIND
+  // the row data of the first two tiles: memory returns in order, so waiting for the rows must not mean waiting for 256 KB)
   float b[2][kW / 2];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const f32x4* f = (const f32x4*)g.F + ((2 * wv + cb) * 32) * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < kW / 8; ++q) {
-      const f32x4 v = f[q * 64];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) b[cb][4 * q + e] = v[e];
-    }
-  }
   // ---- per-thread constants --------------------------------------------------------------------------------------
   const int c = tid;  // fill role: column c of the operand tile
   float d[3] = {0.f, 0.f, 0.f}, ac = 0.f;
@@ -152,13 +172,10 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       const long long n = n0 + tid;
       raw.ok = n < N;
       const long long nc = raw.ok ? n : N - 1;
-      if (g.w.dirs) {
+      // (one path for both sources, no branch: a branch here made the wave wait for memory before it had asked for its weights)
+      const float* src = g.w.dirs ? g.w.dirs + 3 * nc : g.x + (nc >> 2) * g.ld;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) raw.q[i] = g.w.dirs[3 * nc + i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) raw.q[i] = g.x[(nc >> 2) * g.ld + i];
-      }
+      for (int i = 0; i < 4; ++i) raw.q[i] = src[(i == 3 && g.w.dirs) ? 2 : i];
     }
     if (KIND == kBwd1 && tid >= 64 && tid < 64 + 3 * kRows) {
       const int t = tid - 64, r = t / 3, i = t - 3 * r;
@@ -214,7 +231,10 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     const int rr = fill_row(i);
     float val;
     if (KIND == kFwd1) {
-      val = icnn_act(in.a[0] * d[0] + in.a[1] * d[1] + in.a[2] * d[2]);
+      {
+        const float pre = in.a[0] * d[0] + in.a[1] * d[1] + in.a[2] * d[2];
+        val = fmaxf(pre, float(kIcnnSlope) * pre);  // = icnn_act for every finite pre (slope < 1), one instruction fewer
+      }
     } else if (KIND == kFwd2) {
       val = ac * mask_factor(in.w, c & 31);
     } else {
@@ -343,19 +363,46 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     f32x4* z = &ring.v[0][0][0];
     for (int i = tid; i < 4 * kRows * 4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  __syncthreads();
   {
     const RowRaw r0 = rows_issue(tile_of(0));
     const RowRaw r1 = rows_issue(tile_of(1));
+    {  // (chain 0's half of the weights; chain 1's is requested between the rows of the first fill below: the CU's vector-memory
+       // path takes 64 bytes a clock, so 256 KB of fragments occupy it for ~4 k cycles whatever the wave does meanwhile.  Requesting
+       // them under the first chain 0 instead -- a conditional definition -- made the allocator keep them in VGPRs: spills)
+      const f32x4* f = (const f32x4*)g.F + ((2 * wv) * 32) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < kW / 8; ++q) {
+        const f32x4 v = f[q * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[0][4 * q + e] = v[e];
+      }
+    }
+    PIPE_STAMP(10);
+    __syncthreads();  // (the ring is zeroed)
+    PIPE_STAMP(11);
     rows_commit(r0, 0);
     rows_commit(r1, 1);
+    PIPE_STAMP(12);
   }
   __syncthreads();
+  PIPE_STAMP(13);
   const long long dump_tile = n_tiles;  // the spare tile behind the last one (VbT, U0out)
   {
     float* vb_tile = KIND == kBwd1 ? g.VbT + tile_of(0) * 8 * 1024 : nullptr;
+    const f32x4* f = (const f32x4*)g.F + ((2 * wv + 1) * 32) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < kRows; ++i) fill_step(i, fill_load(i, 0), Xs[0], vb_tile);
+    for (int i0 = 0; i0 < kRows; i0 += 8) {  // (eight rows' inputs requested before the first is used)
+      SideIn ins[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ins[j] = fill_load(i0 + j, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 v = f[(i0 + j) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[1][4 * (i0 + j) + e] = v[e];
+        fill_step(i0 + j, ins[j], Xs[0], vb_tile);
+      }
+    }
   }
 
   // one chain: 32 steps of (16-byte LDS read, 4 MFMAs, `side(kq)`) over the operand image Xc
@@ -368,17 +415,9 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     for (int kq = 0; kq < kW / 8; ++kq) {
       const f32x4 xn = xq[(kq + 1 < kW / 8 ? kq + 1 : kq) * (kXq / 4)];
       const SideIn in_next = side_in(kq + 1 < kW / 8 ? kq + 1 : kq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (kq == 0 && e == 0) {
-          f32x16 zero;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[e], b[cb][0], zero, 0, 0, 0);
-        } else {
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[e], b[cb][4 * kq + e], acc[cb], 0, 0, 0);
-        }
-      }
+      if (kq == 0) mfma_x4<true, false>(acc[cb], x4, b[cb][0], b[cb][1], b[cb][2], b[cb][3]);
+      else if (kq == kW / 8 - 1) mfma_x4<false, true>(acc[cb], x4, b[cb][4 * kq], b[cb][4 * kq + 1], b[cb][4 * kq + 2], b[cb][4 * kq + 3]);
+      else mfma_x4<false, false>(acc[cb], x4, b[cb][4 * kq], b[cb][4 * kq + 1], b[cb][4 * kq + 2], b[cb][4 * kq + 3]);
 #ifndef DPLL_PIPE_NOSIDE
       side(kq, in);
 #endif
@@ -386,7 +425,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       in = in_next;
       // the order the step is meant to issue in: behind every MFMA a share of the step's other work (the scheduler otherwise
       // clusters the MFMAs, and the matrix pipe idles through the side work behind them)
-#ifndef DPLL_PIPE_NOSCHED
+#ifdef DPLL_PIPE_SCHED_GROUPS
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA

@@ -1198,18 +1198,27 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
     } while (0)
     if (t_mesh_gemm == 2) DPLL_FWD_BF16(2);
     else if (t_mesh_gemm == 3) DPLL_FWD_BF16(3);
-    else if (t_mesh_gemm == 0) {  // the default: one wave per SIMD, software pipelined (dpll_icnn_pipe.hip)
+    else if (t_mesh_gemm == 0 && pl.n_tiles > 2 * dpll_pipe::kMaxBlocks) {
+      // the default beyond two row tiles per CU: one wave per SIMD, software pipelined (dpll_icnn_pipe.hip)
       if (int rc = dpll_pipe::fwd1(stream, q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1))) return rc;
       mesh_mark(stream);
       if (int rc = dpll_pipe::fwd2(stream, q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_ATf), (const float*)a,
                                    (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0), (float*)P)) return rc;
-    } else {  // mesh_gemm = 1: the 8-wave kernels of rounds 1-4 (kept for A/B measurements)
+    } else {
+      // up to two tiles per CU (the 4096-pair benchmark batch) the 8-wave kernels of rounds 1-4 are ~2 us per launch ahead: a
+      // launch is then prologue-bound and eight waves start the 256 KB fragment load sooner; mesh_gemm = 1 runs
+      // them at every size (A/B measurements).  With mesh_gemm = 0 U0 leaves in the layout the pipelined icnn_bwd1 reads.
       hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
                          (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1));
       mesh_mark(stream);
-      hipLaunchKernelGGL(icnn_fwd2_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
-                         (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
-                         (float*)P, U1t);
+      if (t_mesh_gemm == 0)
+        hipLaunchKernelGGL(icnn_fwd2_mfma<true>, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
+                           (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
+                           (float*)P, U1t);
+      else
+        hipLaunchKernelGGL(icnn_fwd2_mfma<false>, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
+                           (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
+                           (float*)P, U1t);
     }
 #undef DPLL_FWD_BF16
   } else {

@@ -555,6 +555,9 @@ __global__ __launch_bounds__(512) void icnn_fwd1_mfma(const float* __restrict__ 
   }
 }
 
+// U0T: U0 leaves in the accumulator layout the pipelined icnn_bwd1 (dpll_icnn_pipe.hip) reads -- block (tile, wave pair), per lane
+// the float4 (4 (wave & 1) + reg / 4) -- instead of row-major
+template <bool U0T>
 __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ x, long long ld, long long N,
                                                       IcnnWeights<float> w, const float* __restrict__ AT,
                                                       const float* __restrict__ a, const uint32_t* __restrict__ M1,
@@ -592,13 +595,19 @@ __global__ __launch_bounds__(512) void icnn_fwd2_mfma(const float* __restrict__ 
     }
     __syncthreads();
     const f32x16 acc = mfma_tile(Xs, bfrag, l31, half);
+    f32x4 u0t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = mfma_row(reg, half);
       const float pre0 = Qs[row][0] * wd0[0] + Qs[row][1] * wd0[1] + Qs[row][2] * wd0[2];
       const float u0 = acc[reg] * icnn_mask(pre0);
       Ys[row * kXs + col] = u0;
-      if (n0 + row < N) U0[(n0 + row) * kW + col] = u0;
+      if (U0T) {
+        u0t[reg & 3] = u0;
+        if ((reg & 3) == 3) ((f32x4*)(U0 + (tile * 4 + (wv >> 1)) * 2048))[(4 * (wv & 1) + (reg >> 2)) * 64 + lane] = u0t;
+      } else if (n0 + row < N) {
+        U0[(n0 + row) * kW + col] = u0;
+      }
     }
     __syncthreads();
     {  // P[row][i]: thread -> (row = t >> 4, part = t & 15), columns part + 16 m

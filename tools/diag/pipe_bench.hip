@@ -53,15 +53,15 @@ int main(int argc, char** argv) {
     static unsigned long long st[256][16];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_pipe_stamps), sizeof(st));
     const int nb = dpll_pipe::blocks(N);
-    printf("%s batch %lld: %.2f us per launch (back to back); stamps (100 MHz ticks -> ns x10), median over %d workgroups, relative to entry:\n", names[k], batch, ms * 1e3 / reps, nb);
+    printf("%s batch %lld: %.2f us per launch (back to back); stamps in units of 100 s_memtime ticks (the counter runs at the shader clock, ~2.1 GHz under this load), median over %d workgroups, relative to entry:\n", names[k], batch, ms * 1e3 / reps, nb);
     const char* lab[16] = {"entry", "loop top", "t0 start", "t0 chain0", "t0 chain1", "t0 commit", "t1 start", "t1 chain0", "t1 chain1", "t1 commit",
-                           "t2 start", "t2 chain0", "t2 chain1", "t2 commit", "drained", "end"};
-    for (int i = 1; i < 16; ++i) {
+                           "loads issued", "ring zeroed", "rows in ring", "barrier", "drained", "end"};
+    for (int i : {10, 11, 12, 13, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15}) {
       std::vector<long long> d;
       for (int b = 0; b < nb; ++b) if (st[b][i] > st[b][0]) d.push_back((long long)(st[b][i] - st[b][0]));
       if (d.empty()) continue;
       std::sort(d.begin(), d.end());
-      printf("  %-10s %8.2f us (max %.2f)\n", lab[i], d[d.size() / 2] * 0.01, d.back() * 0.01);
+      printf("  %-10s %8.2f (max %.2f)\n", lab[i], d[d.size() / 2] * 0.01, d.back() * 0.01);
     }
     unsigned long long lo = ~0ull, hi = 0;
     for (int b = 0; b < nb; ++b) { lo = std::min(lo, st[b][0]); hi = std::max(hi, st[b][15]); }
