@@ -16,6 +16,7 @@ message is too long for it (mesh systems: 67 k gradients are bandwidth, not late
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -106,9 +107,12 @@ class GradientAllReduce:
     so that the SUM all-reduce yields the global batch mean directly (no extra scaling kernel);
     with unequal shards pass ``global_batch`` to weight by ``1 / global_batch`` instead.
 
-    ``transport``: ``'auto'`` (peer-memory one-shot kernel if the buffer fits and its self-test passes,
-    else the backend's collective), ``'peer'`` or ``'collective'``.  ``fuse`` (peer transport): the exchange is
-    done by the loss launch's own finalize kernel instead of a kernel after it."""
+    ``transport``: ``'auto'`` = the backend's collective (RCCL: ``north_star``'s single all-reduce of loss and gradients) --
+    unless the environment carries ``DPLL_PEER_EXCHANGE=1``, which lets ``'auto'`` take the peer-memory one-shot kernel when
+    the buffer fits and its self-test passes.  The hand-written exchange has only ever run with several processes on ONE
+    device; until it has crossed real xGMI once it is opt-in (``'peer'`` asks for it explicitly).  ``'collective'`` forces
+    RCCL.  ``fuse`` (peer transport): the exchange is done by the loss launch's own finalize kernel instead of a kernel after
+    it."""
 
     def __init__(self, system, group=None, global_batch: int = 0, transport: str = 'auto', fuse: bool = True) -> None:
         self.system = system
@@ -123,6 +127,8 @@ class GradientAllReduce:
             raise ValueError(transport)
         if transport == 'peer' and not fits:
             raise ValueError('gradient buffer too long for the peer-memory all-reduce')
+        if transport == 'auto' and os.environ.get('DPLL_PEER_EXCHANGE', '0') != '1':
+            transport = 'collective'
         if transport != 'collective' and fits and self.world > 1:
             try:
                 peer = PeerAllReduce(group)

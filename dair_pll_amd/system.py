@@ -199,6 +199,7 @@ class MultibodyTerms(Module):
 
     def forward(self, q: Tensor, v: Tensor, u: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
         assert self._owner is not None
+        self._owner._check_no_actuation(u)
         return self._owner._terms(q, v)
 
 
@@ -528,11 +529,21 @@ class MultibodyLearnableSystem(Module):
                                               _ptr(iters), _ptr(workspace), ws_bytes, self._stream()))
         return loss, grad, total
 
+    def _check_no_actuation(self, u: Tensor) -> None:
+        """The models this build takes have no actuators (``n_u = 0``: no ``<transmission>`` in the reference's URDFs, and its
+        callers pass inputs of width 0, ``multibody_learnable_system.py:311``, ``drake_experiment.py:219``).  An input of
+        non-zero width would enter the reference's ``lagrangian_forces(q, v, u, inertia)`` as ``B u``
+        (``multibody_terms.py:142-146, 235-236``); here it is REFUSED rather than dropped (round 4 dropped it silently)."""
+        if u is not None and u.shape[-1] != 0:
+            raise _capi.DpllError(f'actuation inputs are not supported: u has width {u.shape[-1]}, the model has n_u = 0 '
+                                  '(the kernels have no B u term; a silent drop would be wrong dynamics)')
+
     def contactnets_loss(self, x: Tensor, u: Tensor, x_plus: Tensor, loss_pool=None) -> Tensor:
         """``(*, n_x), (*, ?), (*, n_x) -> (*,)`` ContactNets loss
         (``multibody_learnable_system.py:104-197``); differentiable with respect to the module's
         parameters (the backward pass re-runs the fused kernel with ``grad_output`` as weights)."""
-        del u, loss_pool  # n_u = 0 for the supported systems; pools are accepted and ignored
+        del loss_pool  # (pools are accepted and ignored)
+        self._check_no_actuation(u)
         batch_shape = x.shape[:-1]
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
@@ -751,7 +762,8 @@ class MultibodyLearnableSystem(Module):
         """``(*, n_q), (*, n_v), (*, ?) -> (*, n_v)`` next velocity by Anitescu's convex contact
         model (``multibody_learnable_system.py:199-304``).  Differentiable with respect to the module's
         parameters and to ``q, v`` (implicit differentiation of the cone solve, ``dpll_step_backward``)."""
-        del u, dynamics_pool
+        del dynamics_pool
+        self._check_no_actuation(u)
         batch_shape = q.shape[:-1]
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state', keep_graph=True)
         return self._differentiable_step(x)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))

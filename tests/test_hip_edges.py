@@ -128,6 +128,11 @@ def test_errors_are_loud():
         system.contactnets_loss(x.cpu(), torch.zeros((8, 0)), xp.cpu())
     with pytest.raises(_capi.DpllError):
         system.contactnets_loss(x[:0], torch.zeros((0, 0), device='cuda:0'), xp[:0])
+    # an actuation input of non-zero width on a model without actuators is refused, not dropped (multibody_terms.py:142-146)
+    with pytest.raises(_capi.DpllError, match='actuation'):
+        system.contactnets_loss(x, torch.zeros((8, 1), device='cuda:0'), xp)
+    with pytest.raises(_capi.DpllError, match='actuation'):
+        system.forward_dynamics(*system.space.q_v(x), torch.ones((8, 2), device='cuda:0'))
 
 
 def test_wide_build_matches_chunks_with_weights():

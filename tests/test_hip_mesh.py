@@ -81,27 +81,49 @@ def test_mesh_loss_gradients_dynamics(golden, dtype, case):
     assert np.abs(traj.detach().cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4)
 
 
-def test_mesh_large_batch_matches_float64_path(golden):
-    """4096 items (16384 support queries): the float32 kernels against the float64 kernels on the same
-    inputs; tiny fractions of mask flips (a hidden unit within rounding of zero) are tolerated."""
+@pytest.mark.parametrize('form', ['f64', 'f32', 'f32 8-wave kernels', 'bf16 2 planes', 'bf16 3 planes'])
+def test_benchmark_batch_mesh_4096(golden, form):
+    """BASELINE configs[3] at its stated size: the 4096 benchmark pairs (16,384 support queries) through the reference's own
+    DeepSupportConvex / HomogeneousICNN loss (oracle/gen_golden.py: record_mesh_bench_batch) -- per-item loss, batch mean and
+    every gradient incl. the 67,328 network weights -- against the float64 kernels, the exact float32 MFMA kernels (pipelined
+    and 8-wave) and both split-bf16 forms.  (Round 4 held this size only against this repository's own float64 kernels.)"""
+    g = golden('cube_mesh_4096')
+    pairs = golden(str(g['pairs_from']))
+    f64 = form == 'f64'
+    dtype = torch.float64 if f64 else torch.float32
+    system = build(g, dtype)
+    if not f64:
+        system.set_solver(mesh_gemm={'f32': 0, 'f32 8-wave kernels': 1, 'bf16 2 planes': 2, 'bf16 3 planes': 3}[form])
+    x, xp = torch.tensor(pairs['x'], dtype=dtype, device='cuda:0'), torch.tensor(pairs['x_plus'], dtype=dtype, device='cuda:0')
+    loss = system.contact_forces(x, xp)[0].cpu().double().numpy()
+    err = np.abs(loss - g['loss'])
+    if f64:
+        assert err.max() < 1e-10, err.max()
+    else:
+        # float32: a hidden unit within rounding of zero can take the other LeakyReLU branch (another vertex of the learned
+        # shape): a handful of items may sit at 1e-4, the rest far below
+        assert err.max() < 1e-4 and np.quantile(err, 0.995) < 1e-5, (err.max(), np.quantile(err, 0.995))
+    keep = torch.tensor(g['keep'], device='cuda:0')
+    assert bool(keep.all())  # (no item of this batch sits on the |phi| kink: the whole-batch gradients are the float32 reference too)
+    total = system.contactnets_loss_and_grad(x, xp)
+    assert abs(total.item() - float(g['loss_mean'])) < (1e-12 if f64 else 1e-6)
+    for name, param in system.named_parameters():
+        ref = g['grad/' + name]
+        err = np.abs(param.grad.cpu().double().numpy() - ref).max()
+        assert err <= (1e-9 if f64 else 2e-3) * max(np.abs(ref).max(), 1.0 if f64 else 1e-12), (name, err, np.abs(ref).max())
+
+
+def test_mesh_large_batch_support_points_float32_vs_float64(golden):
+    """The support points of the 16,384 queries: float32 kernels against float64 kernels -- the fraction of queries whose
+    float32 evaluation lands on another vertex (a mask flip) stays tiny."""
     g = golden('cube_mesh_literal')
-    big = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'cube_box_4096.npz'))
-    x64 = torch.tensor(big['x'], device='cuda:0')
+    big = golden('cube_box_4096')
     xp64 = torch.tensor(big['x_plus'], device='cuda:0')
     s64, s32 = build(g, torch.float64), build(g, torch.float32)
     p64 = s64.support_points(xp64).cpu().numpy()
     p32 = s32.support_points(xp64.float()).cpu().double().numpy()
     err = np.abs(p64 - p32).max(-1).max(-1)
     assert (err > 1e-5).mean() < 2e-3
-    l64 = s64.contact_forces(x64, xp64)[0].cpu().numpy()
-    l32 = s32.contact_forces(x64.float(), xp64.float())[0].cpu().double().numpy()
-    assert np.quantile(np.abs(l64 - l32), 0.995) < 1e-5
-    t64 = s64.contactnets_loss_and_grad(x64, xp64).item()
-    t32 = s32.contactnets_loss_and_grad(x64.float(), xp64.float()).item()
-    assert abs(t64 - t32) < 1e-5 * max(1.0, abs(t64))
-    for (name, a), (_, b) in zip(s64.named_parameters(), s32.named_parameters()):
-        ga, gb = a.grad.cpu().numpy(), b.grad.cpu().double().numpy()
-        assert np.abs(ga - gb).max() <= 5e-3 * np.abs(ga).max(), name
 
 
 def test_learned_shape_export(golden, tmp_path):

@@ -67,7 +67,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     xp = torch.tensor(g['x_plus'][:batch], device='cuda:0')
     full = system.contactnets_loss_and_grad(x, xp).clone()
     full_grad = system.grad_buffer().clone()
-    reducer = GradientAllReduce(system, global_batch=batch)
+    reducer = GradientAllReduce(system, global_batch=batch, transport='peer')  # ('auto' is RCCL unless DPLL_PEER_EXCHANGE=1)
     assert reducer.transport == 'peer'
     lo, hi = shard_bounds(batch, rank, world)
     system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
@@ -94,12 +94,12 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         assert torch.equal(system.grad_buffer(), fused_result)
     assert reducer.peer.healthy()
     # a separate exchange kernel after the launch gives bitwise the same row
-    unfused = GradientAllReduce(system, global_batch=batch, fuse=False)
+    unfused = GradientAllReduce(system, global_batch=batch, transport='peer', fuse=False)
     assert unfused.transport == 'peer' and not unfused.fused and system._fused_ar is None
     system.contactnets_loss_and_grad(x[lo:hi], xp[lo:hi])
     assert torch.equal(unfused.all_reduce_mean(), fused_result)
     # a tail batch smaller than the world: ranks with an empty shard launch a zero row and still take part (fused exchange)
-    tail = GradientAllReduce(system, global_batch=1)
+    tail = GradientAllReduce(system, global_batch=1, transport='peer')
     lo1, hi1 = shard_bounds(1, rank, world)
     system.contactnets_loss_and_grad(x[lo1:hi1], xp[lo1:hi1])
     tail_reduced = tail.all_reduce_mean().clone()
@@ -139,7 +139,7 @@ def _xgmi_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     xp = torch.tensor(g['x_plus'][:batch], device=device)
     lo, hi = shard_bounds(batch, rank, world)
     results = {}
-    for transport in ('collective', 'auto'):
+    for transport in ('collective', 'auto', 'peer'):
         system = MultibodyLearnableSystem({'cube': os.path.join(ASSET_DIR, 'cube.urdf')}, float(g['dt']), dtype=torch.float64,
                                           device=str(device))
         reducer = GradientAllReduce(system, global_batch=batch, transport=transport)
@@ -151,9 +151,10 @@ def _xgmi_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     full.contactnets_loss_and_grad(x, xp)
     for transport, (reduced, used) in results.items():
         assert (reduced - full.grad_buffer()).abs().max() < 1e-14, (transport, used)
-    np.save(os.path.join(out_dir, f'rank{rank}.npy'), results['auto'][0].cpu().numpy())
+    assert results['auto'][1] == 'collective' or os.environ.get('DPLL_PEER_EXCHANGE') == '1'  # RCCL unless opted in
+    np.save(os.path.join(out_dir, f'rank{rank}.npy'), results['peer'][0].cpu().numpy())
     with open(os.path.join(out_dir, f'transport{rank}.txt'), 'w') as handle:
-        handle.write(results['auto'][1])
+        handle.write(results['peer'][1])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -79,6 +79,13 @@ def test_compute_calls_fail_loudly_without_gpu_tensors():
         system.simulate(x.unsqueeze(-2), torch.zeros(2, 1), 3)
     with pytest.raises(AssertionError):
         system._check_input(torch.zeros(2, 12), 13, 'x')
+    # actuation inputs of non-zero width are refused before anything is launched (the reference would add B u,
+    # multibody_terms.py:142-146; dropping them silently would be wrong dynamics)
+    for call in (lambda: system.contactnets_loss(x, torch.zeros(2, 1), x),
+                 lambda: system.forward_dynamics(x[:, :7], x[:, 7:], torch.ones(2, 3)),
+                 lambda: system.multibody_terms(x[:, :7], x[:, 7:], torch.ones(2, 1))):
+        with pytest.raises(_capi.DpllError, match='actuation'):
+            call()
 
 
 def test_library_exports_every_declared_symbol():

@@ -113,3 +113,34 @@ def test_recorded_solver_problems_satisfy_kkt(golden, case):
         assert (kkt['primal'] / size).max() < 1e-13
         assert (kkt['dual'] / size).max() < 1e-10
         assert (kkt['complementarity'] / size**2).max() < 1e-10
+
+
+def test_mesh_benchmark_batch_fixture_subset(golden):
+    """cube_mesh_4096 (BASELINE configs[3], reference run in chunks of 256): the oracle on every 16th pair reproduces the
+    recorded per-item losses, and the fixture's network is the one of cube_mesh_literal."""
+    g = golden('cube_mesh_4096')
+    pairs = golden(str(g['pairs_from']))
+    system = oracle_from_golden(g)
+    rows = np.arange(0, g['loss'].shape[0], 16)
+    with torch.no_grad():
+        loss = system.contactnets_loss(torch.tensor(pairs['x'][rows]), torch.tensor(pairs['x_plus'][rows]))
+    assert np.abs(loss.numpy() - g['loss'][rows]).max() < 1e-12
+    assert abs(float(g['loss_mean']) - g['loss'].mean()) < 1e-15
+    lit = golden('cube_mesh_literal')
+    key = 'param/' + PREFIX + '1.network.hidden_weights.0'
+    assert np.array_equal(g[key], lit[key])
+
+
+def test_elbow_benchmark_batch_kept_subset(golden):
+    """elbow_box_4096: the reference-run gradients over the items off the |phi| kink (what the float32 kernels are held
+    to) are the oracle's autograd on the same subset."""
+    g = golden('elbow_box_4096')
+    keep = g['keep']
+    assert 0.5 < keep.mean() < 1.0 and (g['terms/phi_min'][keep] >= 1e-6).all()
+    system = oracle_from_golden(g).requires_grad_()
+    loss = system.contactnets_loss(torch.tensor(g['x'][keep]), torch.tensor(g['x_plus'][keep]))
+    loss.mean().backward()
+    assert abs(loss.mean().item() - float(g['loss_mean_keep'])) < 1e-13
+    for name, param in system.named_parameters().items():
+        ref = g['grad_keep/' + name]
+        assert np.abs(param.grad.numpy() - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), name
