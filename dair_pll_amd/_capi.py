@@ -198,6 +198,7 @@ def make_forest_desc(system_spec, dt: float, inertia_mode: str = 'reference_lite
     desc.n_bodies, desc.n_q, desc.n_v = n_b, q_off, v_off
     desc.max_depth = max(desc.depth[b] for b in range(n_b))
     contact = 0
+    ground = set(system_spec.ground_geoms())
     for g, (b, geom, align_b) in enumerate(geoms):
         desc.geom_body[g] = b
         desc.geom_kind[g] = GEOM_KINDS[geom.kind]
@@ -209,6 +210,8 @@ def make_forest_desc(system_spec, dt: float, inertia_mode: str = 'reference_lite
             desc.geom_origin[g][r] = origin[r]
             for c in range(3):
                 desc.geom_rot[g][r][c] = frame[r][c]
+        if g not in ground:  # a geometry welded to the world does not meet the ground (urdf.SystemSpec.anchored_bodies)
+            continue
         for slot in range(1 if geom.kind == 'sphere' else 4):
             desc.contact_geom[contact], desc.contact_slot[contact] = g, slot
             contact += 1

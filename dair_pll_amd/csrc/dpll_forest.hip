@@ -724,14 +724,19 @@ int check_desc(const dpll_forest_desc_t* d) {
       return dpll_fail(-2, "dpll_forest_model_create: boxes, spheres and polygons (learned shapes run on the general build)%s");
     if (kind == DPLL_GEOM_POLYGON && (d->geom_nverts[g] < 4 || d->geom_nverts[g] > DPLL_MAX_POLYGON_VERTICES))
       return dpll_fail(-2, "dpll_forest_model_create: a polygon has 4 to 8 vertices%s");
-    for (int s = 0; s < (kind == DPLL_GEOM_SPHERE ? 1 : 4); ++s, ++contacts)
+    // a geometry on a body welded to the world (the root of a fixed-base model) is ANCHORED: it does not meet the ground, which
+    // sits on the world body too (Drake filters anchored-anchored candidates, drake_utils.py:178-184) -- it lists no witnesses
+    const bool anchored = d->joint_kind[d->geom_body[g]] == kJointFixed;
+    for (int s = 0; s < (anchored ? 0 : (kind == DPLL_GEOM_SPHERE ? 1 : 4)); ++s, ++contacts)
       if (contacts >= d->n_contacts || d->contact_geom[contacts] != g || d->contact_slot[contacts] != s)
-        return dpll_fail(-1, "dpll_forest_model_create: contacts must list every geometry's witnesses in order, then the candidates%s");
+        return dpll_fail(-1, "dpll_forest_model_create: contacts must list the witnesses of every geometry that can move, in order, then the candidates%s");
   }
   for (int p = 0; p < d->n_pairs; ++p, ++contacts) {
     const int a = d->pair_a[p], b = d->pair_b[p];
     if (a < 0 || b < 0 || a >= d->n_geoms || b >= d->n_geoms || a == b || d->geom_body[a] == d->geom_body[b])
       return dpll_fail(-1, "dpll_forest_model_create: a candidate joins geometries of two different bodies%s");
+    if (d->joint_kind[d->geom_body[a]] == kJointFixed && d->joint_kind[d->geom_body[b]] == kJointFixed)
+      return dpll_fail(-1, "dpll_forest_model_create: a candidate between two geometries welded to the world%s");
     if (contacts >= d->n_contacts || d->contact_geom[contacts] >= 0 || d->contact_slot[contacts] != p)
       return dpll_fail(-1, "dpll_forest_model_create: contacts must list every geometry's witnesses in order, then the candidates%s");
   }

@@ -385,7 +385,7 @@ class SystemSpec:
     finds them, and every geometry of one model against every geometry of another (Drake filters nothing between models)."""
     names: List[str]
     models: List[ModelSpec]
-    pairs: List[Tuple[int, int]] = field(default_factory=list)
+    pairs: List[Tuple[int, int]] = field(default_factory=list)  # (never between two geometries welded to the world)
 
     @property
     def bodies(self) -> List[BodySpec]:
@@ -426,9 +426,27 @@ class SystemSpec:
     def n_v(self) -> int:
         return sum((0 if spec.fixed_base else 6) + spec.n_joints for spec in self.models)
 
+    def anchored_bodies(self) -> set:
+        """Bodies welded to the world: the root of a fixed-base model (links welded to it were folded into it at parse time).
+        Drake calls their geometries anchored and filters every anchored-anchored pair out of ``GetCollisionCandidates``
+        (``drake_utils.py:178-184``); the ground half-space sits on the world body, so an anchored geometry has NO ground
+        contacts and no candidate with the anchored geometry of another fixed-base model."""
+        out, first = set(), 0
+        for spec in self.models:
+            if spec.fixed_base:
+                out.add(first)
+            first += len(spec.bodies)
+        return out
+
+    def ground_geoms(self) -> List[int]:
+        """indices into :meth:`geoms` of the geometries that collide with the ground (those of bodies that can move)"""
+        anchored = self.anchored_bodies()
+        return [g for g, (body, _) in enumerate(self.geoms()) if body not in anchored]
+
     @property
     def n_contacts(self) -> int:
-        return sum(1 if geom.kind == 'sphere' else 4 for _, geom in self.geoms()) + len(self.pairs)
+        geoms = self.geoms()
+        return sum(1 if geoms[g][1].kind == 'sphere' else 4 for g in self.ground_geoms()) + len(self.pairs)
 
     def friction_init(self) -> List[float]:
         return [self.models[0].ground_mu] + [geom.mu for _, geom in self.geoms()]
@@ -447,11 +465,14 @@ def build_system_spec(models) -> SystemSpec:
         own |= {(offset + a, offset + b) for a, b in spec.pairs}
     model_of = [m for m, spec in enumerate(specs) for _ in spec.geoms()]
     geoms = system.geoms()
+    anchored = system.anchored_bodies()
     pairs = []
     for ga in range(len(geoms)):
         for gb in range(ga + 1, len(geoms)):
             swap = TYPE_ORDER[geoms[ga][1].kind] > TYPE_ORDER[geoms[gb][1].kind]
             pair = (gb, ga) if swap else (ga, gb)
+            if geoms[ga][0] in anchored and geoms[gb][0] in anchored:
+                continue  # both welded to the world: no such candidate in Drake
             if model_of[ga] != model_of[gb] or pair in own:
                 pairs.append(pair)
     system.pairs = pairs

@@ -122,8 +122,11 @@ typedef struct dpll_forest_desc {
   double geom_origin[DPLL_FOREST_MAX_GEOMS][3];
   double geom_rot[DPLL_FOREST_MAX_GEOMS][3][3];
   int32_t pair_a[DPLL_FOREST_MAX_PAIRS], pair_b[DPLL_FOREST_MAX_PAIRS];
-  /* contact c, in the reference's order: witness contact_slot[c] of geometry contact_geom[c] against the ground -- every
-   * geometry's 4 (a sphere's 1) in geometry order --, then (contact_geom[c] = -1) the contact of candidate contact_slot[c] */
+  /* contact c, in the reference's order: witness contact_slot[c] of geometry contact_geom[c] against the ground -- the 4 (a
+   * sphere's 1) of every geometry whose body can move, in geometry order; a geometry on a body welded to the world (joint kind
+   * FIXED: the root of a fixed-base model) is anchored like the ground itself and lists none (Drake filters anchored-anchored
+   * candidates, drake_utils.py:178-184) --, then (contact_geom[c] = -1) the contact of candidate contact_slot[c]; no candidate
+   * joins two anchored geometries */
   int32_t contact_geom[DPLL_FOREST_MAX_CONTACTS], contact_slot[DPLL_FOREST_MAX_CONTACTS];
 } dpll_forest_desc_t;
 

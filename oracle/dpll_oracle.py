@@ -221,11 +221,14 @@ def system_spec(urdfs, mesh_representation: str = 'deep_support') -> Dict:
     merged = {'name': '+'.join(urdfs.keys()), 'bodies': bodies, 'n_joints': sum(spec['n_joints'] for spec in specs),
               'ground_mu': GROUND_MU, 'n_q': q_off, 'n_v': v_off, 'models': specs, 'fixed_base': False}
     table = geometry_table(merged)
+    anchored = anchored_bodies(merged)
     pairs = []
     for ia in range(1, len(table)):
         for ib in range(ia + 1, len(table)):
             swap = _TYPE_ORDER[table[ia]['kind']] > _TYPE_ORDER[table[ib]['kind']]
             pair = (ib, ia) if swap else (ia, ib)
+            if table[ia]['body'] in anchored and table[ib]['body'] in anchored:
+                continue  # (both welded to the world: Drake filters anchored-anchored candidates)
             if model_of_geom[ia - 1] != model_of_geom[ib - 1] or pair in own:
                 pairs.append(pair)
     merged['pairs'] = pairs
@@ -270,6 +273,21 @@ def collision_candidates(root, spec: Dict) -> List[Tuple[int, int]]:
             swap = _TYPE_ORDER[table[ia]['kind']] > _TYPE_ORDER[table[ib]['kind']]
             pairs.append((ib, ia) if swap else (ia, ib))
     return pairs
+
+
+def anchored_bodies(spec: Dict) -> set:
+    """Bodies welded to the world: the root of a fixed-base model (links welded to it are folded into it when the URDF is
+    parsed).  Drake calls their geometries ANCHORED and filters every anchored-anchored pair out of GetCollisionCandidates
+    (drake_utils.py:178-184) -- the ground half-space sits on the world body, so an anchored geometry has no ground contacts and
+    no candidate with the anchored geometry of another fixed-base model."""
+    return {index for index, body in enumerate(spec['bodies'])
+            if body['parent'] < 0 and (body.get('fixed') or spec.get('fixed_base'))}
+
+
+def ground_geometries(spec: Dict) -> List[int]:
+    """indices into geometry_table of the geometries that collide with the ground: those of bodies that can move"""
+    anchored = anchored_bodies(spec)
+    return [index for index, geom in enumerate(geometry_table(spec)) if index > 0 and geom['body'] not in anchored]
 
 
 def geometry_table(spec: Dict) -> List[Dict]:
@@ -954,7 +972,8 @@ class OracleSystem:
         self.n_q, self.n_v = state_sizes(self.spec)
         self.n_x = self.n_q + self.n_v
         # witness points per geometry: 4 (box: geometry.py:490; mesh: :47-48), 1 for a sphere (:440-452)
-        self.n_contacts = sum(1 if g['kind'] == 'sphere' else N_QUERY for g in self.geoms[1:]) + len(self.spec['pairs'])
+        self.ground_geoms = ground_geometries(self.spec)  # (an anchored geometry has no ground contacts)
+        self.n_contacts = sum(1 if self.geoms[g]['kind'] == 'sphere' else N_QUERY for g in self.ground_geoms) + len(self.spec['pairs'])
         pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
                               for b in self.spec['bodies']], dtype=torch.float64)
         # theta_0 = pi_o_to_theta(drake inertia), reference multibody_terms.py:186-188
@@ -1094,7 +1113,7 @@ class OracleSystem:
         R_WC, p_WoCo_W, Jv_V_WC_W = geometry_kinematics(self.spec, q)
         mu_all = torch.abs(self.friction)  # :321-324
         phis, jacs, mus = [], [], []
-        for b_index in range(1, len(self.geoms)):
+        for b_index in self.ground_geoms:
             a_index = 0
             mu = 2 * mu_all[a_index] * mu_all[b_index] / (mu_all[a_index] + mu_all[b_index])  # :471
             R_WA = R_WC[..., a_index, :, :]

@@ -257,8 +257,11 @@ def build_reference_system(urdf, inertia_mode: str, mesh_seed: int = 0, mesh_rep
     ct.friction_params = Parameter(torch.tensor([g['mu'] for g in geoms]), requires_grad=True)
     n_g = len(geoms)
     # ground pairs in geometry order, then the body-body candidates (quirk Q8: Drake's order is not specified)
-    ct.collision_candidates = torch.tensor([[0] * (n_g - 1) + [a for a, _ in spec['pairs']],
-                                            list(range(1, n_g)) + [b for _, b in spec['pairs']]]).long()
+    # (Drake's GetCollisionCandidates has no anchored-anchored pair: the geometries of a body welded to the world do not meet
+    # the ground, which sits on the world body -- O.ground_geometries)
+    ground = O.ground_geometries(spec)
+    ct.collision_candidates = torch.tensor([[0] * len(ground) + [a for a, _ in spec['pairs']],
+                                            ground + [b for _, b in spec['pairs']]]).long()
 
     mt = MultibodyTerms.__new__(MultibodyTerms)
     nn.Module.__init__(mt)
@@ -405,6 +408,54 @@ def record_bench_batch(name: str, n_pairs: int = 4096, seed: int = 0) -> None:
     print(f'{name}: {n_pairs} of {x_all.shape[0]} pairs, loss mean {loss.mean().item():.6e}')
 
 
+def kept_subset_gradients(system, x: torch.Tensor, x_plus: torch.Tensor, chunk: int = 0) -> dict:
+    """What the float32 checks at the BASELINE sizes compare with: the reference's own signed distances at x+ (their smallest
+    magnitude per item), the items kept -- those off the |phi| kink of the loss, where the sign of phi and with it the
+    gradient flips with float32 rounding of the inputs --, and the reference-run mean loss and gradients over the kept items."""
+    with torch.no_grad():
+        phi_min = torch.cat([system.multibody_terms(*system.space.q_v(xp), torch.zeros(xp.shape[:-1] + (0,)))[3].abs().min(-1).values
+                             for xp in x_plus.split(chunk or x_plus.shape[0])])
+    keep = phi_min >= 1e-6
+    xk, xpk = x[keep], x_plus[keep]
+    system.zero_grad()
+    total = 0.0
+    for xc, xpc in zip(xk.split(chunk or xk.shape[0]), xpk.split(chunk or xk.shape[0])):
+        part = system.contactnets_loss(xc, torch.zeros(xc.shape[:-1] + (0,)), xpc).sum() / xk.shape[0]
+        part.backward()
+        total += part.item()
+    out = {'terms/phi_min': phi_min.numpy(), 'keep': keep.numpy(), 'loss_mean_keep': np.array(total)}
+    for key, value in named_grads(system).items():
+        out['grad_keep/' + key] = value
+    return out
+
+
+def record_mesh_bench_batch(name: str = 'cube_mesh_4096', pairs_from: str = 'cube_box_4096', chunk: int = 256) -> None:
+    """BASELINE configs[3] at its stated size: the reference's own DeepSupportConvex / HomogeneousICNN loss
+    (geometry.py:255-325, deep_support_function.py:213-266) on the 4096 benchmark pairs of `pairs_from`, in chunks of 256 so that
+    autograd's (B, 256, 256) weight gradient stays small; per-item loss, batch mean and every gradient incl. the network's.
+    The pairs themselves are not stored again (the tests read them from `pairs_from`)."""
+    pairs = np.load(os.path.join(GOLDEN, pairs_from + '.npz'))
+    x, x_plus = torch.tensor(pairs['x']), torch.tensor(pairs['x_plus'])
+    mesh = os.path.join(ASSETS, 'contactnets_cube_mesh.urdf')
+    system, _ = build_reference_system(mesh, 'reference_literal')
+    out = {'urdf': os.path.basename(mesh), 'dt': DT, 'inertia_mode': 'reference_literal', 'pairs_from': pairs_from}
+    for key, value in named_values(system).items():
+        out['param/' + key] = value
+    system.zero_grad()
+    losses = []
+    for xc, xpc in zip(x.split(chunk), x_plus.split(chunk)):
+        loss = system.contactnets_loss(xc, torch.zeros(xc.shape[:-1] + (0,)), xpc)
+        (loss.sum() / x.shape[0]).backward()
+        losses.append(loss.detach())
+    loss = torch.cat(losses)
+    out.update({'loss': loss.numpy(), 'loss_mean': loss.mean().numpy()})
+    for key, value in named_grads(system).items():
+        out['grad/' + key] = value
+    out.update(kept_subset_gradients(system, x, x_plus, chunk))
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print(f'{name}: {x.shape[0]} pairs of {pairs_from}, loss mean {loss.mean().item():.6e}, kept {int(out["keep"].sum())}')
+
+
 def elbow_rollouts(n_traj: int = 40, steps: int = 120, seed: int = 0) -> torch.Tensor:
     """BASELINE configs[2] inputs exactly as SURVEY 8d specifies them: ``n_traj`` initial states from the
     reference's own ``UniformSampler(space, ELBOW_SAMPLER_RANGE, x_0=ELBOW_X_0)`` (reference
@@ -449,6 +500,7 @@ def record_elbow_bench_batch(name: str = 'elbow_box_4096', n_pairs: int = 4096, 
         out['param/' + key] = value
     for key, value in named_grads(system).items():
         out['grad/' + key] = value
+    out.update(kept_subset_gradients(system, x, x_plus))
     np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
     print(f'{name}: {n_pairs} of {x_all.shape[0]} pairs, loss mean {float(mean_loss):.6e}, max {loss.max().item():.3e}')
 
@@ -720,6 +772,7 @@ def main() -> None:
     record_case('cube_mesh_literal', os.path.join(ASSETS, 'contactnets_cube_mesh.urdf'), mx, mxp,
                 'reference_literal')
     record_elbow_bench_batch()
+    record_mesh_bench_batch()
     record_slice_fixture()
     record_dynamics_gradients()
     record_general_cases()

@@ -76,7 +76,10 @@ def test_system_spec_of_several_models():
     desc = _capi.make_forest_desc(mixed, 0.0068)
     assert [desc.joint_kind[b] for b in range(3)] == [_capi.JOINT_FIXED, 0, _capi.JOINT_FLOATING]
     assert [desc.q_index[b] for b in range(3)] == [0, 0, 1] and [desc.v_index[b] for b in range(3)] == [0, 0, 1]
-    assert [desc.contact_geom[c] for c in range(desc.n_contacts)] == [0] * 4 + [1] + [2] * 4 + [-1, -1]
+    # the mast is welded to the world: anchored like the ground, so it has no ground witnesses (Drake filters anchored-anchored
+    # candidates, drake_utils.py:178-184) -- the arm's tip, the cube's four corners, then the two candidates
+    assert mixed.anchored_bodies() == {0} and mixed.ground_geoms() == [1, 2] and mixed.n_contacts == 7
+    assert [desc.contact_geom[c] for c in range(desc.n_contacts)] == [1] + [2] * 4 + [-1, -1]
     # limits: seventeen cubes are one body too many
     many = build_system_spec({f'c{i}': parse_urdf(os.path.join(ASSET_DIR, 'cube.urdf')) for i in range(13)})
     with pytest.raises(NotImplementedError):
@@ -85,6 +88,47 @@ def test_system_spec_of_several_models():
     urdfs, _ = urdfs_of('pendulum_cube')
     merged = O.system_spec(urdfs)
     assert O.state_sizes(merged) == (8, 7) and merged['pairs'] == [(a + 1, b + 1) for a, b in mixed.pairs]
+
+
+def test_a_fixed_base_that_touches_the_ground_adds_nothing(tmp_path):
+    """a body welded to the world is anchored.  Two pendulums whose masts stand on z = 0 -- one sunk 5 cm into the
+    ground -- next to each other: neither mast has ground witnesses, the two masts are no candidate of each other (anchored -
+    anchored), so the sunk mast adds no penetration penalty and no gradient on its box lengths: loss and next state of the system
+    are the oracle's (whose candidates are Drake's rule, not this repository's habit)."""
+    text = open(os.path.join(ASSET_DIR, 'pendulum.urdf')).read()
+    mount = '<origin xyz="0.2 0.1 0.2" rpy="0 0 0.3"/>'
+    assert mount in text
+
+    def system_with(z_a, z_b):
+        paths = {}
+        for tag, xy, z in (('a', '1.0 0.1', z_a), ('b', '-1.0 0.1', z_b)):  # (far apart: no candidate is ever active)
+            path = tmp_path / f'pendulum_{tag}_{z}.urdf'
+            path.write_text(text.replace(mount, f'<origin xyz="{xy} {z}" rpy="0 0 0.3"/>'))
+            paths[tag] = str(path)
+        return build_system_spec({k: parse_urdf(v) for k, v in paths.items()}), paths
+
+    sunk, sunk_paths = system_with(0.15, 0.10)   # mast b: its box (0.3 tall) reaches 5 cm below z = 0
+    assert sunk.anchored_bodies() == {0, 2} and sunk.ground_geoms() == [1, 3] and sunk.n_contacts == 2 + len(sunk.pairs)
+    assert all(not ({a, b} <= {0, 2}) for a, b in sunk.pairs)  # no mast-mast candidate
+    merged = O.system_spec(sunk_paths)
+    assert merged['pairs'] == [(a + 1, b + 1) for a, b in sunk.pairs] and O.ground_geometries(merged) == [2, 4]
+    desc = _capi.make_forest_desc(sunk, 0.0068)
+    theta, friction, lengths = forest.params_of(sunk)  # the URDFs' values in the forest build's layout
+    rng = np.random.default_rng(3)
+    x = np.concatenate((rng.uniform(0.8, 2.2, (16, 2)), rng.normal(0, 2.0, (16, 2))), -1)  # (two joint angles | two rates)
+    oracle = O.OracleSystem(sunk_paths, 0.0068)
+    with torch.no_grad():
+        x_next_ref = oracle.step(torch.tensor(x)).numpy()
+        loss_ref = oracle.contactnets_loss(torch.tensor(x), torch.tensor(x_next_ref)).numpy()
+    out = forest.loss(desc, theta, friction, lengths, x, x_next_ref)
+    assert np.abs(out['loss'] - loss_ref).max() < 1e-10 * max(1.0, np.abs(loss_ref).max())
+    M, a, phi, J = forest.terms(desc, theta, friction, lengths, x_next_ref)
+    assert phi.shape[-1] == sunk.n_contacts and (phi[:, 2:] > 0.5).all()  # two tips, then candidates a metre and more apart
+    x_next, _ = forest.step(desc, theta, friction, lengths, x)
+    assert np.abs(x_next - x_next_ref).max() < 1e-9
+    n_b, n_g = sunk.n_bodies, len(sunk.geoms())
+    mast_lengths = out['grad'][10 * n_b + 1 + n_g + 24 * 2:10 * n_b + 1 + n_g + 24 * 2 + 3]  # geometry 2 = the sunk mast's box
+    assert np.abs(mast_lengths).max() == 0.0
 
 
 @pytest.mark.parametrize('name', list(FOREST))
