@@ -10,7 +10,7 @@
 //   dWd1 = p_bar u1^T,  dWd0 = p_bar u0^T,  v_bar = (Wd0^T p_bar) . m0,  d|Wh| = v_bar u1^T,
 //   u1_bar = Wd1^T p_bar + |Wh|^T v_bar,  d|wout| = u1_bar . m1, then the sign of the raw weights.
 #pragma once
-#include "dpll_core.hpp"
+#include "dpll_terms.hpp"  // (DPLL_HD, tsqrt: nothing of the solver or the item kernels)
 
 namespace dpll {
 

@@ -17,7 +17,7 @@ from . import default_opts
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 _SRC = os.path.join(_HERE, 'forestsim.cpp')
-_HEADERS = [os.path.join(_REPO, 'dair_pll_amd', 'csrc', name) for name in ('dpll_forest.hpp', 'dpll_core.hpp')]
+_HEADERS = [os.path.join(_REPO, 'dair_pll_amd', 'csrc', name) for name in ('dpll_forest.hpp', 'dpll_core.hpp', 'dpll_terms.hpp', 'dpll_solver.hpp', 'dpll_contact.hpp', 'dpll_loss.hpp', 'dpll_step.hpp')]
 _LIB = os.path.join(_HERE, 'libforestsim.so')
 _lib = None
 GEO_STRIDE = 24

@@ -11,6 +11,7 @@ static thread_local uint64_t g_reject_mask = 0;
 static std::vector<uint64_t> g_reject_masks;
 #define DPLL_ITER_HOOK(it, active, alpha) do { if ((active) && !((alpha) == 1) && (it) < 64) g_reject_mask |= (1ull << (it)); } while (0)
 
+#include "../../dair_pll_amd/csrc/dpll_core.hpp"
 #include "../../dair_pll_amd/csrc/dpll_icnn.hpp"
 
 using namespace dpll;

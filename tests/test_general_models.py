@@ -530,3 +530,24 @@ def test_gpu_workspace_is_exactly_what_dpll_workspace_bytes_says(golden, name):
                                            xp.stride(0), batch, None, 1.0 / batch, None, grad.data_ptr(), total.data_ptr(), None, None,
                                            ws.data_ptr(), need - 1, system._stream())
             assert rc != 0
+
+
+@pytest.mark.gpu
+def test_poisoned_locals_build():
+    """The regression gate of DESIGN.md 4a / csrc/Makefile (GENERAL_EXTRA): a build of the general translation units in which
+    EVERY automatic variable is pre-filled with clang's poison pattern (``make -C dair_pll_amd/csrc poison-check``, also built by
+    ``__graft_entry__.build()``) must pass the step-backward tests of the 3-joint models -- the four tests that failed for the
+    round-4 flags, where the backend's promote-alloca pass decided what the kernel wrote for the length gradients.  Runs them
+    in a child process against that library; skips LOUDLY when the variant has not been built."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(repo, 'tools', 'diag', 'variants', 'libdpll_hip_poison.so')
+    if not os.path.exists(lib):
+        pytest.skip('POISON CHECK NOT RUN: tools/diag/variants/libdpll_hip_poison.so is missing -- build it with '
+                    '`make -C dair_pll_amd/csrc poison-check` (or __graft_entry__.build())')
+    env = dict(os.environ, DPLL_HIP_LIBRARY=lib)
+    run = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-q', '-x', '-p', 'no:cacheprovider',
+                          '-k', 'step_backward and (gripper or grasp)'], env=env, cwd=repo, capture_output=True, text=True, timeout=900)
+    tail = run.stdout.strip().splitlines()[-1] if run.stdout.strip() else run.stderr[-400:]
+    assert run.returncode == 0 and ' passed' in tail and 'failed' not in tail, tail

@@ -28,13 +28,15 @@ for name in (sys.argv[1:] or SYSTEMS):
         for _ in range(3):
             system.contactnets_loss_and_grad(x, xp)
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        start.record()
-        for _ in range(10):
-            system.contactnets_loss_and_grad(x, xp)
-        end.record()
-        torch.cuda.synchronize()
-        loss_us = start.elapsed_time(end) / 10 * 1e3
+        loss_us = float('inf')
+        for _ in range(3):  # (best of three timings of ten calls, after the three warm-up calls above: round 4's table carried a
+            torch.cuda.synchronize()  # 7.1 ms outlier for chain6 f32 from a single timing)
+            start.record()
+            for _ in range(10):
+                system.contactnets_loss_and_grad(x, xp)
+            end.record()
+            torch.cuda.synchronize()
+            loss_us = min(loss_us, start.elapsed_time(end) / 10 * 1e3)
         with torch.no_grad():
             system.simulate(x.unsqueeze(-2), torch.zeros((batch, 1), device='cuda:0'), 8)
             torch.cuda.synchronize()
