@@ -20,7 +20,7 @@ GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 21  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 22  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,7 +36,7 @@ class ModelDesc(ctypes.Structure):
                 ('geom_body', c_int32 * MAX_GEOMS), ('geom_kind', c_int32 * MAX_GEOMS), ('geom_nverts', c_int32 * MAX_GEOMS), ('n_pairs', c_int32),
                 ('pair_a', c_int32 * MAX_PAIRS), ('pair_b', c_int32 * MAX_PAIRS), ('rotated', c_int32),
                 ('body_rot', ((c_double * 3) * 3) * MAX_BODIES), ('geom_rot', ((c_double * 3) * 3) * MAX_GEOMS),
-                ('joint_kind', c_int32 * MAX_JOINTS), ('reserved', c_int32)]
+                ('joint_kind', c_int32 * MAX_JOINTS), ('n_u', c_int32), ('act_joint', c_int32 * MAX_JOINTS), ('reserved', c_int32)]
 
 
 # ---- the forest build (csrc/dpll_forest.hpp): several models in one system, any number of joints / geometries / candidates ----
@@ -75,7 +75,7 @@ class SolverOpts(ctypes.Structure):
 
 class Params(ctypes.Structure):
     """``dpll_params_t``"""
-    _fields_ = [('theta', c_void_p), ('friction', c_void_p), ('lengths', c_void_p)]
+    _fields_ = [('theta', c_void_p), ('friction', c_void_p), ('lengths', c_void_p), ('u', c_void_p), ('ld_u', ctypes.c_int64)]
 
 
 class AdamState(ctypes.Structure):
@@ -140,6 +140,9 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
     for p, (a, b) in enumerate(spec.pairs):
         desc.pair_a[p], desc.pair_b[p] = a, b
     desc.n_pairs = len(spec.pairs)
+    desc.n_u = len(spec.actuators)  # (B u of the reference's lagrangian_forces, multibody_terms.py:142-146: general build)
+    for k, joint in enumerate(spec.actuators):
+        desc.act_joint[k] = joint
     return desc
 
 

@@ -16,7 +16,22 @@ template <typename T, int NJ, int NG = NJ + 1> struct Derived {
   T habs[NG][3];  // |length_params| of a box (geometry.py:393-403); [0] = |length_param|, the radius of a sphere (:415-456)
   T mu_pair[kMaxPairs];  // general build: pair coefficient of the two geometries of body-body candidate p
   const T* geo;   // the raw geometry parameter blocks (stride MD::kGeoStride): a Polygon's vertices are read from here
+  // general build, actuated models: the ITEM's generalized joint forces B u (multibody_terms.py:142-146) -- not a parameter, but
+  // it rides here because every item function already takes the block; zero unless a kernel fills it per item (load_actuation)
+  T tau[NJ > 0 ? NJ : 1];
 };
+
+// the item's actuation: tau[j] = sum of the inputs u[k] whose actuator drives joint j + 1 (u: the item's row, or nullptr)
+template <typename T, int NJ, int NG, class MD>
+DPLL_HD void load_actuation(const MD& md, const T* u, Derived<T, NJ, NG>& dp) {
+  DPLL_UNROLL for (int j = 0; j < (NJ > 0 ? NJ : 1); ++j) dp.tau[j] = T(0);
+  if constexpr (MD::kGeneral && NJ > 0) {
+    if (u) {
+      DPLL_UNROLL for (int k = 0; k < NJ; ++k)
+        DPLL_UNROLL for (int j = 0; j < NJ; ++j) dp.tau[j] += (k < md.n_u && md.act_joint[k] == j) ? u[k] : T(0);
+    }
+  }
+}
 
 template <typename T, int NJ, int NG, class MD>
 DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, const T* lengths, Derived<T, NJ, NG>& dp) {
@@ -35,6 +50,7 @@ DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, cons
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dp.habs[g][i] = lengths ? tabs(lengths[MD::kGeoStride * g + i]) : T(0);
   }
   dp.geo = lengths;
+  DPLL_UNROLL for (int j = 0; j < (NJ > 0 ? NJ : 1); ++j) dp.tau[j] = T(0);
   if constexpr (MD::kGeneral) {
     // pair coefficient of the two geometries of a body-body candidate (the group behind the geometries has none of its own)
     DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) {
@@ -94,6 +110,9 @@ DPLL_HD void compute_terms(const MD& md, const Derived<T, NJ, NG>& dp, const T* 
   mass_matrix<T, NJ>(t.kin, dp.iota, t.M);
   T F[NV];
   bias_forces<T, NJ>(md, t.kin, dp.iota, v, F, t.Vw, t.Vu, t.AGw, t.AGu);
+  if constexpr (MD::kGeneral && NJ > 0) {  // + B u: the actuators' generalized forces on their joints' coordinates
+    DPLL_UNROLL for (int j = 0; j < NJ; ++j) F[6 + j] += dp.tau[j];
+  }
   cholesky<T, NV>(t.M, t.LM, t.invdM);
   chol_solve<T, NV>(t.LM, t.invdM, F, t.a);
 }

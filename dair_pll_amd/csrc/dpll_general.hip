@@ -34,7 +34,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
   hipLaunchKernelGGL((gen_loss_kernel<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, general_desc(m), m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp,
                      batch, (const T*)weights, scale, (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad,
-                     (const T*)nullptr, (T*)nullptr, (const double*)nullptr);
+                     (const T*)nullptr, (T*)nullptr, (const double*)nullptr, (const T*)p->u, (long long)p->ld_u);
   if (int rc = dpll_check_launch("gen_loss_kernel")) return rc;
   if (want_grad) return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)loss_total, stream, m, adam);
   return 0;
@@ -48,7 +48,8 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL((gen_simulate_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, general_desc(m), m->opts[dtype],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps, (T*)out,
-                     ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr, (const double*)nullptr);
+                     ld_item, ld_step, write_x0, (int*)iters, (const T*)nullptr, (const double*)nullptr,
+                     steps == 1 ? (const T*)p->u : (const T*)nullptr, (long long)p->ld_u);  // (rollouts run unactuated, as sim_step does)
   return dpll_check_launch("gen_simulate_kernel");
 }
 
@@ -62,7 +63,8 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
     return dpll_fail(-3, "dpll_step_backward: workspace too small%s");
   hipLaunchKernelGGL((gen_step_backward_kernel<T, NJ>), dim3(rows + 1), dim3(kWave), 0, stream, general_desc(m), m->opts[DPLL_F64],
                      (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch,
-                     (double*)workspace, (T*)grad_x, ld_gx, (const T*)nullptr, (T*)nullptr, (const double*)nullptr);
+                     (double*)workspace, (T*)grad_x, ld_gx, (const T*)nullptr, (T*)nullptr, (const double*)nullptr, (const T*)p->u,
+                     (long long)p->ld_u);
   if (int rc = dpll_check_launch("gen_step_backward_kernel")) return rc;
   return finalize_rows<T, NJ>((double*)workspace, rows, (T*)grad, (T*)nullptr, stream);
 }
@@ -74,7 +76,7 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
   const long long blocks = (batch + kWave - 1) / kWave;
   hipLaunchKernelGGL((gen_terms_kernel<T, NJ>), dim3((int)blocks), dim3(kWave), 0, stream, general_desc(m), (const T*)p->theta,
                      (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J, (T*)phi, (T*)a,
-                     (const T*)nullptr, (const double*)nullptr);
+                     (const T*)nullptr, (const double*)nullptr, (const T*)p->u, (long long)p->ld_u);
   return dpll_check_launch("gen_terms_kernel");
 }
 

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
                                                          double scale, T* __restrict__ loss, T* __restrict__ force,
                                                          int* __restrict__ iters, double* __restrict__ partials, int want_grad,
                                                          const T* __restrict__ wit, T* __restrict__ rbar,
-                                                         const double* __restrict__ pdirs) {
+                                                         const double* __restrict__ pdirs,
+                                                         const T* __restrict__ u = nullptr, long long ld_u = 0) {
   using D = GD<T, NJ>;
   static_assert(D::G == 16 && kIPW == 4, "16 contact slots per item");
   const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(kWave) void gen_loss_kernel(GeneralDesc md, SolverO
     const long long item = base + slot;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;  // idle groups shadow the last item: every lane stays live for DPP
+    load_actuation<T, NJ>(md, u ? u + it * ld_u : (const T*)nullptr, dp);
     T xr[D::NX], xpr[D::NX];
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = x[it * ld_x + i]; xpr[i] = xp[it * ld_xp + i]; }
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(kWave) void gen_simulate_kernel(GeneralDesc md, Sol
                                                              const T* __restrict__ x0, long long ld_x, long long batch,
                                                              long long steps, T* __restrict__ out, long long ld_item,
                                                              long long ld_step, int write_x0, int* __restrict__ iters,
-                                                             const T* __restrict__ wit, const double* __restrict__ pdirs) {
+                                                             const T* __restrict__ wit, const double* __restrict__ pdirs,
+                                                             const T* __restrict__ u = nullptr, long long ld_u = 0) {
   using D = GD<T, NJ>;
   const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
   Derived<T, NJ, kNG> dp;
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(kWave) void gen_simulate_kernel(GeneralDesc md, Sol
     const long long item = base + slot;
     const bool valid = item < batch;
     const long long it = valid ? item : batch - 1;
+    load_actuation<T, NJ>(md, u ? u + it * ld_u : (const T*)nullptr, dp);
     const bool writer = valid && cidx == 0;
     T xr[D::NX];
 #pragma unroll
@@ -222,7 +226,8 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
                                                                   const T* __restrict__ gx, long long ld_g, long long batch,
                                                                   double* __restrict__ partials, T* __restrict__ xbar_out,
                                                                   long long ld_xb, const T* __restrict__ wit, T* __restrict__ rbar,
-                                                                  const double* __restrict__ pdirs) {
+                                                                  const double* __restrict__ pdirs,
+                                                                  const T* __restrict__ u = nullptr, long long ld_u = 0) {
   using D = GD<T, NJ>;
   using C = double;
   const int lane = threadIdx.x, cidx = lane % D::G, slot = lane / D::G;
@@ -250,6 +255,12 @@ __global__ __launch_bounds__(kWave) void gen_step_backward_kernel(GeneralDesc md
     C xr[D::NX], gr[D::NX], xb[D::NX];
 #pragma unroll
     for (int i = 0; i < D::NX; ++i) { xr[i] = C(x[it * ld_x + i]); gr[i] = valid ? C(gx[it * ld_g + i]) : C(0); xb[i] = C(0); }
+    {  // the item's actuation inputs, in the compute type
+      C u_c[NJ > 0 ? NJ : 1];
+#pragma unroll
+      for (int k = 0; k < (NJ > 0 ? NJ : 1); ++k) u_c[k] = (u && k < md.n_u) ? C(u[it * ld_u + k]) : C(0);
+      load_actuation<C, NJ>(md, u ? u_c : (const C*)nullptr, dp);
+    }
     // (an idle group's seed is zero, so what it adds to the sums below is zero)
     if constexpr (MESH) {
       C wt[1][3], rb[1][3] = {{C(0), C(0), C(0)}}, rba[1][3] = {{C(0), C(0), C(0)}};
@@ -288,13 +299,15 @@ __global__ __launch_bounds__(kWave) void gen_terms_kernel(GeneralDesc md, const 
                                                           const T* __restrict__ lengths, const T* __restrict__ x, long long ld_x,
                                                           long long batch, T* __restrict__ Dout, T* __restrict__ Mout,
                                                           T* __restrict__ Jout, T* __restrict__ phiout, T* __restrict__ aout,
-                                                          const T* __restrict__ wit, const double* __restrict__ pdirs) {
+                                                          const T* __restrict__ wit, const double* __restrict__ pdirs,
+                                                          const T* __restrict__ u = nullptr, long long ld_u = 0) {
   using D = GD<T, NJ>;
   constexpr int NV = D::NV, K = D::K;
   Derived<T, NJ, kNG> dp;
   derive_params<T, NJ>(md, theta, friction, lengths, dp);
   const long long it = (long long)blockIdx.x * kWave + threadIdx.x;
   if (it >= batch) return;
+  load_actuation<T, NJ>(md, u ? u + it * ld_u : (const T*)nullptr, dp);
   T xr[D::NX];
 #pragma unroll
   for (int i = 0; i < D::NX; ++i) xr[i] = x[it * ld_x + i];

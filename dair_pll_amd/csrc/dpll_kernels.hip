@@ -1754,6 +1754,11 @@ int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long lo
   if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "%s: dtype must be DPLL_F32 or DPLL_F64", who);
   if (!p || !p->theta || !p->friction || !p->lengths) return fail(-1, "%s: null parameter pointer", who);
   if (batch < 0) return fail(-1, "%s: negative batch", who);
+  // actuation inputs: only a model with actuators takes them (anything else would be a silent drop of B u), with rows of at
+  // least n_u numbers
+  const int n_u = m->forest ? 0 : m->desc.n_u;
+  if (p->u && n_u == 0) return fail(-1, "%s: actuation inputs (params->u) for a model without actuators", who);
+  if (p->u && p->ld_u < n_u) return fail(-1, "%s: ld_u smaller than n_u", who);
   return 0;
 }
 
@@ -1778,7 +1783,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 21; }
+int dpll_abi_version(void) { return 22; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1839,6 +1844,15 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");
   if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL)
     return fail(-1, "dpll_model_create: unknown inertia_mode%s");
+  // actuators (B u of lagrangian_forces, multibody_terms.py:142-146): the general build without learned shapes
+  if (desc->n_u < 0 || desc->n_u > desc->n_joints) return fail(-1, "dpll_model_create: n_u must be between 0 and n_joints%s");
+  if (desc->n_u > 0) {
+    if (!general) return fail(-2, "dpll_model_create: actuated joints need the general build (n_geoms > 0)%s");
+    for (int g = 0; g < desc->n_geoms; ++g)
+      if (desc->geom_kind[g] == DPLL_GEOM_MESH) return fail(-2, "dpll_model_create: actuated joints on a model with learned shapes are not built%s");
+    for (int k = 0; k < desc->n_u; ++k)
+      if (desc->act_joint[k] < 0 || desc->act_joint[k] >= desc->n_joints) return fail(-1, "dpll_model_create: act_joint out of range%s");
+  }
   dpll_model* m = new (std::nothrow) dpll_model;
   if (!m) return fail(-4, "dpll_model_create: out of memory%s");
   std::memcpy(&m->desc, desc, sizeof(ModelDesc));
@@ -2121,6 +2135,7 @@ int check_mesh_call(const dpll_model_t* model, int dtype, const dpll_params_t* p
   if (!model) return fail(-1, "%s: null model", who);
   if (dtype != DPLL_F32 && dtype != DPLL_F64) return fail(-1, "%s: bad dtype", who);
   if (params && (!params->theta || !params->friction)) return fail(-1, "%s: null parameter pointer", who);
+  if (params && params->u) return fail(-1, "%s: actuation inputs (params->u) for a model without actuators", who);
   t_mesh_gemm = dtype == DPLL_F32 ? model->opts[DPLL_F32].mesh_gemm : 0;  // (the float64 path has no matrix-core form)
   return check_mesh(model, mesh, who);
 }

@@ -278,6 +278,7 @@ DPLL_HD void step_state_adjoint(const MD& md, const Derived<T, NJ, NG>& dp, cons
     DPLL_UNROLL for (int i = 0; i < 3; ++i) dps.habs[g][i] = S(TA(dp.habs[g][i]));
   }
   DPLL_UNROLL for (int p = 0; p < kMaxPairs; ++p) dps.mu_pair[p] = S(TA(dp.mu_pair[p]));
+  DPLL_UNROLL for (int j = 0; j < (NJ > 0 ? NJ : 1); ++j) dps.tau[j] = S(TA(dp.tau[j]));
   dps.geo = nullptr;
   S geo_s[MD::kGeneral ? NG * MD::kGeoStride : 1];  // a polygon's vertices as constants of the dual passes
   if constexpr (MD::kGeneral) {

@@ -121,6 +121,8 @@ struct ModelDesc {
   double body_rot[kMaxBodies][3][3];  // inertial parameters' frame -> the kernels' frame of the body
   double geom_rot[kMaxGeoms][3][3];   // geometry frame in the kernels' frame of its body; geom_origin is in the geometry frame
   int32_t joint_kind[kMaxJoints];     // kJointRevolute | kJointPrismatic (general build; the fast builds: revolute)
+  int32_t n_u;                        // actuators (general build): input k is a generalized force on joint act_joint[k] + 1
+  int32_t act_joint[kMaxJoints];
   int32_t reserved;
   static constexpr bool kGeneral = false;
   static constexpr int kGeoStride = 3;  // numbers per geometry in the `lengths` parameter block: a box's length_params

@@ -13,6 +13,7 @@ on a ROCm device and the HIP library is built.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from typing import Dict, List, Optional, Tuple
@@ -199,18 +200,20 @@ class MultibodyTerms(Module):
 
     def forward(self, q: Tensor, v: Tensor, u: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
         assert self._owner is not None
-        self._owner._check_no_actuation(u)
-        return self._owner._terms(q, v)
+        with self._owner._actuated(self._owner._actuation(u, q.shape[:-1])):
+            return self._owner._terms(q, v)
 
 
 class _LossFunction(torch.autograd.Function):
     """Per-item loss with the hand-written adjoint as its backward."""
 
     @staticmethod
-    def forward(ctx, system, x, x_plus, *params):  # pylint: disable=arguments-differ
+    def forward(ctx, system, x, x_plus, u, *params):  # pylint: disable=arguments-differ
         ctx.system = system
+        ctx.u = u  # (actuation inputs of the call, (B, n_u) or None: data, no gradient)
         ctx.save_for_backward(x, x_plus)
-        return system._launch_loss(x, x_plus, weights=None, scale=1.0, want_grad=False)[0]
+        with system._actuated(u):
+            return system._launch_loss(x, x_plus, weights=None, scale=1.0, want_grad=False)[0]
 
     @staticmethod
     def backward(ctx, grad_output):  # pylint: disable=arguments-differ
@@ -219,9 +222,10 @@ class _LossFunction(torch.autograd.Function):
         # a buffer of its own: the shared one is what the parameters' .grad alias after a fused step, and autograd adds
         # what is returned here ON TOP of .grad
         own = torch.empty(1 + system._packed().numel(), dtype=system.dtype, device=x.device)
-        _, flat_grad, _ = system._launch_loss(x, x_plus, weights=grad_output.contiguous(), scale=1.0, want_grad=True,
-                                              grad_out=own)
-        return (None, None, None) + tuple(system._split_flat(flat_grad))
+        with system._actuated(ctx.u):
+            _, flat_grad, _ = system._launch_loss(x, x_plus, weights=grad_output.contiguous(), scale=1.0, want_grad=True,
+                                                  grad_out=own)
+        return (None, None, None, None) + tuple(system._split_flat(flat_grad))
 
 
 class _StepFunction(torch.autograd.Function):
@@ -230,16 +234,19 @@ class _StepFunction(torch.autograd.Function):
     implicit differentiation of the cone solve."""
 
     @staticmethod
-    def forward(ctx, system, x, *params):  # pylint: disable=arguments-differ
+    def forward(ctx, system, x, u, *params):  # pylint: disable=arguments-differ
         ctx.system = system
+        ctx.u = u
         ctx.save_for_backward(x)
-        return system._step(x)
+        with system._actuated(u):
+            return system._step(x)
 
     @staticmethod
     def backward(ctx, grad_x_next):  # pylint: disable=arguments-differ
         (x,) = ctx.saved_tensors
-        flat_grad, grad_x = ctx.system._step_backward(x, grad_x_next.contiguous(), want_state=ctx.needs_input_grad[1])
-        return (None, grad_x) + tuple(ctx.system._split_flat(flat_grad))
+        with ctx.system._actuated(ctx.u):
+            flat_grad, grad_x = ctx.system._step_backward(x, grad_x_next.contiguous(), want_state=ctx.needs_input_grad[1])
+        return (None, grad_x, None) + tuple(ctx.system._split_flat(flat_grad))
 
 
 class MultibodyLearnableSystem(Module):
@@ -298,6 +305,7 @@ class MultibodyLearnableSystem(Module):
         self.grad_world = 1      # set by distributed.GradientAllReduce
         self.global_batch = 0
         self._fused_ar: Optional[ctypes.c_void_p] = None  # peer all-reduce handle: the exchange rides in the loss launch
+        self._u: Optional[Tensor] = None  # actuation inputs of the call in flight (see _actuated)
         self._grad_reduced = False  # the last contactnets_loss_and_grad already summed [loss | gradients] over the ranks
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -476,7 +484,9 @@ class MultibodyLearnableSystem(Module):
     def _params_struct(self, flat: Tensor) -> _capi.Params:
         n_b, slots = self.spec.n_bodies, self._geom_slots()
         base, size = flat.data_ptr(), flat.element_size()
-        return _capi.Params(base, base + 10 * n_b * size, base + (10 * n_b + slots + 1) * size)
+        u = self._u  # the actuation inputs of the call in flight (see _actuated), or None
+        return _capi.Params(base, base + 10 * n_b * size, base + (10 * n_b + slots + 1) * size,
+                            u.data_ptr() if u is not None else None, u.stride(0) if u is not None else 0)
 
     @staticmethod
     def _stream() -> int:
@@ -529,33 +539,56 @@ class MultibodyLearnableSystem(Module):
                                               _ptr(iters), _ptr(workspace), ws_bytes, self._stream()))
         return loss, grad, total
 
-    def _check_no_actuation(self, u: Tensor) -> None:
-        """The models this build takes have no actuators (``n_u = 0``: no ``<transmission>`` in the reference's URDFs, and its
-        callers pass inputs of width 0, ``multibody_learnable_system.py:311``, ``drake_experiment.py:219``).  An input of
-        non-zero width would enter the reference's ``lagrangian_forces(q, v, u, inertia)`` as ``B u``
-        (``multibody_terms.py:142-146, 235-236``); here it is REFUSED rather than dropped (round 4 dropped it silently)."""
-        if u is not None and u.shape[-1] != 0:
-            raise _capi.DpllError(f'actuation inputs are not supported: u has width {u.shape[-1]}, the model has n_u = 0 '
-                                  '(the kernels have no B u term; a silent drop would be wrong dynamics)')
+    def _actuation(self, u: Optional[Tensor], batch_shape) -> Optional[Tensor]:
+        """The actuation inputs of a call as the kernels take them -- ``(B, n_u)`` rows on the device in the system's dtype -- or
+        ``None``.  The reference's ``lagrangian_forces(q, v, u, inertia)`` carries ``B u`` (``multibody_terms.py:142-146,
+        235-236``): a model with ``<transmission>`` elements has ``n_u`` actuators (general build, ``urdf.ModelSpec.actuators``).
+        An input of width 0 means "no actuation" for any model (what ``sim_step`` passes, ``multibody_learnable_system.py:311``);
+        a non-empty input for a model WITHOUT actuators, or of the wrong width, is refused rather than dropped."""
+        n_u = self.spec.n_u
+        if u is None or u.shape[-1] == 0:
+            return None
+        if u.shape[-1] != n_u:
+            raise _capi.DpllError(f'actuation inputs of width {u.shape[-1]} for a model with n_u = {n_u} actuators'
+                                  + (' (the model has no <transmission>: a silent drop of B u would be wrong dynamics)' if n_u == 0 else ''))
+        if tuple(u.shape[:-1]) != tuple(batch_shape):
+            raise _capi.DpllError(f'actuation inputs of batch shape {tuple(u.shape[:-1])} for states of batch shape {tuple(batch_shape)}')
+        if not u.is_cuda:
+            raise _capi.DpllError('actuation inputs must live on the ROCm device like the states')
+        return u.detach().reshape(-1, n_u).to(self.dtype).contiguous()
+
+    @contextlib.contextmanager
+    def _actuated(self, u: Optional[Tensor]):
+        """the actuation inputs of the launches made inside the block (``_params_struct`` hands them to the library)"""
+        previous, self._u = self._u, u
+        try:
+            yield
+        finally:
+            self._u = previous
 
     def contactnets_loss(self, x: Tensor, u: Tensor, x_plus: Tensor, loss_pool=None) -> Tensor:
         """``(*, n_x), (*, ?), (*, n_x) -> (*,)`` ContactNets loss
         (``multibody_learnable_system.py:104-197``); differentiable with respect to the module's
         parameters (the backward pass re-runs the fused kernel with ``grad_output`` as weights)."""
         del loss_pool  # (pools are accepted and ignored)
-        self._check_no_actuation(u)
         batch_shape = x.shape[:-1]
+        uf = self._actuation(u, batch_shape)
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
         self._packed()
-        loss = _LossFunction.apply(self, xf, xpf, *self._param_list())
+        loss = _LossFunction.apply(self, xf, xpf, uf, *self._param_list())
         return loss.reshape(batch_shape)
 
-    def contactnets_loss_and_grad(self, x: Tensor, x_plus: Tensor, accumulate: bool = False) -> Tensor:
+    def contactnets_loss_and_grad(self, x: Tensor, x_plus: Tensor, accumulate: bool = False, u: Optional[Tensor] = None) -> Tensor:
         """Fused training step: mean loss over the batch AND its parameter gradients in one pass,
         i.e. what ``loss = system.contactnets_loss(x, u, x_plus).mean(); loss.backward()`` produces
         (``drake_experiment.py:202-224`` + ``experiment.py:355-359``).  Returns the mean loss as a
-        one-element device tensor (no host sync) and writes ``.grad`` of every parameter."""
+        one-element device tensor (no host sync) and writes ``.grad`` of every parameter.  ``u``: actuation inputs of an
+        actuated model (:meth:`_actuation`)."""
+        with self._actuated(self._actuation(u, x.shape[:-1])):
+            return self._loss_and_grad(x, x_plus, accumulate)
+
+    def _loss_and_grad(self, x: Tensor, x_plus: Tensor, accumulate: bool) -> Tensor:
         xf = self._check_input(x, self.space.n_x, 'x')
         xpf = self._check_input(x_plus, self.space.n_x, 'x_plus')
         denom = self.global_batch if self.global_batch > 0 else xf.shape[0] * self.grad_world
@@ -752,21 +785,22 @@ class MultibodyLearnableSystem(Module):
     def _wants_graph(self, x: Tensor) -> bool:
         return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._param_list()))
 
-    def _differentiable_step(self, x: Tensor) -> Tensor:
+    def _differentiable_step(self, x: Tensor, u: Optional[Tensor] = None) -> Tensor:
         self._packed()
         if self._wants_graph(x):
-            return _StepFunction.apply(self, x, *self._param_list())
-        return self._step(x.detach())
+            return _StepFunction.apply(self, x, u, *self._param_list())
+        with self._actuated(u):
+            return self._step(x.detach())
 
     def forward_dynamics(self, q: Tensor, v: Tensor, u: Tensor, dynamics_pool=None) -> Tensor:
         """``(*, n_q), (*, n_v), (*, ?) -> (*, n_v)`` next velocity by Anitescu's convex contact
         model (``multibody_learnable_system.py:199-304``).  Differentiable with respect to the module's
         parameters and to ``q, v`` (implicit differentiation of the cone solve, ``dpll_step_backward``)."""
         del dynamics_pool
-        self._check_no_actuation(u)
         batch_shape = q.shape[:-1]
+        uf = self._actuation(u, batch_shape)
         x = self._check_input(torch.cat((q, v), -1), self.space.n_x, 'state', keep_graph=True)
-        return self._differentiable_step(x)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))
+        return self._differentiable_step(x, uf)[:, self.space.n_q:].reshape(batch_shape + (self.space.n_v,))
 
     def sim_step(self, x: Tensor, carry: Tensor) -> Tuple[Tensor, Tensor]:
         """``Integrator.partial_step`` callback (``multibody_learnable_system.py:306-313``)."""

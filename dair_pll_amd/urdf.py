@@ -74,6 +74,14 @@ class ModelSpec:
     fixed_base: bool = False
     mount_origin: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0])   # of a fixed base: its root frame in the world
     mount_rotation: List[List[float]] = field(default_factory=lambda: _identity())
+    # actuators: the URDF's <transmission> elements in file order, each on one joint (Drake adds a JointActuator per
+    # transmission; the reference's lagrangian_forces carries B u, multibody_terms.py:142-146).  Entry k = index of the
+    # actuated joint (joint j drives body j + 1) -- the width of the `u` the model takes is len(actuators)
+    actuators: List[int] = field(default_factory=list)
+
+    @property
+    def n_u(self) -> int:
+        return len(self.actuators)
 
     @property
     def n_joints(self) -> int:
@@ -128,6 +136,7 @@ class ModelSpec:
         exactly one box (or mesh) per body, no frame turned against its parent's"""
         kinds = {geom.kind for _, geom in self.geoms()}
         return (self.n_joints <= 1 and not self.rotated() and all(b.joint_kind == 'revolute' for b in self.bodies)
+                and not self.actuators  # (B u is built into the general build only)
                 and all(len(b.geoms) == 1 for b in self.bodies) and kinds in ({'box'}, {'mesh'})
                 and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0) and not self.pairs)
 
@@ -283,6 +292,17 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
             raise ValueError('the link welded to the world must be the root of the model')
         spec.fixed_base, spec.mount_origin, spec.mount_rotation = True, mount[1], mount[2]
     spec.pairs = _collision_candidates(root, spec)
+    # actuators (<transmission><joint name=...>): the joint's place among the model's moving joints = its child's body index - 1
+    joint_child = {joint.get('name'): joint.find('child').get('link') for joint in root.findall('joint')}
+    body_index = {body.name: index for index, body in enumerate(spec.bodies)}
+    for transmission in root.findall('transmission'):
+        named = transmission.find('joint')
+        if named is None or named.get('name') not in joint_child:
+            raise ValueError('a <transmission> must name one joint of the model')
+        child = joint_child[named.get('name')]
+        if child not in body_index or body_index[child] == 0:
+            raise NotImplementedError(f'transmission on joint {named.get("name")!r}: a fixed joint cannot be actuated')
+        spec.actuators.append(body_index[child] - 1)
     return spec
 
 
@@ -402,6 +422,10 @@ class SystemSpec:
     def is_fast(self) -> bool:
         return False
 
+    @property
+    def n_u(self) -> int:
+        return sum(spec.n_u for spec in self.models)
+
     def contact_slots(self) -> List[int]:
         """the forest build's contacts ARE the model's (no padding slots)"""
         return list(range(self.n_contacts))
@@ -482,6 +506,9 @@ def build_system_spec(models) -> SystemSpec:
 def check_forest_supported(system: SystemSpec) -> None:
     """What the forest build takes; anything else fails loudly at construction."""
     geoms = system.geoms()
+    if system.n_u > 0:
+        raise NotImplementedError('actuated joints (<transmission>) run on the general build: one model of at most '
+                                  f'{MAX_JOINTS} joints and {MAX_GEOMS} geometries')
     if system.n_bodies > FOREST_MAX_BODIES:
         raise NotImplementedError(f'at most {FOREST_MAX_BODIES} bodies per system')
     if not 1 <= len(geoms) <= FOREST_MAX_GEOMS:
@@ -508,6 +535,8 @@ def check_supported(spec: ModelSpec) -> None:
     if spec.n_joints > MAX_JOINTS:
         raise NotImplementedError(f'at most {MAX_JOINTS} joints')
     geoms = spec.geoms()
+    if spec.actuators and any(geom.kind == 'mesh' for _, geom in geoms):
+        raise NotImplementedError('actuated joints on a model with learned shapes (DeepSupportConvex) are not built')
     if not 1 <= len(geoms) <= MAX_GEOMS:
         raise NotImplementedError(f'between 1 and {MAX_GEOMS} collision geometries')
     for index, body in enumerate(spec.bodies):

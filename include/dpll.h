@@ -87,6 +87,12 @@ typedef struct dpll_model_desc {
   double body_rot[DPLL_MAX_BODIES][3][3];
   double geom_rot[DPLL_MAX_GEOMS][3][3];
   int32_t joint_kind[DPLL_MAX_JOINTS];     /* general build: dpll_joint_kind of joint j + 1 (the fast builds: revolute) */
+  /* Actuation (general build): the reference's lagrangian_forces(q, v, u, inertia) carries B u (multibody_terms.py:142-146,
+   * 235-236) -- input k of `u` (dpll_params_t.u, n_u numbers per item) is a generalized force on the coordinate of joint
+   * act_joint[k] + 1 (one JointActuator per <transmission> of the URDF, in file order; gear ratio 1).  n_u = 0: no actuators
+   * (every system of the reference).  The fast builds take n_u = 0 only. */
+  int32_t n_u;
+  int32_t act_joint[DPLL_MAX_JOINTS];
   int32_t reserved;
 } dpll_model_desc_t;
 
@@ -177,6 +183,11 @@ typedef struct dpll_params {
                            geometry g's block: box length_params (3) | sphere length_param (1) | polygon vertices
                            (geom_nverts, 3) row-major; the rest of a block, and the whole block behind the geometries', is padding
                            (its gradient comes back zero) */
+  const void* u;        /* actuation inputs of the call, (batch, n_u) with row stride ld_u elements, dtype of the call: the u of
+                           contactnets_loss(x, u, x_plus) / forward_dynamics(q, v, u) (multibody_learnable_system.py:104, 199).
+                           NULL = no actuation (required when the model has n_u = 0; rollouts -- dpll_simulate with steps > 1 --
+                           run unactuated as the reference's sim_step does, :311) */
+  int64_t ld_u;
 } dpll_params_t;
 
 const char* dpll_last_error(void);

@@ -184,6 +184,10 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     spec = {'name': root.get('name'), 'bodies': bodies, 'n_joints': len(bodies) - 1, 'ground_mu': GROUND_MU}
     spec['fixed_base'] = 'mount' in bodies[0]
     spec['pairs'] = collision_candidates(root, spec)
+    # actuators: one JointActuator per <transmission> in file order (Drake's parser), each a generalized force on its joint's
+    # coordinate -- the B of reference multibody_terms.py:142-146.  Entry k = index of the actuated joint (joint j drives body j + 1)
+    joint_child = {joint.get('name'): joint.find('child').get('link') for joint in root.findall('joint')}
+    spec['actuators'] = [sorted_names.index(joint_child[t.find('joint').get('name')]) - 1 for t in root.findall('transmission')]
     return spec
 
 
@@ -559,9 +563,11 @@ def mass_matrix(spec: Dict, q: Tensor, inertia: Tensor, inertia_mode: str) -> Te
     return total
 
 
-def lagrangian_forces(spec: Dict, q: Tensor, v: Tensor, inertia: Tensor, inertia_mode: str) -> Tensor:
-    """F(q, v) = gamma^T(-C + tau_g) of reference multibody_terms.py:142-146 (n_u = 0):
-    F = -sum_b S_b^T (I_b (A_b - G_b) + V_b x* I_b V_b), G_b = gravity as a spatial accel."""
+def lagrangian_forces(spec: Dict, q: Tensor, v: Tensor, inertia: Tensor, inertia_mode: str, u: Optional[Tensor] = None) -> Tensor:
+    """F(q, v, u) = gamma^T(-C + B u + tau_g) of reference multibody_terms.py:142-146:
+    F = -sum_b S_b^T (I_b (A_b - G_b) + V_b x* I_b V_b), G_b = gravity as a spatial accel; + B u: input k of `u` on the coordinate
+    of joint spec['actuators'][k] (gamma is the identity on joint coordinates).  `u` of width 0 (what every caller of the
+    reference passes for its unactuated systems, and sim_step always) adds nothing."""
     rot, _, jac, vel, acc = chain_kinematics(spec, q, v)
     g_world = torch.tensor([0., 0., GRAVITY_Z], dtype=q.dtype)
     total = None
@@ -573,6 +579,13 @@ def lagrangian_forces(spec: Dict, q: Tensor, v: Tensor, inertia: Tensor, inertia
         wrench = (i6 @ (acc[index] - grav).unsqueeze(-1)).squeeze(-1) + force_cross(vel[index], momentum)
         term = -(jac[index].transpose(-1, -2) @ wrench.unsqueeze(-1)).squeeze(-1)
         total = term if total is None else total + term
+    if u is not None and u.shape[-1] > 0:
+        actuators = spec.get('actuators', [])
+        assert u.shape[-1] == len(actuators), 'u must have one column per <transmission> of the model'
+        columns = torch.zeros(len(actuators), total.shape[-1], dtype=q.dtype)
+        for k, joint in enumerate(actuators):
+            columns[k, spec['bodies'][joint + 1].get('v_index', 6 + joint)] = 1.0
+        total = total + u @ columns
     return total
 
 
@@ -1024,12 +1037,12 @@ class OracleSystem:
         return x[..., :self.n_q], x[..., self.n_q:]
 
     # -- terms -----------------------------------------------------------------------
-    def lagrangian_terms(self, q: Tensor, v: Tensor) -> Tuple[Tensor, Tensor]:
+    def lagrangian_terms(self, q: Tensor, v: Tensor, u: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """LagrangianTerms.forward, reference multibody_terms.py:214-237."""
         inertia = theta_to_spatial_inertia(self.theta)
         inertia = inertia.expand(q.shape[:-1] + inertia.shape)
         M = mass_matrix(self.spec, q, inertia, self.inertia_mode)
-        F = lagrangian_forces(self.spec, q, v, inertia, self.inertia_mode)
+        F = lagrangian_forces(self.spec, q, v, inertia, self.inertia_mode, u)
         return M, torch.linalg.solve(M, F)
 
     def support_points(self, geom_index: int, directions: Tensor) -> Tensor:
@@ -1162,20 +1175,20 @@ class OracleSystem:
         J_t = (mu_rep.reshape(-1, 1, 1) * Jc[..., :2, :]).reshape(Jc.shape[:-3] + (-1, Jc.shape[-1]))
         return phi, torch.cat((J_n, J_t), -2)
 
-    def multibody_terms(self, q: Tensor, v: Tensor):
+    def multibody_terms(self, q: Tensor, v: Tensor, u: Optional[Tensor] = None):
         """MultibodyTerms.forward, reference multibody_terms.py:584-609."""
-        M, a = self.lagrangian_terms(q, v)
+        M, a = self.lagrangian_terms(q, v, u)
         phi, J = self.contact_terms(q)
         D = J @ torch.linalg.solve(M, J.transpose(-1, -2))
         return D, M, J, phi, a
 
     # -- the loss --------------------------------------------------------------------
-    def contactnets_loss(self, x: Tensor, x_plus: Tensor, return_force: bool = False):
+    def contactnets_loss(self, x: Tensor, x_plus: Tensor, return_force: bool = False, u: Optional[Tensor] = None):
         """reference multibody_learnable_system.py:104-197."""
         _, v = self.q_v(x)
         q_plus, v_plus = self.q_v(x_plus)
         dt, eps = self.dt, LOSS_EPS
-        D, M, J, phi, a = self.multibody_terms(q_plus, v_plus)
+        D, M, J, phi, a = self.multibody_terms(q_plus, v_plus, u)
         k = phi.shape[-1]
         P = sappy_reorder_matrix(k, x.dtype)
         J_t = J[..., k:, :]
@@ -1203,11 +1216,11 @@ class OracleSystem:
         return loss
 
     # -- dynamics ----------------------------------------------------------------------
-    def forward_dynamics(self, q: Tensor, v: Tensor, return_impulse: bool = False):
+    def forward_dynamics(self, q: Tensor, v: Tensor, return_impulse: bool = False, u: Optional[Tensor] = None):
         """reference multibody_learnable_system.py:199-304 (the eps=1e6 contact filter at
         :262-269 keeps every contact; Q, q at :288-291 are dead code)."""
         dt = self.dt
-        D, M, J, phi, a = self.multibody_terms(q, v)
+        D, M, J, phi, a = self.multibody_terms(q, v, u)
         k = phi.shape[-1]
         P = sappy_reorder_matrix(k, q.dtype)
         J_M = P.t() @ (J @ torch.linalg.cholesky(torch.inverse(M)))

@@ -220,7 +220,7 @@ def build_reference_system(urdf, inertia_mode: str, mesh_seed: int = 0, mesh_rep
     lt = LagrangianTerms.__new__(LagrangianTerms)
     nn.Module.__init__(lt)
     lt.mass_matrix = lambda q, inertia: O.mass_matrix(spec, q, inertia, inertia_mode)
-    lt.lagrangian_forces = lambda q, v, u, inertia: O.lagrangian_forces(spec, q, v, inertia, inertia_mode)
+    lt.lagrangian_forces = lambda q, v, u, inertia: O.lagrangian_forces(spec, q, v, inertia, inertia_mode, u)  # (+ B u, :142-146)
     pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
                           for b in spec['bodies']])
     lt.inertial_parameters = Parameter(InertialParameterConverter.pi_cm_to_theta(pi_cm), requires_grad=True)
@@ -297,7 +297,10 @@ def named_values(system) -> dict:
 
 
 def record_case(name: str, urdf: str, x: torch.Tensor, x_plus: torch.Tensor, inertia_mode: str,
-                sim_steps: int = 4, sim_rows=None, mesh_representation: str = 'deep_support', prepare=None) -> None:
+                sim_steps: int = 4, sim_rows=None, mesh_representation: str = 'deep_support', prepare=None, u=None) -> None:
+    """``u``: actuation inputs ``(B, n_u)`` of an actuated model, handed to the reference's ``multibody_terms``,
+    ``contactnets_loss`` and ``forward_dynamics`` (its ``sim_step`` -- hence ``step`` / ``simulate`` -- always passes a ``u`` of
+    width 0, multibody_learnable_system.py:311); recorded as ``u``."""
     system, _ = build_reference_system(urdf, inertia_mode, mesh_representation=mesh_representation)
     if prepare is not None:  # e.g. move the parameters off their URDF values before anything is recorded
         prepare(system)
@@ -308,7 +311,10 @@ def record_case(name: str, urdf: str, x: torch.Tensor, x_plus: torch.Tensor, ine
 
     # --- terms at the next state (what the loss evaluates, Q6) -------------------------
     q_plus, v_plus = system.space.q_v(x_plus)
-    u = torch.zeros(x.shape[:-1] + (0,))
+    if u is None:
+        u = torch.zeros(x.shape[:-1] + (0,))
+    else:
+        out['u'] = u.numpy()
     with torch.no_grad():
         D, M, J, phi, a = system.multibody_terms(q_plus, v_plus, u)
     out.update({'terms/D': D.numpy(), 'terms/M': M.numpy(), 'terms/J': J.numpy(), 'terms/phi': phi.numpy(),
@@ -323,8 +329,11 @@ def record_case(name: str, urdf: str, x: torch.Tensor, x_plus: torch.Tensor, ine
     kkt = O.kkt_residuals(J_M, q_s, eps, f_s)
     out['solver_loss/kkt'] = np.array([kkt[k].max().item() for k in ('primal', 'dual', 'complementarity')])
     system.zero_grad()
-    mean_loss = DrakeMultibodyLearnableExperiment.contactnets_loss(None, x.unsqueeze(-2), x_plus.unsqueeze(-2),
-                                                                 system)
+    if u.shape[-1] == 0:
+        mean_loss = DrakeMultibodyLearnableExperiment.contactnets_loss(None, x.unsqueeze(-2), x_plus.unsqueeze(-2),
+                                                                     system)
+    else:  # (the experiment's wrapper builds a u of width 0 itself, drake_experiment.py:219: the system's method with the inputs)
+        mean_loss = system.contactnets_loss(x, u, x_plus).mean()
     mean_loss.backward()
     out['loss_mean'] = mean_loss.detach().numpy()
     for key, value in named_grads(system).items():
@@ -751,6 +760,16 @@ def record_forest_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, s
                     'reference_literal', sim_steps=3)
 
 
+def record_actuated_elbow(name: str = 'elbow_actuated_literal') -> None:
+    """The B u path (reference multibody_terms.py:142-146, 235-236; multibody_learnable_system.py:199-203): the elbow with a
+    <transmission> on its hinge (this repository's assets/elbow_actuated.urdf: none of the reference's URDFs has an actuator),
+    the synthetic elbow pairs and seeded torques of up to 0.5 N m through the reference's own contactnets_loss / forward_dynamics /
+    MultibodyTerms with a non-empty u."""
+    ex, exp_ = elbow_pairs()
+    u = (torch.rand((ex.shape[0], 1), generator=torch.Generator().manual_seed(11)) - 0.5)
+    record_case(name, os.path.join(REPO, 'assets', 'elbow_actuated.urdf'), ex, exp_, 'reference_literal', u=u)
+
+
 def record_elbow_mesh() -> None:
     """contactnets_elbow_mesh.urdf: a DeepSupportConvex on each link (two independent networks), on every 4th of the
     synthetic elbow pairs."""
@@ -773,6 +792,7 @@ def main() -> None:
                 'reference_literal')
     record_elbow_bench_batch()
     record_mesh_bench_batch()
+    record_actuated_elbow()
     record_slice_fixture()
     record_dynamics_gradients()
     record_general_cases()

@@ -39,6 +39,20 @@ def lib():
     return _lib
 
 
+_actuation = None  # (kept alive while the library points at it)
+
+
+def set_actuation(u) -> None:
+    """actuation inputs ``(B, n_u)`` of the next loss / step / step_backward calls on an actuated general model (``None``: none)"""
+    global _actuation
+    if u is None:
+        _actuation = None
+        lib().hostsim_set_actuation(None, ctypes.c_int64(0))
+    else:
+        _actuation = np.ascontiguousarray(u, dtype=np.float64)
+        lib().hostsim_set_actuation(_actuation.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(_actuation.shape[1]))
+
+
 def default_opts(dtype) -> SolverOpts:
     if np.dtype(dtype) == np.float64:
         return SolverOpts(max_iter=100, max_ls=50, tol=1e-13, stall_tol=1e-10, ls_tol=0.9, n_stages=6, stage_max_iter=3,

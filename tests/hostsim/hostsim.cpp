@@ -16,7 +16,19 @@ static std::vector<uint64_t> g_reject_masks;
 
 using namespace dpll;
 
+// actuation inputs of the next calls (general models with actuators): (B, n_u) doubles, or null -- set through
+// hostsim_set_actuation so that the batch entry points keep their argument lists
+static const double* g_actuation = nullptr;
+static int64_t g_actuation_ld = 0;
+
 namespace {
+template <typename T, int NJ, int NG, class MD> void item_actuation(const MD& md, int64_t item, Derived<T, NJ, NG>& dp) {
+  T row[NJ > 0 ? NJ : 1] = {};
+  if (g_actuation)
+    for (int k = 0; k < NJ && k < md.n_u; ++k) row[k] = T(g_actuation[item * g_actuation_ld + k]);
+  load_actuation<T, NJ>(md, g_actuation ? row : (const T*)nullptr, dp);
+}
+
 // the rotation the inertial parameters of body b go through (general models whose frames are turned), or nullptr
 template <class MD> const double (*body_rot_of(const MD& md, int b))[3][3] {
   if constexpr (MD::kGeneral) return (md.rotated & 1) ? &md.body_rot[b] : nullptr;
@@ -39,6 +51,7 @@ void loss_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
     int it = 0;
     const T w = T(scale) * (weights ? weights[i] : T(1));
     g_reject_mask = 0;
+    item_actuation<T, NJ>(md, i, dp);
     loss[i] = loss_item<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, xp + i * NX, 0, w, grad != nullptr, g, f, it);
     if ((int64_t)g_reject_masks.size() < B) g_reject_masks.resize(B);
     g_reject_masks[i] = g_reject_mask;
@@ -82,6 +95,7 @@ void step_batch(const MD& md, const SolverOpts& opt, const T* theta, const T* fr
   for (int64_t i = 0; i < B; ++i) {
     T imp[K][3];
     int it = 0;
+    item_actuation<T, NJ>(md, i, dp);
     step_item<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, x_next + i * NX, imp, it);
     if (iters) iters[i] = it;
   }
@@ -200,6 +214,7 @@ void step_backward_batch(const MD& md, const SolverOpts& opt, const T* theta, co
     LossGrad<T, NJ, NG, GP> g;
     zero_grad(g);
     T xb[NX] = {};
+    item_actuation<T, NJ>(md, i, dp);
     step_item_backward<T, TA, NJ, K, OneLane>(md, dp, opt, x + i * NX, 0, xbar_next + i * NX, g, nullptr, nullptr,
                                               xbar ? &xb : nullptr);
     if (xbar) for (int k = 0; k < NX; ++k) xbar[i * NX + k] = xb[k];
@@ -240,6 +255,9 @@ int general_dispatch(const ModelDesc* md, F0 f0, F1 f1, F2 f2, F3 f3) {
 }  // namespace
 
 extern "C" {
+// actuation inputs (B, n_u) of the next loss / step / step-backward calls on an actuated general model; null = none
+void hostsim_set_actuation(const double* u, int64_t ld_u) { g_actuation = u; g_actuation_ld = ld_u; }
+
 
 int hostsim_loss_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,
                      const double* lengths, const double* x, const double* xp, int64_t B, const double* weights,

@@ -96,7 +96,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.dpll_abi_version() == _capi.ABI_VERSION
-    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 4 + 4 + 1) + 4 + 8 * 9 * (4 + 3) + 4 * (3 + 1)  # (+ 4: padding)
+    assert ctypes.sizeof(_capi.ModelDesc) == 4 + 4 + 8 + 8 + 8 * (9 + 9 + 9) + 4 * (3 + 1 + 3 + 3 + 3 + 1 + 4 + 4 + 1) + 4 + 8 * 9 * (4 + 3) + 4 * 3 + 4 * (1 + 3 + 1)  # (+ 4: padding; joint kinds; n_u, act_joint, reserved)
     # host-only entry points work without a GPU and validate their arguments
     desc = _capi.make_desc(parse_urdf(os.path.join(ASSET_DIR, 'elbow.urdf')), 0.0068)
     handle = ctypes.c_void_p()
