@@ -406,7 +406,10 @@ struct dpll_model {
   dpll::SolverOpts opts[2];
   // a model of the forest build (csrc/dpll_forest.hip): its description on the host and, from the first launch on, on the device
   dpll_forest::ForestDesc* forest = nullptr;
-  void* forest_dev = nullptr;
+  // the forest description's device copies, one per device the handle has launched on (made at the first launch there, under
+  // a mutex, never inside a stream capture: dpll_forest.hip device_desc)
+  static constexpr int kMaxDevices = 16;
+  void* forest_dev[kMaxDevices] = {};
 };
 
 // error reporting shared by the translation units (defined in dpll_kernels.hip)

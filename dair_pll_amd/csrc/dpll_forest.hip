@@ -11,6 +11,8 @@
 // folded 64 at a time and the finalize kernel chains the sum to [theta | friction | lengths] (one thread per parameter).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -488,18 +490,31 @@ __global__ __launch_bounds__(kWave) void forest_terms_kernel(const ForestDesc* _
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 const ForestDesc& host_desc(const dpll_model* m) { return *m->forest; }
 
-// the description's device copy, made at the first launch (never inside a stream capture: callers warm up eagerly)
-const ForestDesc* device_desc(const dpll_model* m) {
-  if (!m->forest_dev) {
+// The description's device copy for the CURRENT device, made at the handle's first launch there: under a mutex (two
+// first calls used to race and leak one allocation), keyed by hipGetDevice() (a handle used with another GPU's stream used to
+// dereference the first GPU's memory), and refused with a clear error while `stream` is being captured (the allocation and the
+// synchronous copy would invalidate the capture: warm up with one eager call first, as include/dpll.h says).
+const ForestDesc* device_desc(const dpll_model* m, hipStream_t stream) {
+  static std::mutex guard;
+  std::lock_guard<std::mutex> lock(guard);
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= dpll_model::kMaxDevices) return nullptr;
+  dpll_model* mm = const_cast<dpll_model*>(m);
+  if (!mm->forest_dev[device]) {
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &status) == hipSuccess && status != hipStreamCaptureStatusNone) {
+      (void)dpll_fail(-5, "%s: the forest description is not on this device yet and the stream is being captured: make one eager call first", "dpll (forest build)");
+      return nullptr;
+    }
     void* dev = nullptr;
     if (hipMalloc(&dev, sizeof(ForestDesc)) != hipSuccess) return nullptr;
     if (hipMemcpy(dev, m->forest, sizeof(ForestDesc), hipMemcpyHostToDevice) != hipSuccess) {
       (void)hipFree(dev);
       return nullptr;
     }
-    const_cast<dpll_model*>(m)->forest_dev = dev;
+    mm->forest_dev[device] = dev;
   }
-  return static_cast<const ForestDesc*>(m->forest_dev);
+  return static_cast<const ForestDesc*>(mm->forest_dev[device]);
 }
 
 int stride_of(const ForestDesc& fd) { return (row_width(fd) + 1) & ~1; }
@@ -538,6 +553,12 @@ int max_rows(const ForestDesc&) { return kMaxLossBlocks; }
 
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* who) {
   if (bytes + sizeof(ForestDesc) + 4096 > 160 * 1024) return dpll_fail(-2, "%s: the model needs more LDS per item than a CU has", who);
+  // (once per kernel, device and size: the attribute call used to be made at every launch)
+  static thread_local size_t allowed[dpll_model::kMaxDevices] = {};
+  int device = 0;
+  (void)hipGetDevice(&device);
+  if (device >= 0 && device < dpll_model::kMaxDevices && bytes <= allowed[device]) return 0;
+  if (device >= 0 && device < dpll_model::kMaxDevices) allowed[device] = bytes > 48 * 1024 ? bytes : allowed[device];
   if (bytes > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
     return dpll_fail(-5, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed", who);
   return 0;
@@ -549,8 +570,8 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
                 long long batch, const void* weights, double scale, void* loss, void* grad, void* loss_total, void* force, int32_t* iters,
                 void* workspace, long long ws_bytes, hipStream_t stream, const AdamArgs* adam) {
   const ForestDesc& fd = host_desc(m);
-  const ForestDesc* dev = device_desc(m);
-  if (!dev) return dpll_fail(-5, "dpll_contactnets_loss (forest build): could not place the model description on the device%s");
+  const ForestDesc* dev = device_desc(m, stream);
+  if (!dev) return dpll_fail(-5, "dpll_contactnets_loss (forest build): could not place the model description on the device (a first call inside a stream capture? make one eager call before capturing)%s");
   const int want_grad = grad != nullptr;
   if (want_grad) {
     if (!workspace || ws_bytes < dpll_forest_api::workspace_bytes(m, batch)) return dpll_fail(-3, "dpll_contactnets_loss: workspace too small%s");
@@ -600,8 +621,8 @@ template <typename T>
 int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, const void* x0, long long ld_x, long long batch, long long steps,
                     void* out, long long ld_item, long long ld_step, int write_x0, int32_t* iters, hipStream_t stream) {
   const ForestDesc& fd = host_desc(m);
-  const ForestDesc* dev = device_desc(m);
-  if (!dev) return dpll_fail(-5, "dpll_simulate (forest build): could not place the model description on the device%s");
+  const ForestDesc* dev = device_desc(m, stream);
+  if (!dev) return dpll_fail(-5, "dpll_simulate (forest build): could not place the model description on the device (a first call inside a stream capture? make one eager call before capturing)%s");
   const int lanes = lanes_per_item<T>(fd), teams = kWave / lanes;
   const size_t arena = arena_bytes<T, double>(fd);
   const size_t lds = teams * (round16((size_t)2 * (fd.n_q + fd.n_v) * sizeof(T)) + arena);
@@ -625,8 +646,8 @@ template <typename T>
 int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, const void* gx, long long ld_g, long long batch,
                          void* grad, void* grad_x, long long ld_gx, void* workspace, long long ws_bytes, hipStream_t stream) {
   const ForestDesc& fd = host_desc(m);
-  const ForestDesc* dev = device_desc(m);
-  if (!dev) return dpll_fail(-5, "dpll_step_backward (forest build): could not place the model description on the device%s");
+  const ForestDesc* dev = device_desc(m, stream);
+  if (!dev) return dpll_fail(-5, "dpll_step_backward (forest build): could not place the model description on the device (a first call inside a stream capture? make one eager call before capturing)%s");
   if (!workspace || ws_bytes < dpll_forest_api::workspace_bytes(m, batch)) return dpll_fail(-3, "dpll_step_backward: workspace too small%s");
   const size_t head = round16((size_t)row_width(fd) * sizeof(double));
   const size_t lds = head + arena_bytes<double, double>(fd) + (grad_x ? arena_bytes<DualT<double>, DualT<double>>(fd, true) : 0);
@@ -662,8 +683,8 @@ template <typename T>
 int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, long long ld_x, long long batch, void* Dm, void* M, void* J, void* phi,
                  void* a, hipStream_t stream) {
   const ForestDesc& fd = host_desc(m);
-  const ForestDesc* dev = device_desc(m);
-  if (!dev) return dpll_fail(-5, "dpll_terms (forest build): could not place the model description on the device%s");
+  const ForestDesc* dev = device_desc(m, stream);
+  if (!dev) return dpll_fail(-5, "dpll_terms (forest build): could not place the model description on the device (a first call inside a stream capture? make one eager call before capturing)%s");
   const size_t lds = arena_bytes<T, double>(fd);
   if (int rc = allow_lds(forest_terms_kernel<T>, lds, "dpll_terms")) return rc;
   hipLaunchKernelGGL((forest_terms_kernel<T>), dim3(grid_for(batch, lds)), dim3(kWave), lds, stream, dev, (const T*)p->theta, (const T*)p->friction,
@@ -716,6 +737,32 @@ int check_desc(const dpll_forest_desc_t* d) {
     n_v += nv;
   }
   if (n_q != d->n_q || n_v != d->n_v || max_depth != d->max_depth) return dpll_fail(-1, "dpll_forest_model_create: n_q / n_v / max_depth do not match the bodies%s");
+  //  what a C caller could get silently wrong: the `rotated` bits against the matrices they announce, hinge axes that
+  // are not unit vectors, coordinate ranges of two bodies that overlap
+  auto is_identity = [](const double (&r)[3][3]) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        if (fabs(r[i][j] - (i == j ? 1.0 : 0.0)) > 1e-12) return false;
+    return true;
+  };
+  bool body_turned = false, geom_turned = false;
+  for (int b = 0; b < d->n_bodies; ++b) body_turned = body_turned || !is_identity(d->body_rot[b]);
+  for (int g = 0; g < d->n_geoms && g < dpll_forest::kMaxGeoms; ++g) geom_turned = geom_turned || !is_identity(d->geom_rot[g]);
+  if (body_turned != ((d->rotated & 1) != 0) || geom_turned != ((d->rotated & 2) != 0))
+    return dpll_fail(-1, "dpll_forest_model_create: rotated must say which of body_rot / geom_rot hold a rotation other than the identity%s");
+  for (int b = 0; b < d->n_bodies; ++b) {
+    const int kind = d->joint_kind[b];
+    if (kind == kJointRevolute || kind == kJointPrismatic) {
+      const double n2 = d->joint_axis[b][0] * d->joint_axis[b][0] + d->joint_axis[b][1] * d->joint_axis[b][1] + d->joint_axis[b][2] * d->joint_axis[b][2];
+      if (fabs(n2 - 1.0) > 1e-9) return dpll_fail(-1, "dpll_forest_model_create: joint_axis must be a unit vector%s");
+    }
+    const int nq_b = kind == kJointFloating ? 7 : (kind == kJointFixed ? 0 : 1);
+    for (int c = 0; c < b; ++c) {
+      const int kc = d->joint_kind[c], nq_c = kc == kJointFloating ? 7 : (kc == kJointFixed ? 0 : 1);
+      if (nq_b > 0 && nq_c > 0 && d->q_index[b] < d->q_index[c] + nq_c && d->q_index[c] < d->q_index[b] + nq_b)
+        return dpll_fail(-1, "dpll_forest_model_create: the coordinate ranges of two bodies overlap%s");
+    }
+  }
   int contacts = 0;
   for (int g = 0; g < d->n_geoms; ++g) {
     if (d->geom_body[g] < 0 || d->geom_body[g] >= d->n_bodies) return dpll_fail(-1, "dpll_forest_model_create: geom_body out of range%s");
@@ -737,6 +784,9 @@ int check_desc(const dpll_forest_desc_t* d) {
       return dpll_fail(-1, "dpll_forest_model_create: a candidate joins geometries of two different bodies%s");
     if (d->joint_kind[d->geom_body[a]] == kJointFixed && d->joint_kind[d->geom_body[b]] == kJointFixed)
       return dpll_fail(-1, "dpll_forest_model_create: a candidate between two geometries welded to the world%s");
+    for (int o = 0; o < p; ++o)
+      if ((d->pair_a[o] == a && d->pair_b[o] == b) || (d->pair_a[o] == b && d->pair_b[o] == a))
+        return dpll_fail(-1, "dpll_forest_model_create: a candidate listed twice%s");
     if (contacts >= d->n_contacts || d->contact_geom[contacts] >= 0 || d->contact_slot[contacts] != p)
       return dpll_fail(-1, "dpll_forest_model_create: contacts must list every geometry's witnesses in order, then the candidates%s");
   }
@@ -754,8 +804,10 @@ long long workspace_bytes(const dpll_model* m, long long batch) {
   return (rows + folded_rows(rows)) * stride_of(fd) * (long long)sizeof(double);
 }
 void release(dpll_model* m) {
-  if (m->forest_dev) (void)hipFree(m->forest_dev);
-  m->forest_dev = nullptr;
+  for (int d = 0; d < dpll_model::kMaxDevices; ++d) {
+    if (m->forest_dev[d]) (void)hipFree(m->forest_dev[d]);  // (hipFree finds the owning device from the pointer)
+    m->forest_dev[d] = nullptr;
+  }
   delete m->forest;
   m->forest = nullptr;
 }

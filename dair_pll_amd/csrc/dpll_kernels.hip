@@ -1317,6 +1317,16 @@ int mesh_forward_all(const dpll_model* m, const MeshPlan& pl, const dpll_mesh_pa
   return 0;
 }
 
+// Does the loss launch of dpll_contactnets_loss_mesh run four racing copies per item?  ONE predicate for the launch and for
+// dpll_racing_copies(what = 4) (the two used to be written out separately and could disagree): a single body, a
+// launch the race shape gives four copies of a full lane group, and the same number of partial rows as the plain launch (the
+// reduce kernel's row count is fixed by the plan)
+template <typename T, int NJ> bool mesh_loss_races(const dpll_model* m, int dtype, long long batch) {
+  if constexpr (NJ != 0) return false;
+  const RaceShape shape = race_shape<T, NJ>(m, dtype, batch);
+  return shape.copies == 4 && shape.lanes == Dims<T, NJ>::G && loss_blocks<T, NJ>(batch, 4, shape.lanes) == loss_blocks<T, NJ>(batch);
+}
+
 template <typename T, int NJ>
 int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const dpll_mesh_params_t* mp, const void* x,
                      long long ld_x, const void* xp, long long ld_xp, long long batch, const void* weights, double scale,
@@ -1340,10 +1350,9 @@ int launch_mesh_loss(const dpll_model* m, int dtype, const dpll_params_t* p, con
   // Racing copies (round 4; what the box cube has run since round 3): a launch of at most 4096 cube pairs gives every item
   // four copies of its cone solve on the SIMDs a 256-wave launch leaves idle -- the copies read the same support points, the
   // winner writes the witness adjoints; four-wave workgroups share one partial row, so the reduce kernel sums as many rows
-  const RaceShape shape = race_shape<T, NJ>(m, dtype, batch);
   bool raced = false;
   if constexpr (NJ == 0) {
-    if (shape.copies == 4 && shape.lanes == Dims<T, NJ>::G && loss_blocks<T, NJ>(batch, 4, shape.lanes) == pl.loss_blocks) {
+    if (mesh_loss_races<T, NJ>(m, dtype, batch)) {
       hipLaunchKernelGGL((loss_kernel<T, NJ, true, false, 4>), dim3(pl.loss_blocks + 1), dim3(kRaceWaves * kWave), 0, stream, (const T*)x, ld_x,
                          (const T*)xp, ld_xp, batch, (const T*)p->theta, (const T*)p->friction, (const T*)nullptr, (const T*)weights, scale,
                          (T*)loss, (T*)force, (int*)iters, (double*)(ws + pl.off_rows), want_grad, (const T*)(ws + pl.off_P),
@@ -1955,8 +1964,7 @@ int dpll_racing_copies(const dpll_model_t* model, int dtype, int64_t batch, int 
   if (model->forest) return what >= 2 && what != 4 ? -1 : 1;
   if (what == 4) {  // the loss launch of dpll_contactnets_loss_mesh: the single-body build races like the box cube (launch_mesh_loss)
     if (model->desc.n_geoms > 0 || model->desc.n_joints != 0) return 1;
-    const RaceShape shape = race_shape(0, dtype == DPLL_F32, model->opts[dtype].portfolio, batch);
-    return (shape.copies == 4 && shape.lanes == kQuery) ? 4 : 1;
+    return (dtype == DPLL_F32 ? mesh_loss_races<float, 0>(model, dtype, batch) : mesh_loss_races<double, 0>(model, dtype, batch)) ? 4 : 1;
   }
   if (what >= 2) {  // the shape of the loss launch: 2 = item workgroups (= partial rows), 3 = lanes of one copy of an item
     if (model->desc.n_geoms > 0 || model->desc.n_joints > 1) return -1;
