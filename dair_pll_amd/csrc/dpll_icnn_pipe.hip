@@ -74,6 +74,9 @@ struct PipeArgs {
   float* P;                // fwd2
   double* partial;         // bwd1
   float* VbT;              // bwd1 (operand tiles for bwd2; one spare tile behind the last)
+  uint32_t* M1b;           // bwd1 (f32): the mask words once more in the order icnn_bwd2_pipe_kernel's scalar loads want them:
+                           // [tile][block of 64 columns (4)][step (16)][j-tile (2)][row parity (2)] -- the 64 words a wave needs for a
+                           // tile are 256 contiguous bytes, and a step's two lane masks two aligned register pairs
 };
 
 __device__ __forceinline__ float mask_factor(uint32_t word, int bit) { return ((word >> bit) & 1u) ? 1.0f : float(kIcnnSlope); }
@@ -107,6 +110,28 @@ __device__ __forceinline__ void mfma_x4(f32x16& acc, const f32x4& x, float w0, f
   }
 }
 
+// ---- the split-bf16 form (BF16 = true: what dpll_solver_opts_t.mesh_gemm = 2 runs).  An f32 operand is the sum of two bf16 planes
+// to 16 significand bits, x = x1 + x2; per 16-deep k-step three products on the bf16 matrix cores -- x1 w2 and x2 w1 into a
+// second accumulator `low`, x1 w1 into `acc`, added once per chain -- as dpll_mesh_bf16.hpp (same planes, same order, so the
+// same numbers).  Unlike the f32 MFMA, v_mfma_f32_32x32x16_bf16 runs on the matrix pipe proper and up to five other
+// instructions hide behind each (tools/diag/mfma_fill.hip): here the pipelined structure pays, and the MFMAs are issued ONE per
+// statement with a share of the step's side work behind each.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+constexpr int kBq = 32 * 8 + 8;       // bf16 elements per 8-deep k-block of the LDS image (8 pad)
+constexpr int kBopElems = 32 * kBq;   // one plane of a 32 x 256 tile: element (row, k) at (k >> 3) * kBq + row * 8 + (k & 7)
+static_assert(2 * kBopElems * 2 == kXopFloats * 4, "two bf16 planes fill exactly the f32 image's bytes");
+
+// acc (+)= a * w on the bf16 matrix cores, the weight vector read from accumulation registers.  FIRST: C = 0.  (hipcc pads
+// nothing inside an asm statement; a dependent MFMA taking the previous result whole as C needs no wait state.)
+template <bool FIRST>
+__device__ __forceinline__ void mfma_bf16(f32x16& acc, const bf16x8& a, const bf16x8& w) {
+  if (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(w));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
+}
+// the wait states an 8-pass XDL result needs before a VALU instruction may read it
+__device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b)); }
+
 // DPP: lane 15 of rows 0 / 2 into every lane of rows 1 / 3 (gfx9 row_bcast:15, row_mask 0xA); other rows read 0
 __device__ __forceinline__ float row_bcast15(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
@@ -123,7 +148,7 @@ __device__ unsigned long long g_pipe_stamps[256][16];
 #define PIPE_STAMP(i) do { } while (0)
 #endif
 
-template <int KIND>
+template <int KIND, bool BF16 = false>
 __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   __shared__ __attribute__((aligned(16))) float Xs[2][kXopFloats];
   __shared__ RowRing ring;
@@ -140,11 +165,30 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   // ---- this wave's 256 x 64 block of the weight matrix: 2 column blocks x 128 k-steps (requested in the prologue, BEHIND
   // the row data of the first two tiles: memory returns in order, so waiting for the rows must not mean waiting for 256 KB)
   float b[2][kW / 2];
+  bf16x8 wb[2][2][kW / 16];  // BF16: [plane][column block][k-step of 16]: 2 x 2 x 16 vectors of 4 registers
   // ---- per-thread constants --------------------------------------------------------------------------------------
   const int c = tid;  // fill role: column c of the operand tile
   float d[3] = {0.f, 0.f, 0.f}, ac = 0.f;
-  if (KIND == kFwd1 || KIND == kBwd1) { d[0] = g.w.Wd0[c]; d[1] = g.w.Wd0[kW + c]; d[2] = g.w.Wd0[2 * kW + c]; }
-  if (KIND == kFwd2) ac = g.a[c];
+  if (!BF16 && (KIND == kFwd1 || KIND == kBwd1)) { d[0] = g.w.Wd0[c]; d[1] = g.w.Wd0[kW + c]; d[2] = g.w.Wd0[2 * kW + c]; }
+  if (!BF16 && KIND == kFwd2) ac = g.a[c];
+  // BF16 fill role: the column PAIR (c0, c0 + 1) -- one 32-bit LDS word per row and plane -- and the rows of parity rpar
+  const int c0 = 2 * (tid & 127), rpar = tid >> 7;
+  float d2[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, ahi[2] = {0.f, 0.f}, alo[2] = {0.f, 0.f};
+  if (BF16) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (KIND == kFwd1 || KIND == kBwd1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d2[j][i] = g.w.Wd0[i * kW + c0 + j];
+      }
+      if (KIND == kFwd2) {  // U1 = |wout[c]| (mask ? 1 : 1/2): its planes are per-column constants (the halving is exact)
+        const float av = g.a[c0 + j];
+        const __bf16 h = (__bf16)av;
+        ahi[j] = (float)h;
+        alo[j] = (float)(__bf16)(av - ahi[j]);
+      }
+    }
+  }
   int col[2];
   float wd0[2][3], wd1[2][3], acol[2];
 #pragma unroll
@@ -180,8 +224,13 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     if (KIND == kBwd1 && tid >= 64 && tid < 64 + 3 * kRows) {
       const int t = tid - 64, r = t / 3, i = t - 3 * r;
       const long long n = n0 + r;
-      const long long nc = n < N ? n : N - 1;
-      const float v = g.RB[icnn_point_index(nc, g.w) + i];
+      const uint32_t nc = (uint32_t)(n < N ? n : N - 1);  // (N < 2^31: the launchers check; a 64-bit division here kept waves 1-2 of
+      const uint32_t item = nc / (uint32_t)g.w.qpi;         //  bwd1 ~3 k cycles behind at the prologue's first barrier)
+      const int jq = (int)(nc - item * (uint32_t)g.w.qpi);
+      int off = g.w.qoff[0];
+#pragma unroll
+      for (int cq = 1; cq < 8; ++cq) off = (jq == cq) ? g.w.qoff[cq] : off;
+      const float v = g.RB[(long long)item * g.w.point_stride + off + i];
       raw.r = n < N ? v : 0.f;
     }
     if (KIND != kFwd1) {
@@ -192,7 +241,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     }
     return raw;
   };
-  auto rows_commit = [&](const RowRaw& raw, int slot) {
+  auto rows_commit = [&](const RowRaw& raw, int slot, long long mask_tile = -1) {
     if (tid < kRows) {
       float q[3] = {0.f, 0.f, 1.f};
       if (raw.ok) {
@@ -210,6 +259,10 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       ((float*)&ring.v[slot][r][1])[i] = raw.r;
     }
     if (KIND != kFwd1) ((uint32_t*)&ring.v[slot][tid >> 3][2])[tid & 7] = raw.m;
+    if (KIND == kBwd1 && !BF16 && g.M1b && mask_tile >= 0) {  // (row tid >> 3, word tid & 7 of tile `mask_tile`)
+      const int row = tid >> 3, word = tid & 7;
+      g.M1b[((mask_tile * 4 + (word >> 1)) * 16 + (row >> 1)) * 4 + (word & 1) * 2 + (row & 1)] = raw.m;
+    }
   };
 
   // ---- side work of the MFMA steps comes in two halves: the LDS reads of a step's inputs are issued ONE STEP AHEAD (side_in),
@@ -247,9 +300,49 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     X[xop(rr, c)] = val;
   };
 
+  // BF16 fill: step i of 16 = row 2 i + rpar of the column pair; Xb = the buffer's two planes; vb_rows = Vb row-major (n, 256)
+  auto fill_load_b = [&](int i, int slot) {
+    const int rr = 2 * i + rpar;
+    SideIn in;
+    in.a = f32x4{0.f, 0.f, 0.f, 0.f}; in.b = in.a; in.w = 0u;
+    if (KIND == kFwd1) in.a = ring.v[slot][rr][0];
+    if (KIND == kFwd2) in.w = ((const uint32_t*)&ring.v[slot][rr][2])[c0 >> 5];
+    if (KIND == kBwd1) { in.a = ring.v[slot][rr][0]; in.b = ring.v[slot][rr][1]; }
+    return in;
+  };
+  auto fill_step_b = [&](int i, const SideIn& in, float* __restrict__ X, float* __restrict__ vb_rows) {
+    const int rr = 2 * i + rpar;
+    bf16x2 hi, lo;
+    if (KIND == kFwd2) {
+      const float f0 = mask_factor(in.w, c0 & 31), f1 = mask_factor(in.w, (c0 & 31) + 1);
+      hi = bf16x2{(__bf16)(ahi[0] * f0), (__bf16)(ahi[1] * f1)};
+      lo = bf16x2{(__bf16)(alo[0] * f0), (__bf16)(alo[1] * f1)};
+    } else {
+      float val[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float pre = in.a[0] * d2[j][0] + in.a[1] * d2[j][1] + in.a[2] * d2[j][2];
+        if (KIND == kFwd1) val[j] = fmaxf(pre, float(kIcnnSlope) * pre);
+        else val[j] = (in.b[0] * d2[j][0] + in.b[1] * d2[j][1] + in.b[2] * d2[j][2]) * icnn_mask(pre);  // rows past N: r_bar = 0
+      }
+      if (KIND == kBwd1) *(float2*)(vb_rows + rr * kW + c0) = float2{val[0], val[1]};
+      hi = bf16x2{(__bf16)val[0], (__bf16)val[1]};  // round to nearest even; the residuals below are exact in f32
+      lo = bf16x2{(__bf16)(val[0] - (float)hi[0]), (__bf16)(val[1] - (float)hi[1])};
+    }
+    uint32_t* plane0 = (uint32_t*)X;  // (two bf16 per word)
+    const int word = ((c0 >> 3) * kBq + rr * 8 + (c0 & 7)) >> 1;
+    plane0[word] = __builtin_bit_cast(uint32_t, hi);
+    plane0[kBopElems / 2 + word] = __builtin_bit_cast(uint32_t, lo);
+  };
+
   // ---- epilogue state ------------------------------------------------------------------------------------------------
   // The two 32-column blocks of a wave are two MFMA chains run one after the other; acc[1] enters tile t still holding chain 1
   // of tile t - 1 (zero before the first tile), whose epilogue runs under chain 0 of tile t
+  f32x16 low[2];  // BF16: the small products of a chain, added to acc once at its end
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) low[cb][r] = 0.f;
   f32x16 acc[2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
@@ -257,6 +350,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
   uint32_t mw = 0u;                        // fwd1: mask words of the chain's block, the word of row r in lane r
   f32x4 u0s = {0.f, 0.f, 0.f, 0.f};        // fwd2: U0 values staged for 16-byte stores
+  float pv[KIND == kFwd2 ? 16 : 1][3];     // fwd2: the chain's support-point terms of this lane's column, one row per accumulator register
   // bwd1: U0 of the chain in accumulator layout (one float4 in use, the next in flight); column sums of the chain in float,
   // the running totals over this workgroup's tiles in double in LDS (14 per thread: registers are the scarce resource)
   f32x4 u0cur = {0.f, 0.f, 0.f, 0.f}, u0nxt = {0.f, 0.f, 0.f, 0.f};
@@ -304,21 +398,10 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       const float u1 = acol[cb] * mask_factor(word, l31);
       u0s[reg & 3] = u0;
       if ((reg & 3) == 3) ((f32x4*)u0_tile)[(4 * cb + (reg >> 2)) * 64] = u0s;  // accumulator layout: float4 (4 cb + reg / 4) of this lane
-      float pr[3];  // this row's support-point terms of the block's 32 columns: summed over the lanes -> Pp[wave, block][row]
+      // this row's support-point terms of the lane's column; summed over the block's 32 columns at the end of the chain (epi_end)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float v = wd1[cb][i] * u1 + wd0[cb][i] * u0;
-        v += dppf<0xB1>(v);   // quad_perm [1,0,3,2]
-        v += dppf<0x4E>(v);   // quad_perm [2,3,0,1]
-        v += dppf<0x141>(v);  // row_half_mirror
-        v += dppf<0x140>(v);  // row_mirror: every lane of a 16-lane row holds the row's sum
-        v += row_bcast15(v);  // rows 1 / 3: + the sum of row 0 / 2 = the half's 32 columns
-        pr[i] = v;
-      }
-      if (l31 == 31) {
-        f32x4* dst = (f32x4*)&Pp[pbuf][2 * wv + cb][row][0];
-        *dst = f32x4{pr[0], pr[1], pr[2], 0.f};
-      }
+      for (int i = 0; i < 3; ++i) pv[KIND == kFwd2 ? reg : 0][i] = wd1[cb][i] * u1 + wd0[cb][i] * u0;
+      (void)pbuf;
     } else {
       const f32x4 r = in.a;
       const float mf = mask_factor(in.w, l31);
@@ -333,8 +416,35 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       for (int i = 0; i < 3; ++i) { t_s1[i] += r[i] * mf; t_g0[i] += r[i] * u0; }
     }
   };
-  auto epi_end = [&](int cb, long long tile) {
+  auto epi_end = [&](int cb, long long tile, int pbuf = 0) {
     const long long n0 = tile * kRows;
+    if constexpr (KIND == kFwd2) {
+      // Sums over the 32 lanes of a half of 16 x 3 values per lane, as a TRANSPOSED butterfly: at every stage a lane keeps half of
+      // its values (which half: one bit of its lane number) and adds its partner's copies of those -- 45 operations per component
+      // instead of 80, and 15 of them cross-lane instead of 80 (round 5: the 15 DPP adds per accumulator register of the straight
+      // row sums were ~4.8 k of fwd2's ~10.5 k non-MFMA cycles per tile).  Pairings: row_mirror (i <-> 15 - i, side = bit 3),
+      // row_half_mirror (i <-> 7 - i, bit 2), quad xor 2 (bit 1), quad xor 1 (bit 0): partners always hold the same set, and lane
+      // j of a 16-lane row ends with the row's sum of register j; the two rows of a half are added through ds_swizzle (i <-> i ^ 16).
+      const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+      float tot[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float s8[8], s4[4], s2[2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s8[r] = (b3 ? pv[r + 8][i] : pv[r][i]) + dppf<0x140>(b3 ? pv[r][i] : pv[r + 8][i]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s4[r] = (b2 ? s8[r + 4] : s8[r]) + dppf<0x141>(b2 ? s8[r] : s8[r + 4]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) s2[r] = (b1 ? s4[r + 2] : s4[r]) + dppf<0x4E>(b1 ? s4[r] : s4[r + 2]);
+        const float s1 = (b0 ? s2[1] : s2[0]) + dppf<0xB1>(b0 ? s2[0] : s2[1]);
+        tot[i] = s1 + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s1), 0x401F));  // + lane ^ 16
+      }
+      if ((lane & 16) == 0) {  // lanes 0..15 of each half: register (lane & 15) = row mfma_row(lane & 15, half)
+        const int reg = lane & 15;
+        f32x4* dst = (f32x4*)&Pp[pbuf][2 * wv + cb][(reg & 3) + 8 * (reg >> 2) + 4 * half][0];
+        *dst = f32x4{tot[0], tot[1], tot[2], 0.f};
+      }
+    }
     if (KIND == kFwd1) {
       if (lane < kRows && n0 + lane < N) g.M1out[(n0 + lane) * kMaskWords + 2 * wv + cb] = mw;
     } else if (KIND == kBwd1) {
@@ -366,7 +476,15 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   {
     const RowRaw r0 = rows_issue(tile_of(0));
     const RowRaw r1 = rows_issue(tile_of(1));
-    {  // (chain 0's half of the weights; chain 1's is requested between the rows of the first fill below: the CU's vector-memory
+    if (BF16) {  // chain 0's planes (fragment order of dpll_mesh_bf16.hpp: plane p at element offset p * 65536)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const bf16x8* f = (const bf16x8*)((const __bf16*)g.F + pl * kW * kW) + ((2 * wv) * 16) * 64 + lane;
+#pragma unroll
+        for (int st = 0; st < kW / 16; ++st) wb[pl][0][st] = f[st * 64];
+      }
+    } else {
+       // (chain 0's half of the weights; chain 1's is requested between the rows of the first fill below: the CU's vector-memory
        // path takes 64 bytes a clock, so 256 KB of fragments occupy it for ~4 k cycles whatever the wave does meanwhile.  Requesting
        // them under the first chain 0 instead -- a conditional definition -- made the allocator keep them in VGPRs: spills)
       const f32x4* f = (const f32x4*)g.F + ((2 * wv) * 32) * 64 + lane;
@@ -380,14 +498,30 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     PIPE_STAMP(10);
     __syncthreads();  // (the ring is zeroed)
     PIPE_STAMP(11);
-    rows_commit(r0, 0);
-    rows_commit(r1, 1);
+    rows_commit(r0, 0, tile_of(0) < n_tiles ? tile_of(0) : -1);
+    rows_commit(r1, 1, tile_of(1) < n_tiles && my_tiles > 1 ? tile_of(1) : -1);
     PIPE_STAMP(12);
   }
   __syncthreads();
   PIPE_STAMP(13);
   const long long dump_tile = n_tiles;  // the spare tile behind the last one (VbT, U0out)
-  {
+  if (BF16) {
+    float* vb_rows = KIND == kBwd1 ? g.VbT + tile_of(0) * kRows * kW : nullptr;
+    const bf16x8* f0 = (const bf16x8*)g.F + ((2 * wv + 1) * 16) * 64 + lane;
+    const bf16x8* f1 = (const bf16x8*)((const __bf16*)g.F + kW * kW) + ((2 * wv + 1) * 16) * 64 + lane;
+#pragma unroll
+    for (int i0 = 0; i0 < 16; i0 += 8) {
+      SideIn ins[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ins[j] = fill_load_b(i0 + j, 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        wb[0][1][i0 + j] = f0[(i0 + j) * 64];
+        wb[1][1][i0 + j] = f1[(i0 + j) * 64];
+        fill_step_b(i0 + j, ins[j], Xs[0], vb_rows);
+      }
+    }
+  } else {
     float* vb_tile = KIND == kBwd1 ? g.VbT + tile_of(0) * 8 * 1024 : nullptr;
     const f32x4* f = (const f32x4*)g.F + ((2 * wv + 1) * 32) * 64 + lane;
 #pragma unroll
@@ -444,6 +578,40 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
 #endif
     }
   };
+  // BF16: one chain = 16 steps of (two 16-byte LDS reads, three MFMAs, one epilogue register behind the first, a fill step behind
+  // every other second one)
+  auto run_chain_b = [&](auto cbc, const float* __restrict__ Xc, auto epi_in, auto fill_in, auto epi, auto fill) {
+    constexpr int cb = decltype(cbc)::value;
+    const bf16x8* x0 = (const bf16x8*)((const __bf16*)Xc + half * kBq + l31 * 8);
+    const bf16x8* x1 = (const bf16x8*)((const __bf16*)Xc + kBopElems + half * kBq + l31 * 8);
+    bf16x8 a0 = x0[0], a1 = x1[0];
+    SideIn ein = epi_in(0), fin = fill_in(0);
+#pragma unroll
+    for (int st = 0; st < kW / 16; ++st) {
+      const int nx = st + 1 < kW / 16 ? st + 1 : st;
+      const bf16x8 a0n = x0[nx * (2 * kBq / 8)], a1n = x1[nx * (2 * kBq / 8)];
+      const SideIn ein_next = epi_in(nx);
+      if (st == 0) mfma_bf16<true>(low[cb], a0, wb[1][cb][st]);
+      else mfma_bf16<false>(low[cb], a0, wb[1][cb][st]);
+      epi(st, ein);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_bf16<false>(low[cb], a1, wb[0][cb][st]);
+      SideIn fin_next = fin;
+      if (st & 1) {
+        fill(st >> 1, fin);
+        fin_next = fill_in((st >> 1) + 1 < 8 ? (st >> 1) + 1 : (st >> 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (st == 0) mfma_bf16<true>(acc[cb], a0, wb[0][cb][st]);
+      else mfma_bf16<false>(acc[cb], a0, wb[0][cb][st]);
+      a0 = a0n; a1 = a1n;
+      ein = ein_next; fin = fin_next;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_settle(acc[cb], low[cb]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[cb][r] += low[cb][r];
+  };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
 
@@ -461,35 +629,45 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     if (KIND == kFwd2 && it >= 2) p_store(it - 2);
     float* Xn = Xs[cur ^ 1];
     const float* Xc = Xs[cur];
-    float* vb_tile = KIND == kBwd1 ? g.VbT + (has_next ? t_next : dump_tile) * 8 * 1024 : nullptr;
+    float* vb_tile = KIND == kBwd1 ? g.VbT + (has_next ? t_next : dump_tile) * 8 * 1024 : nullptr;  // (BF16: 32 rows of 256)
     const int slot_next = (int)((it + 1) & 3), slot_cur = (int)(it & 3), slot_prev = (int)((it + 3) & 3);
     {  // chain 0 | epilogue of chain 1 of the previous tile
       float* u0_tile = KIND == kFwd2 ? g.U0out + ((has_prev ? t_prev : dump_tile) * 4 + wv) * 2048 + lane * 4 : nullptr;
       const int pbuf = (int)((it + 3) & 3);
       epi_begin(1, has_prev ? t_prev : t_cur);
+      if constexpr (BF16)
+        run_chain_b(C0{}, Xc, [&](int st) { return epi_load(1, st, slot_prev); }, [&](int i) { return fill_load_b(i, slot_next); },
+                    [&](int st, const SideIn& in) { epi_step(1, st, in, u0_tile, pbuf); },
+                    [&](int i, const SideIn& in) { fill_step_b(i, in, Xn, vb_tile); });
+      else
       run_chain(C0{}, Xc,
                 [&](int kq) { return (kq & 1) == 0 ? fill_load(kq >> 1, slot_next) : epi_load(1, kq >> 1, slot_prev); },
                 [&](int kq, const SideIn& in) {
                   if ((kq & 1) == 0) fill_step(kq >> 1, in, Xn, vb_tile);
                   else epi_step(1, kq >> 1, in, u0_tile, pbuf);
                 });
-      epi_end(1, has_prev ? t_prev : n_tiles);
+      epi_end(1, has_prev ? t_prev : n_tiles, pbuf);
     }
     if (it < 3) PIPE_STAMP(3 + 4 * (int)it);
     {  // chain 1 | epilogue of chain 0 of this tile
       float* u0_tile = KIND == kFwd2 ? g.U0out + (t_cur * 4 + wv) * 2048 + lane * 4 : nullptr;
       const int pbuf = (int)(it & 3);
       epi_begin(0, t_cur);
+      if constexpr (BF16)
+        run_chain_b(C1{}, Xc, [&](int st) { return epi_load(0, st, slot_cur); }, [&](int i) { return fill_load_b(8 + i, slot_next); },
+                    [&](int st, const SideIn& in) { epi_step(0, st, in, u0_tile, pbuf); },
+                    [&](int i, const SideIn& in) { fill_step_b(8 + i, in, Xn, vb_tile); });
+      else
       run_chain(C1{}, Xc,
                 [&](int kq) { return (kq & 1) == 0 ? fill_load(16 + (kq >> 1), slot_next) : epi_load(0, kq >> 1, slot_cur); },
                 [&](int kq, const SideIn& in) {
                   if ((kq & 1) == 0) fill_step(16 + (kq >> 1), in, Xn, vb_tile);
                   else epi_step(0, kq >> 1, in, u0_tile, pbuf);
                 });
-      epi_end(0, t_cur);
+      epi_end(0, t_cur, pbuf);
     }
     if (it < 3) PIPE_STAMP(4 + 4 * (int)it);
-    rows_commit(raw, (int)((it + 2) & 3));
+    rows_commit(raw, (int)((it + 2) & 3), it + 2 < my_tiles ? tile_of(it + 2) : -1);
     if (it < 3) PIPE_STAMP(5 + 4 * (int)it);
   }
 
@@ -500,7 +678,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     epi_begin(1, t_prev);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) epi_step(1, reg, epi_load(1, reg, (int)((it + 3) & 3)), u0_tile, (int)((it + 3) & 3));
-    epi_end(1, t_prev);
+    epi_end(1, t_prev, (int)((it + 3) & 3));
     if (KIND == kFwd2) {
       __syncthreads();
       if (it >= 2) p_store(it - 2);
@@ -528,6 +706,126 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   PIPE_STAMP(15);
 }
 
+// =================================================================================================================================
+// d|Wh| = Vb^T U1 as a split-K GEMM (round 5; the 8-wave icnn_bwd2_mfma ran at 0.26 of its matrix floor at 4096 pairs).  With the
+// cost model of the f32 MFMA in hand (every VALU / LDS instruction adds to the MFMA time) the kernel is built for the fewest of them:
+//   * a workgroup = four waves, one per SIMD; it owns a 64 x 64 block of the output and one of `n_slabs` slabs of row tiles, its
+//     waves take the slab's tiles in turn -- each wave four accumulators (2 k-tiles x 2 j-tiles), so one step = FOUR independent
+//     MFMAs on two A and two B values;
+//   * A = Vb as the operand tiles icnn_bwd1 left: straight from memory into registers, one 16-byte load per four steps and k-tile,
+//     the next tile's eight loads in flight under this tile's 64 MFMAs -- no LDS staging, no barrier in the loop;
+//   * B = U1 = |wout| (mask ? 1 : 1/2) has two values per column: ONE v_cndmask per value, its lane mask -- lanes 0..31 = row 2 s,
+//     lanes 32..63 = row 2 s + 1 of the step -- an aligned SGPR pair out of a 64-byte scalar load of the compact mask array;
+//   * at the end the four waves' accumulators are summed through LDS in a fixed order: 16 slabs to reduce instead of 64.
+// Per step: 256 cycles of MFMA + ~10 for leaving the MFMA stream + 2 VALU -- ~0.9 of the matrix rate in the loop.
+// =================================================================================================================================
+constexpr int kB2Slabs = 16;
+
+__device__ __forceinline__ float select_by_lane_mask(float if_clear, float if_set, unsigned long long mask) {
+  float out;
+  asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return out;
+}
+// four independent MFMAs of one step: (a0, a1) x (b0, b1)
+__device__ __forceinline__ void mfma_2x2(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1) {
+  // (s_nop 1: b0 / b1 come fresh from a VALU instruction -- the v_cndmask above, itself inside an asm statement, so hipcc pads nothing)
+  asm volatile("s_nop 1\n\t"
+               "v_mfma_f32_32x32x2_f32 %0, %4, %6, %0\n\t"
+               "v_mfma_f32_32x32x2_f32 %1, %4, %7, %1\n\t"
+               "v_mfma_f32_32x32x2_f32 %2, %5, %6, %2\n\t"
+               "v_mfma_f32_32x32x2_f32 %3, %5, %7, %3"
+               : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11) : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
+
+__global__ __launch_bounds__(256) void icnn_bwd2_pipe_kernel(long long N, const float* __restrict__ VbT, const uint32_t* __restrict__ M1b,
+                                                            const float* __restrict__ a, float* __restrict__ slabs, int n_slabs) {
+  __shared__ float red[4][64][64];  // [wave][accumulator, register][lane]
+  // one wave per SIMD has to be CLAIMED: at 143 registers and 64 KB of LDS two of these workgroups fit a CU,
+  // and the dispatcher doubles them up while other CUs idle -- first measurement 42 us per launch, twice the model.  Touching a high
+  // accumulation register lifts the wave's allocation over half the register file.
+  asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127");
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jblk = blockIdx.x & 3, kblk = (blockIdx.x >> 2) & 3, slab = blockIdx.x >> 4;
+  const long long n_tiles = (N + kRows - 1) / kRows;
+  const long long per = (n_tiles + n_slabs - 1) / n_slabs;
+  const long long t_begin = (long long)slab * per, t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
+  const float a0 = a[64 * jblk + l31], a1 = a[64 * jblk + 32 + l31];
+  const float h0 = a0 * float(kIcnnSlope), h1 = a1 * float(kIcnnSlope);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // this lane's A values of a tile: k-tile kt, float4 q (steps 4 q .. 4 q + 3)
+  auto fetch = [&](long long t, f32x4 (&dst)[2][4]) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const f32x4* src = (const f32x4*)(VbT + (t * 8 + 2 * kblk + kt) * 1024) + l31 * 2 + half;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[kt][q] = src[q * 64];
+    }
+  };
+  // The lane masks of FOUR steps' B values = 16 consecutive words of the compact mask array icnn_bwd1 wrote ([tile][block][step]
+  // [j-tile][row parity]): one 64-byte scalar load, requested a group of four steps ahead of its use.  (First version: two 8-byte
+  // scalar loads per step from the (N, 8) array -- every step a miss of the scalar cache, ~450 cycles exposed behind each
+  // step's MFMAs because a wait for scalar loads is a wait for ALL of them: 42 us per launch.)
+  using u32x16 = __attribute__((ext_vector_type(16))) uint32_t;
+  auto load_masks = [&](long long tile, int group) {
+    return *(const u32x16*)(M1b + ((tile * 4 + jblk) * 16 + 4 * group) * 4);
+  };
+  f32x4 cur[2][4], nxt[2][4];
+  long long t = t_begin + wv;
+  u32x16 mk = {}, mkn = {};
+  if (t < t_end) {
+    fetch(t, cur);
+    mk = load_masks(t, 0);
+  }
+  for (; t < t_end; t += 4) {
+    const bool more = t + 4 < t_end;
+    if (more) fetch(t + 4, nxt);
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp) {
+      mkn = grp < 3 ? load_masks(t, grp + 1) : load_masks(more ? t + 4 : t, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int st = 4 * grp + e;
+        const unsigned long long m0 = (unsigned long long)mk[4 * e] | ((unsigned long long)mk[4 * e + 1] << 32);
+        const unsigned long long m1 = (unsigned long long)mk[4 * e + 2] | ((unsigned long long)mk[4 * e + 3] << 32);
+        const float b0 = select_by_lane_mask(h0, a0, m0), b1 = select_by_lane_mask(h1, a1, m1);
+        mfma_2x2(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0][st >> 2][st & 3], cur[1][st >> 2][st & 3], b0, b1);
+      }
+      mk = mkn;
+    }
+    if (more) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[kt][q] = nxt[kt][q];
+    }
+  }
+  // (an XDL result needs 18 wait states before a VALU / LDS instruction may read it: hipcc pads nothing behind an asm statement)
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wv][(2 * i + j) * 16 + r][lane] = acc[i][j][r];
+  __syncthreads();
+  // wave w sums accumulator (kt, jt) = (w >> 1, w & 1) of the four waves, in wave order, and writes it to the slab
+  float* out = slabs + (long long)slab * kW * kW;
+  const int kt = wv >> 1, jt = wv & 1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = (2 * kt + jt) * 16 + r;
+    const float v = (red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane]);
+    out[(64 * kblk + 32 * kt + mfma_row(r, half)) * kW + 64 * jblk + 32 * jt + l31] = v;
+  }
+}
+
 inline int check(const char* what) {
   const hipError_t e = hipGetLastError();
   (void)what;
@@ -540,6 +838,7 @@ namespace dpll_pipe {
 
 int fwd1(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* Af, uint32_t* M1) {
   if (N <= 0) return 0;
+  if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
   g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.M1out = M1;
   hipLaunchKernelGGL(icnn_pipe_kernel<kFwd1>, dim3(blocks(N)), dim3(256), 0, stream, g);
@@ -549,6 +848,7 @@ int fwd1(hipStream_t stream, const float* x, long long ld, long long N, const Ic
 int fwd2(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* ATf, const float* a,
          const uint32_t* M1, float* U0t, float* P) {
   if (N <= 0) return 0;
+  if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
   g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = ATf; g.a = a; g.M1in = M1; g.U0out = U0t; g.P = P;
   hipLaunchKernelGGL(icnn_pipe_kernel<kFwd2>, dim3(blocks(N)), dim3(256), 0, stream, g);
@@ -556,12 +856,55 @@ int fwd2(hipStream_t stream, const float* x, long long ld, long long N, const Ic
 }
 
 int bwd1(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* Af, const float* a,
-         const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT) {
+         const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT, uint32_t* M1b) {
   if (N <= 0) return 0;
+  if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
-  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = VbT;
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = VbT; g.M1b = M1b;
   hipLaunchKernelGGL(icnn_pipe_kernel<kBwd1>, dim3(blocks(N)), dim3(256), 0, stream, g);
   return check("icnn_pipe_kernel<bwd1>");
+}
+
+int bwd2_slabs(long long N) {
+  const long long t = tiles(N) / 4;  // (at least four row tiles per slab: one per wave)
+  return (int)(t < 1 ? 1 : (t > kB2Slabs ? kB2Slabs : t));
+}
+
+int bwd2(hipStream_t stream, long long N, const float* VbT, const uint32_t* M1b, const float* a, float* slabs, int n_slabs) {
+  if (N <= 0 || n_slabs < 1) return -1;
+  hipLaunchKernelGGL(icnn_bwd2_pipe_kernel, dim3(16 * n_slabs), dim3(256), 0, stream, N, VbT, M1b, a, slabs, n_slabs);
+  return check("icnn_bwd2_pipe_kernel");
+}
+
+// ---- the split-bf16 form (2 planes): the same three kernels on the bf16 matrix cores; Ab / ATb = the planes icnn_prep_bf16_kernel<2>
+// writes (dpll_mesh_bf16.hpp), Vb leaves row-major (N rounded up to whole tiles, 256) for icnn_bwd2_bf16
+int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* Ab, uint32_t* M1) {
+  if (N <= 0) return 0;
+  if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
+  PipeArgs g{};
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)Ab; g.M1out = M1;
+  hipLaunchKernelGGL((icnn_pipe_kernel<kFwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  return check("icnn_pipe_kernel<fwd1, bf16>");
+}
+
+int fwd2_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* ATb, const float* a,
+              const uint32_t* M1, float* U0t, float* P) {
+  if (N <= 0) return 0;
+  if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
+  PipeArgs g{};
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)ATb; g.a = a; g.M1in = M1; g.U0out = U0t; g.P = P;
+  hipLaunchKernelGGL((icnn_pipe_kernel<kFwd2, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  return check("icnn_pipe_kernel<fwd2, bf16>");
+}
+
+int bwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* Ab, const float* a,
+              const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb) {
+  if (N <= 0) return 0;
+  if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
+  PipeArgs g{};
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)Ab; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = Vb;
+  hipLaunchKernelGGL((icnn_pipe_kernel<kBwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  return check("icnn_pipe_kernel<bwd1, bf16>");
 }
 
 }  // namespace dpll_pipe

@@ -1043,7 +1043,7 @@ struct MeshPlan {
   long long N, n_tiles;
   int n_nets, loss_blocks, gemm_blocks, b1_blocks, n_slabs, row_stride;
   // one block of buffers per network (offsets relative to the block): the backward of a network needs its own forward
-  size_t off_A, off_AT, off_Af, off_ATf, off_Ab, off_ATb, off_a, off_M1, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
+  size_t off_A, off_AT, off_Af, off_ATf, off_Ab, off_ATb, off_a, off_M1, off_M1b, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
   // shared: support points / their adjoints of all networks (batch, 4 n_nets, 3), the loss kernel's rows + chain matrix,
   // the bodies' world quaternions (batch, n_nets, 4; only for n_nets > 1)
   size_t off_P, off_RB, off_rows, off_bq, off_nets, total;
@@ -1072,6 +1072,7 @@ template <typename T> void plan_network_block(MeshPlan& pl, long long N) {
   pl.off_ATb = take(kMfma ? 2 * 3 * kW * kW : 0);
   pl.off_a = take(sizeof(T) * kW);
   pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
+  pl.off_M1b = take(kMfma ? sizeof(uint32_t) * kMaskWords * kMfmaRows * tiles : 0);  // the same words in the pipelined bwd2's order
   // (float: whole 32-row tiles + one spare -- the pipelined kernels (dpll_icnn_pipe.hip) keep U0 in the accumulator layout
   // of the MFMA and send the stores of tiles that do not exist to the spare one)
   pl.off_U0 = take(sizeof(T) * kW * (kMfma ? kMfmaRows * (tiles + 1) : pl.N));
@@ -1196,7 +1197,13 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
                          (const __bf16*)(nb + pl.off_ATb), (const float*)a, (const uint32_t*)(nb + pl.off_M1),                    \
                          (float*)(nb + pl.off_U0), (float*)P);                                                                    \
     } while (0)
-    if (t_mesh_gemm == 2) DPLL_FWD_BF16(2);
+    if (t_mesh_gemm == 2) {
+      // 2 planes: one wave per SIMD, pipelined (dpll_icnn_pipe.hip) -- on the bf16 matrix cores the side work hides behind the MFMAs
+      if (int rc = dpll_pipe::fwd1_bf16(stream, q.ptr, q.ld, pl.N, w, nb + pl.off_Ab, (uint32_t*)(nb + pl.off_M1))) return rc;
+      mesh_mark(stream);
+      if (int rc = dpll_pipe::fwd2_bf16(stream, q.ptr, q.ld, pl.N, w, nb + pl.off_ATb, (const float*)a, (const uint32_t*)(nb + pl.off_M1),
+                                        (float*)(nb + pl.off_U0), (float*)P)) return rc;
+    }
     else if (t_mesh_gemm == 3) DPLL_FWD_BF16(3);
     else if (t_mesh_gemm == 0 && pl.n_tiles > 2 * dpll_pipe::kMaxBlocks) {
       // the default beyond two row tiles per CU: one wave per SIMD, software pipelined (dpll_icnn_pipe.hip)
@@ -1211,11 +1218,10 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
       hipLaunchKernelGGL(icnn_fwd1_mfma, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
                          (const float*)(nb + pl.off_Af), (uint32_t*)(nb + pl.off_M1));
       mesh_mark(stream);
-      if (t_mesh_gemm == 0)
-        hipLaunchKernelGGL(icnn_fwd2_mfma<true>, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
-                           (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
-                           (float*)P, U1t);
-      else
+      if (t_mesh_gemm == 0) {  // (the pipelined fwd2 is ahead at every size since its row sums are a transposed butterfly)
+        if (int rc = dpll_pipe::fwd2(stream, q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_ATf), (const float*)a,
+                                     (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0), (float*)P)) return rc;
+      } else
         hipLaunchKernelGGL(icnn_fwd2_mfma<false>, dim3(pl.gemm_blocks), dim3(512), 0, stream, q.ptr, q.ld, pl.N, w,
                            (const float*)(nb + pl.off_ATf), (const float*)a, (const uint32_t*)(nb + pl.off_M1), (float*)(nb + pl.off_U0),
                            (float*)P, U1t);
@@ -1239,6 +1245,7 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
                   T* loss_total, hipStream_t stream, const T* adjoints = nullptr, const AdamArgs* adam = nullptr, long long w_offset = 0) {
   char* nb = pl.net(ws, g);
   const T* RB = adjoints ? adjoints : (const T*)(ws + pl.off_RB) + 12 * g;
+  int n_slabs = pl.n_slabs;  // (what the reduce kernel sums: the weight-gradient GEMM in use decides)
   if constexpr (std::is_same<T, float>::value) {
 #define DPLL_BWD_BF16(PL_)                                                                                                         \
     do {                                                                                                                          \
@@ -1250,16 +1257,25 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
                          (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),        \
                          (float*)(nb + pl.off_slabs));                                                                            \
     } while (0)
-    if (t_mesh_gemm == 2) DPLL_BWD_BF16(2);
+    if (t_mesh_gemm == 2) {
+      if (int rc = dpll_pipe::bwd1_bf16(stream, (const float*)q.ptr, q.ld, pl.N, w, nb + pl.off_Ab, (const float*)(nb + pl.off_a),
+                                        (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_U0), (const float*)RB,
+                                        (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb))) return rc;
+      mesh_mark(stream);
+      hipLaunchKernelGGL((icnn_bwd2_bf16<2>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
+                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
+                         (float*)(nb + pl.off_slabs));
+    }
     else if (t_mesh_gemm == 3) DPLL_BWD_BF16(3);
     else if (t_mesh_gemm == 0) {
       if (int rc = dpll_pipe::bwd1(stream, (const float*)q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a),
                                    (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_U0), (const float*)RB,
-                                   (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb))) return rc;
+                                   (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb), (uint32_t*)(nb + pl.off_M1b))) return rc;
       mesh_mark(stream);
-      hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
-                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
-                         (float*)(nb + pl.off_slabs));
+      n_slabs = dpll_pipe::bwd2_slabs(pl.N);  // (<= 16; never more than the plan's count, which the slab buffer is sized for)
+      if (n_slabs > pl.n_slabs) n_slabs = pl.n_slabs;
+      if (int rc = dpll_pipe::bwd2(stream, pl.N, (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1b),
+                                   (const float*)(nb + pl.off_a), (float*)(nb + pl.off_slabs), n_slabs)) return rc;
     } else {
       hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
                          (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),
@@ -1282,7 +1298,7 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
   mesh_mark(stream);
   hipLaunchKernelGGL((icnn_reduce_kernel<T, NB>), dim3(kRedBlocks), dim3(256), 0, stream, w,
                      (const double*)(ws + pl.off_rows), pl.loss_blocks, pl.row_stride, (const double*)(nb + pl.off_b1), pl.b1_blocks,
-                     (const T*)(nb + pl.off_slabs), pl.n_slabs, grad_w, grad_head, loss_total, adam ? *adam : AdamArgs{}, w_offset);
+                     (const T*)(nb + pl.off_slabs), n_slabs, grad_w, grad_head, loss_total, adam ? *adam : AdamArgs{}, w_offset);
   mesh_mark(stream);
   return check_launch("icnn backward");
 }

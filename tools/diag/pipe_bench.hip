@@ -35,12 +35,15 @@ int main(int argc, char** argv) {
   hipMemset(pert, 0, 48); hipMemset(RB, 0, 4 * 3 * N); hipMemset(M1, 0x5a, 4 * 8 * N); hipMemset(U0, 0, 4 * 8192 * (tiles + 1));
   dpll::IcnnWeights<float> w{F, Wd0, Wd1, wout, pert};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[3] = {"fwd1", "fwd2", "bwd1"};
-  for (int k = 0; k < 3; ++k) {
+  const char* names[6] = {"fwd1", "fwd2", "bwd1", "fwd1 bf16x2", "fwd2 bf16x2", "bwd1 bf16x2"};
+  for (int k = 0; k < 6; ++k) {
     auto launch = [&]() {
       if (k == 0) dpll_pipe::fwd1(0, x, 13, N, w, F, M1);
       if (k == 1) dpll_pipe::fwd2(0, x, 13, N, w, F, a, M1, U0, P);
-      if (k == 2) dpll_pipe::bwd1(0, x, 13, N, w, F, a, M1, U0, RB, partial, Vb);
+      if (k == 2) dpll_pipe::bwd1(0, x, 13, N, w, F, a, M1, U0, RB, partial, Vb, nullptr);
+      if (k == 3) dpll_pipe::fwd1_bf16(0, x, 13, N, w, F, M1);   // (F read as two bf16 planes: 256 KB of arbitrary finite numbers)
+      if (k == 4) dpll_pipe::fwd2_bf16(0, x, 13, N, w, F, a, M1, U0, P);
+      if (k == 5) dpll_pipe::bwd1_bf16(0, x, 13, N, w, F, a, M1, U0, RB, partial, Vb);
     };
     for (int i = 0; i < 3; ++i) launch();
     hipDeviceSynchronize();
