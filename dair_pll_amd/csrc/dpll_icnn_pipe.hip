@@ -74,9 +74,6 @@ struct PipeArgs {
   float* P;                // fwd2
   double* partial;         // bwd1
   float* VbT;              // bwd1 (operand tiles for bwd2; one spare tile behind the last)
-  uint32_t* M1b;           // bwd1 (f32): the mask words once more in the order icnn_bwd2_pipe_kernel's scalar loads want them:
-                           // [tile][block of 64 columns (4)][step (16)][j-tile (2)][row parity (2)] -- the 64 words a wave needs for a
-                           // tile are 256 contiguous bytes, and a step's two lane masks two aligned register pairs
 };
 
 __device__ __forceinline__ float mask_factor(uint32_t word, int bit) { return ((word >> bit) & 1u) ? 1.0f : float(kIcnnSlope); }
@@ -241,7 +238,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     }
     return raw;
   };
-  auto rows_commit = [&](const RowRaw& raw, int slot, long long mask_tile = -1) {
+  auto rows_commit = [&](const RowRaw& raw, int slot) {
     if (tid < kRows) {
       float q[3] = {0.f, 0.f, 1.f};
       if (raw.ok) {
@@ -259,10 +256,6 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       ((float*)&ring.v[slot][r][1])[i] = raw.r;
     }
     if (KIND != kFwd1) ((uint32_t*)&ring.v[slot][tid >> 3][2])[tid & 7] = raw.m;
-    if (KIND == kBwd1 && !BF16 && g.M1b && mask_tile >= 0) {  // (row tid >> 3, word tid & 7 of tile `mask_tile`)
-      const int row = tid >> 3, word = tid & 7;
-      g.M1b[((mask_tile * 4 + (word >> 1)) * 16 + (row >> 1)) * 4 + (word & 1) * 2 + (row & 1)] = raw.m;
-    }
   };
 
   // ---- side work of the MFMA steps comes in two halves: the LDS reads of a step's inputs are issued ONE STEP AHEAD (side_in),
@@ -498,8 +491,8 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     PIPE_STAMP(10);
     __syncthreads();  // (the ring is zeroed)
     PIPE_STAMP(11);
-    rows_commit(r0, 0, tile_of(0) < n_tiles ? tile_of(0) : -1);
-    rows_commit(r1, 1, tile_of(1) < n_tiles && my_tiles > 1 ? tile_of(1) : -1);
+    rows_commit(r0, 0);
+    rows_commit(r1, 1);
     PIPE_STAMP(12);
   }
   __syncthreads();
@@ -667,7 +660,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       epi_end(0, t_cur, pbuf);
     }
     if (it < 3) PIPE_STAMP(4 + 4 * (int)it);
-    rows_commit(raw, (int)((it + 2) & 3), it + 2 < my_tiles ? tile_of(it + 2) : -1);
+    rows_commit(raw, (int)((it + 2) & 3));
     if (it < 3) PIPE_STAMP(5 + 4 * (int)it);
   }
 
@@ -706,125 +699,10 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   PIPE_STAMP(15);
 }
 
-// =================================================================================================================================
-// d|Wh| = Vb^T U1 as a split-K GEMM (round 5; the 8-wave icnn_bwd2_mfma ran at 0.26 of its matrix floor at 4096 pairs).  With the
-// cost model of the f32 MFMA in hand (every VALU / LDS instruction adds to the MFMA time) the kernel is built for the fewest of them:
-//   * a workgroup = four waves, one per SIMD; it owns a 64 x 64 block of the output and one of `n_slabs` slabs of row tiles, its
-//     waves take the slab's tiles in turn -- each wave four accumulators (2 k-tiles x 2 j-tiles), so one step = FOUR independent
-//     MFMAs on two A and two B values;
-//   * A = Vb as the operand tiles icnn_bwd1 left: straight from memory into registers, one 16-byte load per four steps and k-tile,
-//     the next tile's eight loads in flight under this tile's 64 MFMAs -- no LDS staging, no barrier in the loop;
-//   * B = U1 = |wout| (mask ? 1 : 1/2) has two values per column: ONE v_cndmask per value, its lane mask -- lanes 0..31 = row 2 s,
-//     lanes 32..63 = row 2 s + 1 of the step -- an aligned SGPR pair out of a 64-byte scalar load of the compact mask array;
-//   * at the end the four waves' accumulators are summed through LDS in a fixed order: 16 slabs to reduce instead of 64.
-// Per step: 256 cycles of MFMA + ~10 for leaving the MFMA stream + 2 VALU -- ~0.9 of the matrix rate in the loop.
-// =================================================================================================================================
-constexpr int kB2Slabs = 16;
-
-__device__ __forceinline__ float select_by_lane_mask(float if_clear, float if_set, unsigned long long mask) {
-  float out;
-  asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(if_clear), "v"(if_set), "s"(mask));
-  return out;
-}
-// four independent MFMAs of one step: (a0, a1) x (b0, b1)
-__device__ __forceinline__ void mfma_2x2(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, float a0, float a1, float b0, float b1) {
-  // (s_nop 1: b0 / b1 come fresh from a VALU instruction -- the v_cndmask above, itself inside an asm statement, so hipcc pads nothing)
-  asm volatile("s_nop 1\n\t"
-               "v_mfma_f32_32x32x2_f32 %0, %4, %6, %0\n\t"
-               "v_mfma_f32_32x32x2_f32 %1, %4, %7, %1\n\t"
-               "v_mfma_f32_32x32x2_f32 %2, %5, %6, %2\n\t"
-               "v_mfma_f32_32x32x2_f32 %3, %5, %7, %3"
-               : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11) : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
-}
-
-__global__ __launch_bounds__(256) void icnn_bwd2_pipe_kernel(long long N, const float* __restrict__ VbT, const uint32_t* __restrict__ M1b,
-                                                            const float* __restrict__ a, float* __restrict__ slabs, int n_slabs) {
-  __shared__ float red[4][64][64];  // [wave][accumulator, register][lane]
-  // one wave per SIMD has to be CLAIMED: at 143 registers and 64 KB of LDS two of these workgroups fit a CU,
-  // and the dispatcher doubles them up while other CUs idle -- first measurement 42 us per launch, twice the model.  Touching a high
-  // accumulation register lifts the wave's allocation over half the register file.
-  asm volatile("v_accvgpr_write_b32 a127, 0" ::: "a127");
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int jblk = blockIdx.x & 3, kblk = (blockIdx.x >> 2) & 3, slab = blockIdx.x >> 4;
-  const long long n_tiles = (N + kRows - 1) / kRows;
-  const long long per = (n_tiles + n_slabs - 1) / n_slabs;
-  const long long t_begin = (long long)slab * per, t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
-  const float a0 = a[64 * jblk + l31], a1 = a[64 * jblk + 32 + l31];
-  const float h0 = a0 * float(kIcnnSlope), h1 = a1 * float(kIcnnSlope);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // this lane's A values of a tile: k-tile kt, float4 q (steps 4 q .. 4 q + 3)
-  auto fetch = [&](long long t, f32x4 (&dst)[2][4]) {
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const f32x4* src = (const f32x4*)(VbT + (t * 8 + 2 * kblk + kt) * 1024) + l31 * 2 + half;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dst[kt][q] = src[q * 64];
-    }
-  };
-  // The lane masks of FOUR steps' B values = 16 consecutive words of the compact mask array icnn_bwd1 wrote ([tile][block][step]
-  // [j-tile][row parity]): one 64-byte scalar load, requested a group of four steps ahead of its use.  (First version: two 8-byte
-  // scalar loads per step from the (N, 8) array -- every step a miss of the scalar cache, ~450 cycles exposed behind each
-  // step's MFMAs because a wait for scalar loads is a wait for ALL of them: 42 us per launch.)
-  using u32x16 = __attribute__((ext_vector_type(16))) uint32_t;
-  auto load_masks = [&](long long tile, int group) {
-    return *(const u32x16*)(M1b + ((tile * 4 + jblk) * 16 + 4 * group) * 4);
-  };
-  f32x4 cur[2][4], nxt[2][4];
-  long long t = t_begin + wv;
-  u32x16 mk = {}, mkn = {};
-  if (t < t_end) {
-    fetch(t, cur);
-    mk = load_masks(t, 0);
-  }
-  for (; t < t_end; t += 4) {
-    const bool more = t + 4 < t_end;
-    if (more) fetch(t + 4, nxt);
-#pragma unroll
-    for (int grp = 0; grp < 4; ++grp) {
-      mkn = grp < 3 ? load_masks(t, grp + 1) : load_masks(more ? t + 4 : t, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int st = 4 * grp + e;
-        const unsigned long long m0 = (unsigned long long)mk[4 * e] | ((unsigned long long)mk[4 * e + 1] << 32);
-        const unsigned long long m1 = (unsigned long long)mk[4 * e + 2] | ((unsigned long long)mk[4 * e + 3] << 32);
-        const float b0 = select_by_lane_mask(h0, a0, m0), b1 = select_by_lane_mask(h1, a1, m1);
-        mfma_2x2(acc[0][0], acc[0][1], acc[1][0], acc[1][1], cur[0][st >> 2][st & 3], cur[1][st >> 2][st & 3], b0, b1);
-      }
-      mk = mkn;
-    }
-    if (more) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cur[kt][q] = nxt[kt][q];
-    }
-  }
-  // (an XDL result needs 18 wait states before a VALU / LDS instruction may read it: hipcc pads nothing behind an asm statement)
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[wv][(2 * i + j) * 16 + r][lane] = acc[i][j][r];
-  __syncthreads();
-  // wave w sums accumulator (kt, jt) = (w >> 1, w & 1) of the four waves, in wave order, and writes it to the slab
-  float* out = slabs + (long long)slab * kW * kW;
-  const int kt = wv >> 1, jt = wv & 1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int e = (2 * kt + jt) * 16 + r;
-    const float v = (red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane]);
-    out[(64 * kblk + 32 * kt + mfma_row(r, half)) * kW + 64 * jblk + 32 * jt + l31] = v;
-  }
-}
+// (d|Wh| = Vb^T U1, the split-K GEMM, stays with the 8-wave icnn_bwd2_mfma: three pipelined versions were built and measured in
+// round 5 -- 64 x 64 output blocks with scalar-loaded lane masks 42 us, the same on a compact mask array 29.1 us, 64 x 256 blocks
+// with sixteen accumulators per wave in AGPRs 30.4 us, main loop at 0.81 of the matrix rate -- none ahead of its 28.7-29.3 us at
+// 4096 pairs (2 row tiles per wave: the launch is prologue- and reduction-bound); NOTEBOOK.md R5.1 has the account.)
 
 inline int check(const char* what) {
   const hipError_t e = hipGetLastError();
@@ -856,24 +734,13 @@ int fwd2(hipStream_t stream, const float* x, long long ld, long long N, const Ic
 }
 
 int bwd1(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const float* Af, const float* a,
-         const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT, uint32_t* M1b) {
+         const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT) {
   if (N <= 0) return 0;
   if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
-  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = VbT; g.M1b = M1b;
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = Af; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = VbT;
   hipLaunchKernelGGL(icnn_pipe_kernel<kBwd1>, dim3(blocks(N)), dim3(256), 0, stream, g);
   return check("icnn_pipe_kernel<bwd1>");
-}
-
-int bwd2_slabs(long long N) {
-  const long long t = tiles(N) / 4;  // (at least four row tiles per slab: one per wave)
-  return (int)(t < 1 ? 1 : (t > kB2Slabs ? kB2Slabs : t));
-}
-
-int bwd2(hipStream_t stream, long long N, const float* VbT, const uint32_t* M1b, const float* a, float* slabs, int n_slabs) {
-  if (N <= 0 || n_slabs < 1) return -1;
-  hipLaunchKernelGGL(icnn_bwd2_pipe_kernel, dim3(16 * n_slabs), dim3(256), 0, stream, N, VbT, M1b, a, slabs, n_slabs);
-  return check("icnn_bwd2_pipe_kernel");
 }
 
 // ---- the split-bf16 form (2 planes): the same three kernels on the bf16 matrix cores; Ab / ATb = the planes icnn_prep_bf16_kernel<2>

@@ -25,13 +25,8 @@ int fwd1(hipStream_t stream, const float* x, long long ld, long long N, const dp
 int fwd2(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const float* ATf,
          const float* a, const uint32_t* M1, float* U0t, float* P);
 // Vb = (RB Wd0) . m0 (-> operand tiles VbT);  U1b = Vb |Wh| + RB Wd1;  partial rows [d|wout| | dWd1 | dWd0] per workgroup
-// (M1b: optional -- the mask words once more, (tiles, 4, 16, 2, 2), in the order bwd2's scalar loads read them)
 int bwd1(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const float* Af,
-         const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT, uint32_t* M1b);
-// d|Wh| = Vb^T U1 as a split-K GEMM over `n_slabs` slabs of rows (U1 rebuilt from the mask words)
-int bwd2(hipStream_t stream, long long N, const float* VbT, const uint32_t* M1b, const float* a, float* slabs, int n_slabs);
-int bwd2_slabs(long long N);  // the slabs bwd2 writes for N rows (<= 16: what the reduce kernel then sums)
-
+         const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT);
 // the same three on the bf16 matrix cores, operands split into 2 bf16 planes (dpll_solver_opts_t.mesh_gemm = 2): Ab / ATb = the
 // weight planes of icnn_prep_bf16_kernel<2>; Vb leaves row-major for icnn_bwd2_bf16
 int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* Ab, uint32_t* M1);

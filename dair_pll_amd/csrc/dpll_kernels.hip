@@ -1043,7 +1043,7 @@ struct MeshPlan {
   long long N, n_tiles;
   int n_nets, loss_blocks, gemm_blocks, b1_blocks, n_slabs, row_stride;
   // one block of buffers per network (offsets relative to the block): the backward of a network needs its own forward
-  size_t off_A, off_AT, off_Af, off_ATf, off_Ab, off_ATb, off_a, off_M1, off_M1b, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
+  size_t off_A, off_AT, off_Af, off_ATf, off_Ab, off_ATb, off_a, off_M1, off_U0, off_Vb, off_U1, off_b1, off_slabs, net_bytes;
   // shared: support points / their adjoints of all networks (batch, 4 n_nets, 3), the loss kernel's rows + chain matrix,
   // the bodies' world quaternions (batch, n_nets, 4; only for n_nets > 1)
   size_t off_P, off_RB, off_rows, off_bq, off_nets, total;
@@ -1072,7 +1072,6 @@ template <typename T> void plan_network_block(MeshPlan& pl, long long N) {
   pl.off_ATb = take(kMfma ? 2 * 3 * kW * kW : 0);
   pl.off_a = take(sizeof(T) * kW);
   pl.off_M1 = take(sizeof(uint32_t) * kMaskWords * pl.N);
-  pl.off_M1b = take(kMfma ? sizeof(uint32_t) * kMaskWords * kMfmaRows * tiles : 0);  // the same words in the pipelined bwd2's order
   // (float: whole 32-row tiles + one spare -- the pipelined kernels (dpll_icnn_pipe.hip) keep U0 in the accumulator layout
   // of the MFMA and send the stores of tiles that do not exist to the spare one)
   pl.off_U0 = take(sizeof(T) * kW * (kMfma ? kMfmaRows * (tiles + 1) : pl.N));
@@ -1245,7 +1244,7 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
                   T* loss_total, hipStream_t stream, const T* adjoints = nullptr, const AdamArgs* adam = nullptr, long long w_offset = 0) {
   char* nb = pl.net(ws, g);
   const T* RB = adjoints ? adjoints : (const T*)(ws + pl.off_RB) + 12 * g;
-  int n_slabs = pl.n_slabs;  // (what the reduce kernel sums: the weight-gradient GEMM in use decides)
+  const int n_slabs = pl.n_slabs;
   if constexpr (std::is_same<T, float>::value) {
 #define DPLL_BWD_BF16(PL_)                                                                                                         \
     do {                                                                                                                          \
@@ -1270,12 +1269,12 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
     else if (t_mesh_gemm == 0) {
       if (int rc = dpll_pipe::bwd1(stream, (const float*)q.ptr, q.ld, pl.N, w, (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a),
                                    (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_U0), (const float*)RB,
-                                   (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb), (uint32_t*)(nb + pl.off_M1b))) return rc;
+                                   (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb))) return rc;
       mesh_mark(stream);
-      n_slabs = dpll_pipe::bwd2_slabs(pl.N);  // (<= 16; never more than the plan's count, which the slab buffer is sized for)
-      if (n_slabs > pl.n_slabs) n_slabs = pl.n_slabs;
-      if (int rc = dpll_pipe::bwd2(stream, pl.N, (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1b),
-                                   (const float*)(nb + pl.off_a), (float*)(nb + pl.off_slabs), n_slabs)) return rc;
+      // (the weight-gradient GEMM stays with the 8-wave kernel: three pipelined versions measured no better, dpll_icnn_pipe.hip)
+      hipLaunchKernelGGL(icnn_bwd2_mfma, dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
+                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
+                         (float*)(nb + pl.off_slabs));
     } else {
       hipLaunchKernelGGL(icnn_bwd1_mfma, dim3(pl.b1_blocks), dim3(512), 0, stream, (const float*)q.ptr, q.ld, pl.N, w,
                          (const float*)(nb + pl.off_Af), (const float*)(nb + pl.off_a), (const uint32_t*)(nb + pl.off_M1),

@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     auto launch = [&]() {
       if (k == 0) dpll_pipe::fwd1(0, x, 13, N, w, F, M1);
       if (k == 1) dpll_pipe::fwd2(0, x, 13, N, w, F, a, M1, U0, P);
-      if (k == 2) dpll_pipe::bwd1(0, x, 13, N, w, F, a, M1, U0, RB, partial, Vb, nullptr);
+      if (k == 2) dpll_pipe::bwd1(0, x, 13, N, w, F, a, M1, U0, RB, partial, Vb);
       if (k == 3) dpll_pipe::fwd1_bf16(0, x, 13, N, w, F, M1);   // (F read as two bf16 planes: 256 KB of arbitrary finite numbers)
       if (k == 4) dpll_pipe::fwd2_bf16(0, x, 13, N, w, F, a, M1, U0, P);
       if (k == 5) dpll_pipe::bwd1_bf16(0, x, 13, N, w, F, a, M1, U0, RB, partial, Vb);
