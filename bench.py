@@ -215,7 +215,10 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
                 'traffic': None, 'kernel': dominant, 'kernel_ms': gemms[dominant],
                 'algorithmic_flops_per_launch': flops, 'all_kernels_ms': mesh_ms,
                 'pipeline_gemm_tflops': 4 * flops / (sum(gemms.values()) * 1e-3) / 1e12,
-                'note': 'v_mfma_f32_32x32x2_f32 (exact f32); peak = dense f32 matrix rate of MI355X_MICROARCH.md'
+                'note': 'v_mfma_f32_32x32x2_f32 (exact f32); peak = dense f32 matrix rate of MI355X_MICROARCH.md.  That rate needs the '
+                        'vector ALU to itself: the f32 MFMA runs on its multipliers, so every VALU / LDS instruction of the fused fill and '
+                        'epilogue adds to the MFMA time (profiles/r05_mfma_fill.txt, r05_mfma_step.txt), and the chip runs these kernels '
+                        'at ~2.15 GHz (matrix floor of one GEMM at 4096 pairs: 15.2 us)'
                         if dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
     passes = [system.profile_loss_kernels(x, xp, reps=200) for _ in range(3)]  # (HIP events on the launch stream, 200 launches each)
     ms_loss, ms_fin = sorted(p[0] for p in passes)[1], sorted(p[1] for p in passes)[1]
@@ -298,12 +301,14 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
             'roofline': {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel') if k in roof}}
 
 
-def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device):
+def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device, mesh_gemm=0):
     """fused rollouts (dpll_simulate: the time loop inside the kernel): one step = one VelocityIntegrator.step of one
     trajectory; algorithmic bytes per step = read x + write x+ (cube 104 B in f32)"""
     dtype = torch.float32 if dtype_name == 'f32' else torch.float64
     x_np, _, dt = load_pairs(batch, 0, workload)
     system = build_system(workload, dtype_name, dt, device)
+    if mesh_gemm:  # the ICNN GEMMs of the learned shape on the bf16 matrix cores (operands split into bf16 planes)
+        system.set_solver(mesh_gemm=mesh_gemm)
     x0 = torch.tensor(x_np, dtype=dtype, device=device).unsqueeze(-2)
     carry = torch.zeros((batch, 1), device=device)
     with torch.no_grad():
@@ -321,7 +326,8 @@ def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device):
     ms = float(np.median(times))
     if workload == 'mesh':  # per step two forward GEMMs of (4 batch) x 256 x 256 (the support points follow the state)
         tflops = 2 * 2.0 * (4 * batch) * 256 * 256 * horizon / (ms * 1e-3) / 1e12
-        return {'workload': f'simulate ({workload}, {horizon} steps per call)', 'dtype': dtype_name, 'batch': batch,
+        return {'workload': f'simulate ({workload}, {horizon} steps per call)' + (f', ICNN GEMMs on the bf16 matrix cores ({mesh_gemm} planes)' if mesh_gemm else ''),
+                'dtype': dtype_name, 'batch': batch,
                 'value': batch * horizon / (ms * 1e-3), 'unit': 'trajectory-steps/s (forward only)', 'ms_per_step': ms / horizon,
                 'kernel_ms': ms, 'launch': 'dpll_simulate_mesh: weights prepared once, 4 kernels per step enqueued by the library',
                 'roofline': {'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -624,6 +630,7 @@ def main() -> None:
                     configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
             try:
                 configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=2))
+                configs.append(run_simulate_config('mesh', 'f32', 4096, 80, 5, device, mesh_gemm=2))
             except Exception as exc:  # noqa: BLE001
                 configs.append({'workload': 'mesh (bf16 planes)', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
             for w, k, fused in (('cube', 400, False), ('cube', 400, True), ('slider', 60, True), ('mesh', 60, True)):

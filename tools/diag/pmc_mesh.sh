@@ -12,7 +12,7 @@ for sub, tag in (('p1', ''), ('p2', ''), ('p3', ' [mesh_gemm=2]')):
     acc = collections.defaultdict(lambda: [0.0, 0])
     try:
         for r in csv.DictReader(open(f'gpurun_out/pmc_mesh/{sub}/run_counter_collection.csv')):
-            m = re.search(r'(icnn_\w+(?:<\d>)?|loss_kernel)', r['Kernel_Name'])
+            m = re.search(r'(icnn_pipe_kernel<[^>]*>|icnn_\w+(?:<\d>)?|loss_kernel)', r['Kernel_Name'])
             if not m:
                 continue
             k = (m.group(1) + tag, r['Counter_Name'])

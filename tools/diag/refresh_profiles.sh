@@ -5,7 +5,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/${TAG}p
 rm -rf $O; mkdir -p $O
 B="--no-cpu-baseline --no-configs"
@@ -26,7 +26,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq1 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph $B > $O/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/pmc_sq1_p1 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph --portfolio 1 $B > $O/pmc_sq1_p1.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d $O/pmc_sq2 -o run -- python3 bench.py --steps 20 --warmup 0 --no-graph $B > $O/pmc_sq2.log 2>&1
-python3 tools/diag/stamps.py > $O/stamps.txt 2>&1
+[ -f tools/diag/libdpll_hip_stamps.so ] && python3 tools/diag/stamps.py > $O/stamps.txt 2>&1  # (the -DDPLL_STAMPS build of the CURRENT ABI: see tools/diag/stamps.py)
 bash tools/diag/pmc_mesh.sh > $O/pmc_mesh.txt 2>&1
 cp -r gpurun_out/pmc_mesh $O/ 2>/dev/null
 python3 tools/diag/time_general.py > $O/general_times.txt 2>&1
@@ -39,7 +39,8 @@ find $O -name 'run_kernel_trace.csv' -delete
 find $O -name '*_agent_info.csv' -delete
 # the summaries profiles/ keeps are made here (the raw counter tables are tens of MB: over gpurun's 64 MiB return limit)
 for f in general_times.txt pmc_mesh.txt forest_times.txt forest_stamps.txt; do cp $O/$f gpurun_out/r03_profiles_$f 2>/dev/null; done
+cp gpurun_out/mesh_pmc.csv gpurun_out/r03_profiles_mesh_pmc.csv 2>/dev/null
 DPLL_PROFILE_DST=gpurun_out/${TAG}_profiles python3 tools/diag/summarize_profiles.py ${TAG}p ${TAG} > gpurun_out/${TAG}_summarize.log 2>&1
-mv gpurun_out/r03_profiles_*.txt gpurun_out/${TAG}_profiles/ 2>/dev/null
+mv gpurun_out/r03_profiles_*.txt gpurun_out/r03_profiles_*.csv gpurun_out/${TAG}_profiles/ 2>/dev/null
 rm -rf $O
 ls gpurun_out/${TAG}_profiles

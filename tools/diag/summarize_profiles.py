@@ -2,10 +2,10 @@
 import csv, json, os, re, shutil, sys
 from collections import defaultdict
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r04p')
+SRC = os.path.join(REPO, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'r05p')
 DST = os.environ.get('DPLL_PROFILE_DST', os.path.join(REPO, 'profiles'))  # (on the GPU box: a directory under gpurun_out/)
 os.makedirs(DST, exist_ok=True)
-TAG = sys.argv[2] if len(sys.argv) > 2 else 'r04'
+TAG = sys.argv[2] if len(sys.argv) > 2 else 'r05'
 KERNEL = 'loss_kernel<float, 0, false'  # <T, NJ, MESH, DENSE>: the box builds
 
 
@@ -21,7 +21,7 @@ def counter_means(path):
 shutil.copy(os.path.join(SRC, 'stats', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_f32_kernel_stats.csv'))
 for sub, name in (('stats_mesh', 'mesh_f32'), ('stats_f64', 'f64'), ('stats_elbow', 'elbow_f32'), ('stats_elbow_f64', 'elbow_f64'),
                   ('stats_b65536', 'f32_b65536'), ('stats_b65536_f64', 'f64_b65536'), ('stats_sim', 'simulate'),
-                  ('stats_mesh_bf16', 'mesh_bf16x3'), ('stats_general', 'general_build'), ('stats_clasp_mesh', 'clasp_mesh'),
+                  ('stats_mesh_bf16', 'mesh_bf16'), ('stats_general', 'general_build'), ('stats_clasp_mesh', 'clasp_mesh'),
                   ('stats_forest', 'forest_build')):
     src = os.path.join(SRC, sub, 'run_kernel_stats.csv')
     if os.path.exists(src):
@@ -58,7 +58,9 @@ old.update({'FETCH_SIZE_KB_per_launch': round(fetch_kb, 2), 'WRITE_SIZE_KB_per_l
             'method': f'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no trace domains), means over {n_f} / {n_w} '
                       'dispatches of python3 bench.py --steps 20 --no-graph; unit KB as reported.'})
 json.dump(old, open(os.path.join(DST, f'{TAG}_hbm_traffic.json'), 'w'), indent=1)
-with open(os.path.join(SRC, 'stamps.txt')) as f:
+text = []
+if os.path.exists(os.path.join(SRC, 'stamps.txt')):
+  with open(os.path.join(SRC, 'stamps.txt')) as f:
     text = [l for l in f.read().splitlines() if 'amdgpu.ids' not in l]
 with open(os.path.join(DST, f'{TAG}_loss_kernel_stamps.txt'), 'w') as f:
     f.write('tools/diag/stamps.py, f32, B=4096, the shipping launch: racing build, 256 four-wave workgroups of 16 items (a wave: 4 items x '
