@@ -20,8 +20,10 @@ GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 22  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 23  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
+MAX_WELD_ROWS = 64  # DPLL_MAX_WELD_ROWS
+INERTIA_COMPOSED = 2  # DPLL_INERTIA_COMPOSED: set by make_desc / make_forest_desc for models with welded links, never by a caller
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (DPLL_HIP_LIBRARY: a diagnostic knob -- tools/diag A/B runs load another build of the same library; never a fallback)
@@ -96,7 +98,8 @@ def make_desc(spec: ModelSpec, dt: float, inertia_mode: str = 'reference_literal
     check_supported(spec)
     desc = ModelDesc()
     desc.n_joints = spec.n_joints
-    desc.inertia_mode = INERTIA_MODES[inertia_mode]
+    # (links welded on with rows of their own: the kernels are handed the bodies' composed inertial vectors, csrc/dpll_weld.hip)
+    desc.inertia_mode = INERTIA_COMPOSED if spec.has_welded_rows() else INERTIA_MODES[inertia_mode]
     desc.dt = dt
     desc.gravity_z = spec.gravity_z
     # The kernels' body frames all coincide at zero joint angles.  A URDF whose joint <origin>s carry a rotation is
@@ -155,7 +158,8 @@ def make_forest_desc(system_spec, dt: float, inertia_mode: str = 'reference_lite
     from .urdf import check_forest_supported
     check_forest_supported(system_spec)
     desc = ForestDesc()
-    desc.inertia_mode = INERTIA_MODES[inertia_mode]
+    # (links welded on with rows of their own: the kernels are handed the bodies' composed inertial vectors, csrc/dpll_weld.hip)
+    desc.inertia_mode = INERTIA_COMPOSED if system_spec.has_welded_rows() else INERTIA_MODES[inertia_mode]
     desc.dt = dt
     desc.gravity_z = system_spec.models[0].gravity_z
     eye = [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]
@@ -227,6 +231,30 @@ def make_forest_desc(system_spec, dt: float, inertia_mode: str = 'reference_lite
     desc.n_contacts = contact
     desc.rotated = (1 if body_rot_turned else 0) | (2 if geom_rot_turned else 0)
     return desc
+
+
+def weld_transform(rotation, origin):
+    """``X`` (10 x 10) with ``iota_body = X iota_link``: an inertial vector ``[m, m c, I_o (xx, yy, zz, xy, xz, yz)]`` given in a
+    link's frame, about the link's origin, taken to the frame of the body the link is welded on -- a point ``p`` of the link
+    sits at ``R p + t`` there.  ``m`` stays, ``h = m c -> R h + m t``, ``I_o -> R I_o R^T + m (|t|^2 1 - t t^T) + 2 (t . R h) 1
+    - t (R h)^T - (R h) t^T`` (the integral of ``|p|^2 1 - p p^T``): linear in the vector, which is why a body's inertia is a sum
+    over its links that the gradient passes through unchanged (``include/dpll.h``: dpll_weld_compose)."""
+    import numpy as np
+    R, t = np.asarray(rotation, dtype=np.float64), np.asarray(origin, dtype=np.float64)
+    X = np.zeros((10, 10))
+    slots = [(0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2)]
+    for j in range(10):
+        e = np.zeros(10)
+        e[j] = 1.0
+        m, h = e[0], e[1:4]
+        I = np.array([[e[4], e[7], e[8]], [e[7], e[5], e[9]], [e[8], e[9], e[6]]])
+        Rh = R @ h
+        I_new = (R @ I @ R.T + m * (t @ t * np.eye(3) - np.outer(t, t))
+                 + 2.0 * (t @ Rh) * np.eye(3) - np.outer(t, Rh) - np.outer(Rh, t))
+        X[0, j] = m
+        X[1:4, j] = Rh + m * t
+        X[4:, j] = [I_new[a, b] for a, b in slots]
+    return X
 
 
 class DpllError(RuntimeError):
@@ -310,6 +338,9 @@ def library() -> ctypes.CDLL:
     lib.dpll_ar_destroy.restype = None
     lib.dpll_terms.argtypes = [c_void_p, c_int, POINTER(Params), c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dpll_weld_compose.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.dpll_weld_compose_backward.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_int, c_void_p]
     _lib = lib
     return lib
 
@@ -326,4 +357,5 @@ EXPORTED_SYMBOLS = ['dpll_last_error', 'dpll_abi_version', 'dpll_model_create', 
                     'dpll_terms', 'dpll_mesh_param_count', 'dpll_mesh_workspace_bytes', 'dpll_contactnets_loss_mesh',
                     'dpll_profile_contactnets_loss_mesh',
                     'dpll_step_mesh', 'dpll_simulate_mesh', 'dpll_mesh_support_points', 'dpll_ar_handle_bytes', 'dpll_ar_create', 'dpll_ar_connect',
-                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh', 'dpll_contactnets_train_step', 'dpll_contactnets_train_step_mesh']
+                    'dpll_ar_allreduce', 'dpll_ar_status', 'dpll_ar_destroy', 'dpll_contactnets_loss_allreduce', 'dpll_terms_mesh', 'dpll_step_backward_mesh', 'dpll_contactnets_train_step', 'dpll_contactnets_train_step_mesh',
+                    'dpll_weld_compose', 'dpll_weld_compose_backward']

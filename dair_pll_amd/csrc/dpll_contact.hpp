@@ -39,7 +39,9 @@ DPLL_HD void derive_params(const MD& md, const T* theta, const T* friction, cons
   DPLL_UNROLL for (int b = 0; b <= NJ; ++b) {
     T th[10];
     DPLL_UNROLL for (int i = 0; i < 10; ++i) th[i] = theta[10 * b + i];
-    theta_to_iota<T>(th, md.inertia_mode, dp.iota[b]);
+    // (mode 2, rows that are composites of welded links, is the general / forest builds': masked out of the specialised ones so
+    // that their code is what it was)
+    theta_to_iota<T>(th, MD::kGeneral ? md.inertia_mode : (md.inertia_mode & 1), dp.iota[b]);
     if constexpr (MD::kGeneral) {
       if (DPLL_ROTATED(md) & 1) rotate_iota<T>(md.body_rot[b], dp.iota[b]);
     }

@@ -714,7 +714,8 @@ int check_desc(const dpll_forest_desc_t* d) {
   if (d->n_contacts < 1 || d->n_contacts > kMaxContacts) return dpll_fail(-2, "dpll_forest_model_create: 1 to 64 contacts%s");
   if (d->n_v < 1 || d->n_v > kMaxV) return dpll_fail(-2, "dpll_forest_model_create: 1 to 32 generalized velocities%s");
   if (!(d->dt > 0.0)) return dpll_fail(-1, "dpll_forest_model_create: dt must be positive%s");
-  if (d->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && d->inertia_mode != DPLL_INERTIA_PHYSICAL)
+  if (d->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && d->inertia_mode != DPLL_INERTIA_PHYSICAL &&
+      d->inertia_mode != DPLL_INERTIA_COMPOSED)
     return dpll_fail(-1, "dpll_forest_model_create: unknown inertia_mode%s");
   if (d->rotated & ~3) return dpll_fail(-1, "dpll_forest_model_create: rotated holds bits 0 and 1 only%s");
   int n_q = 0, n_v = 0, max_depth = 0;

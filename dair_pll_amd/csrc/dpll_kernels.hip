@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WAVES * kWave, DENSE ? 2 : 1) void loss_kernel(cons
   const int slot = lane / (G * RACE);
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
-    if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode & 1, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
     return;
   }
   DPLL_STAMP(0);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(WAVES * kWave) void loss_kernel_wide(const T* __res
   const int lane = threadIdx.x;
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
-    if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    if (want_grad && lane < kWave) write_chain_matrix<T, T, D::NB>(md.inertia_mode & 1, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
     return;
   }
   Derived<T, NJ> dp;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kWave) void step_backward_kernel(ModelDesc md, Solv
   const int slot = lane / D::G;
   const int item_blocks = (int)gridDim.x - 1;  // the last workgroup owns no items: it writes the chain matrix
   if ((int)blockIdx.x == item_blocks) {
-    write_chain_matrix<C, T, D::NB>(md.inertia_mode, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
+    write_chain_matrix<C, T, D::NB>(md.inertia_mode & 1, theta, friction, lengths, partials + (long long)item_blocks * D::PI);
     return;
   }
   C theta_c[D::NB * 10], friction_c[D::NB + 1], lengths_c[D::NB * 3];
@@ -1807,7 +1807,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 22; }
+int dpll_abi_version(void) { return 23; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1866,8 +1866,11 @@ int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
     return fail(-2, "dpll_model_create: rotated frames need the general build (n_geoms > 0)%s");
   }
   if (!(desc->dt > 0.0)) return fail(-1, "dpll_model_create: dt must be positive%s");
-  if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL)
+  if (desc->inertia_mode != DPLL_INERTIA_REFERENCE_LITERAL && desc->inertia_mode != DPLL_INERTIA_PHYSICAL &&
+      desc->inertia_mode != DPLL_INERTIA_COMPOSED)
     return fail(-1, "dpll_model_create: unknown inertia_mode%s");
+  if (desc->inertia_mode == DPLL_INERTIA_COMPOSED && !general)
+    return fail(-2, "dpll_model_create: composed inertial rows (welded links) need the general build (n_geoms > 0)%s");
   // actuators (B u of lagrangian_forces, multibody_terms.py:142-146): the general build without learned shapes
   if (desc->n_u < 0 || desc->n_u > desc->n_joints) return fail(-1, "dpll_model_create: n_u must be between 0 and n_joints%s");
   if (desc->n_u > 0) {

@@ -97,7 +97,7 @@ constexpr int kRaceMaxStages = 8;
 // Plain-old-data model description, passed to kernels by value.
 struct ModelDesc {
   int32_t n_joints;
-  int32_t inertia_mode;  // 0: reference_literal (rotational inertia taken as I_cm / m), 1: physical
+  int32_t inertia_mode;  // 0: reference_literal (rotational inertia taken as I_cm / m), 1: physical, 2: composed (rows are iota)
   double dt;
   double gravity_z;
   double joint_origin[kMaxJoints][3];  // joint j+1 frame origin in the parent body frame
@@ -255,6 +255,10 @@ DPLL_HD double s_exp(const double& x) { return exp(x); }
 template <typename T> DPLL_HD DualT<T> s_exp(const DualT<T>& x) { const T e = s_exp(x.v); return DualT<T>(e, e * x.d); }
 
 template <typename S> DPLL_HD void theta_to_iota(const S (&th)[10], int inertia_mode, S (&iota)[kIota]) {
+  if (inertia_mode == 2) {  // the rows ARE the bodies' inertial vectors (composites of welded links: csrc/dpll_weld.hip)
+    DPLL_UNROLL for (int i = 0; i < kIota; ++i) iota[i] = th[i];
+    return;
+  }
   const S &alpha = th[0], &d1 = th[1], &d2 = th[2], &d3 = th[3], &s12 = th[4], &s23 = th[5], &s13 = th[6],
           &t1 = th[7], &t2 = th[8], &t3 = th[9];
   const S e1 = s_exp(d1), e2 = s_exp(d2), e3 = s_exp(d3);

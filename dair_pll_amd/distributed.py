@@ -168,4 +168,5 @@ class GradientAllReduce:
             self.peer.all_reduce(buf)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        self.system.after_grad_reduce()  # (rows of welded links: chained from the summed buffer)
         return buf

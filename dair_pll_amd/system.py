@@ -181,7 +181,9 @@ class MultibodyTerms(Module):
 
     def __init__(self, spec: ModelSpec, dtype: torch.dtype, device: torch.device) -> None:
         super().__init__()
-        pi_cm = np.array([[b.mass] + [b.mass * c for c in b.com] + list(b.inertia_cm) for b in spec.bodies])
+        # one row per Drake body (multibody_terms.py:161-207): the kernel bodies, or -- a model whose `fixed` joints weld links
+        # that carry mass -- every link in document order, each with its OWN inertia (ModelSpec.inertia_rows)
+        pi_cm = np.array([[r.mass] + [r.mass * c for c in r.com] + list(r.inertia_cm) for r in spec.inertia_rows()])
         theta = np.stack([pi_cm_to_theta(row) for row in pi_cm])  # multibody_terms.py:186-188
         as_t = lambda a: torch.tensor(np.asarray(a), dtype=dtype, device=device)
         self.lagrangian_terms = LagrangianTerms(as_t(theta))
@@ -306,6 +308,18 @@ class MultibodyLearnableSystem(Module):
         self.global_batch = 0
         self._fused_ar: Optional[ctypes.c_void_p] = None  # peer all-reduce handle: the exchange rides in the loss launch
         self._u: Optional[Tensor] = None  # actuation inputs of the call in flight (see _actuated)
+        # links welded on with inertial rows of their own (the reference's parameter tree, multibody_terms.py:161-207): the
+        # kernels take the BODIES' composed inertial vectors, written into the theta block of the flat buffer before a launch
+        # (dpll_weld_compose) and chained back to the rows after it (dpll_weld_compose_backward)
+        self._weld: Optional[Dict[str, object]] = None
+        if self.spec.has_welded_rows():
+            rows = self.spec.inertia_rows()
+            if len(rows) > _capi.MAX_WELD_ROWS:
+                raise NotImplementedError(f'at most {_capi.MAX_WELD_ROWS} inertial rows per system')
+            transforms = np.stack([_capi.weld_transform(row.rotation, row.origin) for row in rows])
+            self._weld = {'n_rows': len(rows), 'mode': _capi.INERTIA_MODES[inertia_mode],
+                          'host': torch.tensor([row.body for row in rows], dtype=torch.int32, device=dev),
+                          'transforms': torch.tensor(transforms, dtype=torch.float64, device=dev).contiguous(), 'grad': None}
         self._grad_reduced = False  # the last contactnets_loss_and_grad already summed [loss | gradients] over the ranks
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -333,6 +347,8 @@ class MultibodyLearnableSystem(Module):
         terms = self.multibody_terms
         n_b, slots, stride = self.spec.n_bodies, self._geom_slots(), self._geo_stride()
         out = [(terms.lagrangian_terms.inertial_parameters, 0), (terms.contact_terms.friction_params, 10 * n_b)]
+        if self._weld is not None:  # (the rows are a tensor of their own: the buffer's theta block holds what they compose to)
+            out = out[1:]
         lengths0 = 10 * n_b + 1 + slots
         # (the general build always carries its lengths block; the specialised mesh builds have none)
         end = lengths0 if self.spec.is_fast() else lengths0 + stride * slots
@@ -350,7 +366,26 @@ class MultibodyLearnableSystem(Module):
         return out, end
 
     def _param_list(self) -> List[Parameter]:
-        return [p for p, _ in self._layout()[0]]
+        head = [] if self._weld is None else [self.multibody_terms.lagrangian_terms.inertial_parameters]
+        return head + [p for p, _ in self._layout()[0]]
+
+    def _weld_call(self, backward: bool, flat_block: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+        """``dpll_weld_compose`` (rows -> the bodies' inertial vectors, into ``flat_block``) or its backward (``flat_block`` = the
+        theta block of a gradient row -> the rows' gradient)"""
+        weld, lib = self._weld, _capi.library()
+        rows = self.multibody_terms.lagrangian_terms.inertial_parameters
+        if not (rows.is_cuda and rows.is_contiguous() and rows.dtype == self.dtype and flat_block.is_contiguous()):
+            raise _capi.DpllError('inertial_parameters must be a contiguous device tensor of the system\'s dtype')
+        if weld['host'].device != rows.device:
+            weld['host'], weld['transforms'] = weld['host'].to(rows.device), weld['transforms'].to(rows.device)
+        args = (_DTYPES[self.dtype], weld['mode'], weld['n_rows'], self.spec.n_bodies, _ptr(weld['host']), _ptr(weld['transforms']))
+        if not backward:
+            _capi.check(lib.dpll_weld_compose(*args, _ptr(rows.data), _ptr(flat_block), self._stream()))
+            return flat_block
+        if out is None:
+            out = torch.empty_like(rows.data)
+        _capi.check(lib.dpll_weld_compose_backward(*args, _ptr(rows.data), _ptr(flat_block), _ptr(out), int(accumulate), self._stream()))
+        return out
 
     def _mesh(self) -> Optional['DeepSupportConvex']:
         for geometry in self.multibody_terms.contact_terms.geometries:
@@ -418,6 +453,8 @@ class MultibodyLearnableSystem(Module):
                 p.data = flat[offset:offset + p.numel()].view(p.shape)
             self._flat = flat
             self._flat_grad = self._grad_buf = self._loss_total = None
+        if self._weld is not None and flat.is_cuda:
+            self._weld_call(False, flat[:10 * self.spec.n_bodies])
         return flat
 
     def _alloc_grad_buffer(self, n_params: int, device) -> None:
@@ -433,8 +470,17 @@ class MultibodyLearnableSystem(Module):
             self._alloc_grad_buffer(self._packed().numel(), self._packed().device)
         return self._grad_buf
 
-    def _split_flat(self, flat: Tensor) -> List[Tensor]:
-        return [flat[offset:offset + p.numel()].view(p.shape) for p, offset in self._layout()[0]]
+    def _split_flat(self, flat: Tensor, weld_out: Optional[Tensor] = None) -> List[Tensor]:
+        """the parameters' pieces of a flat gradient; welded links: the rows' gradient chained from the theta block (into
+        ``weld_out`` when given, else a new tensor)"""
+        head = [] if self._weld is None else [self._weld_call(True, flat[:10 * self.spec.n_bodies], weld_out)]
+        return head + [flat[offset:offset + p.numel()].view(p.shape) for p, offset in self._layout()[0]]
+
+    def after_grad_reduce(self) -> None:
+        """after a data-parallel SUM of :meth:`grad_buffer`: the rows of welded links are not views of that buffer, so their
+        gradient is chained again from its (now summed) theta block -- the chain is linear in it"""
+        if self._weld is not None and self._weld['grad'] is not None and self._flat_grad is not None:
+            self._weld_call(True, self._flat_grad[:10 * self.spec.n_bodies], self._weld['grad'])
 
     # ---- native handle ------------------------------------------------------------------------
     def _model(self) -> ctypes.c_void_p:
@@ -599,7 +645,9 @@ class MultibodyLearnableSystem(Module):
         # accumulate: the old gradients may BE views of the buffer the launch overwrites -- take them out first
         old = [None if (not accumulate or p.grad is None) else p.grad.clone() for p in self._param_list()]
         _, grad, total = self._launch_loss(xf, xpf, None, 1.0 / denom, True, want_loss=False, fused_ar=self._fused_ar)
-        for param, piece, before in zip(self._param_list(), self._split_flat(grad), old):
+        if self._weld is not None and self._weld['grad'] is None:
+            self._weld['grad'] = torch.empty_like(self.multibody_terms.lagrangian_terms.inertial_parameters.data)
+        for param, piece, before in zip(self._param_list(), self._split_flat(grad, None if self._weld is None else self._weld['grad']), old):
             if before is not None:
                 param.grad = before + piece
             elif param.grad is None or param.grad.data_ptr() != piece.data_ptr():
@@ -614,6 +662,9 @@ class MultibodyLearnableSystem(Module):
         (with the gradient exchange of a process group inside the same kernel), the general and the forest build (Adam in the
         kernel that chains the folded rows; single process) and the specialised mesh builds (Adam where the network's weight
         gradients are reduced); not the general build with learned shapes."""
+        if self._weld is not None:
+            raise NotImplementedError('the fused training step updates the flat parameter buffer in the kernel; the inertial rows of '
+                                      'welded links are not part of it: use contactnets_loss_and_grad + an optimizer')
         if self._mesh() is not None:
             return self._mesh_train_step(x, x_plus, adam)
         if not self.spec.is_fast() and self.grad_world > 1:
@@ -867,14 +918,15 @@ class MultibodyLearnableSystem(Module):
         friction = self.multibody_terms.contact_terms.get_friction_coefficients().detach().cpu()
         out: Dict[str, float] = {}
         labels = self._body_labels()
-        for index, body in enumerate(self.spec.bodies):
-            label = labels[index]
+        for index, label in enumerate(self._row_labels()):  # one set per Drake body: a row of inertial_parameters
             pi_cm = theta_to_pi_cm(theta[index])
             out[f'{label}_m'] = float(pi_cm[0])
             for axis, value in zip('xyz', pi_cm[1:4] / pi_cm[0]):
                 out[f'{label}_com_{axis}'] = float(value)
             for name, value in zip(('I_xx', 'I_yy', 'I_zz', 'I_xy', 'I_xz', 'I_yz'), pi_cm[4:]):
                 out[f'{label}_{name}'] = float(value)
+        for index, body in enumerate(self.spec.bodies):
+            label = labels[index]
             mine = [g for g, (b, _) in enumerate(self.spec.geoms()) if b == index]
             for count, g in enumerate(mine):
                 # one geometry per body is all the reference's key scheme distinguishes; further ones get a suffix
@@ -884,7 +936,7 @@ class MultibodyLearnableSystem(Module):
                     for axis, value in zip('xyz', geometry.get_half_lengths().detach().cpu().reshape(-1)):
                         out[f'{prefix}_len_{axis}'] = 2 * float(value)
                 elif isinstance(geometry, Sphere):
-                    out[f'{prefix}_radius'] = float(geometry.get_radius())
+                    out[f'{prefix}_radius'] = float(geometry.get_radius().detach())
                 elif isinstance(geometry, Polygon):
                     out.update({f'{prefix}_{key}': value for key, value in geometry.scalars().items()})
                 out[f'{prefix}_mu'] = float(friction[g + 1])
@@ -896,6 +948,16 @@ class MultibodyLearnableSystem(Module):
         if not self.forest or len(self.spec.models) == 1:
             return [body.name for body in self.spec.bodies]
         return [f'{self.spec.names[m]}_{body.name}' for m, body in zip(self.spec.body_model(), self.spec.bodies)]
+
+    def _row_labels(self) -> List[str]:
+        """the names of the rows of ``inertial_parameters`` (:meth:`_body_labels` unless links are welded on)"""
+        if self._weld is None:
+            return self._body_labels()
+        rows = self.spec.inertia_rows()
+        if not self.forest or len(self.spec.models) == 1:
+            return [row.name for row in rows]
+        model = self.spec.body_model()
+        return [f'{self.spec.names[model[row.body]]}_{row.name}' for row in rows]
 
     def _pi_cm(self) -> np.ndarray:
         from .inertia import theta_to_pi_cm
@@ -959,10 +1021,15 @@ class MultibodyLearnableSystem(Module):
         meshes = self.extract_meshes()
         bodies = []
         body_model = self.spec.body_model() if self.forest else [0] * self.spec.n_bodies
-        for index, body in enumerate(self.spec.bodies):
+        # one entry per row of inertial_parameters = per URDF link that carries mass (a link welded on by a `fixed` joint keeps
+        # its own <inertial> and its own <collision> elements: GeomSpec.link)
+        rows = self.spec.inertia_rows()
+        row_model = [body_model[row.body] for row in rows]
+        for index, row in enumerate(rows):
+            body = self.spec.bodies[row.body]
             shapes = []  # this link's <collision> elements in order
-            for g, (b, _) in enumerate(self.spec.geoms()):
-                if b != index:
+            for g, (b, geom) in enumerate(self.spec.geoms()):
+                if b != row.body or (geom.link or body.name) != row.name:
                     continue
                 geometry = self.multibody_terms.contact_terms.geometries[g + 1]
                 if isinstance(geometry, Box):
@@ -979,13 +1046,13 @@ class MultibodyLearnableSystem(Module):
                     export.save_string(os.path.join(self.output_urdfs_dir, obj_name), export.mesh_to_obj(*meshes[body.name]))
                     shape = ('mesh', {'filename': obj_name})
                 shapes.append((shape, float(friction[g + 1])))
-            bodies.append((body.name, pi_cm[index], shapes))
+            bodies.append((row.name, pi_cm[index], shapes))
         new_urdfs = {}
         for model, (name, source) in enumerate(self.urdfs.items()):
             # (several models may come from ONE file -- two cubes -- so a model's file carries its name when there are several)
             base = os.path.basename(source) if len(self.urdfs) == 1 else f'{name}.urdf'
             target = os.path.join(self.output_urdfs_dir, base)
-            mine = [entry for entry, owner in zip(bodies, body_model) if owner == model]
+            mine = [entry for entry, owner in zip(bodies, row_model) if owner == model]
             export.save_string(target, export.render_urdf(source, mine))
             new_urdfs[name] = target
         return new_urdfs

@@ -39,6 +39,7 @@ class GeomSpec:
     mesh_file: Optional[str] = None
     vertices: Optional[List[List[float]]] = None
     rotation: List[List[float]] = field(default_factory=lambda: _identity())  # R_BG: the geometry frame in its body's
+    link: Optional[str] = None  # the URDF link the <collision> element belongs to (its body's name unless the link is welded on)
 
 
 @dataclass
@@ -57,6 +58,20 @@ class BodySpec:
 
 
 @dataclass
+class InertiaRow:
+    """One row of the reference's ``inertial_parameters`` -- one Drake body (``multibody_terms.py:161-207``): a URDF link ALONE,
+    its mass, centre of mass and central inertia in its own frame, the kernel body that carries it and the link's frame in that
+    body's (the identity for the body's own link; a link a ``fixed`` joint welds on sits at the joint's ``<origin>``)."""
+    name: str
+    body: int
+    mass: float
+    com: List[float]
+    inertia_cm: List[float]
+    origin: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0])
+    rotation: List[List[float]] = field(default_factory=lambda: _identity())
+
+
+@dataclass
 class ModelSpec:
     name: str
     bodies: List[BodySpec]
@@ -71,6 +86,11 @@ class ModelSpec:
     welded: dict = field(default_factory=dict)
     # the root link is welded to the world (a URDF whose root is a link named `world`: Drake welds it, and the reference gives
     # the model a FixedBaseSpace, drake_utils.py:329-332): no base coordinates
+    # the links as Drake sees them: every <link> in document order (the order of Drake's body indices, hence of the rows of the
+    # reference's inertial_parameters), a welded link's frame in its host body's frame, every link's OWN inertia
+    link_order: List[str] = field(default_factory=list)
+    welded_frames: dict = field(default_factory=dict)   # welded link -> (origin, rotation) in the frame of the body it ends up in
+    own_inertia: dict = field(default_factory=dict)     # link -> (mass, com, inertia_cm) before anything was folded into it
     fixed_base: bool = False
     mount_origin: List[float] = field(default_factory=lambda: [0.0, 0.0, 0.0])   # of a fixed base: its root frame in the world
     mount_rotation: List[List[float]] = field(default_factory=lambda: _identity())
@@ -82,6 +102,36 @@ class ModelSpec:
     @property
     def n_u(self) -> int:
         return len(self.actuators)
+
+    def inertia_rows(self) -> List[InertiaRow]:
+        """The rows of ``inertial_parameters``.  A model without welded links: one per body, in body order (what every round
+        so far had).  A model whose ``fixed`` joints weld links that carry mass: one per LINK in document order, as the
+        reference's parameter tree has them (``drake_utils.py:129-146``: Drake's bodies in index order) -- a kernel body's
+        inertia is then the sum of its links' (``csrc/dpll_weld.hip``).  A welded link without mass and inertia (a frame) has
+        no row: the reference's ``theta`` has no finite value for it (``log m``)."""
+        index = {body.name: i for i, body in enumerate(self.bodies)}
+        heavy = []
+        for name in self.welded:
+            mass, _, inertia = self.own_inertia[name]
+            if mass > 0.0:
+                heavy.append(name)
+            elif mass < 0.0 or any(v != 0.0 for v in inertia):
+                raise ValueError(f'link {name}: a welded link needs a positive mass or no inertia at all')
+        if not heavy:
+            return [InertiaRow(body.name, i, body.mass, list(body.com), list(body.inertia_cm)) for i, body in enumerate(self.bodies)]
+        rows = []
+        for name in self.link_order:
+            if name in index:
+                mass, com, inertia = self.own_inertia[name]
+                rows.append(InertiaRow(name, index[name], mass, list(com), list(inertia)))
+            elif name in heavy:
+                mass, com, inertia = self.own_inertia[name]
+                origin, rotation = self.welded_frames[name]
+                rows.append(InertiaRow(name, index[self.welded[name]], mass, list(com), list(inertia), list(origin), rotation))
+        return rows
+
+    def has_welded_rows(self) -> bool:
+        return len(self.inertia_rows()) != len(self.bodies)
 
     @property
     def n_joints(self) -> int:
@@ -137,6 +187,7 @@ class ModelSpec:
         kinds = {geom.kind for _, geom in self.geoms()}
         return (self.n_joints <= 1 and not self.rotated() and all(b.joint_kind == 'revolute' for b in self.bodies)
                 and not self.actuators  # (B u is built into the general build only)
+                and not self.has_welded_rows()  # (rows of welded links: composed for the general / forest builds)
                 and all(len(b.geoms) == 1 for b in self.bodies) and kinds in ({'box'}, {'mesh'})
                 and all(b.parent == i - 1 for i, b in enumerate(self.bodies) if i > 0) and not self.pairs)
 
@@ -245,6 +296,7 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
             else:
                 raise NotImplementedError('only <box>, <sphere> and <mesh> collision geometry is supported')
             body.geoms[first].rotation = _rotation(c_origin)
+            body.geoms[first].link = body.name
         by_name[body.name] = body
         order.append(body.name)
     joints = []
@@ -267,8 +319,10 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
                        _vec(j_origin.get('xyz') if j_origin is not None else None), [a / norm for a in axis],
                        _rotation(j_origin), joint.get('type') if joint.get('type') in ('prismatic', 'fixed') else 'revolute'))
         children.add(joints[-1][1])
-    welded = {}
-    joints = _weld_fixed_joints(by_name, order, joints, welded)
+    welded, frames = {}, {}
+    link_order = list(order)
+    own_inertia = {name: (by_name[name].mass, list(by_name[name].com), list(by_name[name].inertia_cm)) for name in order}
+    joints = _weld_fixed_joints(by_name, order, joints, welded, frames)
     children = {child for _, child, *_ in joints}
     roots = [name for name in order if name not in children]
     if len(roots) != 1:
@@ -286,7 +340,8 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
                 chain.append(child)
     if len(chain) != len(order):
         raise ValueError('disconnected links')
-    spec = ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain], welded=welded)
+    spec = ModelSpec(name=root.get('name'), bodies=[by_name[name] for name in chain], welded=welded, link_order=link_order,
+                     welded_frames=frames, own_inertia=own_inertia)
     if mount is not None:
         if welded.get(mount[0], mount[0]) != chain[0]:
             raise ValueError('the link welded to the world must be the root of the model')
@@ -306,13 +361,14 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> ModelSpe
     return spec
 
 
-def _weld_fixed_joints(by_name, order, joints, welded):
+def _weld_fixed_joints(by_name, order, joints, welded, frames):
     """A `fixed` joint welds its child to its parent: the two links are ONE rigid body.  Drake keeps a welded link as a
     body of its own (with inertial parameters of its own: the reference would learn them separately,
     multibody_terms.py:161-207); the kernels' bodies are the links that move against each other, so here the child is folded
     into its parent at parse time -- mass, centre of mass and central inertia combined (parallel axes), its collision
-    geometries and the joints hanging off it re-expressed in the parent's frame -- and the parent's learnable inertia stands
-    for both (a documented deviation of the parameter tree, not of the dynamics).  Returns the remaining joints."""
+    geometries and the joints hanging off it re-expressed in the parent's frame.  The parameter tree keeps the reference's
+    shape all the same: ``frames`` records where every welded link sits in the body it ends up in, and
+    :meth:`ModelSpec.inertia_rows` lists the links' own inertias, one learnable row each.  Returns the remaining joints."""
     def central(body):
         ixx, iyy, izz, ixy, ixz, iyz = body.inertia_cm
         return [[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]]
@@ -354,36 +410,42 @@ def _weld_fixed_joints(by_name, order, joints, welded):
         order.remove(child_name)
         del by_name[child_name]
         welded[child_name] = parent_name
+        frames[child_name] = (list(origin), rotation)
         for name, target in list(welded.items()):
-            if target == child_name:
+            if target == child_name:  # a link welded to the child earlier (innermost first) moves on with it
                 welded[name] = parent_name
+                inner_origin, inner_rotation = frames[name]
+                frames[name] = ([origin[i] + sum(rotation[i][k] * inner_origin[k] for k in range(3)) for i in range(3)],
+                                _matmul(rotation, inner_rotation))
     return joints
 
 
 def _collision_candidates(root, spec: ModelSpec) -> List[Tuple[int, int]]:
-    """Geometry pairs on two different bodies that can collide: Drake filters bodies connected by a joint, and the pairs a
-    ``drake:collision_filter_group`` lists under ``drake:ignored_collision_filter_group``
-    (``assets/contactnets_elbow.urdf:74-78`` of the reference)."""
-    index = {body.name: i for i, body in enumerate(spec.bodies)}
-    index.update({name: index[target] for name, target in spec.welded.items()})
+    """Geometry pairs on two different bodies that can collide: Drake filters the two LINKS a joint connects, links welded
+    together (one body here), and the pairs a ``drake:collision_filter_group`` lists under
+    ``drake:ignored_collision_filter_group`` (``assets/contactnets_elbow.urdf:74-78`` of the reference) -- groups name links, so a
+    link welded onto a body is filtered on its own: the geometries it brought along, not the whole body."""
     groups, ignores = {}, []
     for element in root:
         if element.tag.endswith('collision_filter_group'):
             name = element.get('name')
-            groups[name] = {index[m.get('link')] for m in element if m.tag.endswith('member')}
+            groups[name] = {m.get('link') for m in element if m.tag.endswith('member')}
             ignores += [(name, i.get('name')) for i in element if i.tag.endswith('ignored_collision_filter_group')]
     excluded = set()
     for first, second in ignores:
         for a in groups.get(first, ()):
             for b in groups.get(second, ()):
-                excluded.add((min(a, b), max(a, b)))
+                excluded |= {(a, b), (b, a)}
+    adjacent = set()
+    for joint in root.findall('joint'):
+        ends = (joint.find('parent').get('link'), joint.find('child').get('link'))
+        adjacent |= {ends, ends[::-1]}
     pairs = []
     geoms = spec.geoms()
     for ga, (ba, geom_a) in enumerate(geoms):
         for gb, (bb, geom_b) in enumerate(geoms):
-            if gb <= ga or ba == bb or (min(ba, bb), max(ba, bb)) in excluded:
-                continue
-            if spec.bodies[bb].parent == ba or spec.bodies[ba].parent == bb:
+            links = ((geom_a.link or spec.bodies[ba].name), (geom_b.link or spec.bodies[bb].name))
+            if gb <= ga or ba == bb or links in excluded or links in adjacent:
                 continue
             pairs.append((gb, ga) if TYPE_ORDER[geom_a.kind] > TYPE_ORDER[geom_b.kind] else (ga, gb))
     return pairs
@@ -421,6 +483,18 @@ class SystemSpec:
 
     def is_fast(self) -> bool:
         return False
+
+    def inertia_rows(self) -> List[InertiaRow]:
+        """the models' rows one after the other (``drake_utils.py:129-146``), ``body`` counted over the system"""
+        out, first = [], 0
+        for spec in self.models:
+            for row in spec.inertia_rows():
+                out.append(InertiaRow(row.name, first + row.body, row.mass, row.com, row.inertia_cm, row.origin, row.rotation))
+            first += len(spec.bodies)
+        return out
+
+    def has_welded_rows(self) -> bool:
+        return any(spec.has_welded_rows() for spec in self.models)
 
     @property
     def n_u(self) -> int:

@@ -43,7 +43,11 @@ extern "C" {
 #define DPLL_GEN_SLOTS (DPLL_MAX_GEOMS + 1)
 
 enum dpll_dtype { DPLL_F32 = 0, DPLL_F64 = 1 };
-enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1 };
+/* DPLL_INERTIA_COMPOSED (general and forest builds): the rows of dpll_params_t.theta are not theta-format parameters but the
+ * bodies' inertial vectors [m, m c (3), I_o (xx, yy, zz, xy, xz, yz)] themselves -- what dpll_weld_compose below writes for a
+ * model whose URDF welds links together; `grad` then holds d loss / d (those vectors), which dpll_weld_compose_backward chains
+ * to the links' own parameters. */
+enum dpll_inertia_mode { DPLL_INERTIA_REFERENCE_LITERAL = 0, DPLL_INERTIA_PHYSICAL = 1, DPLL_INERTIA_COMPOSED = 2 };
 #define DPLL_MAX_POLYGON_VERTICES 8
 #define DPLL_GEOM_BLOCK (3 * DPLL_MAX_POLYGON_VERTICES) /* numbers per geometry in the general build's `lengths` block */
 
@@ -398,6 +402,24 @@ int dpll_contactnets_train_step_mesh(const dpll_model_t* model, int dtype, const
                                      const void* x, int64_t ld_x, const void* x_plus, int64_t ld_xp, int64_t batch, const void* weights,
                                      double scale, void* grad, void* loss_total, void* workspace, int64_t workspace_bytes,
                                      const dpll_adam_t* adam, void* stream);
+
+/* ---- links welded together by `fixed` joints --------------------------------------------------------------------------------
+ * Drake keeps a link that a `fixed` joint welds to another as a body of its own, and the reference learns one theta row per
+ * Drake body (multibody_terms.py:161-207: inertial_parameters is (n_bodies_drake, 10)); the kernels' bodies are the links that
+ * move against each other.  These two calls are the map between the two: row r (theta format, the link alone in its own
+ * frame) belongs to kernel body host[r], whose inertial vector is
+ *     iota_b = sum over rows r with host[r] == b of  X_r  theta_to_iota(theta_r, inertia_mode)
+ * with X_r (10 x 10, row-major, double) the rigid transform of an inertial vector from the link's frame to the body's (the
+ * identity for the body's own link; linear because [m, m c, I_o] transforms linearly).  inertia_mode: REFERENCE_LITERAL or
+ * PHYSICAL, applied per row as the reference applies it per Drake body.  All pointers are device memory; n_rows <= 64.
+ *   dpll_weld_compose:           theta_rows (n_rows, 10) -> iota (n_bodies, 10), the `theta` of a DPLL_INERTIA_COMPOSED model
+ *   dpll_weld_compose_backward:  grad_iota (n_bodies, 10) = the theta block of a gradient row of such a model
+ *                                -> grad_theta_rows (n_rows, 10); overwritten, or added to when accumulate != 0 */
+#define DPLL_MAX_WELD_ROWS 64
+int dpll_weld_compose(int dtype, int inertia_mode, int n_rows, int n_bodies, const int32_t* host, const double* transforms,
+                      const void* theta_rows, void* iota, void* stream);
+int dpll_weld_compose_backward(int dtype, int inertia_mode, int n_rows, int n_bodies, const int32_t* host, const double* transforms,
+                               const void* theta_rows, const void* grad_iota, void* grad_theta_rows, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

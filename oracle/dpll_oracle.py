@@ -86,6 +86,52 @@ def _origin_rotation(origin) -> List[List[float]]:
     return rpy_matrix(_floats(origin.get('rpy') if origin is not None else None, 3))
 
 
+_IDENTITY = [[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]]
+
+
+def _fold_welds(links: Dict, order: List[str], joints: List, welds: List):
+    """Links welded to another link by a `fixed` joint.  In Drake such a link stays a body of its own -- with its own spatial
+    inertia, hence its own row of the reference's inertial_parameters (multibody_terms.py:161-207) -- that has no coordinate:
+    it rides on the link it is welded to.  Here it is taken off the list of moving bodies: its frame in its host (the first
+    link up the welds that is not itself welded on) is the product of the joint <origin>s on the way; its collision geometries
+    and the joints hanging off it are re-expressed in the host's frame; its inertia is NOT merged into the host's -- it
+    stays a row of its own, carried by the host (mass_matrix / lagrangian_forces sum over the rows).
+    Returns ({welded link with mass: (host, origin, rot, the link's own dict)}, {every welded link: host}); `order` and `joints`
+    are edited in place."""
+    def mat(a, b):
+        return [[sum(a[i][k] * b[k][j] for k in range(3)) for j in range(3)] for i in range(3)]
+
+    def at(rot, origin, point):
+        return [origin[i] + sum(rot[i][k] * point[k] for k in range(3)) for i in range(3)]
+
+    direct = {child: (parent, origin, rot) for parent, child, origin, rot in welds}
+    frames = {}
+    for name in direct:
+        host, origin, rot = direct[name]
+        while host in direct:  # welded onto a welded link: one more frame on the way up
+            up, up_origin, up_rot = direct[host]
+            origin, rot, host = at(up_rot, up_origin, origin), mat(up_rot, rot), up
+        frames[name] = (host, origin, rot)
+    carried = {}
+    for name, (host, origin, rot) in frames.items():
+        link = links[name]
+        for geom in link['geoms']:
+            moved = dict(geom)
+            moved['origin'] = at(rot, origin, geom['origin'])
+            moved['rot'] = mat(rot, geom['rot'])
+            links[host]['geoms'].append(moved)
+        if link['mass'] > 0.0:
+            carried[name] = (host, origin, rot, link)
+        else:
+            assert link['mass'] == 0.0 and not any(link['inertia_cm']), 'a welded link needs a positive mass or no inertia at all'
+        order.remove(name)
+    for index, (parent, child, j_origin, axis, j_rot, kind) in enumerate(joints):
+        if parent in frames:
+            host, origin, rot = frames[parent]
+            joints[index] = (host, child, at(rot, origin, j_origin), axis, mat(rot, j_rot), kind)
+    return carried, {name: frame[0] for name, frame in frames.items()}
+
+
 def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     """Parses one floating-base serial chain with revolute joints and box / mesh collision
     geometry.  Mirrors what the reference obtains from Drake: bodies with (m, com, I_cm)
@@ -130,7 +176,7 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
                     mu = float(element.get('value'))
             assert mu is not None, 'collision without drake:mu_static'
             geometry = col.find('geometry')
-            geom = {'origin': _floats(c_origin.get('xyz') if c_origin is not None else None, 3), 'mu': mu,
+            geom = {'origin': _floats(c_origin.get('xyz') if c_origin is not None else None, 3), 'mu': mu, 'link': name,
                     'rot': _origin_rotation(c_origin)}  # R_BG (inspector.GetPoseInFrame, multibody_terms.py:356)
             if geometry.find('box') is not None:
                 size = _floats(geometry.find('box').get('size'), 3)
@@ -149,6 +195,7 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
         order.append(name)
     children = set()
     joints = []
+    welds = []
     for joint in root.findall('joint'):
         j_origin = joint.find('origin')
         parent = joint.find('parent').get('link')
@@ -158,14 +205,20 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
             # drake_utils.py:329-332): its root has no coordinates; the mount is the joint's <origin>
             links[child]['mount'] = (_floats(j_origin.get('xyz') if j_origin is not None else None, 3), _origin_rotation(j_origin))
             continue
-        assert joint.get('type') in ('continuous', 'revolute', 'prismatic'), 'only revolute and prismatic joints supported'
-
+        assert joint.get('type') in ('continuous', 'revolute', 'prismatic', 'fixed'), 'only revolute, prismatic and fixed joints'
+        if joint.get('type') == 'fixed':
+            # a link welded to another: Drake keeps it as a body of its own with no coordinate (see _fold_welds below)
+            welds.append((parent, child, _floats(j_origin.get('xyz') if j_origin is not None else None, 3), _origin_rotation(j_origin)))
+            continue
         axis = _floats(joint.find('axis').get('xyz'), 3) if joint.find('axis') is not None else [1., 0., 0.]
         norm = math.sqrt(sum(a * a for a in axis))
         joints.append((parent, child, _floats(j_origin.get('xyz') if j_origin is not None else None, 3),
                        [a / norm for a in axis], _origin_rotation(j_origin),
                        'prismatic' if joint.get('type') == 'prismatic' else 'revolute'))
         children.add(child)
+    link_order = list(order)
+    carried, hosts = _fold_welds(links, order, joints, welds)
+    children = {child for _, child, *_ in joints}
     roots = [n for n in order if n not in children]
     assert len(roots) == 1, 'one chain per file (reference drake_utils.py:309-335)'
     # breadth-first order from the root: body 0 is the floating base.
@@ -183,6 +236,20 @@ def parse_urdf(path: str, mesh_representation: str = 'deep_support') -> Dict:
     bodies = [links[n] for n in sorted_names]
     spec = {'name': root.get('name'), 'bodies': bodies, 'n_joints': len(bodies) - 1, 'ground_mu': GROUND_MU}
     spec['fixed_base'] = 'mount' in bodies[0]
+    # the rows of the reference's inertial_parameters: one per Drake body (multibody_terms.py:161-207, drake_utils.py:129-146).
+    # Without welded links these are the bodies, in body order; with them every link in document order -- Drake's body index
+    # order -- each with its own (m, com, I_cm), the body that carries it and its frame there.
+    if carried:
+        spec['inertia_rows'] = []
+        for name in link_order:
+            if name in sorted_names:
+                body = links[name]
+                spec['inertia_rows'].append({'name': name, 'body': sorted_names.index(name), 'mass': body['mass'], 'com': body['com'],
+                                             'inertia_cm': body['inertia_cm'], 'origin': [0., 0., 0.], 'rot': _IDENTITY})
+            elif name in carried:
+                host, origin, rot, link = carried[name]
+                spec['inertia_rows'].append({'name': name, 'body': sorted_names.index(host), 'mass': link['mass'], 'com': link['com'],
+                                             'inertia_cm': link['inertia_cm'], 'origin': origin, 'rot': rot})
     spec['pairs'] = collision_candidates(root, spec)
     # actuators: one JointActuator per <transmission> in file order (Drake's parser), each a generalized force on its joint's
     # coordinate -- the B of reference multibody_terms.py:142-146.  Entry k = index of the actuated joint (joint j drives body j + 1)
@@ -222,8 +289,14 @@ def system_spec(urdfs, mesh_representation: str = 'deep_support') -> Dict:
         geom_off += n_geoms
         q_off += base_q + spec['n_joints']
         v_off += base_v + spec['n_joints']
+    rows, first = [], 0
+    for spec in specs:
+        rows += [dict(row, body=first + row['body']) for row in inertia_rows(spec)]
+        first += len(spec['bodies'])
     merged = {'name': '+'.join(urdfs.keys()), 'bodies': bodies, 'n_joints': sum(spec['n_joints'] for spec in specs),
               'ground_mu': GROUND_MU, 'n_q': q_off, 'n_v': v_off, 'models': specs, 'fixed_base': False}
+    if any('inertia_rows' in spec for spec in specs):
+        merged['inertia_rows'] = rows
     table = geometry_table(merged)
     anchored = anchored_bodies(merged)
     pairs = []
@@ -253,26 +326,31 @@ def collision_candidates(root, spec: Dict) -> List[Tuple[int, int]]:
     geometry_table: what Drake's GetCollisionCandidates (drake_utils.py:178-184) keeps beyond the ground pairs --
     geometries of two bodies that no joint connects (Drake filters adjacent bodies) and no drake:collision_filter_group
     excludes (assets/contactnets_elbow.urdf:74-78) -- each pair swapped into the reference's type order (:294-297)."""
-    index = {body['name']: i for i, body in enumerate(spec['bodies'])}
     groups, ignores = {}, []
     for element in root:
         if element.tag.endswith('collision_filter_group'):
-            groups[element.get('name')] = {index[m.get('link')] for m in element if m.tag.endswith('member')}
+            groups[element.get('name')] = {m.get('link') for m in element if m.tag.endswith('member')}  # (groups name LINKS)
             ignores += [(element.get('name'), i.get('name')) for i in element
                         if i.tag.endswith('ignored_collision_filter_group')]
     excluded = set()
     for first, second in ignores:
         for a in groups.get(first, ()):
             for b in groups.get(second, ()):
-                excluded.add((min(a, b), max(a, b)))
+                excluded |= {(a, b), (b, a)}
     table = geometry_table(spec)
+    adjacent = set()
+    for joint in root.findall('joint'):
+        ends = (joint.find('parent').get('link'), joint.find('child').get('link'))
+        adjacent |= {ends, ends[::-1]}
     pairs = []
     for ia in range(1, len(table)):
         for ib in range(ia + 1, len(table)):
             ba, bb = table[ia]['body'], table[ib]['body']
-            if ba == bb or (min(ba, bb), max(ba, bb)) in excluded:
+            if ba == bb or (table[ia]['link'], table[ib]['link']) in excluded:
                 continue
-            if spec['bodies'][bb]['parent'] == ba or spec['bodies'][ba]['parent'] == bb:
+            # Drake's default filter is between the two LINKS a joint connects (welded-together links, which are one body here,
+            # are filtered as a set: ba == bb above) -- a link welded onto a joint's parent is NOT adjacent to the joint's child
+            if (table[ia]['link'], table[ib]['link']) in adjacent:
                 continue
             swap = _TYPE_ORDER[table[ia]['kind']] > _TYPE_ORDER[table[ib]['kind']]
             pairs.append((ib, ia) if swap else (ia, ib))
@@ -550,15 +628,36 @@ def chain_kinematics(spec: Dict, q: Tensor, v: Optional[Tensor] = None):
     return rot, org, jac, vel, acc
 
 
+def inertia_rows(spec: Dict) -> List[Dict]:
+    """The Drake bodies that carry inertia, in the order of the rows of the reference's inertial_parameters
+    (multibody_terms.py:161-207): what parse_urdf / system_spec recorded for models with welded links, else the bodies."""
+    if 'inertia_rows' in spec:
+        return spec['inertia_rows']
+    return [{'name': body['name'], 'body': index, 'mass': body['mass'], 'com': body['com'], 'inertia_cm': body['inertia_cm'],
+             'origin': [0., 0., 0.], 'rot': _IDENTITY} for index, body in enumerate(spec['bodies'])]
+
+
+def _carried_frame(row: Dict, dtype) -> Optional[Tensor]:
+    """motion transform from the coordinates of the body that carries a welded link to the link's own (at the link's origin);
+    None for the body's own link"""
+    if row['rot'] == _IDENTITY and not any(row['origin']):
+        return None
+    e_cp = torch.tensor(row['rot'], dtype=dtype).t()
+    p = torch.tensor(row['origin'], dtype=dtype)
+    return torch.cat((torch.cat((e_cp, torch.zeros(3, 3, dtype=dtype)), -1), torch.cat((-e_cp @ skew(p), e_cp), -1)), -2)
+
+
 def mass_matrix(spec: Dict, q: Tensor, inertia: Tensor, inertia_mode: str) -> Tensor:
     """M(q) = sum_b S_b^T I_b S_b; equals gamma^T M_drake gamma of reference
     multibody_terms.py:131 (same kinetic energy, dair_pll velocity coordinates).
     ``inertia``: (*, n_bodies, 10) as passed by LagrangianTerms.forward (:228-234)."""
     _, _, jac, _, _ = chain_kinematics(spec, q)
     total = None
-    for index in range(len(spec['bodies'])):
+    for index, row in enumerate(inertia_rows(spec)):  # (a welded link: a Drake body without a coordinate, riding on its host)
         i6 = spatial_inertia_6x6(inertia[..., index, :], inertia_mode)
-        term = jac[index].transpose(-1, -2) @ i6 @ jac[index]
+        x_lb = _carried_frame(row, q.dtype)
+        s_l = jac[row['body']] if x_lb is None else x_lb @ jac[row['body']]
+        term = s_l.transpose(-1, -2) @ i6 @ s_l
         total = term if total is None else total + term
     return total
 
@@ -571,13 +670,22 @@ def lagrangian_forces(spec: Dict, q: Tensor, v: Tensor, inertia: Tensor, inertia
     rot, _, jac, vel, acc = chain_kinematics(spec, q, v)
     g_world = torch.tensor([0., 0., GRAVITY_Z], dtype=q.dtype)
     total = None
-    for index in range(len(spec['bodies'])):
+    for index, row in enumerate(inertia_rows(spec)):
         i6 = spatial_inertia_6x6(inertia[..., index, :], inertia_mode)
-        g_body = (rot[index].transpose(-1, -2) @ g_world.unsqueeze(-1)).squeeze(-1)
+        b = row['body']
+        x_lb = _carried_frame(row, q.dtype)
+        if x_lb is None:
+            r_l, s_l, v_l, a_l = rot[b], jac[b], vel[b], acc[b]
+        else:  # a welded link: a joint without a coordinate -- its motion is its host's, seen from its own frame
+            r_l = rot[b] @ torch.tensor(row['rot'], dtype=q.dtype)
+            s_l = x_lb @ jac[b]
+            v_l = (x_lb @ vel[b].unsqueeze(-1)).squeeze(-1)
+            a_l = (x_lb @ acc[b].unsqueeze(-1)).squeeze(-1)
+        g_body = (r_l.transpose(-1, -2) @ g_world.unsqueeze(-1)).squeeze(-1)
         grav = torch.cat((torch.zeros_like(g_body), g_body), -1)
-        momentum = (i6 @ vel[index].unsqueeze(-1)).squeeze(-1)
-        wrench = (i6 @ (acc[index] - grav).unsqueeze(-1)).squeeze(-1) + force_cross(vel[index], momentum)
-        term = -(jac[index].transpose(-1, -2) @ wrench.unsqueeze(-1)).squeeze(-1)
+        momentum = (i6 @ v_l.unsqueeze(-1)).squeeze(-1)
+        wrench = (i6 @ (a_l - grav).unsqueeze(-1)).squeeze(-1) + force_cross(v_l, momentum)
+        term = -(s_l.transpose(-1, -2) @ wrench.unsqueeze(-1)).squeeze(-1)
         total = term if total is None else total + term
     if u is not None and u.shape[-1] > 0:
         actuators = spec.get('actuators', [])
@@ -988,7 +1096,7 @@ class OracleSystem:
         self.ground_geoms = ground_geometries(self.spec)  # (an anchored geometry has no ground contacts)
         self.n_contacts = sum(1 if self.geoms[g]['kind'] == 'sphere' else N_QUERY for g in self.ground_geoms) + len(self.spec['pairs'])
         pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
-                              for b in self.spec['bodies']], dtype=torch.float64)
+                              for b in inertia_rows(self.spec)], dtype=torch.float64)
         # theta_0 = pi_o_to_theta(drake inertia), reference multibody_terms.py:186-188
         self.theta = pi_cm_to_theta(pi_cm).to(dtype)
         self.friction = torch.tensor([g['mu'] for g in self.geoms], dtype=dtype)

@@ -221,8 +221,9 @@ def build_reference_system(urdf, inertia_mode: str, mesh_seed: int = 0, mesh_rep
     nn.Module.__init__(lt)
     lt.mass_matrix = lambda q, inertia: O.mass_matrix(spec, q, inertia, inertia_mode)
     lt.lagrangian_forces = lambda q, v, u, inertia: O.lagrangian_forces(spec, q, v, inertia, inertia_mode, u)  # (+ B u, :142-146)
+    # one row per Drake body (multibody_terms.py:161-207): a link welded on by a `fixed` joint has a row of its own
     pi_cm = torch.tensor([[b['mass']] + [b['mass'] * c for c in b['com']] + b['inertia_cm']
-                          for b in spec['bodies']])
+                          for b in O.inertia_rows(spec)])
     lt.inertial_parameters = Parameter(InertialParameterConverter.pi_cm_to_theta(pi_cm), requires_grad=True)
 
     ct = ContactTerms.__new__(ContactTerms)
@@ -621,6 +622,17 @@ def record_general_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, 
         record_case(name + '_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3)
 
 
+def record_welded_case(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+    """a URDF whose `fixed` joints weld links that carry mass (assets/welded_arm.urdf: five links, two of them
+    moving against each other).  The reference's parameter tree has one theta row per Drake body -- (5, 10) here -- and its
+    LagrangianTerms.forward converts every row and hands all of them to the mass-matrix / force closures
+    (multibody_terms.py:228-234), which here sum over the rows with a welded link riding on its host (O.mass_matrix)."""
+    urdf = os.path.join(REPO, 'assets', 'welded_arm.urdf')
+    x, x_plus = general_tosses(urdf, n_traj, steps, keep_every, seed)
+    record_case('welded_arm_literal', urdf, x, x_plus, 'reference_literal', sim_steps=3)
+    record_case('welded_arm_physical', urdf, x[::4].clone(), x_plus[::4].clone(), 'physical', sim_steps=2)
+
+
 def record_polygon_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
     """SURVEY 8f-4, Polygon (geometry.py:220-252: a learnable vertex set, support query = the 4 vertices furthest along
     the direction) through the reference's own classes: the cube with its mesh read as the 8-vertex polygon (the
@@ -796,6 +808,7 @@ def main() -> None:
     record_slice_fixture()
     record_dynamics_gradients()
     record_general_cases()
+    record_welded_case()
     record_elbow_mesh()
     record_polygon_cases()
     record_pair_cases()

@@ -23,6 +23,9 @@ MODELS = ['chain3', 'vee', 'ballcube', 'mace', 'polycube', 'wedge', 'clasp', 'cl
           'pincer', 'grasp', 'slider']
 # model -> (URDF under assets/, what a <mesh> element is read as)
 SOURCES = {'polycube': ('cube_mesh.urdf', 'polygon'), 'wedge': ('wedge.urdf', 'polygon'), 'clasp_ball': ('clasp_ball.urdf', 'polygon')}
+# assets/welded_arm.urdf: links welded on by `fixed` joints, each with its own row of inertial_parameters (tests/test_welded_links.py
+# holds the rest of its tests; the host build's tests here take the kernels' per-body rows)
+WITH_WELDS = MODELS + ['welded_arm']
 P = 'multibody_terms.'
 STRIDE = 24  # numbers per geometry in the general build's lengths block (DPLL_GEOM_BLOCK)
 SLOTS = 4    # geometry slots of the general build: three geometries + a body-body pair (DPLL_GEN_SLOTS)
@@ -125,7 +128,7 @@ def align_pair_frames(spec, J, D, J_ref):
     return J, D
 
 
-@pytest.mark.parametrize('name', MODELS)
+@pytest.mark.parametrize('name', WITH_WELDS)
 def test_oracle_reproduces_the_reference_run(golden, name):
     g = golden(name + '_literal')
     system = oracle_from(g, name).requires_grad_()
@@ -205,7 +208,7 @@ def gpu_system(g, name, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', MODELS)
+@pytest.mark.parametrize('name', WITH_WELDS)
 @pytest.mark.parametrize('dtype', [torch.float64, torch.float32])
 def test_gpu_loss_gradients_dynamics(golden, name, dtype):
     g = golden(name + '_literal')
@@ -249,7 +252,7 @@ def test_gpu_loss_gradients_dynamics(golden, name, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', MODELS)
+@pytest.mark.parametrize('name', WITH_WELDS)
 def test_gpu_terms(golden, name):
     g = golden(name + '_literal')
     system = gpu_system(g, name, torch.float64)

@@ -500,7 +500,10 @@ def test_fixed_joints_weld_links_into_one_body(tmp_path):
     assert np.abs(np.array(base.geoms[1].origin) - (o + R @ np.array([0.01, 0, 0]))).max() < 1e-15
     assert np.abs(np.array(spec.bodies[1].joint_origin) - (o + R @ np.array([0, 0.03, 0]))).max() < 1e-15
     assert np.abs(np.array(spec.bodies[1].joint_rotation) - R).max() < 1e-15 and spec.bodies[1].parent == 0
-    # arm is the child of the body the bracket became: no candidate between them; the filter group resolved the welded name
-    assert spec.pairs == []
+    # Drake filters LINKS: the hinge joins bracket and arm and the group lists the same two, so the bracket's sphere (geometry 1)
+    # and the arm's box have no candidate -- the base's own box and the arm's box do (base and arm share no joint)
+    assert spec.pairs == [(0, 2)]
     system = MultibodyLearnableSystem({'welded': str(path)}, 0.0068, device='cpu')
-    assert system.space.n_x == 15 and system.multibody_terms.lagrangian_terms.inertial_parameters.shape == (2, 10)
+    # the parameter tree keeps one row per LINK (Drake's bodies, multibody_terms.py:161-207): tests/test_welded_links.py
+    assert system.space.n_x == 15 and system.multibody_terms.lagrangian_terms.inertial_parameters.shape == (3, 10)
+    assert [(row.name, row.body) for row in spec.inertia_rows()] == [('base', 0), ('bracket', 0), ('arm', 1)]
