@@ -20,7 +20,7 @@ GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 23  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 24  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 MAX_WELD_ROWS = 64  # DPLL_MAX_WELD_ROWS
 INERTIA_COMPOSED = 2  # DPLL_INERTIA_COMPOSED: set by make_desc / make_forest_desc for models with welded links, never by a caller
@@ -53,7 +53,7 @@ JOINT_FLOATING, JOINT_FIXED = 2, 3
 class ForestDesc(ctypes.Structure):
     """``dpll_forest_desc_t``"""
     _fields_ = [('n_bodies', c_int32), ('n_geoms', c_int32), ('n_pairs', c_int32), ('n_contacts', c_int32), ('n_q', c_int32),
-                ('n_v', c_int32), ('inertia_mode', c_int32), ('rotated', c_int32), ('max_depth', c_int32), ('reserved', c_int32),
+                ('n_v', c_int32), ('inertia_mode', c_int32), ('rotated', c_int32), ('max_depth', c_int32), ('n_u', c_int32),
                 ('dt', c_double), ('gravity_z', c_double),
                 ('parent', c_int32 * FOREST_MAX_BODIES), ('joint_kind', c_int32 * FOREST_MAX_BODIES),
                 ('q_index', c_int32 * FOREST_MAX_BODIES), ('v_index', c_int32 * FOREST_MAX_BODIES), ('depth', c_int32 * FOREST_MAX_BODIES),
@@ -62,7 +62,8 @@ class ForestDesc(ctypes.Structure):
                 ('geom_body', c_int32 * FOREST_MAX_GEOMS), ('geom_kind', c_int32 * FOREST_MAX_GEOMS), ('geom_nverts', c_int32 * FOREST_MAX_GEOMS),
                 ('geom_origin', (c_double * 3) * FOREST_MAX_GEOMS), ('geom_rot', ((c_double * 3) * 3) * FOREST_MAX_GEOMS),
                 ('pair_a', c_int32 * FOREST_MAX_PAIRS), ('pair_b', c_int32 * FOREST_MAX_PAIRS),
-                ('contact_geom', c_int32 * FOREST_MAX_CONTACTS), ('contact_slot', c_int32 * FOREST_MAX_CONTACTS)]
+                ('contact_geom', c_int32 * FOREST_MAX_CONTACTS), ('contact_slot', c_int32 * FOREST_MAX_CONTACTS),
+                ('act_body', c_int32 * FOREST_MAX_V)]
 
 
 class SolverOpts(ctypes.Structure):
@@ -199,6 +200,10 @@ def make_forest_desc(system_spec, dt: float, inertia_mode: str = 'reference_lite
             desc.dof_body[v_off + i] = first
         for j in range(n_joints):
             desc.dof_body[v_off + (0 if fixed else 6) + j] = first + 1 + j
+        # actuators: the models' <transmission>s one after the other (the plant's actuator order); joint j drives body j + 1
+        for joint in spec.actuators:
+            desc.act_body[desc.n_u] = first + 1 + joint
+            desc.n_u += 1
         n_b += len(spec.bodies)
         q_off += (0 if fixed else 7) + n_joints
         v_off += (0 if fixed else 6) + n_joints

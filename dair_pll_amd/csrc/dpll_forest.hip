@@ -257,7 +257,8 @@ __global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_loss_kernel(con
                                                             const T* __restrict__ x, long long ld_x, const T* __restrict__ xp, long long ld_xp,
                                                             long long batch, const T* __restrict__ weights, double scale, T* __restrict__ loss,
                                                             T* __restrict__ force, int* __restrict__ iters, double* __restrict__ partials,
-                                                            int want_grad, int row_stride, unsigned arena_stride) {
+                                                            int want_grad, int row_stride, unsigned arena_stride,
+                                                            const T* __restrict__ u, long long ld_u) {
   using Team = GroupTeam<G>;
   __shared__ ForestDesc fd;
   fetch_desc(fdp, fd);
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_loss_kernel(con
   for (int e = rank; e < width; e += G) row[e] = 0.0;
   Forest<T, double, Team> prog(fd, A);
   prog.derive(theta, friction, lengths);
+  prog.load_actuation((const T*)nullptr);  // (no inputs: B u = 0 until an item brings its own)
   const int K = fd.n_contacts;
   for (long long base = (long long)blockIdx.x * Team::kTeams; base < batch; base += (long long)gridDim.x * Team::kTeams) {
     const long long mine = base + team;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_loss_kernel(con
     const long long item = valid ? mine : batch - 1;  // (an idle team shadows the last item with weight zero: it meets every barrier)
     const T w = valid ? T(scale) * (weights ? weights[item] : T(1)) : T(0);
     int n_it = 0;
+    if (u) prog.load_actuation(u + item * ld_u);
     const T L = prog.loss(x + item * ld_x, xp + item * ld_xp, lengths, opt, w, want_grad != 0, row, n_it);
     if (valid && rank == 0) {
       if (loss) loss[item] = L;
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_simulate_kernel
                                                                 const T* __restrict__ friction, const T* __restrict__ lengths,
                                                                 const T* __restrict__ x0, long long ld_x, long long batch, long long steps,
                                                                 T* __restrict__ out, long long ld_item, long long ld_step, int write_x0,
-                                                                int* __restrict__ iters, unsigned arena_stride) {
+                                                                int* __restrict__ iters, unsigned arena_stride, const T* __restrict__ u,
+                                                                long long ld_u) {
   using Team = GroupTeam<G>;
   __shared__ ForestDesc fd;
   fetch_desc(fdp, fd);
@@ -378,6 +382,7 @@ __global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_simulate_kernel
   A.carve(forest_smem + Team::kTeams * state_bytes + (size_t)team * arena_stride, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
   Forest<T, double, Team> prog(fd, A);
   prog.derive(theta, friction, lengths);
+  prog.load_actuation((const T*)nullptr);  // (no inputs: B u = 0 until an item brings its own)
   for (long long base = (long long)blockIdx.x * Team::kTeams; base < batch; base += (long long)gridDim.x * Team::kTeams) {
     const long long mine = base + team;
     const bool valid = mine < batch;
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(kWave, DPLL_FOREST_OCC) void forest_simulate_kernel
       dst += ld_step;
     }
     int total = 0;
+    if (u) prog.load_actuation(u + item * ld_u);  // (the launcher passes inputs for one step only: dpll_step)
     for (long long s = 0; s < steps; ++s) {
       total += prog.step(cur, lengths, opt, nxt);
       for (int i = rank; i < nx; i += G) {
@@ -411,7 +417,8 @@ __global__ __launch_bounds__(kWave) void forest_step_backward_kernel(const Fores
                                                                      const T* __restrict__ friction, const T* __restrict__ lengths,
                                                                      const T* __restrict__ x, long long ld_x, const T* __restrict__ gx,
                                                                      long long ld_g, long long batch, double* __restrict__ partials,
-                                                                     int row_stride, T* __restrict__ xbar_out, long long ld_xb) {
+                                                                     int row_stride, T* __restrict__ xbar_out, long long ld_xb,
+                                                                     const T* __restrict__ u, long long ld_u) {
   __shared__ ForestDesc fd;
   fetch_desc(fdp, fd);
   const int width = row_width(fd);
@@ -425,8 +432,10 @@ __global__ __launch_bounds__(kWave) void forest_step_backward_kernel(const Fores
   for (int e = threadIdx.x; e < width; e += kWave) row[e] = 0.0;
   Forest<double, double, WaveTeam> prog(fd, A);
   prog.derive(theta, friction, lengths);
+  prog.load_actuation((const T*)nullptr);  // (no inputs: B u = 0 until an item brings its own)
   ForestBackward<WaveTeam> back(fd, A, B);
   for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    if (u) prog.load_actuation(u + item * ld_u);
     back.run(x + item * ld_x, gx + item * ld_g, theta, friction, lengths, opt, row, STATE ? xbar_out + item * ld_xb : (T*)nullptr);
     __syncthreads();
   }
@@ -440,15 +449,17 @@ __global__ __launch_bounds__(kWave) void forest_terms_kernel(const ForestDesc* _
                                                              const T* __restrict__ friction, const T* __restrict__ lengths,
                                                              const T* __restrict__ x, long long ld_x, long long batch, T* __restrict__ Dout,
                                                              T* __restrict__ Mout, T* __restrict__ Jout, T* __restrict__ phiout,
-                                                             T* __restrict__ aout) {
+                                                             T* __restrict__ aout, const T* __restrict__ u, long long ld_u) {
   __shared__ ForestDesc fd;
   fetch_desc(fdp, fd);
   Arena<T, double> A;
   A.carve(forest_smem, fd.n_bodies, fd.n_v, fd.n_q, fd.n_contacts, fd.n_geoms, fd.n_pairs);
   Forest<T, double, WaveTeam> prog(fd, A);
   prog.derive(theta, friction, lengths);
+  prog.load_actuation((const T*)nullptr);  // (no inputs: B u = 0 until an item brings its own)
   const int nv = fd.n_v, K = fd.n_contacts;
   for (long long item = blockIdx.x; item < batch; item += gridDim.x) {
+    if (u) prog.load_actuation(u + item * ld_u);
     prog.load_state(x + item * ld_x);
     prog.terms();
     prog.contacts(lengths);
@@ -596,7 +607,7 @@ int launch_loss(const dpll_model* m, int dtype, const dpll_params_t* p, const vo
 #define DPLL_FOREST_LOSS(G_)                                                                                                                    \
     hipLaunchKernelGGL((forest_loss_kernel<T, G_>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[dtype], (const T*)p->theta,                \
                        (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)xp, ld_xp, batch, (const T*)weights, scale,   \
-                       (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad, stride, (unsigned)arena)
+                       (T*)loss, (T*)force, (int*)iters, (double*)workspace, want_grad, stride, (unsigned)arena, (const T*)p->u, (long long)p->ld_u)
     if (lanes == 16) DPLL_FOREST_LOSS(16);
 #if DPLL_FOREST_HALF
     else if (lanes == 32) DPLL_FOREST_LOSS(32);
@@ -626,12 +637,14 @@ int launch_simulate(const dpll_model* m, int dtype, const dpll_params_t* p, cons
   const int lanes = lanes_per_item<T>(fd), teams = kWave / lanes;
   const size_t arena = arena_bytes<T, double>(fd);
   const size_t lds = teams * (round16((size_t)2 * (fd.n_q + fd.n_v) * sizeof(T)) + arena);
+  // (actuation inputs belong to ONE step: dpll_step; a rollout runs unactuated, as the reference's sim_step passes a u of width 0)
+  const T* sim_u = steps == 1 ? (const T*)p->u : (const T*)nullptr;
 #define DPLL_FOREST_SIM(G_)                                                                                                                     \
   do {                                                                                                                                          \
     if (int rc = allow_lds(forest_simulate_kernel<T, G_>, lds, "dpll_simulate")) return rc;                                                      \
     hipLaunchKernelGGL((forest_simulate_kernel<T, G_>), dim3(grid_for(batch, lds, teams)), dim3(kWave), lds, stream, dev, m->opts[dtype],         \
                        (const T*)p->theta, (const T*)p->friction, (const T*)p->lengths, (const T*)x0, ld_x, batch, steps, (T*)out, ld_item,      \
-                       ld_step, write_x0, (int*)iters, (unsigned)arena);                                                                         \
+                       ld_step, write_x0, (int*)iters, (unsigned)arena, sim_u, (long long)p->ld_u);                    \
   } while (0)
   if (lanes == 16) DPLL_FOREST_SIM(16);
 #if DPLL_FOREST_HALF
@@ -664,11 +677,11 @@ int launch_step_backward(const dpll_model* m, const dpll_params_t* p, const void
   if (grad_x)
     hipLaunchKernelGGL((forest_step_backward_kernel<T, true>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[DPLL_F64], (const T*)p->theta,
                        (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch, (double*)workspace, stride,
-                       (T*)grad_x, ld_gx);
+                       (T*)grad_x, ld_gx, (const T*)p->u, (long long)p->ld_u);
   else
     hipLaunchKernelGGL((forest_step_backward_kernel<T, false>), dim3(rows), dim3(kWave), lds, stream, dev, m->opts[DPLL_F64], (const T*)p->theta,
                        (const T*)p->friction, (const T*)p->lengths, (const T*)x, ld_x, (const T*)gx, ld_g, batch, (double*)workspace, stride,
-                       (T*)nullptr, 0LL);
+                       (T*)nullptr, 0LL, (const T*)p->u, (long long)p->ld_u);
   if (int rc = dpll_check_launch("forest_step_backward_kernel")) return rc;
   double* folded = (double*)workspace + (long long)cap * stride;
   const int n_folded = (int)folded_rows(rows);
@@ -688,7 +701,7 @@ int launch_terms(const dpll_model* m, const dpll_params_t* p, const void* x, lon
   const size_t lds = arena_bytes<T, double>(fd);
   if (int rc = allow_lds(forest_terms_kernel<T>, lds, "dpll_terms")) return rc;
   hipLaunchKernelGGL((forest_terms_kernel<T>), dim3(grid_for(batch, lds)), dim3(kWave), lds, stream, dev, (const T*)p->theta, (const T*)p->friction,
-                     (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J, (T*)phi, (T*)a);
+                     (const T*)p->lengths, (const T*)x, ld_x, batch, (T*)Dm, (T*)M, (T*)J, (T*)phi, (T*)a, (const T*)p->u, (long long)p->ld_u);
   return dpll_check_launch("forest_terms_kernel");
 }
 
@@ -718,6 +731,7 @@ int check_desc(const dpll_forest_desc_t* d) {
       d->inertia_mode != DPLL_INERTIA_COMPOSED)
     return dpll_fail(-1, "dpll_forest_model_create: unknown inertia_mode%s");
   if (d->rotated & ~3) return dpll_fail(-1, "dpll_forest_model_create: rotated holds bits 0 and 1 only%s");
+  if (d->n_u < 0 || d->n_u > dpll_forest::kMaxV) return dpll_fail(-1, "dpll_forest_model_create: n_u must be between 0 and 32%s");
   int n_q = 0, n_v = 0, max_depth = 0;
   for (int b = 0; b < d->n_bodies; ++b) {
     const int kind = d->joint_kind[b], parent = d->parent[b];
@@ -738,6 +752,14 @@ int check_desc(const dpll_forest_desc_t* d) {
     n_v += nv;
   }
   if (n_q != d->n_q || n_v != d->n_v || max_depth != d->max_depth) return dpll_fail(-1, "dpll_forest_model_create: n_q / n_v / max_depth do not match the bodies%s");
+  // actuators: each on a revolute or prismatic joint, no joint twice
+  for (int k = 0; k < d->n_u; ++k) {
+    const int b = d->act_body[k];
+    if (b < 0 || b >= d->n_bodies || (d->joint_kind[b] != kJointRevolute && d->joint_kind[b] != kJointPrismatic))
+      return dpll_fail(-1, "dpll_forest_model_create: act_body must name bodies on revolute or prismatic joints%s");
+    for (int j = 0; j < k; ++j)
+      if (d->act_body[j] == b) return dpll_fail(-1, "dpll_forest_model_create: two actuators on one joint%s");
+  }
   //  what a C caller could get silently wrong: the `rotated` bits against the matrices they announce, hinge axes that
   // are not unit vectors, coordinate ranges of two bodies that overlap
   auto is_identity = [](const double (&r)[3][3]) {
@@ -797,6 +819,7 @@ int check_desc(const dpll_forest_desc_t* d) {
 
 int n_x(const dpll_model* m) { return m->forest->n_q + m->forest->n_v; }
 int n_contacts(const dpll_model* m) { return m->forest->n_contacts; }
+int n_u(const dpll_model* m) { return host_desc(m).n_u; }
 int param_count(const dpll_model* m) { return dpll_forest::param_count(*m->forest); }
 long long workspace_bytes(const dpll_model* m, long long batch) {
   const ForestDesc& fd = *m->forest;

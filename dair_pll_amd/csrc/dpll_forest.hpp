@@ -50,7 +50,7 @@ constexpr int kGeoStride = 3 * kMaxPolyVerts;
 
 // Plain-old-data description (include/dpll.h: dpll_forest_desc_t); lives in device memory, read through uniform loads
 struct ForestDesc {
-  int32_t n_bodies, n_geoms, n_pairs, n_contacts, n_q, n_v, inertia_mode, rotated, max_depth, reserved;
+  int32_t n_bodies, n_geoms, n_pairs, n_contacts, n_q, n_v, inertia_mode, rotated, max_depth, n_u;
   double dt, gravity_z;
   int32_t parent[kMaxBodies];       // -1: the world
   int32_t joint_kind[kMaxBodies];   // kJointRevolute | kJointPrismatic | kJointFloating | kJointFixed
@@ -68,6 +68,7 @@ struct ForestDesc {
   // contact c: witness contact_slot[c] of geometry contact_geom[c] against the ground, or (contact_geom[c] < 0) the contact of
   // candidate contact_slot[c]; in the reference's order (geometries in order, then the candidates)
   int32_t contact_geom[kMaxContacts], contact_slot[kMaxContacts];
+  int32_t act_body[kMaxV];          // actuator k drives the joint of this body (B u of lagrangian_forces, multibody_terms.py:142-146)
 };
 
 // ---- the team that works on an item -----------------------------------------------------------------------------------------
@@ -118,6 +119,7 @@ template <typename S, typename SA> struct Arena {
   S *iota, *mu_g, *mu_p, *habs;
   S *Vw, *Vu, *AGw, *AGu, *Wn, *Wf, *comp;
   S *M, *LM, *invdM, *a, *F;
+  S *tau;                               // [nv] actuation B u of the call (zeros for an unactuated system)
   S *J;                                 // [K][3][nv]
   ContactRec<S>* ct;
   SA* dirs;                             // [np][3]: candidate directions in the frame of A
@@ -145,7 +147,7 @@ template <typename S, typename SA> struct Arena {
       iota = m.take<S>(kIota * nb); mu_g = m.take<S>(ng); mu_p = m.take<S>(np > 0 ? np : 1); habs = m.take<S>(3 * ng);
       Vw = m.take<S>(3 * nb); Vu = m.take<S>(3 * nb); AGw = m.take<S>(3 * nb); AGu = m.take<S>(3 * nb);
       Wn = m.take<S>(3 * nb); Wf = m.take<S>(3 * nb); comp = m.take<S>(kIota * nb);
-      M = m.take<S>(nv * nv); LM = m.take<S>(nv * nv); invdM = m.take<S>(nv); a = m.take<S>(nv); F = m.take<S>(nv);
+      M = m.take<S>(nv * nv); LM = m.take<S>(nv * nv); invdM = m.take<S>(nv); a = m.take<S>(nv); F = m.take<S>(nv); tau = m.take<S>(nv);
       J = m.take<S>((size_t)K * 3 * nv);
       ct = nullptr;
       dirs = m.take<SA>(3 * (np > 0 ? np : 1)); setA = setB = nullptr;
@@ -163,7 +165,7 @@ template <typename S, typename SA> struct Arena {
     iota = m.take<S>(kIota * nb); mu_g = m.take<S>(ng); mu_p = m.take<S>(np > 0 ? np : 1); habs = m.take<S>(3 * ng);
     Vw = m.take<S>(3 * nb); Vu = m.take<S>(3 * nb); AGw = m.take<S>(3 * nb); AGu = m.take<S>(3 * nb);
     Wn = m.take<S>(3 * nb); Wf = m.take<S>(3 * nb); comp = m.take<S>(kIota * nb);
-    M = m.take<S>(nv * nv); LM = m.take<S>(nv * nv); invdM = m.take<S>(nv); a = m.take<S>(nv); F = m.take<S>(nv);
+    M = m.take<S>(nv * nv); LM = m.take<S>(nv * nv); invdM = m.take<S>(nv); a = m.take<S>(nv); F = m.take<S>(nv); tau = m.take<S>(nv);
     J = m.take<S>((size_t)K * 3 * nv);
     ct = m.take<ContactRec<S>>(K);
     dirs = m.take<SA>(3 * (np > 0 ? np : 1)); setA = m.take<SA>(3 * kMaxPolyVerts); setB = m.take<SA>(3 * kMaxPolyVerts);
@@ -409,7 +411,7 @@ template <typename S, typename SA, class Team> struct Forest {
       } else if (kind != kJointFixed) {
         S ax[3];
         DPLL_UNROLL for (int i = 0; i < 3; ++i) ax[i] = cst<S>(fd.joint_axis[b][i]);
-        A.F[vi] = kind == kJointPrismatic ? -dot3(ax, wf) : -dot3(ax, wn);
+        A.F[vi] = (kind == kJointPrismatic ? -dot3(ax, wf) : -dot3(ax, wn)) + A.tau[vi];  // (+ B u)
       }
     }
     Team::sync();
@@ -1066,6 +1068,16 @@ template <typename S, typename SA, class Team> struct Forest {
   }
 
   // ---- state in / out -----------------------------------------------------------------------------------------------------------
+  // B u of the item: `u` = its actuation inputs (fd.n_u numbers) or nullptr (no inputs: zeros, what the reference's sim_step
+  // passes, multibody_learnable_system.py:311); data, not a variable of any derivative
+  template <typename X> DPLL_HD void load_actuation(const X* u) {
+    for (int i = Team::rank(); i < A.nv; i += Team::kSize) A.tau[i] = S(0);
+    Team::sync();
+    if (u != nullptr) {
+      for (int k = Team::rank(); k < fd.n_u; k += Team::kSize) A.tau[fd.v_index[fd.act_body[k]]] = cst<S>(double(u[k]));
+      Team::sync();
+    }
+  }
   template <typename X> DPLL_HD void load_state(const X* x) {
     for (int i = Team::rank(); i < A.nq; i += Team::kSize) A.q[i] = cst<SA>(double(x[i]));
     for (int i = Team::rank(); i < A.nv; i += Team::kSize) A.v[i] = cst<S>(double(x[A.nq + i]));
@@ -1450,6 +1462,8 @@ template <class Team> struct ForestBackward {
                              X* xbar) {
     Forest<Du, Du, Team> dual(fd, B);
     dual.derive(theta, friction, lengths);
+    for (int i = Team::rank(); i < A.nv; i += Team::kSize) B.tau[i] = Du(A.tau[i], 0.0);  // (B u of the item: data)
+    Team::sync();
     for (int e = Team::rank(); e < 3 * A.np; e += Team::kSize) B.dirs[e] = Du(A.dirs[e]);  // the primal pass's directions: constants
     Team::sync();
     const D dt = fd.dt, idt = 1.0 / dt, mieps = -1.0 / kDynamicsEps;

@@ -14,6 +14,7 @@ namespace dpll_forest_api {
 int check_desc(const dpll_forest_desc_t* desc);
 int n_x(const dpll_model* m);
 int n_contacts(const dpll_model* m);
+int n_u(const dpll_model* m);  // actuators: the width of dpll_params_t.u
 int param_count(const dpll_model* m);
 long long workspace_bytes(const dpll_model* m, long long batch);
 void release(dpll_model* m);  // the device copy of the description

@@ -1780,7 +1780,7 @@ int check_common(const dpll_model* m, int dtype, const dpll_params_t* p, long lo
   if (batch < 0) return fail(-1, "%s: negative batch", who);
   // actuation inputs: only a model with actuators takes them (anything else would be a silent drop of B u), with rows of at
   // least n_u numbers
-  const int n_u = m->forest ? 0 : m->desc.n_u;
+  const int n_u = m->forest ? dpll_forest_api::n_u(m) : m->desc.n_u;
   if (p->u && n_u == 0) return fail(-1, "%s: actuation inputs (params->u) for a model without actuators", who);
   if (p->u && p->ld_u < n_u) return fail(-1, "%s: ld_u smaller than n_u", who);
   return 0;
@@ -1807,7 +1807,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 23; }
+int dpll_abi_version(void) { return 24; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");

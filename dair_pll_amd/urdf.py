@@ -580,9 +580,6 @@ def build_system_spec(models) -> SystemSpec:
 def check_forest_supported(system: SystemSpec) -> None:
     """What the forest build takes; anything else fails loudly at construction."""
     geoms = system.geoms()
-    if system.n_u > 0:
-        raise NotImplementedError('actuated joints (<transmission>) run on the general build: one model of at most '
-                                  f'{MAX_JOINTS} joints and {MAX_GEOMS} geometries')
     if system.n_bodies > FOREST_MAX_BODIES:
         raise NotImplementedError(f'at most {FOREST_MAX_BODIES} bodies per system')
     if not 1 <= len(geoms) <= FOREST_MAX_GEOMS:

@@ -117,7 +117,8 @@ typedef struct dpll_model_desc {
 #define DPLL_JOINT_FIXED 3
 
 typedef struct dpll_forest_desc {
-  int32_t n_bodies, n_geoms, n_pairs, n_contacts, n_q, n_v, inertia_mode, rotated, max_depth, reserved;
+  int32_t n_bodies, n_geoms, n_pairs, n_contacts, n_q, n_v, inertia_mode, rotated, max_depth;
+  int32_t n_u;                                 /* actuators (see act_body below); 0: dpll_params_t.u must be NULL */
   double dt, gravity_z;
   int32_t parent[DPLL_FOREST_MAX_BODIES];      /* -1 for a root, else a body listed before this one */
   int32_t joint_kind[DPLL_FOREST_MAX_BODIES];  /* dpll_joint_kind | DPLL_JOINT_FLOATING | DPLL_JOINT_FIXED */
@@ -138,6 +139,10 @@ typedef struct dpll_forest_desc {
    * candidates, drake_utils.py:178-184) --, then (contact_geom[c] = -1) the contact of candidate contact_slot[c]; no candidate
    * joins two anchored geometries */
   int32_t contact_geom[DPLL_FOREST_MAX_CONTACTS], contact_slot[DPLL_FOREST_MAX_CONTACTS];
+  /* actuator k (a URDF <transmission>, in the plant's order: the models one after the other, each in file order) drives the
+   * revolute / prismatic joint of body act_body[k]: column k of dpll_params_t.u is added to that joint's generalized force --
+   * the B u of lagrangian_forces (multibody_terms.py:142-146) */
+  int32_t act_body[DPLL_FOREST_MAX_V];
 } dpll_forest_desc_t;
 
 typedef struct dpll_solver_opts {

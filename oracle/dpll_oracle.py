@@ -297,6 +297,12 @@ def system_spec(urdfs, mesh_representation: str = 'deep_support') -> Dict:
               'ground_mu': GROUND_MU, 'n_q': q_off, 'n_v': v_off, 'models': specs, 'fixed_base': False}
     if any('inertia_rows' in spec for spec in specs):
         merged['inertia_rows'] = rows
+    # actuators of the plant: the models' <transmission>s one after the other (Drake's JointActuator order); an entry is the index
+    # of the actuated joint as lagrangian_forces reads it: joint j drives body j + 1 of the merged list
+    merged['actuators'], first = [], 0
+    for spec in specs:
+        merged['actuators'] += [first + joint for joint in spec.get('actuators', [])]
+        first += len(spec['bodies'])
     table = geometry_table(merged)
     anchored = anchored_bodies(merged)
     pairs = []

@@ -707,7 +707,11 @@ FOREST_CASES = {
     'rake': {'rake': 'rake.urdf'},                                        # one body, 5 geometries (2 boxes, 3 spheres)
     'two_cubes': {'cube_a': 'cube.urdf', 'cube_b': 'cube.urdf'},          # two models: two free cubes that can collide
     'pendulum_cube': {'pendulum': 'pendulum.urdf', 'cube': 'cube.urdf'},  # a fixed-base model next to a free one
+    # actuated systems (record_actuated_forest): motors on three of five hinges; a motor on a fixed-base model next to a free cube
+    'chain6_actuated': {'chain6_actuated': 'chain6_actuated.urdf'},
+    'pendulum_actuated_cube': {'pendulum': 'pendulum_actuated.urdf', 'cube': 'cube.urdf'},
 }
+ACTUATED_FOREST_CASES = ('chain6_actuated', 'pendulum_actuated_cube')
 
 
 def forest_tosses(name: str, n_traj: int, steps: int, keep_every: int, seed: int):
@@ -747,7 +751,7 @@ def forest_tosses(name: str, n_traj: int, steps: int, keep_every: int, seed: int
         pos = torch.cat((side + 0.01 * torch.randn((n_traj, 1), generator=gen), 0.02 * torch.randn((n_traj, 1), generator=gen),
                          0.05 + 0.07 * torch.rand((n_traj, 1), generator=gen)), -1)
         lin = torch.cat((-6.0 * side + 0.3 * torch.randn((n_traj, 1), generator=gen), 0.4 * torch.randn((n_traj, 2), generator=gen)), -1)
-        if name == 'pendulum_cube':  # the cube is thrown at the mast / under the arm
+        if name in ('pendulum_cube', 'pendulum_actuated_cube'):  # the cube is thrown at the mast / under the arm
             pos = torch.cat((0.2 - 0.1 + 0.02 * torch.randn((n_traj, 1), generator=gen), 0.1 + 0.02 * torch.randn((n_traj, 1), generator=gen),
                              0.05 + 0.05 * torch.rand((n_traj, 1), generator=gen)), -1)
             lin = torch.cat((0.8 + 0.3 * torch.randn((n_traj, 1), generator=gen), 0.3 * torch.randn((n_traj, 2), generator=gen)), -1)
@@ -761,7 +765,8 @@ def forest_tosses(name: str, n_traj: int, steps: int, keep_every: int, seed: int
     return urdfs, x, x_plus
 
 
-def record_forest_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0, names=tuple(FOREST_CASES)) -> None:
+def record_forest_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, seed: int = 0,
+                        names=tuple(name for name in FOREST_CASES if name not in ACTUATED_FOREST_CASES)) -> None:
     """SURVEY 8f-3, what the reference's generality reaches beyond one short tree: several models in one system (init_urdfs with
     more than one entry: a ProductSpace of the models' spaces, candidates between the models), a model welded to the world
     (FixedBaseSpace), five joints, five geometries on a body, ten candidates -- through the reference's own MultibodyTerms /
@@ -770,6 +775,19 @@ def record_forest_cases(n_traj: int = 8, steps: int = 36, keep_every: int = 3, s
         urdfs, x, x_plus = forest_tosses(name, n_traj, steps, keep_every, seed)
         record_case(name + '_literal', urdfs if len(urdfs) > 1 or name == 'pendulum_cube' else next(iter(urdfs.values())), x, x_plus,
                     'reference_literal', sim_steps=3)
+
+
+def record_actuated_forest(n_traj: int = 6, steps: int = 36, keep_every: int = 3, seed: int = 0) -> None:
+    """B u (reference multibody_terms.py:142-146) on systems beyond one short tree: a six-link chain with motors on three of its
+    hinges (listed out of joint order: column k of u is the k-th <transmission>), and a fixed-base pendulum with a motor on its
+    pivot next to a free cube (the plant's actuators are the models' one after the other) -- seeded torques of up to 0.05 N m
+    through the reference's own contactnets_loss / forward_dynamics / MultibodyTerms with a non-empty u."""
+    for name in ACTUATED_FOREST_CASES:
+        urdfs, x, x_plus = forest_tosses(name, n_traj, steps, keep_every, seed)
+        _, spec = build_reference_system(urdfs, 'reference_literal')
+        n_u = len(spec['actuators'])
+        u = 0.1 * (torch.rand((x.shape[0], n_u), generator=torch.Generator().manual_seed(13)) - 0.5)
+        record_case(name + '_literal', urdfs if len(urdfs) > 1 else next(iter(urdfs.values())), x, x_plus, 'reference_literal', sim_steps=3, u=u)
 
 
 def record_actuated_elbow(name: str = 'elbow_actuated_literal') -> None:
@@ -813,6 +831,7 @@ def main() -> None:
     record_polygon_cases()
     record_pair_cases()
     record_forest_cases()
+    record_actuated_forest()
 
 
 if __name__ == '__main__':

@@ -40,6 +40,20 @@ def lib():
     return _lib
 
 
+_actuation = None
+
+
+def set_actuation(u) -> None:
+    """actuation inputs ``(B, n_u)`` of the next loss / step / terms / step_backward calls on an actuated system (``None``: none)"""
+    global _actuation
+    if u is None:
+        _actuation = None
+        lib().forestsim_set_actuation(None, c_int64(0))
+    else:
+        _actuation = np.ascontiguousarray(u, dtype=np.float64)
+        lib().forestsim_set_actuation(_actuation.ctypes.data_as(c_void_p), c_int64(_actuation.shape[1]))
+
+
 def params_of(system_spec):
     """(theta, friction, lengths) at their URDF values: friction (1 + n_geoms,), lengths (n_geoms, 24) -- a box's half lengths, a
     sphere's radius in column 0, a polygon's vertices row-major"""

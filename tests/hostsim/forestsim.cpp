@@ -11,6 +11,11 @@ using namespace dpll_forest;
 
 namespace {
 
+// actuation inputs of the calls that follow (forestsim_set_actuation): row i = the B u inputs of item i, or none
+const double* g_u = nullptr;
+int64_t g_ld_u = 0;
+const double* item_u(int64_t i) { return g_u ? g_u + i * g_ld_u : nullptr; }
+
 template <typename S, typename SA> struct Item {
   std::vector<char> storage;
   Arena<S, SA> arena;
@@ -30,6 +35,7 @@ int loss_batch(const ForestDesc& fd, const SolverOpts& opt, const T* theta, cons
   for (int64_t i = 0; i < B; ++i) {
     int it = 0;
     const T w = T(scale) * (weights ? weights[i] : T(1));
+    prog.load_actuation(item_u(i));
     const T L = prog.loss(x + i * nx, xp + i * nx, lengths, opt, w, grad != nullptr, row.data(), it);
     if (loss) loss[i] = L;
     if (iters) iters[i] = it;
@@ -53,6 +59,7 @@ int step_batch(const ForestDesc& fd, const SolverOpts& opt, const T* theta, cons
   const int nx = fd.n_q + fd.n_v;
   prog.derive(theta, friction, lengths);
   for (int64_t i = 0; i < B; ++i) {
+    prog.load_actuation(item_u(i));
     const int it = prog.step(x + i * nx, lengths, opt, x_next + i * nx);
     if (iters) iters[i] = it;
   }
@@ -67,6 +74,7 @@ int terms_batch(const ForestDesc& fd, const T* theta, const T* friction, const T
   const int nx = fd.n_q + fd.n_v, nv = fd.n_v, K = fd.n_contacts;
   prog.derive(theta, friction, lengths);
   for (int64_t i = 0; i < B; ++i) {
+    prog.load_actuation(item_u(i));
     prog.load_state(x + i * nx);
     prog.terms();
     prog.contacts(lengths);
@@ -96,8 +104,10 @@ int step_backward_batch(const ForestDesc& fd, const SolverOpts& opt, const doubl
   const int nx = fd.n_q + fd.n_v;
   std::vector<double> row(row_width(fd), 0.0);
   prog.derive(theta, friction, lengths);
-  for (int64_t i = 0; i < B; ++i)
+  for (int64_t i = 0; i < B; ++i) {
+    prog.load_actuation(item_u(i));
     back.run(x + i * nx, xbar_next + i * nx, theta, friction, lengths, opt, row.data(), xbar ? xbar + i * nx : (double*)nullptr);
+  }
   for (int k = 0; k < param_count(fd); ++k) grad[k] = chain_param(fd, theta, friction, lengths, row.data(), k);
   return 0;
 }
@@ -105,6 +115,8 @@ int step_backward_batch(const ForestDesc& fd, const SolverOpts& opt, const doubl
 }  // namespace
 
 extern "C" {
+// the actuation inputs (B, ld) of the batch calls that follow; nullptr: none
+void forestsim_set_actuation(const double* u, int64_t ld) { g_u = u; g_ld_u = ld; }
 int forestsim_step_backward_f64(const ForestDesc* fd, const SolverOpts* opt, const double* theta, const double* friction, const double* lengths,
                                 const double* x, const double* xbar_next, int64_t B, double* grad, double* xbar) {
   return step_backward_batch(*fd, *opt, theta, friction, lengths, x, xbar_next, B, grad, xbar);
