@@ -8,14 +8,13 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dpll.h"
-#include "dpll_terms.hpp"
+#include "dpll_weld.hpp"
 
 int dpll_fail(int code, const char* fmt, const char* detail = "");  // (dpll_kernels.hip)
 int dpll_check_launch(const char* what);
 
 namespace {
 
-using dpll::DualT;
 using dpll::kIota;
 
 // thread (b, i): component i of body b's inertial vector
@@ -24,38 +23,17 @@ __global__ void weld_compose_kernel(int inertia_mode, int n_rows, int n_bodies, 
                                     const double* __restrict__ X, const T* __restrict__ theta, T* __restrict__ iota) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_bodies * kIota) return;
-  const int b = t / kIota, i = t % kIota;
-  double total = 0.0;
-  for (int r = 0; r < n_rows; ++r) {
-    if (host[r] != b) continue;
-    double th[10], io[kIota];
-    for (int k = 0; k < 10; ++k) th[k] = double(theta[10 * r + k]);
-    dpll::theta_to_iota<double>(th, inertia_mode, io);
-    const double* row = X + (size_t)r * 100 + i * 10;
-    for (int j = 0; j < kIota; ++j) total += row[j] * io[j];
-  }
-  iota[t] = T(total);
+  iota[t] = T(dpll::weld_compose_entry<T>(inertia_mode, n_rows, host, X, theta, t / kIota, t % kIota));
 }
 
-// thread (r, c): d / d theta_r[c] = sum_i g[host r][i] sum_j X_r[i][j] d iota_r[j] / d theta_r[c]
+// thread (r, c): entry c of row r's gradient
 template <typename T>
 __global__ void weld_backward_kernel(int inertia_mode, int n_rows, const int32_t* __restrict__ host, const double* __restrict__ X,
                                      const T* __restrict__ theta, const T* __restrict__ grad_iota, T* __restrict__ grad_theta,
                                      int accumulate) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_rows * 10) return;
-  const int r = t / 10, c = t % 10;
-  DualT<double> th[10], io[kIota];
-  for (int k = 0; k < 10; ++k) th[k] = DualT<double>(double(theta[10 * r + k]), k == c ? 1.0 : 0.0);
-  dpll::theta_to_iota<DualT<double>>(th, inertia_mode, io);
-  const T* g = grad_iota + 10 * host[r];
-  double total = 0.0;
-  for (int i = 0; i < kIota; ++i) {
-    const double* row = X + (size_t)r * 100 + i * 10;
-    double xd = 0.0;
-    for (int j = 0; j < kIota; ++j) xd += row[j] * io[j].d;
-    total += double(g[i]) * xd;
-  }
+  const double total = dpll::weld_backward_entry<T>(inertia_mode, host, X, theta, grad_iota, t / 10, t % 10);
   grad_theta[t] = T(accumulate ? double(grad_theta[t]) + total : total);
 }
 

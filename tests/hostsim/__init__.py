@@ -22,7 +22,7 @@ _lib = None
 
 def build(force: bool = False, sanitize: bool = False) -> str:
     out = _LIB if not sanitize else os.path.join(_HERE, 'libhostsim_asan.so')
-    parts = ('dpll_core', 'dpll_terms', 'dpll_solver', 'dpll_contact', 'dpll_loss', 'dpll_step', 'dpll_icnn')  # (the umbrella and its parts)
+    parts = ('dpll_core', 'dpll_terms', 'dpll_solver', 'dpll_contact', 'dpll_loss', 'dpll_step', 'dpll_icnn', 'dpll_weld')  # (the umbrella and its parts)
     newest = max([os.path.getmtime(_SRC)] + [os.path.getmtime(_CORE.replace('dpll_core', part)) for part in parts])
     if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
         flags = ['-O0', '-fsanitize=address,undefined', '-fno-omit-frame-pointer'] if sanitize else ['-O2']  # -O0: 35 s build instead of 4.5 min
@@ -51,6 +51,29 @@ def set_actuation(u) -> None:
     else:
         _actuation = np.ascontiguousarray(u, dtype=np.float64)
         lib().hostsim_set_actuation(_actuation.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(_actuation.shape[1]))
+
+
+def weld_compose(inertia_mode: int, host, transforms, theta_rows, n_bodies: int) -> np.ndarray:
+    """``dpll_weld_compose`` on the host: (n_rows, 10) theta rows -> (n_bodies, 10) inertial vectors"""
+    host = np.ascontiguousarray(host, dtype=np.int32)
+    transforms = np.ascontiguousarray(transforms, dtype=np.float64)
+    theta_rows = np.ascontiguousarray(theta_rows, dtype=np.float64)
+    iota = np.zeros((n_bodies, 10))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib().hostsim_weld_compose(ctypes.c_int(inertia_mode), ctypes.c_int(len(host)), ctypes.c_int(n_bodies), p(host), p(transforms), p(theta_rows), p(iota))
+    return iota
+
+
+def weld_backward(inertia_mode: int, host, transforms, theta_rows, grad_iota) -> np.ndarray:
+    """``dpll_weld_compose_backward`` on the host: d loss / d (bodies' inertial vectors) -> d loss / d (theta rows)"""
+    host = np.ascontiguousarray(host, dtype=np.int32)
+    transforms = np.ascontiguousarray(transforms, dtype=np.float64)
+    theta_rows = np.ascontiguousarray(theta_rows, dtype=np.float64)
+    grad_iota = np.ascontiguousarray(grad_iota, dtype=np.float64)
+    out = np.zeros_like(theta_rows)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib().hostsim_weld_backward(ctypes.c_int(inertia_mode), ctypes.c_int(len(host)), p(host), p(transforms), p(theta_rows), p(grad_iota), p(out))
+    return out
 
 
 def default_opts(dtype) -> SolverOpts:

@@ -12,6 +12,7 @@ static std::vector<uint64_t> g_reject_masks;
 #define DPLL_ITER_HOOK(it, active, alpha) do { if ((active) && !((alpha) == 1) && (it) < 64) g_reject_mask |= (1ull << (it)); } while (0)
 
 #include "../../dair_pll_amd/csrc/dpll_core.hpp"
+#include "../../dair_pll_amd/csrc/dpll_weld.hpp"
 #include "../../dair_pll_amd/csrc/dpll_icnn.hpp"
 
 using namespace dpll;
@@ -257,6 +258,17 @@ int general_dispatch(const ModelDesc* md, F0 f0, F1 f1, F2 f2, F3 f3) {
 extern "C" {
 // actuation inputs (B, n_u) of the next loss / step / step-backward calls on an actuated general model; null = none
 void hostsim_set_actuation(const double* u, int64_t ld_u) { g_actuation = u; g_actuation_ld = ld_u; }
+
+// dpll_weld_compose / dpll_weld_compose_backward on the host: the entries the device kernels compute, one thread each
+// (dair_pll_amd/csrc/dpll_weld.hpp)
+void hostsim_weld_compose(int inertia_mode, int n_rows, int n_bodies, const int32_t* host, const double* X, const double* theta,
+                          double* iota) {
+  for (int t = 0; t < n_bodies * kIota; ++t) iota[t] = weld_compose_entry<double>(inertia_mode, n_rows, host, X, theta, t / kIota, t % kIota);
+}
+void hostsim_weld_backward(int inertia_mode, int n_rows, const int32_t* host, const double* X, const double* theta,
+                           const double* grad_iota, double* grad_theta) {
+  for (int t = 0; t < n_rows * 10; ++t) grad_theta[t] = weld_backward_entry<double>(inertia_mode, host, X, theta, grad_iota, t / 10, t % 10);
+}
 
 
 int hostsim_loss_f64(const ModelDesc* md, const SolverOpts* opt, const double* theta, const double* friction,

@@ -245,3 +245,53 @@ def test_gpu_training_moves_every_row_and_the_fused_step_refuses(golden):
     (oracle.step(torch.tensor(g['x'][rows])) * w).sum().backward()
     ref = oracle.named_parameters()[THETA].grad
     assert (theta.grad.cpu() - ref).abs().max() <= 1e-7 * max(ref.abs().max().item(), 1e-3)
+
+
+def test_host_build_of_the_composition_and_of_the_composed_model(golden):
+    """The code the device runs, on the host (tests/hostsim compiles csrc/dpll_weld.hpp and csrc/dpll_core.hpp): (1) the
+    composition against the numpy restatement above and its backward against central differences; (2) the per-item math of the
+    general build with a DPLL_INERTIA_COMPOSED description -- loss, the gradient chained back to the five rows, the next
+    state -- against the reference run."""
+    import hostsim
+    from test_general_models import fixture_params, reference_gradient
+    for mode, physical, fixture in ((0, False, 'welded_arm_literal'), (1, True, 'welded_arm_physical')):
+        g = golden(fixture)
+        spec = parse_urdf(URDF)
+        rows = spec.inertia_rows()
+        host = [row.body for row in rows]
+        X = np.stack([_capi.weld_transform(row.rotation, row.origin) for row in rows])
+        theta_rows = g['param/' + THETA]
+        iota = hostsim.weld_compose(mode, host, X, theta_rows, len(spec.bodies))
+        expected = np.zeros_like(iota)
+        for r, row in enumerate(rows):
+            expected[row.body] += X[r] @ iota_of(theta_to_pi_cm(theta_rows[r]), physical)
+        assert np.abs(iota - expected).max() < 1e-15
+        w = np.random.default_rng(0).standard_normal(iota.shape)
+        chained = hostsim.weld_backward(mode, host, X, theta_rows, w)
+        for r in range(len(rows)):
+            for c in range(10):
+                e = np.zeros_like(theta_rows)
+                e[r, c] = 1e-6
+                fd = ((hostsim.weld_compose(mode, host, X, theta_rows + e, 2) - hostsim.weld_compose(mode, host, X, theta_rows - e, 2)) * w).sum() / 2e-6
+                assert abs(fd - chained[r, c]) <= 1e-7 * max(1.0, np.abs(chained).max()), (r, c)
+        # the composed model through the kernels' per-item math
+        desc = make_desc_of(spec, float(g['dt']), str(g['inertia_mode']))
+        assert desc.inertia_mode == _capi.INERTIA_COMPOSED
+        _, friction, lengths = fixture_params(g, spec)
+        out = hostsim.loss(desc, iota, friction, lengths, g['x'], g['x_plus'])
+        assert np.abs(out['loss'] - g['loss']).max() < 1e-12
+        n_b = len(spec.bodies)
+        grad_rows = hostsim.weld_backward(mode, host, X, theta_rows, out['grad'][:10 * n_b].reshape(n_b, 10))
+        ref = g['grad/' + THETA]
+        assert np.abs(grad_rows - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        named = {key: g[key] for key in g.files if key.startswith('grad/')}
+        named['grad/' + THETA] = np.zeros((n_b, 10))  # (the theta block of the flat layout is d / d iota here: compared above)
+        rest = reference_gradient(named, spec)
+        assert np.abs(out['grad'][10 * n_b:] - rest[10 * n_b:]).max() <= 1e-9 * max(1.0, np.abs(rest).max())
+        x_next, iters = hostsim.step(desc, iota, friction, lengths, g['x'])
+        assert iters.max() < 100 and np.abs(x_next - g['dynamics/x_next']).max() < 1e-10 * max(1.0, np.abs(g['dynamics/x_next']).max())
+
+
+def make_desc_of(spec, dt, inertia_mode):
+    from dair_pll_amd._capi import make_desc
+    return make_desc(spec, dt, inertia_mode)
