@@ -248,6 +248,14 @@ extern __shared__ __align__(16) char forest_smem[];
 #ifndef DPLL_FOREST_OCC
 #define DPLL_FOREST_OCC 2
 #endif
+// partial rows (= one-wave workgroups) of a gradient launch at most: DPLL_FOREST_OCC per SIMD on every CU.  Round 5, 4096 items,
+// f32 loss + gradients: OCC 3 with 3072 rows / OCC 4 with 4096 rows (every item resident at once) against the shipped 2 / 2048:
+// cube 168 / 188 vs 141 us, two_cubes 513 / 522 vs 364, gripper 516 / 549 vs 350, chain6 2173 / 2230 vs 1926 -- the register
+// budget of 170 / 128 costs more than the extra resident waves return
+#ifndef DPLL_FOREST_MAX_ROWS
+#define DPLL_FOREST_MAX_ROWS kMaxLossBlocks
+#endif
+constexpr int kForestMaxRows = DPLL_FOREST_MAX_ROWS;
 
 // ---- ContactNets loss, forward + backward ------------------------------------------------------------------------------------
 // G: lanes per item (16: four items per wave; 64: one).  LDS: [the teams' partial rows | the teams' arenas]
@@ -553,14 +561,14 @@ int grid_for(long long batch, size_t lds_bytes, int items_per_wave = 1) {
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 4 * DPLL_FOREST_OCC) per_cu = 4 * DPLL_FOREST_OCC;
   long long blocks = 256 * per_cu;
-  if (blocks > kMaxLossBlocks) blocks = kMaxLossBlocks;
+  if (blocks > kForestMaxRows) blocks = kForestMaxRows;
   if (blocks > batch) blocks = batch;
   return (int)(blocks < 1 ? 1 : blocks);
 }
 long long folded_rows(long long rows) { return (rows + kFold - 1) / kFold; }
 // rows a gradient launch may write, whatever the batch, dtype and lanes per item: what the workspace is laid out for
 // ([rows (max_rows) | folded rows])
-int max_rows(const ForestDesc&) { return kMaxLossBlocks; }
+int max_rows(const ForestDesc&) { return kForestMaxRows; }
 
 template <typename K> int allow_lds(K kernel, size_t bytes, const char* who) {
   if (bytes + sizeof(ForestDesc) + 4096 > 160 * 1024) return dpll_fail(-2, "%s: the model needs more LDS per item than a CU has", who);
