@@ -108,6 +108,22 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
                                       device='cuda:0')
     single.contactnets_loss_and_grad(x[:1], xp[:1])
     assert (tail_reduced - single.grad_buffer()).abs().max() < 1e-15
+    # links welded on with rows of their own (tests/test_welded_links.py): the rows' gradient is not a view of the exchanged buffer,
+    # it is chained again from the summed theta block (system.after_grad_reduce) -- sharded + exchange == the full batch
+    gw = np.load(os.path.join(GOLDEN_DIR, 'welded_arm_literal.npz'))
+    welded = MultibodyLearnableSystem({'welded_arm': os.path.join(ASSET_DIR, 'welded_arm.urdf')}, float(gw['dt']), dtype=torch.float64,
+                                      device='cuda:0')
+    xw, xpw = torch.tensor(gw['x'], device='cuda:0'), torch.tensor(gw['x_plus'], device='cuda:0')
+    theta = welded.multibody_terms.lagrangian_terms.inertial_parameters
+    welded.contactnets_loss_and_grad(xw, xpw)
+    whole = theta.grad.clone()
+    assert whole.shape == (5, 10)
+    wred = GradientAllReduce(welded, global_batch=xw.shape[0], transport='peer')
+    lo, hi = shard_bounds(xw.shape[0], rank, world)
+    welded.contactnets_loss_and_grad(xw[lo:hi], xpw[lo:hi])
+    wred.all_reduce_mean()
+    wred.check_healthy()
+    assert (theta.grad - whole).abs().max() <= 1e-13 * whole.abs().max()
     np.save(os.path.join(out_dir, f'rank{rank}.npy'), reduced.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
