@@ -295,3 +295,41 @@ def test_host_build_of_the_composition_and_of_the_composed_model(golden):
 def make_desc_of(spec, dt, inertia_mode):
     from dair_pll_amd._capi import make_desc
     return make_desc(spec, dt, inertia_mode)
+
+
+def test_a_welded_frame_without_mass_has_no_row(tmp_path):
+    """a `fixed` joint to a link without mass and inertia (a frame: a sensor mount, a tool centre point) -- the reference's theta
+    has no finite value for it (log m), so it carries no row; its geometry still rides on its host.  A massless link WITH inertia
+    is refused, and so is it by the oracle's parser."""
+    link = ('<link name="{name}"><inertial><origin xyz="0 0 0"/><mass value="{m}"/>'
+            '<inertia ixx="{i}" iyy="{i}" izz="{i}" ixy="0" ixz="0" iyz="0"/></inertial>{col}</link>')
+    box = ('<collision><geometry><box size="0.1 0.06 0.04"/></geometry><drake:proximity_properties><drake:mu_static value="0.3"/>'
+           '</drake:proximity_properties></collision>')
+    ball = ('<collision><origin xyz="0.01 0 0"/><geometry><sphere radius="0.01"/></geometry><drake:proximity_properties>'
+            '<drake:mu_static value="0.2"/></drake:proximity_properties></collision>')
+
+    def urdf(frame_inertia):
+        return ('<?xml version="1.0"?><robot name="framed" xmlns:drake="https://drake.mit.edu/">'
+                + link.format(name='base', m=0.3, i=2e-4, col=box) + link.format(name='frame', m=0.0, i=frame_inertia, col=ball)
+                + link.format(name='lump', m=0.05, i=1e-5, col='')
+                + '<joint name="a" type="fixed"><parent link="base"/><child link="frame"/><origin xyz="0.05 0 0.02" rpy="0 0 0.3"/></joint>'
+                + '<joint name="b" type="fixed"><parent link="frame"/><child link="lump"/><origin xyz="0 0.01 0"/></joint></robot>')
+    path = tmp_path / 'framed.urdf'
+    path.write_text(urdf(0.0))
+    spec = parse_urdf(str(path))
+    assert [body.name for body in spec.bodies] == ['base'] and spec.welded == {'frame': 'base', 'lump': 'base'}
+    assert [(row.name, row.body) for row in spec.inertia_rows()] == [('base', 0), ('lump', 0)] and spec.has_welded_rows()
+    assert [geom.kind for geom in spec.bodies[0].geoms] == ['box', 'sphere'] and spec.bodies[0].geoms[1].link == 'frame'
+    # the lump sits in the base through both joints
+    from dair_pll_amd.urdf import _rotation
+    import xml.etree.ElementTree as ET
+    R = np.array(_rotation(ET.fromstring('<origin rpy="0 0 0.3"/>')))
+    assert np.abs(np.array(spec.inertia_rows()[1].origin) - (np.array([0.05, 0, 0.02]) + R @ np.array([0, 0.01, 0]))).max() < 1e-15
+    assert [(row['name'], row['body']) for row in O.inertia_rows(O.parse_urdf(str(path)))] == [('base', 0), ('lump', 0)]
+    system = MultibodyLearnableSystem({'framed': str(path)}, 0.0068, device='cpu')
+    assert system.multibody_terms.lagrangian_terms.inertial_parameters.shape == (2, 10) and 'lump_m' in system.scalars()
+    path.write_text(urdf(1e-6))
+    with pytest.raises(ValueError, match='welded link'):
+        parse_urdf(str(path)).inertia_rows()
+    with pytest.raises(AssertionError):
+        O.parse_urdf(str(path))
