@@ -234,6 +234,22 @@ for name in ('two_cubes', 'pendulum_cube', 'rake', 'chain6'):
         forest.step(desc, theta, friction, lengths, g['x'][:n], dtype=dtype)
     forest.terms(desc, theta, friction, lengths, g['x'][:n])
     forest.step_backward(desc, theta, friction, lengths, g['x'][:4], np.ones_like(g['x'][:4]), want_state=True)
+# actuated systems: the item's B u block of the arena (tests/test_actuation.py)
+import test_actuation as TA
+from dair_pll_amd.urdf import build_system_spec, parse_urdf
+for name in TA.FOREST_ACTUATED:
+    g = np.load({os.path.join(here, 'golden')!r} + '/' + name + '_literal.npz')
+    spec = build_system_spec({{key: parse_urdf(path) for key, path in TA.forest_urdfs(name).items()}})
+    desc = _capi.make_forest_desc(spec, float(g['dt']), str(g['inertia_mode']))
+    theta, friction, lengths = T.fixture_params(g, spec)
+    n = 6
+    forest.set_actuation(g['u'][:n])
+    for dtype in (np.float64, np.float32):
+        forest.loss(desc, theta, friction, lengths, g['x'][:n], g['x_plus'][:n], dtype=dtype)
+        forest.step(desc, theta, friction, lengths, g['x'][:n], dtype=dtype)
+    forest.terms(desc, theta, friction, lengths, g['x'][:n])
+    forest.step_backward(desc, theta, friction, lengths, g['x'][:4], np.ones_like(g['x'][:4]), want_state=True)
+    forest.set_actuation(None)
 print('sanitized ok')
 '''
     asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so']).decode().strip()

@@ -119,11 +119,39 @@ for dtype in (np.float64, np.float32):
     out = hostsim.loss(desc, theta, friction, lengths, g['x'][:32], g['x_plus'][:32], dtype=dtype)
     hostsim.step(desc, theta, friction, lengths, g['x'][:32], dtype=dtype)
 hostsim.step_backward(desc, theta, friction, lengths, g['x'][:8], np.ones_like(g['x'][:8]), want_state=True)
+# the general build with links welded on (composed inertial rows, tests/test_welded_links.py) and with an actuator
+from dair_pll_amd import _capi
+from dair_pll_amd.urdf import parse_urdf
+from test_general_models import fixture_params
+golden = {os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')!r}
+assets = {ASSET_DIR!r}
+g = np.load(golden + '/welded_arm_literal.npz')
+spec = parse_urdf(assets + '/welded_arm.urdf')
+rows = spec.inertia_rows()
+host, X = [row.body for row in rows], np.stack([_capi.weld_transform(row.rotation, row.origin) for row in rows])
+theta_rows = g['param/multibody_terms.lagrangian_terms.inertial_parameters']
+iota = hostsim.weld_compose(0, host, X, theta_rows, len(spec.bodies))
+desc = _capi.make_desc(spec, float(g['dt']))
+_, friction, lengths = fixture_params(g, spec)
+for dtype in (np.float64, np.float32):
+    out = hostsim.loss(desc, iota, friction, lengths, g['x'][:16], g['x_plus'][:16], dtype=dtype)
+    hostsim.step(desc, iota, friction, lengths, g['x'][:16], dtype=dtype)
+hostsim.weld_backward(0, host, X, theta_rows, out['grad'][:20].reshape(2, 10))
+hostsim.step_backward(desc, iota, friction, lengths, g['x'][:4], np.ones_like(g['x'][:4]), want_state=True)
+g = np.load(golden + '/elbow_actuated_literal.npz')
+spec = parse_urdf(assets + '/elbow_actuated.urdf')
+desc = _capi.make_desc(spec, float(g['dt']))
+theta, friction, lengths = fixture_params(g, spec)
+hostsim.set_actuation(g['u'][:16])
+hostsim.loss(desc, theta, friction, lengths, g['x'][:16], g['x_plus'][:16])
+hostsim.step(desc, theta, friction, lengths, g['x'][:16])
+hostsim.step_backward(desc, theta, friction, lengths, g['x'][:4], np.ones_like(g['x'][:4]), want_state=True)
+hostsim.set_actuation(None)
 print('sanitized ok')
 '''
     asan = subprocess.check_output(['gcc', '-print-file-name=libasan.so']).decode().strip()
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS='detect_leaks=0', PYTHONPATH=os.path.dirname(__file__))
-    result = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    result = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=1500)
     assert result.returncode == 0 and 'sanitized ok' in result.stdout, result.stderr[-2000:]
     assert 'runtime error' not in result.stderr
 
