@@ -195,6 +195,12 @@ class Timer:
         return 'eager' + (f' (hipGraph capture failed: {self.capture_error})' if self.capture_error else '')
 
 
+# dpll_solver_opts_t.mesh_gemm: the forms of the float32 ICNN GEMM kernels beside the default (0: exact f32 MFMA)
+MESH_GEMM_FORMS = {1: 'ICNN GEMMs: f32 MFMA, the 8-wave kernels', 2: 'ICNN GEMMs on the bf16 matrix cores, 2 planes',
+                   3: 'ICNN GEMMs on the bf16 matrix cores, 3 planes',
+                   4: 'ICNN GEMMs on the fp16 matrix cores, 2 planes with the low one scaled by 2^11: f32-grade products'}
+
+
 def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
@@ -294,7 +300,7 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
                       else 'gen_loss_kernel + row fold + finalize (general build: one lane per contact slot)')
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'kernel': kernel, 'kernel_ms': step_ms}
     if mesh_gemm:
-        workload = f'{workload} (ICNN GEMMs on the bf16 matrix cores, {mesh_gemm} planes)'
+        workload = f'{workload} ({MESH_GEMM_FORMS[mesh_gemm]})'
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
             'racing_copies': system.racing_copies(batch), 'kernel_ms': roof['kernel_ms'], 'mean_loss': system.contactnets_loss_and_grad(x, xp).item(),
@@ -326,7 +332,7 @@ def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device, m
     ms = float(np.median(times))
     if workload == 'mesh':  # per step two forward GEMMs of (4 batch) x 256 x 256 (the support points follow the state)
         tflops = 2 * 2.0 * (4 * batch) * 256 * 256 * horizon / (ms * 1e-3) / 1e12
-        return {'workload': f'simulate ({workload}, {horizon} steps per call)' + (f', ICNN GEMMs on the bf16 matrix cores ({mesh_gemm} planes)' if mesh_gemm else ''),
+        return {'workload': f'simulate ({workload}, {horizon} steps per call)' + (f', {MESH_GEMM_FORMS[mesh_gemm]}' if mesh_gemm else ''),
                 'dtype': dtype_name, 'batch': batch,
                 'value': batch * horizon / (ms * 1e-3), 'unit': 'trajectory-steps/s (forward only)', 'ms_per_step': ms / horizon,
                 'kernel_ms': ms, 'launch': 'dpll_simulate_mesh: weights prepared once, 4 kernels per step enqueued by the library',
@@ -399,8 +405,9 @@ def main() -> None:
     parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
     parser.add_argument('--workload', choices=['cube', 'elbow', 'mesh'], default='cube',
                         help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]; mesh = configs[3]')
-    parser.add_argument('--mesh-gemm', type=int, choices=[0, 2, 3], default=0,
-                        help='mesh workload: form of the ICNN GEMM kernels (0 = f32 MFMA, 2 / 3 = bf16 matrix cores on 2 / 3 bf16 planes)')
+    parser.add_argument('--mesh-gemm', type=int, choices=[0, 1, 2, 3, 4], default=0,
+                        help='mesh workload: form of the ICNN GEMM kernels (0 = f32 MFMA, 1 = its 8-wave kernels, 2 / 3 = bf16 matrix cores on 2 / 3 '
+                             'bf16 planes, 4 = two fp16 planes, f32-grade)')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     parser.add_argument('--portfolio', type=int, default=None,
                         help='diagnostic: racing copies of the cone solve per item (1 = none; default: what the library picks) -- the '
@@ -629,10 +636,12 @@ def main() -> None:
                 except Exception as exc:  # noqa: BLE001
                     configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
             try:
+                configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=4))
+                configs.append(run_simulate_config('mesh', 'f32', 4096, 80, 5, device, mesh_gemm=4))
                 configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=2))
                 configs.append(run_simulate_config('mesh', 'f32', 4096, 80, 5, device, mesh_gemm=2))
             except Exception as exc:  # noqa: BLE001
-                configs.append({'workload': 'mesh (bf16 planes)', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
+                configs.append({'workload': 'mesh (16-bit planes)', 'dtype': 'f32', 'batch': 4096, 'error': repr(exc)})
             for w, k, fused in (('cube', 400, False), ('cube', 400, True), ('slider', 60, True), ('mesh', 60, True)):
                 try:
                     configs.append(run_train_config('f32', 4096, k, device, fused, w))

@@ -20,7 +20,7 @@ GEOM_KINDS = {'box': 0, 'sphere': 1, 'polygon': 2, 'mesh': 3}  # dpll_geom_kind
 JOINT_KINDS = {'revolute': 0, 'prismatic': 1}
 GEOM_BLOCK = 24  # DPLL_GEOM_BLOCK: numbers per geometry in the general build's `lengths` block
 F32, F64 = 0, 1
-ABI_VERSION = 24  # dpll_abi_version() of include/dpll.h as bound below
+ABI_VERSION = 25  # dpll_abi_version() of include/dpll.h as bound below
 INERTIA_MODES = {'reference_literal': 0, 'physical': 1}
 MAX_WELD_ROWS = 64  # DPLL_MAX_WELD_ROWS
 INERTIA_COMPOSED = 2  # DPLL_INERTIA_COMPOSED: set by make_desc / make_forest_desc for models with welded links, never by a caller

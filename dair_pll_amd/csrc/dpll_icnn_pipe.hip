@@ -121,10 +121,38 @@ static_assert(2 * kBopElems * 2 == kXopFloats * 4, "two bf16 planes fill exactly
 
 // acc (+)= a * w on the bf16 matrix cores, the weight vector read from accumulation registers.  FIRST: C = 0.  (hipcc pads
 // nothing inside an asm statement; a dependent MFMA taking the previous result whole as C needs no wait state.)
-template <bool FIRST>
+// F16: the two planes are fp16 numbers in the same 16-bit containers (dpll_mesh_bf16.hpp: mesh_gemm = 4), the instruction is the
+// fp16 one of the same shape and rate
+template <bool FIRST, bool F16 = false>
 __device__ __forceinline__ void mfma_bf16(f32x16& acc, const bf16x8& a, const bf16x8& w) {
-  if (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(w));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
+  if constexpr (F16) {
+    if (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(w));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
+  } else {
+    if (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(w));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(w));
+  }
+}
+// the two 16-bit planes of a value: bf16 (hi, residual) or fp16 (hi, residual x 2^11), as 16-bit patterns
+constexpr float kF16LowScale = 2048.f;
+template <bool F16> __device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
+  if constexpr (F16) {
+    const _Float16 h = (_Float16)v;
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (_Float16)((v - (float)h) * kF16LowScale));
+  } else {
+    const __bf16 h = (__bf16)v;  // round to nearest even; the residual is exact in f32
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+  }
+}
+template <bool F16> __device__ __forceinline__ float plane_value(unsigned short bits) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, bits);
+  else return (float)__builtin_bit_cast(__bf16, bits);
+}
+template <bool F16> __device__ __forceinline__ unsigned short plane_bits(float v) {  // (v is exactly representable: a plane value halved)
+  if constexpr (F16) return __builtin_bit_cast(unsigned short, (_Float16)v);
+  else return __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 // the wait states an 8-pass XDL result needs before a VALU instruction may read it
 __device__ __forceinline__ void mfma_settle(f32x16& a, f32x16& b) { asm volatile("s_nop 7\n\ts_nop 4" : "+v"(a), "+v"(b)); }
@@ -145,7 +173,7 @@ __device__ unsigned long long g_pipe_stamps[256][16];
 #define PIPE_STAMP(i) do { } while (0)
 #endif
 
-template <int KIND, bool BF16 = false>
+template <int KIND, bool BF16 = false, bool F16 = false>
 __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   __shared__ __attribute__((aligned(16))) float Xs[2][kXopFloats];
   __shared__ RowRing ring;
@@ -180,9 +208,10 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       }
       if (KIND == kFwd2) {  // U1 = |wout[c]| (mask ? 1 : 1/2): its planes are per-column constants (the halving is exact)
         const float av = g.a[c0 + j];
-        const __bf16 h = (__bf16)av;
-        ahi[j] = (float)h;
-        alo[j] = (float)(__bf16)(av - ahi[j]);
+        unsigned short hb, lb;
+        split2<F16>(av, hb, lb);
+        ahi[j] = plane_value<F16>(hb);
+        alo[j] = plane_value<F16>(lb);  // (F16: already scaled by 2^11)
       }
     }
   }
@@ -305,11 +334,11 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   };
   auto fill_step_b = [&](int i, const SideIn& in, float* __restrict__ X, float* __restrict__ vb_rows) {
     const int rr = 2 * i + rpar;
-    bf16x2 hi, lo;
+    unsigned short h0, h1, l0, l1;
     if (KIND == kFwd2) {
       const float f0 = mask_factor(in.w, c0 & 31), f1 = mask_factor(in.w, (c0 & 31) + 1);
-      hi = bf16x2{(__bf16)(ahi[0] * f0), (__bf16)(ahi[1] * f1)};
-      lo = bf16x2{(__bf16)(alo[0] * f0), (__bf16)(alo[1] * f1)};
+      h0 = plane_bits<F16>(ahi[0] * f0); h1 = plane_bits<F16>(ahi[1] * f1);
+      l0 = plane_bits<F16>(alo[0] * f0); l1 = plane_bits<F16>(alo[1] * f1);
     } else {
       float val[2];
 #pragma unroll
@@ -319,13 +348,13 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
         else val[j] = (in.b[0] * d2[j][0] + in.b[1] * d2[j][1] + in.b[2] * d2[j][2]) * icnn_mask(pre);  // rows past N: r_bar = 0
       }
       if (KIND == kBwd1) *(float2*)(vb_rows + rr * kW + c0) = float2{val[0], val[1]};
-      hi = bf16x2{(__bf16)val[0], (__bf16)val[1]};  // round to nearest even; the residuals below are exact in f32
-      lo = bf16x2{(__bf16)(val[0] - (float)hi[0]), (__bf16)(val[1] - (float)hi[1])};
+      split2<F16>(val[0], h0, l0);
+      split2<F16>(val[1], h1, l1);
     }
-    uint32_t* plane0 = (uint32_t*)X;  // (two bf16 per word)
+    uint32_t* plane0 = (uint32_t*)X;  // (two 16-bit values per word)
     const int word = ((c0 >> 3) * kBq + rr * 8 + (c0 & 7)) >> 1;
-    plane0[word] = __builtin_bit_cast(uint32_t, hi);
-    plane0[kBopElems / 2 + word] = __builtin_bit_cast(uint32_t, lo);
+    plane0[word] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    plane0[kBopElems / 2 + word] = (uint32_t)l0 | ((uint32_t)l1 << 16);
   };
 
   // ---- epilogue state ------------------------------------------------------------------------------------------------
@@ -584,26 +613,26 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       const int nx = st + 1 < kW / 16 ? st + 1 : st;
       const bf16x8 a0n = x0[nx * (2 * kBq / 8)], a1n = x1[nx * (2 * kBq / 8)];
       const SideIn ein_next = epi_in(nx);
-      if (st == 0) mfma_bf16<true>(low[cb], a0, wb[1][cb][st]);
-      else mfma_bf16<false>(low[cb], a0, wb[1][cb][st]);
+      if (st == 0) mfma_bf16<true, F16>(low[cb], a0, wb[1][cb][st]);
+      else mfma_bf16<false, F16>(low[cb], a0, wb[1][cb][st]);
       epi(st, ein);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_bf16<false>(low[cb], a1, wb[0][cb][st]);
+      mfma_bf16<false, F16>(low[cb], a1, wb[0][cb][st]);
       SideIn fin_next = fin;
       if (st & 1) {
         fill(st >> 1, fin);
         fin_next = fill_in((st >> 1) + 1 < 8 ? (st >> 1) + 1 : (st >> 1));
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (st == 0) mfma_bf16<true>(acc[cb], a0, wb[0][cb][st]);
-      else mfma_bf16<false>(acc[cb], a0, wb[0][cb][st]);
+      if (st == 0) mfma_bf16<true, F16>(acc[cb], a0, wb[0][cb][st]);
+      else mfma_bf16<false, F16>(acc[cb], a0, wb[0][cb][st]);
       a0 = a0n; a1 = a1n;
       ein = ein_next; fin = fin_next;
       __builtin_amdgcn_sched_barrier(0);
     }
     mfma_settle(acc[cb], low[cb]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[cb][r] += low[cb][r];
+    for (int r = 0; r < 16; ++r) acc[cb][r] += low[cb][r] * (F16 ? 1.f / kF16LowScale : 1.f);  // (F16: the low plane travels scaled by 2^11)
   };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
@@ -745,32 +774,35 @@ int bwd1(hipStream_t stream, const float* x, long long ld, long long N, const Ic
 
 // ---- the split-bf16 form (2 planes): the same three kernels on the bf16 matrix cores; Ab / ATb = the planes icnn_prep_bf16_kernel<2>
 // writes (dpll_mesh_bf16.hpp), Vb leaves row-major (N rounded up to whole tiles, 256) for icnn_bwd2_bf16
-int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* Ab, uint32_t* M1) {
+int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* Ab, uint32_t* M1, bool f16) {
   if (N <= 0) return 0;
   if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
   g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)Ab; g.M1out = M1;
-  hipLaunchKernelGGL((icnn_pipe_kernel<kFwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  if (f16) hipLaunchKernelGGL((icnn_pipe_kernel<kFwd1, true, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((icnn_pipe_kernel<kFwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
   return check("icnn_pipe_kernel<fwd1, bf16>");
 }
 
 int fwd2_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* ATb, const float* a,
-              const uint32_t* M1, float* U0t, float* P) {
+              const uint32_t* M1, float* U0t, float* P, bool f16) {
   if (N <= 0) return 0;
   if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
   g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)ATb; g.a = a; g.M1in = M1; g.U0out = U0t; g.P = P;
-  hipLaunchKernelGGL((icnn_pipe_kernel<kFwd2, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  if (f16) hipLaunchKernelGGL((icnn_pipe_kernel<kFwd2, true, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((icnn_pipe_kernel<kFwd2, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
   return check("icnn_pipe_kernel<fwd2, bf16>");
 }
 
 int bwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* Ab, const float* a,
-              const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb) {
+              const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb, bool f16) {
   if (N <= 0) return 0;
   if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
   g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)Ab; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = Vb;
-  hipLaunchKernelGGL((icnn_pipe_kernel<kBwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  if (f16) hipLaunchKernelGGL((icnn_pipe_kernel<kBwd1, true, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL((icnn_pipe_kernel<kBwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
   return check("icnn_pipe_kernel<bwd1, bf16>");
 }
 

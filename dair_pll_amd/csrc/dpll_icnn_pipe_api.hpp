@@ -27,12 +27,13 @@ int fwd2(hipStream_t stream, const float* x, long long ld, long long N, const dp
 // Vb = (RB Wd0) . m0 (-> operand tiles VbT);  U1b = Vb |Wh| + RB Wd1;  partial rows [d|wout| | dWd1 | dWd0] per workgroup
 int bwd1(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const float* Af,
          const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* VbT);
-// the same three on the bf16 matrix cores, operands split into 2 bf16 planes (dpll_solver_opts_t.mesh_gemm = 2): Ab / ATb = the
-// weight planes of icnn_prep_bf16_kernel<2>; Vb leaves row-major for icnn_bwd2_bf16
-int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* Ab, uint32_t* M1);
+// the same three on the 16-bit matrix cores, operands split into 2 planes: bf16 (dpll_solver_opts_t.mesh_gemm = 2) or, f16 = true,
+// fp16 with the low plane scaled by 2^11 (mesh_gemm = 4: f32-grade products, dpll_mesh_bf16.hpp); Ab / ATb = the weight planes of
+// icnn_prep_bf16_kernel<2, f16>; Vb leaves row-major for icnn_bwd2_bf16
+int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* Ab, uint32_t* M1, bool f16 = false);
 int fwd2_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* ATb,
-              const float* a, const uint32_t* M1, float* U0t, float* P);
+              const float* a, const uint32_t* M1, float* U0t, float* P, bool f16 = false);
 int bwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* Ab,
-              const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb);
+              const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb, bool f16 = false);
 
 }  // namespace dpll_pipe

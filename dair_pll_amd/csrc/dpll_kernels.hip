@@ -1179,6 +1179,8 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
       hipLaunchKernelGGL((icnn_prep_bf16_kernel<2>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + pl.off_Ab), (__bf16*)(nb + pl.off_ATb), (float*)a);
     if (prep && t_mesh_gemm == 3)
       hipLaunchKernelGGL((icnn_prep_bf16_kernel<3>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + pl.off_Ab), (__bf16*)(nb + pl.off_ATb), (float*)a);
+    if (prep && t_mesh_gemm == 4)  // two fp16 planes, the low one scaled by 2^11: f32-grade products (dpll_mesh_bf16.hpp)
+      hipLaunchKernelGGL((icnn_prep_bf16_kernel<2, true>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + pl.off_Ab), (__bf16*)(nb + pl.off_ATb), (float*)a);
   }
   if (prep && !split_prep)
     hipLaunchKernelGGL((icnn_prep_kernel<T>), dim3(kW * kW / 256), dim3(256), 0, stream, w, A, AT, a,
@@ -1196,12 +1198,14 @@ int mesh_forward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, Q
                          (const __bf16*)(nb + pl.off_ATb), (const float*)a, (const uint32_t*)(nb + pl.off_M1),                    \
                          (float*)(nb + pl.off_U0), (float*)P);                                                                    \
     } while (0)
-    if (t_mesh_gemm == 2) {
-      // 2 planes: one wave per SIMD, pipelined (dpll_icnn_pipe.hip) -- on the bf16 matrix cores the side work hides behind the MFMAs
-      if (int rc = dpll_pipe::fwd1_bf16(stream, q.ptr, q.ld, pl.N, w, nb + pl.off_Ab, (uint32_t*)(nb + pl.off_M1))) return rc;
+    if (t_mesh_gemm == 2 || t_mesh_gemm == 4) {
+      // 2 planes (bf16, or = 4 fp16): one wave per SIMD, pipelined (dpll_icnn_pipe.hip) -- on the 16-bit matrix cores the side
+      // work hides behind the MFMAs
+      const bool f16 = t_mesh_gemm == 4;
+      if (int rc = dpll_pipe::fwd1_bf16(stream, q.ptr, q.ld, pl.N, w, nb + pl.off_Ab, (uint32_t*)(nb + pl.off_M1), f16)) return rc;
       mesh_mark(stream);
       if (int rc = dpll_pipe::fwd2_bf16(stream, q.ptr, q.ld, pl.N, w, nb + pl.off_ATb, (const float*)a, (const uint32_t*)(nb + pl.off_M1),
-                                        (float*)(nb + pl.off_U0), (float*)P)) return rc;
+                                        (float*)(nb + pl.off_U0), (float*)P, f16)) return rc;
     }
     else if (t_mesh_gemm == 3) DPLL_FWD_BF16(3);
     else if (t_mesh_gemm == 0 && pl.n_tiles > 2 * dpll_pipe::kMaxBlocks) {
@@ -1256,14 +1260,20 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
                          (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),        \
                          (float*)(nb + pl.off_slabs));                                                                            \
     } while (0)
-    if (t_mesh_gemm == 2) {
+    if (t_mesh_gemm == 2 || t_mesh_gemm == 4) {
+      const bool f16 = t_mesh_gemm == 4;
       if (int rc = dpll_pipe::bwd1_bf16(stream, (const float*)q.ptr, q.ld, pl.N, w, nb + pl.off_Ab, (const float*)(nb + pl.off_a),
                                         (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_U0), (const float*)RB,
-                                        (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb))) return rc;
+                                        (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb), f16)) return rc;
       mesh_mark(stream);
-      hipLaunchKernelGGL((icnn_bwd2_bf16<2>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
-                         (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
-                         (float*)(nb + pl.off_slabs));
+      if (f16)
+        hipLaunchKernelGGL((icnn_bwd2_bf16<2, true>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
+                           (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
+                           (float*)(nb + pl.off_slabs));
+      else
+        hipLaunchKernelGGL((icnn_bwd2_bf16<2>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
+                           (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
+                           (float*)(nb + pl.off_slabs));
     }
     else if (t_mesh_gemm == 3) DPLL_BWD_BF16(3);
     else if (t_mesh_gemm == 0) {
@@ -1582,6 +1592,8 @@ int genmesh_hulls(const dpll_model* m, int dtype, const GenMeshPlan& gp, const d
           hipLaunchKernelGGL((icnn_prep_bf16_kernel<2>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + p296.off_Ab), (__bf16*)(nb + p296.off_ATb), (float*)(nb + p296.off_a));
         if (t_mesh_gemm == 3)
           hipLaunchKernelGGL((icnn_prep_bf16_kernel<3>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + p296.off_Ab), (__bf16*)(nb + p296.off_ATb), (float*)(nb + p296.off_a));
+        if (t_mesh_gemm == 4)
+          hipLaunchKernelGGL((icnn_prep_bf16_kernel<2, true>), dim3(kW * kW / 256), dim3(256), 0, stream, w, (__bf16*)(nb + p296.off_Ab), (__bf16*)(nb + p296.off_ATb), (float*)(nb + p296.off_a));
       }
       if (int rc = check_launch("icnn_prep_kernel")) return rc;
     }
@@ -1807,7 +1819,7 @@ int dpll_debug_read_stamps(unsigned long long* host_out, int n_rows) {
 #endif
 
 const char* dpll_last_error(void) { return g_error; }
-int dpll_abi_version(void) { return 24; }
+int dpll_abi_version(void) { return 25; }
 
 int dpll_model_create(const dpll_model_desc_t* desc, dpll_model_t** out) {
   if (!desc || !out) return fail(-1, "dpll_model_create: null argument%s");
@@ -1923,8 +1935,8 @@ int dpll_model_set_solver(dpll_model_t* model, int dtype, const dpll_solver_opts
   if (opts->max_iter < 1 || opts->max_ls < 1 || opts->n_stages < 1 || opts->stage_max_iter < 1 || opts->stage_max_ls < 1 || !(opts->stage_factor >= 1.0))
     return fail(-1, "dpll_model_set_solver: iteration limits must be >= 1%s");
   if (opts->wide < -1 || opts->wide > 1) return fail(-1, "dpll_model_set_solver: wide must be -1, 0 or 1%s");
-  if (opts->mesh_gemm < 0 || opts->mesh_gemm > 3)
-    return fail(-1, "dpll_model_set_solver: mesh_gemm must be 0 (f32 MFMA, pipelined), 1 (f32 MFMA, the 8-wave kernels), 2 or 3 (bf16 planes)%s");
+  if (opts->mesh_gemm < 0 || opts->mesh_gemm > 4)
+    return fail(-1, "dpll_model_set_solver: mesh_gemm must be 0 (f32 MFMA, pipelined), 1 (f32 MFMA, the 8-wave kernels), 2 or 3 (bf16 planes) or 4 (two fp16 planes)%s");
   if (opts->portfolio != 0 && opts->portfolio != 1 && opts->portfolio != 2 && opts->portfolio != 4)
     return fail(-1, "dpll_model_set_solver: portfolio must be 0 (by batch size), 1 (off), 2 or 4%s");
   for (int k = 0; k < 3; ++k)

@@ -31,6 +31,38 @@ template <int PL> __device__ __forceinline__ void split_bf16(float x, __bf16 (&o
   }
 }
 
+// ---- two fp16 planes (dpll_solver_opts_t.mesh_gemm = 4).  fp16 keeps 11 significand bits against bf16's 8: x = h + l with
+// h = fp16(x) and l = fp16(x - h) leaves |x - (h + l)| <= 2^-24 |x| -- the rounding of an f32 number itself -- so THREE products per
+// k-step (h w_h, h w_l + l w_h; the dropped l w_l is 2^-24) give f32-grade products at the 2-plane cost.  The price is fp16's
+// range: the low plane is stored scaled by 2^11 (so it is as far from the subnormals as the high plane; its products go to the
+// `low` accumulator, which is scaled back once), and operands must stay below 65504 in magnitude -- the network's weights,
+// activations of unit directions and |wout| are O(1); see DESIGN.md 5 for what is checked.  The planes travel in the same 16-bit
+// containers as the bf16 ones (fragment order, LDS image): only the split and the MFMA instruction differ.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float kF16LowScale = 2048.f;  // 2^11
+template <bool F16> __device__ __forceinline__ __bf16 enc16(float v) {
+  if constexpr (F16) return __builtin_bit_cast(__bf16, (_Float16)v);
+  else return (__bf16)v;
+}
+template <bool F16> __device__ __forceinline__ float dec16(__bf16 b) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);
+  else return (float)b;
+}
+template <int PL, bool F16> __device__ __forceinline__ void split_planes(float x, __bf16 (&out)[PL]) {
+  if constexpr (F16) {
+    static_assert(PL == 2, "the fp16 form has two planes");
+    out[0] = enc16<true>(x);
+    out[1] = enc16<true>((x - dec16<true>(out[0])) * kF16LowScale);  // (the residual is exact in f32, the scaling a power of two)
+  } else {
+    split_bf16<PL>(x, out);
+  }
+}
+template <bool F16> __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16> constexpr float kLowBack = F16 ? 1.f / kF16LowScale : 1.f;  // what the `low` accumulator is multiplied by at the end
+
 // LDS image of one plane of a 32 x 256 A-operand tile for v_mfma_f32_32x32x16_bf16: lane (row r, half h) feeds k = 16 s +
 // 8 h + j, j = 0..7, of step s -- one aligned 16-byte read; element (row, k) at bop(row, k).  The 8-element pad per k-block
 // puts the two halves of a wave (blocks 2 s and 2 s + 1) on different banks.
@@ -46,15 +78,27 @@ __device__ __forceinline__ int frag_index_bf16(int k, int j) {
 }
 
 // |Wh| and |Wh|^T as PL bf16 planes in fragment order (plane p at offset p * 65536)
-template <int PL>
+template <int PL, bool F16 = false>
 __global__ __launch_bounds__(256) void icnn_prep_bf16_kernel(IcnnWeights<float> w, __bf16* __restrict__ Af, __bf16* __restrict__ ATf,
                                                              float* __restrict__ a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < kW) a[idx] = fabsf(w.wout[idx]);
+  if (idx < kW) {
+    float av = fabsf(w.wout[idx]);
+    if constexpr (F16) {
+      // fp16's range, guarded LOUDLY: a weight of column idx (|Wh|, Wd0, Wd1, wout) at or beyond 2^14 -- or not a number -- would
+      // send an operand plane to infinity somewhere down the pipeline; |wout[idx]| becomes NaN instead, and with it every support
+      // point and the loss (activations of unit directions are bounded by 3 max |Wd0|, U1 by |wout|)
+      bool bad = !(av < 16384.f);
+      for (int k = 0; k < kW; ++k) bad = bad || !(fabsf(w.Wh[k * kW + idx]) < 16384.f);
+      for (int i = 0; i < 3; ++i) bad = bad || !(fabsf(w.Wd0[i * kW + idx]) < 4096.f) || !(fabsf(w.Wd1[i * kW + idx]) < 16384.f);
+      if (bad) av = __builtin_nanf("");
+    }
+    a[idx] = av;
+  }
   if (idx >= kW * kW) return;
   const int k = idx / kW, j = idx % kW;
   __bf16 parts[PL];
-  split_bf16<PL>(fabsf(w.Wh[idx]), parts);
+  split_planes<PL, F16>(fabsf(w.Wh[idx]), parts);
 #pragma unroll
   for (int p = 0; p < PL; ++p) {
     Af[p * kW * kW + frag_index_bf16(k, j)] = parts[p];
@@ -337,7 +381,7 @@ __global__ __launch_bounds__(512) void icnn_bwd1_bf16(const float* __restrict__ 
 // row tiles; wave v the k-tile v >> 1 and the two j-tiles 2 (v & 1), 2 (v & 1) + 1.  Vb comes row-major from icnn_bwd1_bf16
 // (staged through LDS, double buffered); U1 is rebuilt from the mask words and |wout| -- per lane (one column) two constant
 // sets of planes, selected by the mask bit.
-template <int PL>
+template <int PL, bool F16 = false>
 __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* __restrict__ Vb, const uint32_t* __restrict__ M1,
                                                       const float* __restrict__ a, float* __restrict__ slabs) {
   __shared__ float Ls[2][kMfmaRows][128 + 1];
@@ -350,8 +394,8 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
   const long long t_begin = (long long)blockIdx.y * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
   // this lane's columns of U1: j-tiles jtl and jtl + 1 of the piece
   __bf16 ua[2][PL];
-  split_bf16<PL>(a[128 * jq + 32 * jtl + l31], ua[0]);
-  split_bf16<PL>(a[128 * jq + 32 * (jtl + 1) + l31], ua[1]);
+  split_planes<PL, F16>(a[128 * jq + 32 * jtl + l31], ua[0]);
+  split_planes<PL, F16>(a[128 * jq + 32 * (jtl + 1) + l31], ua[1]);
   f32x16 acc0, acc1, low0, low1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; low0[r] = 0.f; low1[r] = 0.f; }
@@ -392,24 +436,24 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
       for (int e = 0; e < 8; ++e) {
         const int row = 16 * s + 8 * half + e;
         __bf16 parts[PL];
-        split_bf16<PL>(Ls[cur][row][32 * ktl + l31], parts);
+        split_planes<PL, F16>(Ls[cur][row][32 * ktl + l31], parts);
         const bool on0 = (Ms[cur][row][jtl] >> l31) & 1u, on1 = (Ms[cur][row][jtl + 1] >> l31) & 1u;
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
           av[p][e] = parts[p];
-          b0[p][e] = on0 ? ua[0][p] : (__bf16)((float)ua[0][p] * float(kIcnnSlope));
-          b1[p][e] = on1 ? ua[1][p] : (__bf16)((float)ua[1][p] * float(kIcnnSlope));
+          b0[p][e] = on0 ? ua[0][p] : enc16<F16>(dec16<F16>(ua[0][p]) * float(kIcnnSlope));
+          b1[p][e] = on1 ? ua[1][p] : enc16<F16>(dec16<F16>(ua[1][p]) * float(kIcnnSlope));
         }
       }
 #pragma unroll
       for (int order = PL - 1; order >= 1; --order)
 #pragma unroll
         for (int i = 0; i <= order; ++i) {
-          low0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], b0[order - i], low0, 0, 0, 0);
-          low1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], b1[order - i], low1, 0, 0, 0);
+          low0 = mfma16<F16>(av[i], b0[order - i], low0);
+          low1 = mfma16<F16>(av[i], b1[order - i], low1);
         }
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], b0[0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], b1[0], acc1, 0, 0, 0);
+      acc0 = mfma16<F16>(av[0], b0[0], acc0);
+      acc1 = mfma16<F16>(av[0], b1[0], acc1);
     }
     if (more) commit(cur ^ 1);
     __syncthreads();
@@ -418,8 +462,8 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int k = 128 * kq + 32 * ktl + mfma_row(reg, half);
-    slab[k * kW + 128 * jq + 32 * jtl + l31] = acc0[reg] + low0[reg];
-    slab[k * kW + 128 * jq + 32 * (jtl + 1) + l31] = acc1[reg] + low1[reg];
+    slab[k * kW + 128 * jq + 32 * jtl + l31] = acc0[reg] + low0[reg] * kLowBack<F16>;
+    slab[k * kW + 128 * jq + 32 * (jtl + 1) + l31] = acc1[reg] + low1[reg] * kLowBack<F16>;
   }
 }
 

@@ -514,6 +514,17 @@ class MultibodyLearnableSystem(Module):
                 value = type(getattr(opts, key))(*value)
             setattr(opts, key, value)
         _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
+        if kwargs.get('mesh_gemm') == 4:
+            # two fp16 planes (csrc/dpll_mesh_bf16.hpp): fp16 ends at 65504.  The weights are checked here, once (one host sync);
+            # should they grow past the bound later the prep kernel turns |wout| into NaN -- no item then has a valid solve
+            for geometry in self._meshes():
+                net = geometry.network
+                for name, bound in (('hidden_weights', 16384.0), ('input_weights', 4096.0)):
+                    for weight in getattr(net, name):
+                        if not bool((weight.detach().abs() < bound).all()):
+                            raise _capi.DpllError(f'mesh_gemm = 4 (fp16 planes) needs |{name}| < {bound:g}: use mesh_gemm = 0')
+                if not bool((net.output_weight.detach().abs() < 16384.0).all()):
+                    raise _capi.DpllError('mesh_gemm = 4 (fp16 planes) needs |output_weight| < 16384: use mesh_gemm = 0')
 
     def _check_input(self, tensor: Tensor, width: int, what: str, keep_graph: bool = False) -> Tensor:
         if tensor.shape[-1] != width:

@@ -166,7 +166,9 @@ typedef struct dpll_solver_opts {
   int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves; like n_stages at most 8 unless portfolio = 1 */
   int32_t f64_refine;       /* DPLL_F64 solves: 1 = float iterations refined in double to `tol` (default), 0 = all double */
   int32_t mesh_gemm;        /* DPLL_F32 mesh pipeline, ICNN GEMMs: 0 = f32 MFMA (exact f32, default: one wave per SIMD, pipelined), 1 = f32 MFMA, the 8-wave kernels of rounds 1-4, 2 / 3 = bf16 matrix cores on
-                               operands split into 2 / 3 bf16 planes (3: f32-grade accuracy, 2: 2^-16 per product) */
+                               operands split into 2 / 3 bf16 planes (3: f32-grade accuracy, 2: 2^-16 per product); 4 = two fp16 planes
+                             * with the low one scaled by 2^11 (x = h + l to 2^-24: f32-grade products at the 2-plane cost; operands must stay below
+                             * 65504 in magnitude -- weights, |wout|, activations of unit directions, support-point adjoints) */
   /* Racing continuation schedules (loss solve, lane-per-contact builds): a launch that leaves SIMDs idle gives every item
    * `portfolio` copies of its lane group; copy 0 runs the schedule above, copy v >= 1 runs (race_stages[v-1],
    * race_factor[v-1]) with race_flags[v-1] (1 = warm start, 2 = full Newton steps only: no line search, so none of its

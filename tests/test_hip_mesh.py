@@ -81,19 +81,19 @@ def test_mesh_loss_gradients_dynamics(golden, dtype, case):
     assert np.abs(traj.detach().cpu().double().numpy() - g['simulate/traj']).max() < (1e-9 if f64 else 5e-4)
 
 
-@pytest.mark.parametrize('form', ['f64', 'f32', 'f32 8-wave kernels', 'bf16 2 planes', 'bf16 3 planes'])
+@pytest.mark.parametrize('form', ['f64', 'f32', 'f32 8-wave kernels', 'bf16 2 planes', 'bf16 3 planes', 'fp16 2 planes'])
 def test_benchmark_batch_mesh_4096(golden, form):
     """BASELINE configs[3] at its stated size: the 4096 benchmark pairs (16,384 support queries) through the reference's own
     DeepSupportConvex / HomogeneousICNN loss (oracle/gen_golden.py: record_mesh_bench_batch) -- per-item loss, batch mean and
     every gradient incl. the 67,328 network weights -- against the float64 kernels, the exact float32 MFMA kernels (pipelined
-    and 8-wave) and both split-bf16 forms.  (Round 4 held this size only against this repository's own float64 kernels.)"""
+    and 8-wave), both split-bf16 forms and the two-fp16-plane form.  (Round 4 held this size only against this repository's own float64 kernels.)"""
     g = golden('cube_mesh_4096')
     pairs = golden(str(g['pairs_from']))
     f64 = form == 'f64'
     dtype = torch.float64 if f64 else torch.float32
     system = build(g, dtype)
     if not f64:
-        system.set_solver(mesh_gemm={'f32': 0, 'f32 8-wave kernels': 1, 'bf16 2 planes': 2, 'bf16 3 planes': 3}[form])
+        system.set_solver(mesh_gemm={'f32': 0, 'f32 8-wave kernels': 1, 'bf16 2 planes': 2, 'bf16 3 planes': 3, 'fp16 2 planes': 4}[form])
     x, xp = torch.tensor(pairs['x'], dtype=dtype, device='cuda:0'), torch.tensor(pairs['x_plus'], dtype=dtype, device='cuda:0')
     loss = system.contact_forces(x, xp)[0].cpu().double().numpy()
     err = np.abs(loss - g['loss'])
@@ -448,10 +448,11 @@ def test_two_learned_shapes_on_random_states_against_the_oracle(golden):
 
 
 @pytest.mark.parametrize('case', CASES + [CLASP])
-@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('mode', [2, 3, 4])
 def test_split_bf16_gemm_forms_meet_the_float32_tolerances(golden, case, mode):
     """dpll_solver_opts_t.mesh_gemm: the ICNN GEMMs on the bf16 matrix cores with the operands split into 2 planes (three
-    products per k-step, "bf16 x 3") or 3 planes (six products, f32-grade) -- csrc/dpll_mesh_bf16.hpp.  The float32
+    products per k-step, "bf16 x 3"), 3 planes (six products, f32-grade) or -- mode 4 -- 2 fp16 planes with the low one scaled by
+    2^11 (three products, f32-grade: fp16 keeps 11 significand bits) -- csrc/dpll_mesh_bf16.hpp.  The float32
     tolerances of the default (exact f32 MFMA) kernels hold for both against the reference-run fixtures."""
     g = golden(case)
     system = build_general(g, torch.float32) if case == CLASP else build(g, torch.float32)
@@ -479,7 +480,8 @@ def test_split_bf16_gemm_forms_on_the_benchmark_batch(golden):
     p64 = s64.support_points(xp64).cpu().numpy()
     t64 = s64.contactnets_loss_and_grad(x64, xp64).item()
     g64 = {n: p.grad.cpu().numpy().copy() for n, p in s64.named_parameters()}
-    for mode, flips_allowed, grad_tol in ((0, 2e-4, 2e-5), (3, 2e-4, 2e-5), (2, 1e-3, 5e-4)):
+    # (mode 4, two fp16 planes, is held to the bars of the exact f32 kernels: its products are f32-grade)
+    for mode, flips_allowed, grad_tol in ((0, 2e-4, 2e-5), (3, 2e-4, 2e-5), (4, 2e-4, 2e-5), (2, 1e-3, 5e-4)):
         s32 = build(g, torch.float32)
         if mode:
             s32.set_solver(mesh_gemm=mode)
@@ -556,3 +558,30 @@ def test_mesh_workspace_is_exactly_what_the_library_asks_for(golden, case):
             assert abs(total.item() - loss.double().mean().item()) <= (1e-12 if dtype == torch.float64 else 1e-6)
             assert lib.dpll_contactnets_loss_mesh(*args, need - 1, system._stream()) != 0
         assert lib.dpll_mesh_workspace_bytes(system._model(), 0, code) == -1
+
+
+def test_fp16_planes_refuse_weights_beyond_their_range(golden):
+    """mesh_gemm = 4 runs the ICNN GEMMs on two fp16 planes: fp16 ends at 65504.  set_solver checks the weights once on the host;
+    weights that grow past the bound AFTERWARDS make the prep kernel turn |wout| into NaN, so that no item has a valid solve --
+    every per-item loss is then NaN or masked to zero like any failed solve (multibody_learnable_system.py:186-192): never a
+    finite wrong number."""
+    from dair_pll_amd import _capi
+    g = golden('cube_mesh_literal')
+    system = build(g, torch.float32)
+    net = system.multibody_terms.contact_terms.geometries[1].network
+    x = torch.tensor(g['x'], dtype=torch.float32, device='cuda:0')
+    xp = torch.tensor(g['x_plus'], dtype=torch.float32, device='cuda:0')
+    with torch.no_grad():
+        keep = net.hidden_weights[0][3, 5].item()
+        net.hidden_weights[0][3, 5] = 3.0e4
+    with pytest.raises(_capi.DpllError, match='fp16'):
+        system.set_solver(mesh_gemm=4)
+    with torch.no_grad():
+        net.hidden_weights[0][3, 5] = keep
+    system.set_solver(mesh_gemm=4)
+    good = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp).detach()
+    assert np.abs(good.cpu().double().numpy() - g['loss']).max() < 1e-4
+    with torch.no_grad():
+        net.hidden_weights[0][3, 5] = 3.0e4  # grown after the check
+    bad = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp).detach()
+    assert bool((~torch.isfinite(bad) | (bad == 0)).all())

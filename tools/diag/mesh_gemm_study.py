@@ -30,7 +30,7 @@ l_ref = ref.contact_forces(x64, xp64)[0].cpu().numpy()
 t_ref = ref.contactnets_loss_and_grad(x64, xp64).item()
 g_ref = {n: p.grad.cpu().numpy().copy() for n, p in ref.named_parameters()}
 out = {}
-for mode in (0, 3, 2):
+for mode in (0, 3, 4, 2):
     s = build(torch.float32, mode)
     pts = s.support_points(xp32).cpu().double().numpy()
     differ = np.abs(pts - p_ref).max(-1) > 1e-5          # a support point that is another vertex of the learned shape
