@@ -225,7 +225,10 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
                         'vector ALU to itself: the f32 MFMA runs on its multipliers, so every VALU / LDS instruction of the fused fill and '
                         'epilogue adds to the MFMA time (profiles/r05_mfma_fill.txt, r05_mfma_step.txt), and the chip runs these kernels '
                         'at ~2.15 GHz (matrix floor of one GEMM at 4096 pairs: 15.2 us)'
-                        if dtype == 'f32' else 'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)'}
+                        if dtype == 'f32' and not mesh_gemm else
+                        (MESH_GEMM_FORMS[mesh_gemm] + ' (csrc/dpll_mesh_bf16.hpp, dpll_icnn_pipe.hip); priced against the f32 matrix rate: the '
+                         'algorithmic work is the f32 GEMM' if dtype == 'f32' else
+                         'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)')}
     passes = [system.profile_loss_kernels(x, xp, reps=200) for _ in range(3)]  # (HIP events on the launch stream, 200 launches each)
     ms_loss, ms_fin = sorted(p[0] for p in passes)[1], sorted(p[1] for p in passes)[1]
     achieved = alg_bytes / (ms_loss * 1e-3) / 1e9

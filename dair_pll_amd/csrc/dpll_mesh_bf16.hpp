@@ -82,23 +82,25 @@ template <int PL, bool F16 = false>
 __global__ __launch_bounds__(256) void icnn_prep_bf16_kernel(IcnnWeights<float> w, __bf16* __restrict__ Af, __bf16* __restrict__ ATf,
                                                              float* __restrict__ a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
+  // fp16's range, guarded LOUDLY (F16): a weight at or beyond 2^14 (Wd0: 2^12) -- or not a number -- would send an operand plane to
+  // infinity somewhere down the pipeline.  The thread that meets one writes NaN instead of its plane entries (|wout|: instead of
+  // the entry of `a`): the second forward GEMM then returns NaN support points, every solve fails and is masked -- never a finite
+  // wrong number.  (Activations of unit directions are bounded by 3 max |Wd0|, U1 by |wout|.)
   if (idx < kW) {
     float av = fabsf(w.wout[idx]);
-    if constexpr (F16) {
-      // fp16's range, guarded LOUDLY: a weight of column idx (|Wh|, Wd0, Wd1, wout) at or beyond 2^14 -- or not a number -- would
-      // send an operand plane to infinity somewhere down the pipeline; |wout[idx]| becomes NaN instead, and with it every support
-      // point and the loss (activations of unit directions are bounded by 3 max |Wd0|, U1 by |wout|)
-      bool bad = !(av < 16384.f);
-      for (int k = 0; k < kW; ++k) bad = bad || !(fabsf(w.Wh[k * kW + idx]) < 16384.f);
-      for (int i = 0; i < 3; ++i) bad = bad || !(fabsf(w.Wd0[i * kW + idx]) < 4096.f) || !(fabsf(w.Wd1[i * kW + idx]) < 16384.f);
-      if (bad) av = __builtin_nanf("");
-    }
+    if constexpr (F16) av = av < 16384.f ? av : __builtin_nanf("");
     a[idx] = av;
   }
   if (idx >= kW * kW) return;
   const int k = idx / kW, j = idx % kW;
   __bf16 parts[PL];
-  split_planes<PL, F16>(fabsf(w.Wh[idx]), parts);
+  float wv = fabsf(w.Wh[idx]);
+  if constexpr (F16) {
+    bool bad = !(wv < 16384.f);
+    if (idx < 3 * kW) bad = bad || !(fabsf(w.Wd0[idx]) < 4096.f) || !(fabsf(w.Wd1[idx]) < 16384.f);
+    if (bad) wv = __builtin_nanf("");
+  }
+  split_planes<PL, F16>(wv, parts);
 #pragma unroll
   for (int p = 0; p < PL; ++p) {
     Af[p * kW * kW + frag_index_bf16(k, j)] = parts[p];

@@ -21,7 +21,7 @@ def counter_means(path):
 shutil.copy(os.path.join(SRC, 'stats', 'run_kernel_stats.csv'), os.path.join(DST, f'{TAG}_bench_f32_kernel_stats.csv'))
 for sub, name in (('stats_mesh', 'mesh_f32'), ('stats_f64', 'f64'), ('stats_elbow', 'elbow_f32'), ('stats_elbow_f64', 'elbow_f64'),
                   ('stats_b65536', 'f32_b65536'), ('stats_b65536_f64', 'f64_b65536'), ('stats_sim', 'simulate'),
-                  ('stats_mesh_bf16', 'mesh_bf16'), ('stats_general', 'general_build'), ('stats_clasp_mesh', 'clasp_mesh'),
+                  ('stats_mesh_bf16', 'mesh_bf16'), ('stats_mesh_f16', 'mesh_f16'), ('stats_general', 'general_build'), ('stats_clasp_mesh', 'clasp_mesh'),
                   ('stats_forest', 'forest_build')):
     src = os.path.join(SRC, sub, 'run_kernel_stats.csv')
     if os.path.exists(src):
