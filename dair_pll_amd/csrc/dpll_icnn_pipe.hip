@@ -70,6 +70,7 @@ struct PipeArgs {
   uint32_t* M1out;         // fwd1
   const float* U0in;       // bwd1 (accumulator layout)
   float* U0out;            // fwd2
+  unsigned* rbmax;         // bwd1, fp16 planes: where the launch leaves the largest |r_bar| it met (its float bits), for icnn_bwd2
   const float* RB;         // bwd1
   float* P;                // fwd2
   double* partial;         // bwd1
@@ -146,6 +147,11 @@ template <bool F16> __device__ __forceinline__ void split2(float v, unsigned sho
     lo = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
   }
 }
+// fp16 planes, adjoint operands: a power of two that takes a row of magnitude m (its largest |entry|) to [1, 2), and its inverse.
+// m = 0 (a row past N, a contact without gradient): the scale is 2^127 and the inverse 0 -- the row's products are zeros either way.
+__device__ __forceinline__ float row_max3(const f32x4& r) { return fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fabsf(r[2])); }
+__device__ __forceinline__ float pow2_up(float m) { return __builtin_bit_cast(float, (254u - ((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu)) << 23); }
+__device__ __forceinline__ float pow2_back(float m) { return __builtin_bit_cast(float, ((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) << 23); }
 template <bool F16> __device__ __forceinline__ float plane_value(unsigned short bits) {
   if constexpr (F16) return (float)__builtin_bit_cast(_Float16, bits);
   else return (float)__builtin_bit_cast(__bf16, bits);
@@ -348,8 +354,11 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
         else val[j] = (in.b[0] * d2[j][0] + in.b[1] * d2[j][1] + in.b[2] * d2[j][2]) * icnn_mask(pre);  // rows past N: r_bar = 0
       }
       if (KIND == kBwd1) *(float2*)(vb_rows + rr * kW + c0) = float2{val[0], val[1]};
-      split2<F16>(val[0], h0, l0);
-      split2<F16>(val[1], h1, l1);
+      // fp16 planes of an ADJOINT row: its magnitude is the data's (the loss scale 1 / batch, the item's weight), so the row goes
+      // to the planes scaled to [1, 2) |Wd0| by a power of two taken from r_bar itself; the epilogue scales the row's results back
+      const float up = (F16 && KIND == kBwd1) ? pow2_up(row_max3(in.b)) : 1.f;
+      split2<F16>(val[0] * up, h0, l0);
+      split2<F16>(val[1] * up, h1, l1);
     }
     uint32_t* plane0 = (uint32_t*)X;  // (two 16-bit values per word)
     const int word = ((c0 >> 3) * kBq + rr * 8 + (c0 & 7)) >> 1;
@@ -361,6 +370,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   // The two 32-column blocks of a wave are two MFMA chains run one after the other; acc[1] enters tile t still holding chain 1
   // of tile t - 1 (zero before the first tile), whose epilogue runs under chain 0 of tile t
   f32x16 low[2];  // BF16: the small products of a chain, added to acc once at its end
+  float rb_seen = 0.f;  // bwd1, fp16 planes: the largest |r_bar| entry of the rows this lane's epilogues met
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -427,7 +437,13 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     } else {
       const f32x4 r = in.a;
       const float mf = mask_factor(in.w, l31);
-      const float u1b = av + r[0] * wd1[cb][0] + r[1] * wd1[cb][1] + r[2] * wd1[cb][2];
+      float avs = av;
+      if constexpr (F16) {
+        const float m = row_max3(r);
+        avs = av * pow2_back(m);  // (the row went through the GEMM scaled by pow2_up(m))
+        rb_seen = fmaxf(rb_seen, m);
+      }
+      const float u1b = avs + r[0] * wd1[cb][0] + r[1] * wd1[cb][1] + r[2] * wd1[cb][2];
       t_abar += u1b * mf;  // rows past N / tiles that do not exist: r_bar = 0 and a zero accumulator
       if ((reg & 3) == 0) {
         u0cur = u0nxt;
@@ -708,6 +724,14 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     }
   }
   PIPE_STAMP(14);
+  if constexpr (KIND == kBwd1 && F16) {
+    // the largest |r_bar| entry of the launch (a non-negative float: its bits order like the number), for icnn_bwd2's global
+    // scale of the adjoint operand -- a maximum, so the order of the atomics does not matter
+    float m = rb_seen;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0 && g.rbmax) atomicMax(g.rbmax, __builtin_bit_cast(unsigned, m));
+  }
   if (KIND == kBwd1) {
     // the two halves of the wave hold different rows of the same columns (threads tid and tid ^ 32)
     __syncthreads();
@@ -796,11 +820,11 @@ int fwd2_bf16(hipStream_t stream, const float* x, long long ld, long long N, con
 }
 
 int bwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const IcnnWeights<float>& w, const void* Ab, const float* a,
-              const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb, bool f16) {
+              const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb, bool f16, unsigned* rbmax) {
   if (N <= 0) return 0;
   if (N >= (1LL << 31)) return -1;  // (row numbers are 32-bit inside the kernels)
   PipeArgs g{};
-  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)Ab; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = Vb;
+  g.x = x; g.ld = ld; g.N = N; g.w = w; g.F = (const float*)Ab; g.a = a; g.M1in = M1; g.U0in = U0t; g.RB = RB; g.partial = partial; g.VbT = Vb; g.rbmax = rbmax;
   if (f16) hipLaunchKernelGGL((icnn_pipe_kernel<kBwd1, true, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((icnn_pipe_kernel<kBwd1, true>), dim3(blocks(N)), dim3(256), 0, stream, g);
   return check("icnn_pipe_kernel<bwd1, bf16>");

@@ -34,6 +34,7 @@ int fwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, con
 int fwd2_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* ATb,
               const float* a, const uint32_t* M1, float* U0t, float* P, bool f16 = false);
 int bwd1_bf16(hipStream_t stream, const float* x, long long ld, long long N, const dpll::IcnnWeights<float>& w, const void* Ab,
-              const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb, bool f16 = false);
+              const float* a, const uint32_t* M1, const float* U0t, const float* RB, double* partial, float* Vb, bool f16 = false,
+              unsigned* rbmax = nullptr);  // (f16: the launch's largest |r_bar| entry, float bits, atomicMax into *rbmax)
 
 }  // namespace dpll_pipe

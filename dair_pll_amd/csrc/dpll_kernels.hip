@@ -1258,22 +1258,25 @@ int mesh_backward(const MeshPlan& pl, int g, const IcnnWeights<T>& w, char* ws, 
       mesh_mark(stream);                                                                                                          \
       hipLaunchKernelGGL((icnn_bwd2_bf16<PL_>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,                           \
                          (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),        \
-                         (float*)(nb + pl.off_slabs));                                                                            \
+                         (float*)(nb + pl.off_slabs), (const unsigned*)nullptr);                                                  \
     } while (0)
     if (t_mesh_gemm == 2 || t_mesh_gemm == 4) {
       const bool f16 = t_mesh_gemm == 4;
+      // (fp16 planes: the word behind the two weight planes of Ab -- zeroed by the prep kernel -- carries the launch's largest |r_bar|
+      // from icnn_bwd1 to icnn_bwd2)
+      unsigned* rbmax = f16 ? reinterpret_cast<unsigned*>(nb + pl.off_Ab + (size_t)2 * 2 * kW * kW) : nullptr;
       if (int rc = dpll_pipe::bwd1_bf16(stream, (const float*)q.ptr, q.ld, pl.N, w, nb + pl.off_Ab, (const float*)(nb + pl.off_a),
                                         (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_U0), (const float*)RB,
-                                        (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb), f16)) return rc;
+                                        (double*)(nb + pl.off_b1), (float*)(nb + pl.off_Vb), f16, rbmax)) return rc;
       mesh_mark(stream);
       if (f16)
         hipLaunchKernelGGL((icnn_bwd2_bf16<2, true>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
                            (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
-                           (float*)(nb + pl.off_slabs));
+                           (float*)(nb + pl.off_slabs), (const unsigned*)rbmax);
       else
         hipLaunchKernelGGL((icnn_bwd2_bf16<2>), dim3(kB2Pieces, pl.n_slabs), dim3(512), 0, stream, pl.N,
                            (const float*)(nb + pl.off_Vb), (const uint32_t*)(nb + pl.off_M1), (const float*)(nb + pl.off_a),
-                           (float*)(nb + pl.off_slabs));
+                           (float*)(nb + pl.off_slabs), (const unsigned*)nullptr);
     }
     else if (t_mesh_gemm == 3) DPLL_BWD_BF16(3);
     else if (t_mesh_gemm == 0) {

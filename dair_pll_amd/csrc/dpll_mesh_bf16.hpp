@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void icnn_prep_bf16_kernel(IcnnWeights<float> 
     if constexpr (F16) av = av < 16384.f ? av : __builtin_nanf("");
     a[idx] = av;
   }
+  // (fp16 planes: the word where icnn_bwd1 leaves the launch's largest |r_bar| for icnn_bwd2 -- the place of a third plane of Af,
+  // which the two-plane forms do not have -- starts every forward at zero)
+  if constexpr (F16) { if (idx == 0) *reinterpret_cast<unsigned*>(Af + 2 * kW * kW) = 0u; }
   if (idx >= kW * kW) return;
   const int k = idx / kW, j = idx % kW;
   __bf16 parts[PL];
@@ -385,7 +388,8 @@ __global__ __launch_bounds__(512) void icnn_bwd1_bf16(const float* __restrict__ 
 // sets of planes, selected by the mask bit.
 template <int PL, bool F16 = false>
 __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* __restrict__ Vb, const uint32_t* __restrict__ M1,
-                                                      const float* __restrict__ a, float* __restrict__ slabs) {
+                                                      const float* __restrict__ a, float* __restrict__ slabs,
+                                                      const unsigned* __restrict__ rbmax) {
   __shared__ float Ls[2][kMfmaRows][128 + 1];
   __shared__ uint32_t Ms[2][kMfmaRows][4];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
@@ -395,6 +399,15 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
   const long long per = (n_tiles + gridDim.y - 1) / gridDim.y;
   const long long t_begin = (long long)blockIdx.y * per, t_end = (t_begin + per < n_tiles) ? t_begin + per : n_tiles;
   // this lane's columns of U1: j-tiles jtl and jtl + 1 of the piece
+  // fp16 planes: Vb is an ADJOINT (its magnitude is the data's: loss scale, item weights) and the rows are this GEMM's contraction
+  // index, so ONE power of two for the whole launch takes it into fp16's range: from the largest |r_bar| entry icnn_bwd1 met
+  // (*rbmax, float bits; Vb = (r_bar . Wd0) . mask).  What matters for a sum over rows is the error relative to the largest rows.
+  float vb_up = 1.f, vb_back = 1.f;
+  if constexpr (F16) {
+    const unsigned e = rbmax ? (*rbmax >> 23) & 0xffu : 127u;
+    vb_up = __builtin_bit_cast(float, (254u - e) << 23);
+    vb_back = __builtin_bit_cast(float, e << 23);  // (e = 0: no row had a gradient -- every product is zero)
+  }
   __bf16 ua[2][PL];
   split_planes<PL, F16>(a[128 * jq + 32 * jtl + l31], ua[0]);
   split_planes<PL, F16>(a[128 * jq + 32 * (jtl + 1) + l31], ua[1]);
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
       for (int e = 0; e < 8; ++e) {
         const int row = 16 * s + 8 * half + e;
         __bf16 parts[PL];
-        split_planes<PL, F16>(Ls[cur][row][32 * ktl + l31], parts);
+        split_planes<PL, F16>(Ls[cur][row][32 * ktl + l31] * vb_up, parts);
         const bool on0 = (Ms[cur][row][jtl] >> l31) & 1u, on1 = (Ms[cur][row][jtl + 1] >> l31) & 1u;
 #pragma unroll
         for (int p = 0; p < PL; ++p) {
@@ -464,8 +477,8 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const int k = 128 * kq + 32 * ktl + mfma_row(reg, half);
-    slab[k * kW + 128 * jq + 32 * jtl + l31] = acc0[reg] + low0[reg] * kLowBack<F16>;
-    slab[k * kW + 128 * jq + 32 * (jtl + 1) + l31] = acc1[reg] + low1[reg] * kLowBack<F16>;
+    slab[k * kW + 128 * jq + 32 * jtl + l31] = (acc0[reg] + low0[reg] * kLowBack<F16>) * vb_back;
+    slab[k * kW + 128 * jq + 32 * (jtl + 1) + l31] = (acc1[reg] + low1[reg] * kLowBack<F16>) * vb_back;
   }
 }
 
