@@ -195,18 +195,19 @@ class Timer:
         return 'eager' + (f' (hipGraph capture failed: {self.capture_error})' if self.capture_error else '')
 
 
-# dpll_solver_opts_t.mesh_gemm: the forms of the float32 ICNN GEMM kernels beside the default (0: exact f32 MFMA)
-MESH_GEMM_FORMS = {1: 'ICNN GEMMs: f32 MFMA, the 8-wave kernels', 2: 'ICNN GEMMs on the bf16 matrix cores, 2 planes',
+# dpll_solver_opts_t.mesh_gemm: the forms of the float32 ICNN GEMM kernels (library default: 4; None below = that default)
+MESH_GEMM_FORMS = {0: 'ICNN GEMMs: exact f32 MFMA, pipelined', 1: 'ICNN GEMMs: f32 MFMA, the 8-wave kernels', 2: 'ICNN GEMMs on the bf16 matrix cores, 2 planes',
                    3: 'ICNN GEMMs on the bf16 matrix cores, 3 planes',
                    4: 'ICNN GEMMs on the fp16 matrix cores, 2 planes with the low one scaled by 2^11: f32-grade products'}
 
 
-def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
+def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=None):
     """roofline object of the dominant kernel, measured live with HIP events on the launch stream"""
     alg_bytes = bytes_per_step(workload, dtype) * batch
     if workload in ('elbow_mesh', 'clasp', 'slider', 'clasp_mesh', 'two_cubes', 'chain6'):
         return None  # no per-kernel utility for these pipelines: run_loss_config prices the whole step
     if workload == 'mesh':
+        form = 4 if mesh_gemm is None else mesh_gemm  # (the library's default: dpll_solver_opts_t.mesh_gemm)
         mesh_ms = system.profile_mesh_kernels(x, xp, reps=50)
         # the mesh pipeline is bounded by its four N x 256 x 256 f32 GEMMs (SURVEY 8d: MFMA); the dominant kernel is
         # the slowest of them, its algorithmic work 2 * N * 256 * 256 flop with N = 4 * batch support queries
@@ -225,8 +226,8 @@ def loss_roofline(system, workload, dtype, batch, x, xp, mesh_gemm=0):
                         'vector ALU to itself: the f32 MFMA runs on its multipliers, so every VALU / LDS instruction of the fused fill and '
                         'epilogue adds to the MFMA time (profiles/r05_mfma_fill.txt, r05_mfma_step.txt), and the chip runs these kernels '
                         'at ~2.15 GHz (matrix floor of one GEMM at 4096 pairs: 15.2 us)'
-                        if dtype == 'f32' and not mesh_gemm else
-                        (MESH_GEMM_FORMS[mesh_gemm] + ' (csrc/dpll_mesh_bf16.hpp, dpll_icnn_pipe.hip); priced against the f32 matrix rate: the '
+                        if dtype == 'f32' and form in (0, 1) else
+                        (MESH_GEMM_FORMS[form] + ' (csrc/dpll_mesh_bf16.hpp, dpll_icnn_pipe.hip); priced against the f32 matrix rate: the '
                          'algorithmic work is the f32 GEMM' if dtype == 'f32' else
                          'float64 path: register-tiled VALU GEMMs (no f64 MFMA form is built)')}
     passes = [system.profile_loss_kernels(x, xp, reps=200) for _ in range(3)]  # (HIP events on the launch stream, 200 launches each)
@@ -272,12 +273,12 @@ def build_system(workload, dtype_name, dt, device):
     return MultibodyLearnableSystem({k: os.path.join(REPO, 'assets', v) for k, v in urdfs.items()}, dt, dtype=dtype, device=str(device))
 
 
-def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device, use_graph=True, steps_per_graph=50, mesh_gemm=0):
+def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device, use_graph=True, steps_per_graph=50, mesh_gemm=None):
     """one single-GPU configuration of the loss path: value, step time, roofline"""
     dtype = torch.float32 if dtype_name == 'f32' else torch.float64
     x_np, xp_np, dt = load_pairs(batch, 0, workload)
     system = build_system(workload, dtype_name, dt, device)
-    if mesh_gemm:  # the ICNN GEMMs on the bf16 matrix cores, operands split into bf16 planes (csrc/dpll_mesh_bf16.hpp)
+    if mesh_gemm is not None:  # another form of the ICNN GEMM kernels than the library's default
         system.set_solver(mesh_gemm=mesh_gemm)
     x, xp = torch.tensor(x_np, dtype=dtype, device=device), torch.tensor(xp_np, dtype=dtype, device=device)
     step = lambda: system.contactnets_loss_and_grad(x, xp)
@@ -302,7 +303,7 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
             kernel = ('forest_loss_kernel + row fold + finalize (forest build: one wave per item, blocks in LDS)' if workload in ('two_cubes', 'chain6')
                       else 'gen_loss_kernel + row fold + finalize (general build: one lane per contact slot)')
             roof = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'kernel': kernel, 'kernel_ms': step_ms}
-    if mesh_gemm:
+    if mesh_gemm is not None:
         workload = f'{workload} ({MESH_GEMM_FORMS[mesh_gemm]})'
     return {'workload': workload, 'dtype': dtype_name, 'batch': batch, 'value': batch * steps / elapsed,
             'unit': 'trajectory-steps/s', 'ms_per_step': elapsed / steps * 1e3, 'steps': steps, 'launch': timer.launch,
@@ -310,13 +311,13 @@ def run_loss_config(workload, dtype_name, batch, steps, warmup, repeats, device,
             'roofline': {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel') if k in roof}}
 
 
-def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device, mesh_gemm=0):
+def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device, mesh_gemm=None):
     """fused rollouts (dpll_simulate: the time loop inside the kernel): one step = one VelocityIntegrator.step of one
     trajectory; algorithmic bytes per step = read x + write x+ (cube 104 B in f32)"""
     dtype = torch.float32 if dtype_name == 'f32' else torch.float64
     x_np, _, dt = load_pairs(batch, 0, workload)
     system = build_system(workload, dtype_name, dt, device)
-    if mesh_gemm:  # the ICNN GEMMs of the learned shape on the bf16 matrix cores (operands split into bf16 planes)
+    if mesh_gemm is not None:
         system.set_solver(mesh_gemm=mesh_gemm)
     x0 = torch.tensor(x_np, dtype=dtype, device=device).unsqueeze(-2)
     carry = torch.zeros((batch, 1), device=device)
@@ -335,7 +336,7 @@ def run_simulate_config(workload, dtype_name, batch, horizon, repeats, device, m
     ms = float(np.median(times))
     if workload == 'mesh':  # per step two forward GEMMs of (4 batch) x 256 x 256 (the support points follow the state)
         tflops = 2 * 2.0 * (4 * batch) * 256 * 256 * horizon / (ms * 1e-3) / 1e12
-        return {'workload': f'simulate ({workload}, {horizon} steps per call)' + (f', {MESH_GEMM_FORMS[mesh_gemm]}' if mesh_gemm else ''),
+        return {'workload': f'simulate ({workload}, {horizon} steps per call)' + (f', {MESH_GEMM_FORMS[mesh_gemm]}' if mesh_gemm is not None else ''),
                 'dtype': dtype_name, 'batch': batch,
                 'value': batch * horizon / (ms * 1e-3), 'unit': 'trajectory-steps/s (forward only)', 'ms_per_step': ms / horizon,
                 'kernel_ms': ms, 'launch': 'dpll_simulate_mesh: weights prepared once, 4 kernels per step enqueued by the library',
@@ -408,9 +409,9 @@ def main() -> None:
     parser.add_argument('--batch', type=int, default=4096, help='pairs per GPU')
     parser.add_argument('--workload', choices=['cube', 'elbow', 'mesh'], default='cube',
                         help='cube = BASELINE configs[1] (the headline metric); elbow = configs[2]; mesh = configs[3]')
-    parser.add_argument('--mesh-gemm', type=int, choices=[0, 1, 2, 3, 4], default=0,
-                        help='mesh workload: form of the ICNN GEMM kernels (0 = f32 MFMA, 1 = its 8-wave kernels, 2 / 3 = bf16 matrix cores on 2 / 3 '
-                             'bf16 planes, 4 = two fp16 planes, f32-grade)')
+    parser.add_argument('--mesh-gemm', type=int, choices=[0, 1, 2, 3, 4], default=None,
+                        help='mesh workload: form of the ICNN GEMM kernels (default: the library\'s, 4 = two fp16 planes, f32-grade; 0 = f32 MFMA, 1 = its '
+                             '8-wave kernels, 2 / 3 = bf16 matrix cores on 2 / 3 bf16 planes)')
     parser.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     parser.add_argument('--portfolio', type=int, default=None,
                         help='diagnostic: racing copies of the cone solve per item (1 = none; default: what the library picks) -- the '
@@ -493,7 +494,7 @@ def main() -> None:
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     x_np, xp_np, dt = load_pairs(args.batch, seed=rank, workload=args.workload)
     system = build_system(args.workload, args.dtype, dt, device)
-    if args.mesh_gemm and args.workload == 'mesh':
+    if args.mesh_gemm is not None and args.workload == 'mesh':
         system.set_solver(mesh_gemm=args.mesh_gemm)
     if args.portfolio is not None:
         system.set_solver(portfolio=args.portfolio)
@@ -639,8 +640,8 @@ def main() -> None:
                 except Exception as exc:  # noqa: BLE001
                     configs.append({'workload': f'simulate ({w})', 'dtype': d, 'batch': b, 'error': repr(exc)})
             try:
-                configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=4))
-                configs.append(run_simulate_config('mesh', 'f32', 4096, 80, 5, device, mesh_gemm=4))
+                configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=0))
+                configs.append(run_simulate_config('mesh', 'f32', 4096, 80, 5, device, mesh_gemm=0))
                 configs.append(run_loss_config('mesh', 'f32', 4096, 200, 20, 3, device, mesh_gemm=2))
                 configs.append(run_simulate_config('mesh', 'f32', 4096, 80, 5, device, mesh_gemm=2))
             except Exception as exc:  # noqa: BLE001

@@ -70,7 +70,7 @@ struct PipeArgs {
   uint32_t* M1out;         // fwd1
   const float* U0in;       // bwd1 (accumulator layout)
   float* U0out;            // fwd2
-  unsigned* rbmax;         // bwd1, fp16 planes: where the launch leaves the largest |r_bar| it met (its float bits), for icnn_bwd2
+  unsigned* rbmax;         // bwd1, fp16 planes: kMaxBlocks words, workgroup b leaves the largest |r_bar| entry it met (float bits) in [b]
   const float* RB;         // bwd1
   float* P;                // fwd2
   double* partial;         // bwd1
@@ -237,11 +237,12 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   }
 
   // ---- row data of a tile: global -> registers (issue) -> LDS ring (commit) -----------------------------------------
-  struct RowRaw { float q[4]; float r; uint32_t m; bool ok; };
+  float rb_seen = 0.f;  // bwd1, fp16 planes: the largest |r_bar| entry of the rows this lane loaded
+  struct RowRaw { float q[4]; float r3[3]; uint32_t m; bool ok; };
   auto rows_issue = [&](long long tile) {
     RowRaw raw;
     const long long n0 = tile * kRows;
-    raw.ok = false; raw.r = 0.f; raw.m = 0u;
+    raw.ok = false; raw.m = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) raw.q[i] = 0.f;
     if (tid < kRows) {  // the row's query direction (raw: explicit direction or the item's quaternion)
@@ -253,8 +254,9 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) raw.q[i] = src[(i == 3 && g.w.dirs) ? 2 : i];
     }
-    if (KIND == kBwd1 && tid >= 64 && tid < 64 + 3 * kRows) {
-      const int t = tid - 64, r = t / 3, i = t - 3 * r;
+    raw.r3[0] = raw.r3[1] = raw.r3[2] = 0.f;
+    if (KIND == kBwd1 && tid >= 64 && tid < 64 + kRows) {  // lane r of wave 1: the three components of row r's adjoint
+      const int r = tid - 64;
       const long long n = n0 + r;
       const uint32_t nc = (uint32_t)(n < N ? n : N - 1);  // (N < 2^31: the launchers check; a 64-bit division here kept waves 1-2 of
       const uint32_t item = nc / (uint32_t)g.w.qpi;         //  bwd1 ~3 k cycles behind at the prologue's first barrier)
@@ -262,8 +264,9 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       int off = g.w.qoff[0];
 #pragma unroll
       for (int cq = 1; cq < 8; ++cq) off = (jq == cq) ? g.w.qoff[cq] : off;
-      const float v = g.RB[(long long)item * g.w.point_stride + off + i];
-      raw.r = n < N ? v : 0.f;
+      const float* src = g.RB + (long long)item * g.w.point_stride + off;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const float v = src[i]; raw.r3[i] = n < N ? v : 0.f; }
     }
     if (KIND != kFwd1) {
       const long long n = n0 + (tid >> 3);
@@ -286,9 +289,13 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
       }
       ring.v[slot][tid][0] = f32x4{q[0], q[1], q[2], 0.f};
     }
-    if (KIND == kBwd1 && tid >= 64 && tid < 64 + 3 * kRows) {
-      const int t = tid - 64, r = t / 3, i = t - 3 * r;
-      ((float*)&ring.v[slot][r][1])[i] = raw.r;
+    if (KIND == kBwd1 && tid >= 64 && tid < 64 + kRows) {
+      // (fp16 planes: component 3 = the power of two that takes the row's results back from the scaled planes, pow2_back of the
+      // row's largest |entry|; the fill forms its inverse from the same bits)
+      const f32x4 rb = f32x4{raw.r3[0], raw.r3[1], raw.r3[2], 0.f};
+      const float m = row_max3(rb);
+      ring.v[slot][tid - 64][1] = f32x4{raw.r3[0], raw.r3[1], raw.r3[2], F16 ? pow2_back(m) : 0.f};
+      if constexpr (F16) rb_seen = fmaxf(rb_seen, m);
     }
     if (KIND != kFwd1) ((uint32_t*)&ring.v[slot][tid >> 3][2])[tid & 7] = raw.m;
   };
@@ -370,7 +377,6 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   // The two 32-column blocks of a wave are two MFMA chains run one after the other; acc[1] enters tile t still holding chain 1
   // of tile t - 1 (zero before the first tile), whose epilogue runs under chain 0 of tile t
   f32x16 low[2];  // BF16: the small products of a chain, added to acc once at its end
-  float rb_seen = 0.f;  // bwd1, fp16 planes: the largest |r_bar| entry of the rows this lane's epilogues met
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -437,12 +443,7 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
     } else {
       const f32x4 r = in.a;
       const float mf = mask_factor(in.w, l31);
-      float avs = av;
-      if constexpr (F16) {
-        const float m = row_max3(r);
-        avs = av * pow2_back(m);  // (the row went through the GEMM scaled by pow2_up(m))
-        rb_seen = fmaxf(rb_seen, m);
-      }
+      const float avs = F16 ? av * r[3] : av;  // (fp16 planes: the row went through the GEMM scaled by 1 / r[3], rows_commit)
       const float u1b = avs + r[0] * wd1[cb][0] + r[1] * wd1[cb][1] + r[2] * wd1[cb][2];
       t_abar += u1b * mf;  // rows past N / tiles that do not exist: r_bar = 0 and a zero accumulator
       if ((reg & 3) == 0) {
@@ -725,12 +726,16 @@ __global__ __launch_bounds__(256) void icnn_pipe_kernel(PipeArgs g) {
   }
   PIPE_STAMP(14);
   if constexpr (KIND == kBwd1 && F16) {
-    // the largest |r_bar| entry of the launch (a non-negative float: its bits order like the number), for icnn_bwd2's global
-    // scale of the adjoint operand -- a maximum, so the order of the atomics does not matter
-    float m = rb_seen;
+    // the largest |r_bar| entry this workgroup met (a non-negative float: its bits order like the number), for icnn_bwd2's global
+    // scale of the adjoint operand
+    // (the rows are loaded by lanes 0..31 of wave 1: that wave folds their maxima and leaves the workgroup's in its own slot --
+    // 1024 atomics on one word cost the launch ~10 us)
+    if (wv == 1) {
+      float m = rb_seen;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (lane == 0 && g.rbmax) atomicMax(g.rbmax, __builtin_bit_cast(unsigned, m));
+      for (int off = 16; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+      if (lane == 0 && g.rbmax) g.rbmax[blockIdx.x] = __builtin_bit_cast(unsigned, m);
+    }
   }
   if (KIND == kBwd1) {
     // the two halves of the wave hold different rows of the same columns (threads tid and tid ^ 32)

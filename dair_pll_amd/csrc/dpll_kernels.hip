@@ -690,7 +690,10 @@ SolverOpts default_opts(int dtype, int n_joints = 0, bool general = false) {
   o.loss_n_stages = (!general && n_joints == 1) ? 5 : 0;
   o.loss_stage_factor = 2.5;
   o.f64_refine = 1;
-  o.mesh_gemm = 0;
+  // the float32 ICNN GEMMs: two fp16 planes (dpll_mesh_bf16.hpp) -- f32-grade products (against float64 on the benchmark batch: no
+  // support point on another vertex, loss error 4e-8, worst gradient error 1.4e-6; the f32 MFMA form: 0, 5e-8, 1.1e-6) at 98 us per
+  // step instead of 140; 0 selects the f32 MFMA kernels
+  o.mesh_gemm = 4;
   // racing copies of the loss solve (launches of <= 4096 cube pairs: 4 copies): the schedules that, together with the one
   // above, had the lowest worst case over EIGHT 4096-pair samples of the reference's 57,812 toss pairs, the benchmark batch
   // among them (tools/diag/race_schedules.py and its multi-sample search; all cold starts on full Newton steps): slowest

@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void icnn_prep_bf16_kernel(IcnnWeights<float> 
     if constexpr (F16) av = av < 16384.f ? av : __builtin_nanf("");
     a[idx] = av;
   }
-  // (fp16 planes: the word where icnn_bwd1 leaves the launch's largest |r_bar| for icnn_bwd2 -- the place of a third plane of Af,
-  // which the two-plane forms do not have -- starts every forward at zero)
-  if constexpr (F16) { if (idx == 0) *reinterpret_cast<unsigned*>(Af + 2 * kW * kW) = 0u; }
+  // (fp16 planes: the 256 words where the workgroups of icnn_bwd1 leave the largest |r_bar| they met for icnn_bwd2 -- the place of
+  // a third plane of Af, which the two-plane forms do not have -- start every forward at zero)
+  if constexpr (F16) { if (idx < 256) reinterpret_cast<unsigned*>(Af + 2 * kW * kW)[idx] = 0u; }
   if (idx >= kW * kW) return;
   const int k = idx / kW, j = idx % kW;
   __bf16 parts[PL];
@@ -404,7 +404,15 @@ __global__ __launch_bounds__(512) void icnn_bwd2_bf16(long long N, const float* 
   // (*rbmax, float bits; Vb = (r_bar . Wd0) . mask).  What matters for a sum over rows is the error relative to the largest rows.
   float vb_up = 1.f, vb_back = 1.f;
   if constexpr (F16) {
-    const unsigned e = rbmax ? (*rbmax >> 23) & 0xffu : 127u;
+    // (256 words, one per workgroup of icnn_bwd1: lanes fold them -- bits of non-negative floats order like the numbers)
+    unsigned top = 0u;
+    if (rbmax) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) top = max(top, rbmax[64 * q + lane]);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) top = max(top, (unsigned)__shfl_xor((int)top, off));
+    }
+    const unsigned e = rbmax ? (top >> 23) & 0xffu : 127u;
     vb_up = __builtin_bit_cast(float, (254u - e) << 23);
     vb_back = __builtin_bit_cast(float, e << 23);  // (e = 0: no row had a gradient -- every product is zero)
   }

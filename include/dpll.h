@@ -165,10 +165,13 @@ typedef struct dpll_solver_opts {
   double loss_stage_factor; /* continuation schedule of the loss solve (eps 1e-3) when it differs from the dynamics solve's */
   int32_t loss_n_stages;    /* 0 = n_stages / stage_factor for both solves; like n_stages at most 8 unless portfolio = 1 */
   int32_t f64_refine;       /* DPLL_F64 solves: 1 = float iterations refined in double to `tol` (default), 0 = all double */
-  int32_t mesh_gemm;        /* DPLL_F32 mesh pipeline, ICNN GEMMs: 0 = f32 MFMA (exact f32, default: one wave per SIMD, pipelined), 1 = f32 MFMA, the 8-wave kernels of rounds 1-4, 2 / 3 = bf16 matrix cores on
-                               operands split into 2 / 3 bf16 planes (3: f32-grade accuracy, 2: 2^-16 per product); 4 = two fp16 planes
-                             * with the low one scaled by 2^11 (x = h + l to 2^-24: f32-grade products at the 2-plane cost; operands must stay below
-                             * 65504 in magnitude -- weights, |wout|, activations of unit directions, support-point adjoints) */
+  int32_t mesh_gemm;        /* DPLL_F32 mesh pipeline, form of the ICNN GEMM kernels.  4 (default) = two fp16 planes, the low one scaled by
+                             * 2^11: x = h + l to 2^-24, so the three products per k-step are f32-grade, at the cost of the 2-plane forms;
+                             * adjoint operands are scaled into fp16's range by powers of two taken from the data; weights must stay
+                             * below 2^14 (|input_weights.0| below 2^12) -- beyond, every solve of the launch is invalidated (NaN support
+                             * points), never a finite wrong number.  0 = f32 MFMA (v_mfma_f32_32x32x2_f32; one wave per SIMD, pipelined),
+                             * 1 = f32 MFMA, the 8-wave kernels of rounds 1-4, 2 / 3 = bf16 matrix cores on 2 / 3 bf16 planes (2: products
+                             * to 2^-16) */
   /* Racing continuation schedules (loss solve, lane-per-contact builds): a launch that leaves SIMDs idle gives every item
    * `portfolio` copies of its lane group; copy 0 runs the schedule above, copy v >= 1 runs (race_stages[v-1],
    * race_factor[v-1]) with race_flags[v-1] (1 = warm start, 2 = full Newton steps only: no line search, so none of its

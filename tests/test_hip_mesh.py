@@ -483,8 +483,7 @@ def test_split_bf16_gemm_forms_on_the_benchmark_batch(golden):
     # (mode 4, two fp16 planes, is held to the bars of the exact f32 kernels: its products are f32-grade)
     for mode, flips_allowed, grad_tol in ((0, 2e-4, 2e-5), (3, 2e-4, 2e-5), (4, 2e-4, 2e-5), (2, 1e-3, 5e-4)):
         s32 = build(g, torch.float32)
-        if mode:
-            s32.set_solver(mesh_gemm=mode)
+        s32.set_solver(mesh_gemm=mode)  # (0 is not the library's default: the fp16-plane form, 4, is)
         p32 = s32.support_points(xp64.float()).cpu().double().numpy()
         assert (np.abs(p64 - p32).max(-1) > 1e-5).mean() <= flips_allowed, mode
         t32 = s32.contactnets_loss_and_grad(x64.float(), xp64.float()).item()

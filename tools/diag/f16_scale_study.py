@@ -9,7 +9,7 @@ def build(dtype, mode=0):
     s = MultibodyLearnableSystem({'m': os.path.join(REPO, 'assets', 'cube_mesh.urdf')}, float(big['dt']), dtype=dtype, device='cuda:0')
     s.load_state_dict({name: torch.tensor(g['param/' + name]) for name, _ in s.named_parameters()})
     s.multibody_terms.contact_terms.geometries[1].perturbations = torch.tensor(g[f'param/{GEOM}1.perturbations'], dtype=dtype, device='cuda:0')
-    if mode: s.set_solver(mesh_gemm=mode)
+    if dtype == torch.float32: s.set_solver(mesh_gemm=mode)
     return s
 x64 = torch.tensor(big['x'], device='cuda:0'); xp64 = torch.tensor(big['x_plus'], device='cuda:0')
 for gb in (4096, 4096*256, 4096*65536, 4096*2**24):

@@ -17,7 +17,7 @@ def build(dtype, mode=0):
     s = MultibodyLearnableSystem({'m': os.path.join(REPO, 'assets', 'cube_mesh.urdf')}, float(big['dt']), dtype=dtype, device='cuda:0')
     s.load_state_dict({name: torch.tensor(g['param/' + name]) for name, _ in s.named_parameters()})
     s.multibody_terms.contact_terms.geometries[1].perturbations = torch.tensor(g[f'param/{GEOM}1.perturbations'], dtype=dtype, device='cuda:0')
-    if mode:
+    if dtype == torch.float32:
         s.set_solver(mesh_gemm=mode)
     return s
 

@@ -2,8 +2,8 @@
 # SQ counters of the mesh pipeline's kernels (diagnostic)
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 O=gpurun_out/pmc_mesh; rm -rf $O; mkdir -p $O
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/p1 -o run -- python3 bench.py --workload mesh --steps 10 --warmup 0 --no-graph --no-cpu-baseline > $O/p1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -o run -- python3 bench.py --workload mesh --steps 10 --warmup 0 --no-graph --no-cpu-baseline > $O/p2.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/p1 -o run -- python3 bench.py --workload mesh --mesh-gemm 0 --steps 10 --warmup 0 --no-graph --no-cpu-baseline > $O/p1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $O/p2 -o run -- python3 bench.py --workload mesh --mesh-gemm 0 --steps 10 --warmup 0 --no-graph --no-cpu-baseline > $O/p2.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/p3 -o run -- python3 bench.py --workload mesh --mesh-gemm 2 --steps 10 --warmup 0 --no-graph --no-cpu-baseline > $O/p3.log 2>&1
 python3 - <<'PY'
 import csv, collections, re

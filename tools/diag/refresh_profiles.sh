@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_elbow -o run --
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_elbow_f64 -o run -- python3 bench.py --workload elbow --dtype f64 --steps 300 --warmup 20 $B > $O/stats_elbow_f64.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b65536 -o run -- python3 bench.py --batch 65536 --steps 100 --warmup 20 $B > $O/stats_b65536.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b65536_f64 -o run -- python3 bench.py --batch 65536 --dtype f64 --steps 100 --warmup 20 $B > $O/stats_b65536_f64.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mesh -o run -- python3 bench.py --workload mesh --steps 50 --warmup 50 $B > $O/stats_mesh.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mesh -o run -- python3 bench.py --workload mesh --mesh-gemm 0 --steps 50 --warmup 50 $B > $O/stats_mesh.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mesh_bf16 -o run -- python3 bench.py --workload mesh --mesh-gemm 2 --steps 50 --warmup 50 $B > $O/stats_mesh_bf16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mesh_f16 -o run -- python3 bench.py --workload mesh --mesh-gemm 4 --steps 50 --warmup 50 $B > $O/stats_mesh_f16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sim -o run -- python3 tools/diag/sim_bench.py > $O/stats_sim.log 2>&1
