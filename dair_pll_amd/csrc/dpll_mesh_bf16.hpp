@@ -1,6 +1,7 @@
 // dpll_mesh_bf16.hpp -- the ICNN GEMM kernels on the bf16 matrix cores with SPLIT operands; included by dpll_kernels.hip
-// behind dpll_mesh_kernels.hpp.  An option of the mesh pipeline (dpll_solver_opts_t.mesh_gemm); the exact-f32 MFMA kernels
-// stay the default and the parity reference.
+// behind dpll_mesh_kernels.hpp.  Forms of the mesh pipeline's GEMMs (dpll_solver_opts_t.mesh_gemm): 2 / 3 bf16 planes (below) and, since
+// the end of round 5 the DEFAULT, 4 = two fp16 planes (further down: f32-grade products at the 2-plane cost).  The f32 MFMA kernels
+// (mesh_gemm = 0 / 1) remain selectable and are what every earlier round measured.
 //
 // gfx950 runs v_mfma_f32_32x32x2_f32 at 1/16 of the bf16 rate (64 cycles for 4 kflop against 32 cycles for 32 kflop).  An
 // f32 number is the exact sum of three bf16 numbers (8 + 8 + 8 significand bits), x = x1 + x2 + x3, and a product of two
