@@ -321,6 +321,9 @@ class MultibodyLearnableSystem(Module):
                           'host': torch.tensor([row.body for row in rows], dtype=torch.int32, device=dev),
                           'transforms': torch.tensor(transforms, dtype=torch.float64, device=dev).contiguous(), 'grad': None}
         self._grad_reduced = False  # the last contactnets_loss_and_grad already summed [loss | gradients] over the ranks
+        # the default form of the float32 ICNN GEMMs needs weights inside fp16's range: checked now and after every load_state_dict
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._fp16_range_or_f32_mfma())
+        self._fp16_range_or_f32_mfma()
 
     # ---- parameters ---------------------------------------------------------------------------
     def _geom_slots(self) -> int:
@@ -513,18 +516,39 @@ class MultibodyLearnableSystem(Module):
             if isinstance(value, (tuple, list)):  # (the racing schedules: three entries each)
                 value = type(getattr(opts, key))(*value)
             setattr(opts, key, value)
-        _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
         if kwargs.get('mesh_gemm') == 4:
-            # two fp16 planes (csrc/dpll_mesh_bf16.hpp): fp16 ends at 65504.  The weights are checked here, once (one host sync);
-            # should they grow past the bound later the prep kernel turns |wout| into NaN -- no item then has a valid solve
-            for geometry in self._meshes():
-                net = geometry.network
-                for name, bound in (('hidden_weights', 16384.0), ('input_weights', 4096.0)):
-                    for weight in getattr(net, name):
-                        if not bool((weight.detach().abs() < bound).all()):
-                            raise _capi.DpllError(f'mesh_gemm = 4 (fp16 planes) needs |{name}| < {bound:g}: use mesh_gemm = 0')
-                if not bool((net.output_weight.detach().abs() < 16384.0).all()):
-                    raise _capi.DpllError('mesh_gemm = 4 (fp16 planes) needs |output_weight| < 16384: use mesh_gemm = 0')
+            self._check_fp16_range()  # (raises before anything is changed)
+        _capi.check(lib.dpll_model_set_solver(self._model(), code, ctypes.byref(opts)))
+
+    def _fp16_range_or_f32_mfma(self) -> None:
+        """weights outside fp16's range (:meth:`_check_fp16_range`): the float32 mesh pipeline goes to the f32 MFMA kernels, with a
+        warning -- a slower form of the same HIP path, not a fallback off the device"""
+        if self._mesh() is None or self.dtype != torch.float32 or not next(self.parameters()).is_cuda:
+            return
+        try:
+            self._check_fp16_range()
+        except _capi.DpllError as error:
+            import warnings
+            warnings.warn(f'{error} -- selected now')
+            self.set_solver(mesh_gemm=0)
+
+    def _check_fp16_range(self, *_unused) -> None:
+        """The default form of the float32 ICNN GEMMs runs on two fp16 planes (csrc/dpll_mesh_bf16.hpp): fp16 ends at 65504.  The
+        weights are checked on the host when the form is chosen, at construction and after ``load_state_dict`` (one sync each);
+        should they grow past the bound in between, the prep kernel turns the offending entries into NaN -- no item then has a
+        valid solve, never a finite wrong number."""
+        if self.dtype != torch.float32:
+            return
+        for geometry in self._meshes():
+            net = geometry.network
+            for name, bound in (('hidden_weights', 16384.0), ('input_weights', 4096.0)):
+                for weight in getattr(net, name):
+                    if not bool((weight.detach().abs() < bound).all()):
+                        raise _capi.DpllError(f'the fp16-plane form of the ICNN GEMMs (mesh_gemm = 4, the default) needs |{name}| < '
+                                              f'{bound:g}: set_solver(mesh_gemm=0) selects the f32 MFMA kernels')
+            if not bool((net.output_weight.detach().abs() < 16384.0).all()):
+                raise _capi.DpllError('the fp16-plane form of the ICNN GEMMs (mesh_gemm = 4, the default) needs |output_weight| < 16384: '
+                                      'set_solver(mesh_gemm=0) selects the f32 MFMA kernels')
 
     def _check_input(self, tensor: Tensor, width: int, what: str, keep_graph: bool = False) -> Tensor:
         if tensor.shape[-1] != width:

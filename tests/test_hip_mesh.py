@@ -584,3 +584,11 @@ def test_fp16_planes_refuse_weights_beyond_their_range(golden):
         net.hidden_weights[0][3, 5] = 3.0e4  # grown after the check
     bad = system.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp).detach()
     assert bool((~torch.isfinite(bad) | (bad == 0)).all())
+    # a checkpoint with such a weight: load_state_dict switches the system to the f32 MFMA kernels, loudly
+    state = {name: value.clone() for name, value in system.state_dict().items()}
+    fresh = build(g, torch.float32)
+    with pytest.warns(UserWarning, match='fp16'):
+        fresh.load_state_dict(state)
+    with torch.no_grad():  # (the weight is absurd, the arithmetic is not: finite losses from the f32 MFMA kernels)
+        out = fresh.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp)
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
