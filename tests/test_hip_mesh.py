@@ -592,3 +592,30 @@ def test_fp16_planes_refuse_weights_beyond_their_range(golden):
     with torch.no_grad():  # (the weight is absurd, the arithmetic is not: finite losses from the f32 MFMA kernels)
         out = fresh.contactnets_loss(x, torch.zeros((x.shape[0], 0), device='cuda:0'), xp)
     assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize('case', ['cube_mesh_literal', CLASP])
+def test_float32_rollout_gradients_of_both_gemm_forms_against_float64(golden, case):
+    """dpll_step_backward_mesh in float32: the gradient of a 2-step rollout with respect to every parameter (network weights
+    included) with the default fp16-plane form of the ICNN GEMMs and with the f32 MFMA kernels, both against the float64 kernels on
+    the same states -- the adjoints of a rollout are another magnitude than those of the loss (no 1 / batch), which the scaled
+    planes must not care about"""
+    g = golden(case)
+    make = build_general if case == CLASP else build
+    rows = np.linspace(0, g['x'].shape[0] - 1, 24).astype(int)
+    w = torch.rand((len(rows), 2, g['x'].shape[1]), generator=torch.Generator().manual_seed(9), dtype=torch.float64) - 0.5
+
+    def rollout_gradients(dtype, mode):
+        system = make(g, dtype)
+        if mode is not None:
+            system.set_solver(mesh_gemm=mode)
+        x = torch.tensor(g['x'][rows], dtype=dtype, device='cuda:0')
+        traj, _ = system.simulate(x.unsqueeze(-2), torch.zeros((len(rows), 1), device='cuda:0'), 2)
+        (traj[:, 1:] * w.to(dtype).cuda()).sum().backward()
+        return {name: param.grad.cpu().double().numpy().copy() for name, param in system.named_parameters()}
+    ref = rollout_gradients(torch.float64, None)
+    for mode in (4, 0):
+        mine = rollout_gradients(torch.float32, mode)
+        for name, value in ref.items():
+            err = np.abs(mine[name] - value).max()
+            assert err <= 5e-3 * max(np.abs(value).max(), 1e-6), (mode, name, err, np.abs(value).max())
